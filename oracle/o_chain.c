@@ -1,0 +1,146 @@
+/* o_chain.c -- the RX flowgraph of apps/dvbt_rx_demo*.grc, stage after stage, in the
+ * "one item per general_work call" scheduling regime.
+ * TEST INFRASTRUCTURE (see dvbt_oracle.h): used by tests/ as the checker and by bench.py's
+ * cpu_baseline leg as the timed CPU port.  Handles one lock per run (a second sync_start
+ * after superframe lock truncates the run; returns 1 in that case). */
+#include "dvbt_oracle.h"
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+static double now(void)
+{ struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+
+int o_rx_run(const o_cfg *c, const ocf *iq, size_t nsamples, float snr_db, int bsize,
+             int rs_compat, o_rx_taps *t)
+{
+  const int N = c->N, cp = c->cp, P = c->payload;
+  int truncated = 0;
+  double t0;
+  size_t max_sym = nsamples / (size_t)(N + cp) + 2;
+  for (int i = 0; i < 10; i++) t->t_stage[i] = 0;
+  t->acq_n = t->fft_n = t->eq_n = t->sym_n = t->vit_n = t->deint_n = t->rs_n = t->ts_n = 0;
+  t->first_out_symbol = -1; t->n_acquired = 0; t->rs_fail = t->rs_corr = 0;
+
+  /* ---- A1 acquisition */
+  ocf *acq = malloc(sizeof(ocf) * (size_t)N * max_sym);
+  unsigned char *sync_tag = calloc(max_sym, 1);
+  size_t nacq = 0, pos = 0;
+  {
+    t0 = now();
+    o_acq *a = o_acq_new(c, snr_db);
+    int pending = 0;
+    /* forecast :474-481 asks for 2N+cp; 16 more keeps the +-8 tracking window in range */
+    while (pos + (size_t)(2 * N + cp) + 16 <= nsamples && nacq < max_sym) {
+      int consumed, sync, cps; float eps;
+      int produced = o_acq_work(a, iq + pos, acq + nacq * (size_t)N, &consumed, &sync, &cps, &eps);
+      if (sync) pending = 1;
+      if (produced) {
+        sync_tag[nacq] = (unsigned char)pending; pending = 0;
+        if (t->cp_start && nacq < t->meta_cap) t->cp_start[nacq] = cps;
+        if (t->epsilon && nacq < t->meta_cap) t->epsilon[nacq] = eps;
+        nacq++;
+      }
+      pos += (size_t)consumed;
+    }
+    o_acq_free(a);
+    t->t_stage[0] = now() - t0;
+  }
+  t->n_acquired = (int)nacq;
+  if (t->acq_out) { size_t n = nacq < t->acq_cap ? nacq : t->acq_cap; memcpy(t->acq_out, acq, sizeof(ocf) * N * n); t->acq_n = n; }
+
+  /* ---- A2 FFT */
+  ocf *fft = malloc(sizeof(ocf) * (size_t)N * (nacq + 1));
+  t0 = now();
+  for (size_t s = 0; s < nacq; s++) o_fft_forward_shift(N, acq + s * (size_t)N, fft + s * (size_t)N);
+  t->t_stage[1] = now() - t0;
+  free(acq);
+  if (t->fft_out) { size_t n = nacq < t->fft_cap ? nacq : t->fft_cap; memcpy(t->fft_out, fft, sizeof(ocf) * N * n); t->fft_n = n; }
+
+  /* ---- A3 demod (needs item j and j+1: forecast :88-94) */
+  size_t nout = 0;
+  ocf *eq = malloc(sizeof(ocf) * (size_t)P * (nacq + 1));
+  int *symidx = malloc(sizeof(int) * (nacq + 1));
+  {
+    t0 = now();
+    o_demod *d = o_demod_new(c);
+    for (size_t j = 0; j + 1 < nacq; j++) {
+      int sf, si, info[8];
+      if (sync_tag[j] && t->first_out_symbol >= 0) { truncated = 1; break; }
+      int produced = o_demod_work(d, fft + j * (size_t)N, eq + nout * (size_t)P, sync_tag[j], &sf, &si, info);
+      if (t->sym_index && j < t->meta_cap) t->sym_index[j] = si;
+      if (sf) t->first_out_symbol = (int)j;
+      if (produced) symidx[nout++] = si;
+    }
+    o_demod_free(d);
+    t->t_stage[2] = now() - t0;
+  }
+  free(fft); free(sync_tag);
+  if (t->eq_out) { size_t n = nout < t->eq_cap ? nout : t->eq_cap; memcpy(t->eq_out, eq, sizeof(ocf) * P * n); t->eq_n = n; }
+
+  /* ---- A4..A6 demap, symbol de-interleave, bit de-interleave */
+  unsigned char *b0 = malloc((size_t)P * (nout + 1)), *b1 = malloc((size_t)P * (nout + 1)), *b2 = malloc((size_t)P * (nout + 1));
+  {
+    ocf *points = malloc(sizeof(ocf) * c->csize); o_constellation(c, 1.0f, points);
+    int *H = malloc(sizeof(int) * P); o_sym_H(c, H);
+    t0 = now();
+    o_demap(c, points, eq, b0, (size_t)P * nout);
+    t->t_stage[3] = now() - t0; t0 = now();
+    for (size_t s = 0; s < nout; s++) o_sym_interleave(c, H, b0 + s * P, b1 + s * P, symidx[s], 0);
+    t->t_stage[4] = now() - t0; t0 = now();
+    o_bit_deinterleave(c, b1, b2, (size_t)P * nout);
+    t->t_stage[5] = now() - t0;
+    free(points); free(H);
+  }
+  free(eq); free(symidx);
+  {
+    size_t n = nout < t->sym_cap ? nout : t->sym_cap;
+    if (t->demap_out) memcpy(t->demap_out, b0, (size_t)P * n);
+    if (t->symdeint_out) memcpy(t->symdeint_out, b1, (size_t)P * n);
+    if (t->bitdeint_out) memcpy(t->bitdeint_out, b2, (size_t)P * n);
+    t->sym_n = n;
+  }
+  free(b0); free(b1);
+
+  /* ---- A7 Viterbi */
+  size_t vit_cap = (size_t)P * nout * c->m * c->k / (8 * c->n) + 64;
+  unsigned char *vit = malloc(vit_cap);
+  t0 = now();
+  size_t nvit = o_viterbi_decode(c, bsize, b2, (size_t)P * nout, vit);
+  t->t_stage[6] = now() - t0;
+  free(b2);
+  if (t->vit_out) { size_t n = nvit < t->vit_cap ? nvit : t->vit_cap; memcpy(t->vit_out, vit, n); t->vit_n = n; }
+
+  /* ---- A8 byte de-interleave: items of 12*136 bytes, output multiple of 2 (:55-61) */
+  size_t nitems = (nvit / 1632) & ~(size_t)1;
+  unsigned char *dei = malloc(nitems * 1632 + 1);
+  t0 = now();
+  o_conv_deinterleave(vit, dei, nitems * 1632);
+  t->t_stage[7] = now() - t0;
+  free(vit);
+  if (t->deint_out) { size_t n = nitems * 1632 < t->deint_cap ? nitems * 1632 : t->deint_cap; memcpy(t->deint_out, dei, n); t->deint_n = n; }
+
+  /* ---- A9 RS */
+  unsigned char *rso = malloc(nitems * 1504 + 1);
+  {
+    o_rs rs; o_rs_init(&rs);
+    t0 = now();
+    o_rs_dec_block(&rs, dei, rso, nitems * 8, rs_compat, &t->rs_fail, &t->rs_corr);
+    t->t_stage[8] = now() - t0;
+  }
+  free(dei);
+  if (t->rs_out) { size_t n = nitems * 1504 < t->rs_cap ? nitems * 1504 : t->rs_cap; memcpy(t->rs_out, rso, n); t->rs_n = n; }
+
+  /* ---- next: energy descramble */
+  if (t->ts_out) {
+    unsigned char *tso = malloc(nitems * 1504 + 1);
+    t0 = now();
+    size_t n = o_energy_descramble(rso, nitems, tso);
+    t->t_stage[9] = now() - t0;
+    if (n > t->ts_cap) n = t->ts_cap;
+    memcpy(t->ts_out, tso, n); t->ts_n = n;
+    free(tso);
+  }
+  free(rso);
+  return truncated;
+}

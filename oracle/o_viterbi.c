@@ -1,0 +1,152 @@
+/* o_viterbi.c -- depuncture + K=7 hard-decision Viterbi with 8-step path bytes.
+ * TEST INFRASTRUCTURE (see dvbt_oracle.h).
+ * Restates lib/viterbi_decoder_impl.cc:61-65,95-124,149-153,192-324 and the SSE2 kernels
+ * lib/d_viterbi.c:261-285 (init), :461-576 (butterfly2), :680-735 (get_output),
+ * parity table lib/d_tab.c:24-57.  The 16-byte SSE2 lanes are written as plain 64-entry
+ * uint8 arrays in the same state order (state s = byte s), so gcc -O3 -msse2 vectorises it.
+ * Pinned bit-for-bit against oracle/_ref (the reference's own d_viterbi.c) by
+ * tests/test_oracle_ref_viterbi.py. */
+#include "dvbt_oracle.h"
+#include <string.h>
+#include <stdlib.h>
+
+static unsigned char branchtab[2][32];
+static int branch_ready = 0;
+
+static int parity8(int x) { x ^= x >> 4; x ^= x >> 2; x ^= x >> 1; return x & 1; }
+
+static void branch_init(void)
+{ /* d_viterbi.c:272-277: POLYA=0x4f, POLYB=0x6d */
+  if (branch_ready) return;
+  for (int i = 0; i < 32; i++) {
+    branchtab[0][i] = (unsigned char)parity8((2 * i) & 0x4f);
+    branchtab[1][i] = (unsigned char)parity8((2 * i) & 0x6d);
+  }
+  branch_ready = 1;
+}
+
+void o_vit_core_init(o_vit_core *v, int ntraceback)
+{
+  branch_init();
+  int sp = v->store_pos;           /* store_pos is NOT reset by the reference (B-2) */
+  memset(v, 0, sizeof *v);
+  v->store_pos = sp;
+  v->ntraceback = ntraceback;
+}
+
+/* one trellis step; d_viterbi.c:483-524 (and its copy :533-575) */
+static void step(const unsigned char *metric0, const unsigned char *path0,
+                 unsigned char *metric1, unsigned char *path1,
+                 unsigned char s0, unsigned char s1)
+{
+  for (int b = 0; b < 32; b++) {
+    unsigned char metsvm, metsv;
+    if (s0 == 2)      { metsvm = branchtab[1][b] ^ s1; metsv = (unsigned char)(1 - metsvm); }
+    else if (s1 == 2) { metsvm = branchtab[0][b] ^ s0; metsv = (unsigned char)(1 - metsvm); }
+    else { metsvm = (unsigned char)((branchtab[0][b] ^ s0) + (branchtab[1][b] ^ s1));
+           metsv = (unsigned char)(2 - metsvm); }
+    unsigned char m0 = (unsigned char)(metric0[b] + metsv);
+    unsigned char m1 = (unsigned char)(metric0[b + 32] + metsvm);
+    unsigned char m2 = (unsigned char)(metric0[b] + metsvm);
+    unsigned char m3 = (unsigned char)(metric0[b + 32] + metsv);
+    int d0 = (signed char)(unsigned char)(m0 - m1) > 0;
+    int d1 = (signed char)(unsigned char)(m2 - m3) > 0;
+    unsigned char sh0 = (unsigned char)(path0[b] << 1);
+    unsigned char sh1 = (unsigned char)((path0[b + 32] << 1) + 1);
+    metric1[2 * b]     = d0 ? m0 : m1;
+    metric1[2 * b + 1] = d1 ? m2 : m3;
+    path1[2 * b]       = d0 ? sh0 : sh1;
+    path1[2 * b + 1]   = d1 ? sh0 : sh1;
+  }
+}
+
+/* d_viterbi_butterfly2_sse2: two trellis steps on 4 depunctured symbols */
+void o_vit_butterfly2(o_vit_core *v, const unsigned char *sym)
+{
+  unsigned char m1[64], p1[64];
+  step(v->metric, v->path, m1, p1, sym[0], sym[1]);
+  step(m1, p1, v->metric, v->path, sym[2], sym[3]);
+}
+
+/* d_viterbi_get_output_sse2 :680-735 */
+unsigned char o_vit_get_output(o_vit_core *v)
+{
+  int nt = v->ntraceback;
+  v->store_pos = (v->store_pos + 1) % nt;
+  memcpy(v->pp[v->store_pos], v->path, 64);
+  int best = 0, bestm = v->metric[0], minm = v->metric[0];
+  for (int i = 1; i < 64; i++) {
+    if (v->metric[i] > bestm) { bestm = v->metric[i]; best = i; }
+    if (v->metric[i] < minm) minm = v->metric[i];
+  }
+  int pos = v->store_pos;
+  for (int i = 0; i < nt - 1; i++) {
+    best = v->pp[pos][best] >> 2;
+    pos = (pos - 1 + nt) % nt;
+  }
+  unsigned char out = v->pp[pos][best];
+  for (int i = 0; i < 64; i++) { v->path[i] = 0; v->metric[i] = (unsigned char)(v->metric[i] - minm); }
+  return out;
+}
+
+/* viterbi_decoder_impl.cc:61-65 */
+static const unsigned char P12[2]  = { 1, 1 };
+static const unsigned char P23[4]  = { 1, 1, 0, 1 };
+static const unsigned char P34[6]  = { 1, 1, 0, 1, 1, 0 };
+static const unsigned char P56[10] = { 1, 1, 0, 1, 1, 0, 0, 1, 1, 0 };
+static const unsigned char P78[14] = { 1, 1, 0, 1, 0, 1, 0, 1, 1, 0, 0, 1, 1, 0 };
+
+const unsigned char *o_vit_puncture(int cr, int *len)
+{
+  switch (cr) {
+    case O_C2_3: *len = 4;  return P23;
+    case O_C3_4: *len = 6;  return P34;
+    case O_C5_6: *len = 10; return P56;
+    case O_C7_8: *len = 14; return P78;
+    default:     *len = 2;  return P12;
+  }
+}
+
+int o_vit_ntraceback(int cr)
+{ /* viterbi_decoder_impl.cc:95-124 */
+  switch (cr) { case O_C2_3: return 9; case O_C3_4: return 10; case O_C5_6: return 15;
+                case O_C7_8: return 24; default: return 5; }
+}
+
+/* viterbi_decoder_impl.cc:192-324 for a stream that starts with a reset (d_init = 0) */
+size_t o_viterbi_decode(const o_cfg *c, int bsize, const unsigned char *in, size_t nsym,
+                        unsigned char *out)
+{
+  int plen; const unsigned char *punct = o_vit_puncture(c->code_rate, &plen);
+  int nt = o_vit_ntraceback(c->code_rate);
+  int d_nsymbols = bsize * c->n / c->m;          /* :149 */
+  int d_nbits = 2 * c->k * bsize;                /* :151 */
+  size_t nblocks = nsym / (size_t)d_nsymbols;
+  unsigned char *bits = malloc((size_t)d_nbits + 32);
+  o_vit_core v; v.store_pos = 0;
+  o_vit_core_init(&v, nt);
+  size_t out_count = 0;
+  for (size_t nb = 0; nb < nblocks; nb++) {
+    /* depuncture :241-256 */
+    int count = 0;
+    for (int i = 0; i < d_nsymbols; i++)
+      for (int j = c->m - 1; j >= 0; j--) {
+        while (punct[count % (2 * c->k)] == 0) bits[count++] = 2;
+        bits[count++] = (in[nb * d_nsymbols + i] >> j) & 1;
+        while (punct[count % (2 * c->k)] == 0) bits[count++] = 2;
+      }
+    /* decode :261-292 */
+    for (int ic = 0; ic < d_nbits; ic++) {
+      if ((ic % 4) == 0) {
+        o_vit_butterfly2(&v, &bits[ic & ~3]);
+        if (ic > 0 && (ic % 16) == 8) {
+          unsigned char ch = o_vit_get_output(&v);
+          if (out_count >= (size_t)nt) out[out_count - nt] = ch;   /* d_init==0 for the whole first call */
+          out_count++;
+        }
+      }
+    }
+  }
+  free(bits);
+  return out_count >= (size_t)nt ? out_count - nt : 0;
+}

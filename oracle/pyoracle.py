@@ -1,0 +1,192 @@
+"""ctypes binding of oracle/liboracle.so (the CPU restatement of the reference RX path).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py; never from the product package (dvbt_amd/).
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+_REF = os.path.join(_HERE, "_ref", "libdviterbi_ref.so")
+
+QPSK, QAM16, QAM64 = 0, 1, 2
+NH = 0
+C1_2, C2_3, C3_4, C5_6, C7_8 = 0, 1, 2, 3, 4
+T2k, T8k = 0, 1
+G1_32, G1_16, G1_8, G1_4 = 0, 1, 2, 3
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB) or any(
+            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB)
+            for f in os.listdir(_HERE) if f.endswith((".c", ".h"))):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference/lib") and (force or not os.path.exists(_REF)):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+class Cfg(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "constellation", "hierarchy", "code_rate", "guard", "mode", "include_cell_id", "cell_id",
+        "N", "cp", "Kmin", "Kmax", "payload", "zeros_left", "zeros_right",
+        "csize", "step", "m", "alpha", "k", "n")] + [
+        ("norm", C.c_float), ("n_cpilot", C.c_int), ("n_tps", C.c_int), ("n_spilot", C.c_int),
+        ("cpilot", C.POINTER(C.c_int)), ("tps", C.POINTER(C.c_int))]
+
+
+class RS(C.Structure):
+    _fields_ = [("exp", C.c_ubyte * 256), ("log", C.c_ubyte * 256), ("l", C.c_ubyte * 256),
+                ("g", C.c_ubyte * 17)]
+
+
+class VitCore(C.Structure):
+    _fields_ = [("metric", C.c_ubyte * 64), ("path", C.c_ubyte * 64), ("pp", (C.c_ubyte * 64) * 24),
+                ("store_pos", C.c_int), ("ntraceback", C.c_int)]
+
+
+class Taps(C.Structure):
+    _fields_ = [
+        ("acq_out", C.c_void_p), ("acq_cap", C.c_size_t), ("acq_n", C.c_size_t),
+        ("fft_out", C.c_void_p), ("fft_cap", C.c_size_t), ("fft_n", C.c_size_t),
+        ("eq_out", C.c_void_p), ("eq_cap", C.c_size_t), ("eq_n", C.c_size_t),
+        ("demap_out", C.c_void_p), ("symdeint_out", C.c_void_p), ("bitdeint_out", C.c_void_p),
+        ("sym_cap", C.c_size_t), ("sym_n", C.c_size_t),
+        ("vit_out", C.c_void_p), ("vit_cap", C.c_size_t), ("vit_n", C.c_size_t),
+        ("deint_out", C.c_void_p), ("deint_cap", C.c_size_t), ("deint_n", C.c_size_t),
+        ("rs_out", C.c_void_p), ("rs_cap", C.c_size_t), ("rs_n", C.c_size_t),
+        ("ts_out", C.c_void_p), ("ts_cap", C.c_size_t), ("ts_n", C.c_size_t),
+        ("cp_start", C.c_void_p), ("epsilon", C.c_void_p), ("sym_index", C.c_void_p),
+        ("meta_cap", C.c_size_t),
+        ("first_out_symbol", C.c_int), ("n_acquired", C.c_int),
+        ("rs_fail", C.c_int), ("rs_corr", C.c_int),
+        ("t_stage", C.c_double * 10)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB)
+        L = _lib
+        L.o_tx_symbols_for_packets.restype = C.c_size_t
+        L.o_tx_symbols_for_packets.argtypes = [C.POINTER(Cfg), C.c_size_t]
+        L.o_tx_generate.restype = C.c_size_t
+        L.o_tx_generate.argtypes = [C.POINTER(Cfg), C.c_void_p, C.c_size_t, C.c_float, C.c_void_p,
+                                    C.c_size_t, C.c_void_p]
+        L.o_viterbi_decode.restype = C.c_size_t
+        L.o_viterbi_decode.argtypes = [C.POINTER(Cfg), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.o_energy_descramble.restype = C.c_size_t
+        L.o_energy_descramble.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.o_rx_run.restype = C.c_int
+        L.o_rx_run.argtypes = [C.POINTER(Cfg), C.c_void_p, C.c_size_t, C.c_float, C.c_int, C.c_int,
+                               C.POINTER(Taps)]
+        L.o_rs_decode.restype = C.c_int
+        L.o_vit_get_output.restype = C.c_ubyte
+        L.o_acq_new.restype = C.c_void_p
+        L.o_demod_new.restype = C.c_void_p
+    return _lib
+
+
+def ref_lib():
+    """The reference's own d_viterbi.c/d_tab.c compiled unmodified (oracle/_ref)."""
+    build()
+    if not os.path.exists(_REF):
+        return None
+    return C.CDLL(_REF)
+
+
+def cfg(constellation, code_rate, mode, guard=G1_32, hierarchy=NH, include_cell_id=0, cell_id=0):
+    c = Cfg()
+    lib().o_cfg_init(C.byref(c), constellation, hierarchy, code_rate, guard, mode, include_cell_id, cell_id)
+    return c
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def make_ts(npackets, seed):
+    """188-byte packets, byte0 = 0x47, payload uniform from a seeded generator."""
+    rng = np.random.RandomState(seed)
+    ts = rng.randint(0, 256, size=(npackets, 188)).astype(np.uint8)
+    ts[:, 0] = 0x47
+    return ts.reshape(-1)
+
+
+def tx_scale(c):
+    """TX multiply_const * RX multiply_const of the demo flowgraphs (apps/dvbt_{tx,rx}_demo*.grc)."""
+    return float(np.float32(0.0022097087) * np.float32(0.0022097087 if c.mode == T2k else 0.00055242272))
+
+
+def tx(c, ts, scale=None, lead_in=0, tail=0, want_freq=False):
+    """TS bytes -> complex64 baseband at the 64/7 Msps tap. lead_in/tail: zero samples added."""
+    L = lib()
+    npk = len(ts) // 188
+    nsym = L.o_tx_symbols_for_packets(C.byref(c), npk)
+    n = nsym * (c.N + c.cp)
+    iq = np.zeros(lead_in + n + tail, dtype=np.complex64)
+    freq = np.zeros((nsym, c.N), dtype=np.complex64) if want_freq else None
+    if scale is None:
+        scale = tx_scale(c)
+    body = iq[lead_in:lead_in + n]
+    w = L.o_tx_generate(C.byref(c), _p(ts), npk, C.c_float(scale), _p(body), n,
+                        _p(freq) if want_freq else None)
+    assert w == n
+    return (iq, freq) if want_freq else iq
+
+
+def rx(c, iq, snr_db=30.0, bsize=768, rs_compat=0, want=("rs",), max_sym_taps=None):
+    """Run the whole oracle chain; returns dict of requested taps + metadata."""
+    L = lib()
+    iq = np.ascontiguousarray(iq, dtype=np.complex64)
+    nsym = len(iq) // (c.N + c.cp) + 2
+    ns = nsym if max_sym_taps is None else min(nsym, max_sym_taps)
+    t = Taps()
+    bufs = {}
+
+    def alloc(name, shape, dtype):
+        bufs[name] = np.zeros(shape, dtype=dtype)
+        return _p(bufs[name])
+    if "acq" in want:
+        t.acq_out = alloc("acq", (ns, c.N), np.complex64); t.acq_cap = ns
+    if "fft" in want:
+        t.fft_out = alloc("fft", (ns, c.N), np.complex64); t.fft_cap = ns
+    if "eq" in want:
+        t.eq_out = alloc("eq", (ns, c.payload), np.complex64); t.eq_cap = ns
+    if "demap" in want:
+        t.demap_out = alloc("demap", (ns, c.payload), np.uint8)
+    if "symdeint" in want:
+        t.symdeint_out = alloc("symdeint", (ns, c.payload), np.uint8)
+    if "bitdeint" in want:
+        t.bitdeint_out = alloc("bitdeint", (ns, c.payload), np.uint8)
+    t.sym_cap = ns
+    vitcap = nsym * c.payload * c.m * c.k // (8 * c.n) + 64
+    if "vit" in want:
+        t.vit_out = alloc("vit", (vitcap,), np.uint8); t.vit_cap = vitcap
+    if "deint" in want:
+        t.deint_out = alloc("deint", (vitcap,), np.uint8); t.deint_cap = vitcap
+    if "rs" in want:
+        t.rs_out = alloc("rs", (vitcap,), np.uint8); t.rs_cap = vitcap
+    if "ts" in want:
+        t.ts_out = alloc("ts", (vitcap,), np.uint8); t.ts_cap = vitcap
+    t.cp_start = alloc("cp_start", (nsym,), np.int32)
+    t.epsilon = alloc("epsilon", (nsym,), np.float32)
+    t.sym_index = alloc("sym_index", (nsym,), np.int32)
+    t.meta_cap = nsym
+    trunc = L.o_rx_run(C.byref(c), _p(iq), len(iq), C.c_float(snr_db), bsize, rs_compat, C.byref(t))
+    out = {"truncated": trunc, "n_acquired": t.n_acquired, "first_out_symbol": t.first_out_symbol,
+           "rs_fail": t.rs_fail, "rs_corr": t.rs_corr, "t_stage": list(t.t_stage)}
+    for k, n in (("acq", t.acq_n), ("fft", t.fft_n), ("eq", t.eq_n), ("demap", t.sym_n),
+                 ("symdeint", t.sym_n), ("bitdeint", t.sym_n), ("vit", t.vit_n), ("deint", t.deint_n),
+                 ("rs", t.rs_n), ("ts", t.ts_n)):
+        if k in bufs:
+            out[k] = bufs[k][:n]
+    for k in ("cp_start", "epsilon", "sym_index"):
+        out[k] = bufs[k][:t.n_acquired]
+    return out

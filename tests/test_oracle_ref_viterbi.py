@@ -1,0 +1,108 @@
+"""Pin the oracle's Viterbi restatement bit-for-bit against the REFERENCE's own kernels.
+
+oracle/_ref/libdviterbi_ref.so is lib/d_viterbi.c + lib/d_tab.c + lib/d_metrics.c compiled
+unmodified (oracle/Makefile target `ref`).  Both are driven in the calling pattern of
+viterbi_decoder_impl::general_work (lib/viterbi_decoder_impl.cc:261-292): butterfly2 every 4
+depunctured symbols, get_output when in_count % 16 == 8.
+"""
+import ctypes as C
+import numpy as np
+import pytest
+
+
+def _aligned(n):
+    raw = np.zeros(n + 64, np.uint8)
+    off = (-raw.ctypes.data) % 16
+    return raw[off:off + n]
+
+
+def _run_ref(ref, syms, ntb):
+    m0, m1, p0, p1 = (_aligned(64) for _ in range(4))
+    ref.d_viterbi_chunks_init_sse2(m0.ctypes.data_as(C.c_void_p), p0.ctypes.data_as(C.c_void_p))
+    out = []
+    ch = C.c_ubyte()
+    ref.d_viterbi_get_output_sse2.restype = C.c_ubyte
+    for ic in range(0, len(syms), 4):
+        s = syms[ic:ic + 4]
+        ref.d_viterbi_butterfly2_sse2(s.ctypes.data_as(C.c_void_p), m0.ctypes.data_as(C.c_void_p),
+                                      m1.ctypes.data_as(C.c_void_p), p0.ctypes.data_as(C.c_void_p),
+                                      p1.ctypes.data_as(C.c_void_p))
+        if ic > 0 and ic % 16 == 8:
+            ref.d_viterbi_get_output_sse2(m0.ctypes.data_as(C.c_void_p), p0.ctypes.data_as(C.c_void_p),
+                                          ntb, C.byref(ch))
+            out.append((ch.value, bytes(m0)))
+    return out
+
+
+def _run_oracle(po, syms, ntb):
+    L = po.lib()
+    v = po.VitCore()
+    L.o_vit_core_init(C.byref(v), ntb)
+    out = []
+    for ic in range(0, len(syms), 4):
+        s = syms[ic:ic + 4]
+        L.o_vit_butterfly2(C.byref(v), s.ctypes.data_as(C.c_void_p))
+        if ic > 0 and ic % 16 == 8:
+            ch = L.o_vit_get_output(C.byref(v))
+            out.append((ch, bytes(v.metric)))
+    return out
+
+
+def _encode(ref, data):
+    sym = np.zeros(len(data) * 16, np.uint8)
+    ref.d_encode(sym.ctypes.data_as(C.c_void_p), data.ctypes.data_as(C.c_void_p), len(data), 0)
+    return sym
+
+
+PUNCT = {5: [1, 1], 9: [1, 1, 0, 1], 10: [1, 1, 0, 1, 1, 0], 15: [1, 1, 0, 1, 1, 0, 0, 1, 1, 0],
+         24: [1, 1, 0, 1, 0, 1, 0, 1, 1, 0, 0, 1, 1, 0]}
+
+
+@pytest.mark.parametrize("ntb", [5, 9, 10, 15, 24])
+@pytest.mark.parametrize("ber", [0.0, 0.02, 0.08])
+def test_oracle_viterbi_equals_reference_kernels(po, ntb, ber):
+    ref = po.ref_lib()
+    if ref is None:
+        pytest.skip("oracle/_ref not built (reference tree absent and no prebuilt .so)")
+    rng = np.random.RandomState(100 + ntb)
+    nbytes = 1400
+    data = rng.randint(0, 256, nbytes).astype(np.uint8)
+    sym = _encode(ref, data)
+    flips = rng.rand(len(sym)) < ber
+    sym = (sym ^ flips).astype(np.uint8)
+    p = np.array(PUNCT[ntb], np.uint8)
+    mask = np.tile(p, len(sym) // len(p) + 1)[:len(sym)]
+    sym[mask == 0] = 2                      # erasures exactly as the block's depuncturer inserts them
+    n = (len(sym) // 16) * 16
+    a = _run_ref(ref, sym[:n], ntb)
+    b = _run_oracle(po, sym[:n], ntb)
+    assert len(a) == len(b) == n // 16
+    assert [x[0] for x in a] == [x[0] for x in b]       # decoded bytes
+    assert [x[1] for x in a] == [x[1] for x in b]       # renormalised metrics after every output
+    dec = np.array([x[0] for x in a], np.uint8)
+    if ber == 0.0:
+        # SURVEY App. F "Viterbi delay": out[i+T] == data[i]
+        assert (dec[ntb:] == data[:len(dec) - ntb]).all()
+
+
+def test_block_decode_matches_stream(po):
+    """o_viterbi_decode (block restatement incl. depuncture) == kernels driven by hand."""
+    ref = po.ref_lib()
+    if ref is None:
+        pytest.skip("oracle/_ref not built")
+    c = po.cfg(po.QAM64, po.C7_8, po.T8k)
+    rng = np.random.RandomState(5)
+    data = rng.randint(0, 256, 672 * 3).astype(np.uint8)
+    sym = _encode(ref, data)
+    p = np.array(PUNCT[24], np.uint8)
+    mask = np.tile(p, len(sym) // 14 + 1)[:len(sym)]
+    kept = sym[mask == 1]
+    nb = len(kept) // 6
+    packed = np.zeros(nb, np.uint8)
+    for j in range(6):
+        packed |= (kept[j:nb * 6:6] << (5 - j)).astype(np.uint8)
+    out = np.zeros(len(data) + 64, np.uint8)
+    n = po.lib().o_viterbi_decode(C.byref(c), 768, packed.ctypes.data_as(C.c_void_p), len(packed),
+                                  out.ctypes.data_as(C.c_void_p))
+    assert n == 672 * 3 - 24
+    assert (out[:n] == data[:n]).all()
