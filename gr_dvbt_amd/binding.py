@@ -1,0 +1,185 @@
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+_SO = os.path.join(_HERE, "lib", "libdvbt_hip.so")
+_SRC = os.path.join(_HERE, "csrc", "dvbt_hip.hip")
+
+QPSK, QAM16, QAM64 = 0, 1, 2
+NH = 0
+C1_2, C2_3, C3_4, C5_6, C7_8 = 0, 1, 2, 3, 4
+T2k, T8k = 0, 1
+G1_32, G1_16, G1_8, G1_4 = 0, 1, 2, 3
+(TAP_ACQ, TAP_FFT, TAP_EQ, TAP_DEMAP, TAP_SYMDEINT, TAP_BITDEINT, TAP_VITERBI, TAP_DEINT, TAP_RS,
+ TAP_TS, TAP_CP_START, TAP_SYMBOL_INDEX) = range(12)
+
+
+class DvbtError(RuntimeError):
+    pass
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def build(force=False):
+    """Compile the HIP extension for gfx950 in-tree (cross-compiles without a GPU)."""
+    srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))]
+    srcs.append(os.path.join(_ROOT, "include", "dvbt_hip.h"))
+    if not force and os.path.exists(_SO) and all(os.path.getmtime(s) <= os.path.getmtime(_SO) for s in srcs):
+        return _SO
+    os.makedirs(os.path.dirname(_SO), exist_ok=True)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+           "-o", _SO, _SRC]
+    subprocess.check_call(cmd)
+    return _SO
+
+
+class RxParams(C.Structure):
+    _fields_ = [("constellation", C.c_int), ("hierarchy", C.c_int), ("code_rate", C.c_int),
+                ("guard_interval", C.c_int), ("transmission_mode", C.c_int), ("include_cell_id", C.c_int),
+                ("cell_id", C.c_int), ("snr_db", C.c_float), ("viterbi_bsize", C.c_int),
+                ("rs_oracle_compat", C.c_int), ("descramble", C.c_int), ("max_samples", C.c_size_t),
+                ("device", C.c_int), ("viterbi_chunk_bytes", C.c_int)]
+
+
+class RxReport(C.Structure):
+    _fields_ = [("status", C.c_int32), ("n_symbols", C.c_int32), ("first_out_symbol", C.c_int32),
+                ("n_out_symbols", C.c_int32), ("cp_start0", C.c_int32), ("reserved0", C.c_int32),
+                ("n_viterbi_bytes", C.c_int64), ("n_rs_items", C.c_int64), ("n_rs_bytes", C.c_int64),
+                ("n_ts_bytes", C.c_int64), ("rs_fail_words", C.c_int32), ("rs_corrected_symbols", C.c_int32)]
+
+
+class Dims(C.Structure):
+    _fields_ = [("fft_length", C.c_int), ("cp_length", C.c_int), ("Kmax", C.c_int), ("payload_length", C.c_int),
+                ("zeros_on_left", C.c_int), ("m", C.c_int), ("cr_k", C.c_int), ("cr_n", C.c_int),
+                ("norm", C.c_float), ("ntraceback", C.c_int), ("info_bits_per_symbol", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libdvbt_hip.so. Fails loudly when the extension is missing: there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise DvbtError(f"{_SO} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(the product path has no CPU fallback)")
+        L = C.CDLL(_SO)
+        L.dvbt_last_error.restype = C.c_char_p
+        L.dvbt_version.restype = C.c_char_p
+        L.dvbt_rx_create.argtypes = [C.POINTER(RxParams), C.POINTER(C.c_void_p)]
+        L.dvbt_rx_segment_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(RxReport)]
+        L.dvbt_rx_segment_enqueue_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.dvbt_rx_segment_finish.argtypes = [C.c_void_p, C.POINTER(RxReport)]
+        L.dvbt_rx_read_tap.restype = C.c_int64
+        L.dvbt_rx_read_tap.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        L.dvbt_rx_tap_device_ptr.restype = C.c_void_p
+        L.dvbt_rx_tap_device_ptr.argtypes = [C.c_void_p, C.c_int]
+        L.dvbt_rx_stage_ms.restype = C.c_double
+        L.dvbt_rx_stage_ms.argtypes = [C.c_void_p, C.c_char_p]
+        L.dvbt_rx_enable_timing.argtypes = [C.c_void_p, C.c_int]
+        L.dvbt_rx_enable_taps.argtypes = [C.c_void_p, C.c_int]
+        L.dvbt_rx_destroy.argtypes = [C.c_void_p]
+        L.dvbt_get_dims.argtypes = [C.c_int] * 5 + [C.POINTER(Dims)]
+        _lib = L
+    return _lib
+
+
+def _chk(r):
+    if r < 0:
+        raise DvbtError(f"libdvbt_hip error {r}: {lib().dvbt_last_error().decode()}")
+    return r
+
+
+def device_count():
+    return lib().dvbt_device_count()
+
+
+def get_dims(constellation, code_rate, mode, guard=G1_32, hierarchy=NH):
+    d = Dims()
+    _chk(lib().dvbt_get_dims(constellation, hierarchy, code_rate, guard, mode, C.byref(d)))
+    return d
+
+
+class Rx:
+    """Device-resident DVB-T receive chain (segment API of include/dvbt_hip.h)."""
+
+    _TAP_DTYPE = {TAP_ACQ: np.complex64, TAP_FFT: np.complex64, TAP_EQ: np.complex64, TAP_CP_START: np.int32,
+                  TAP_SYMBOL_INDEX: np.int32}
+
+    def __init__(self, constellation, code_rate, mode, max_samples, guard=G1_32, hierarchy=NH, snr_db=30.0,
+                 viterbi_bsize=768, rs_oracle_compat=0, descramble=1, device=0, viterbi_chunk_bytes=0, taps=False):
+        self.L = lib()
+        self.p = RxParams(constellation, hierarchy, code_rate, guard, mode, 0, 0, snr_db, viterbi_bsize,
+                          rs_oracle_compat, descramble, max_samples, device, viterbi_chunk_bytes)
+        self.h = C.c_void_p()
+        _chk(self.L.dvbt_rx_create(C.byref(self.p), C.byref(self.h)))
+        self.dims = get_dims(constellation, code_rate, mode, guard, hierarchy)
+        if taps:
+            _chk(self.L.dvbt_rx_enable_taps(self.h, 1))
+        self.report = None
+
+    def run(self, iq):
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        rep = RxReport()
+        _chk(self.L.dvbt_rx_segment_run(self.h, iq.ctypes.data_as(C.c_void_p), len(iq), C.byref(rep)))
+        self.report = rep
+        return rep
+
+    def enqueue_device(self, dptr, nsamples, stream=None):
+        _chk(self.L.dvbt_rx_segment_enqueue_device(self.h, C.c_void_p(dptr), nsamples,
+                                                   C.c_void_p(stream) if stream else None))
+
+    def finish(self):
+        rep = RxReport()
+        _chk(self.L.dvbt_rx_segment_finish(self.h, C.byref(rep)))
+        self.report = rep
+        return rep
+
+    def tap(self, tap):
+        r = self.report
+        d = self.dims
+        sizes = {TAP_ACQ: r.n_symbols * d.fft_length * 8, TAP_FFT: r.n_symbols * d.fft_length * 8,
+                 TAP_EQ: r.n_out_symbols * d.payload_length * 8, TAP_DEMAP: r.n_out_symbols * d.payload_length,
+                 TAP_SYMDEINT: r.n_out_symbols * d.payload_length, TAP_BITDEINT: r.n_out_symbols * d.payload_length,
+                 TAP_VITERBI: r.n_viterbi_bytes, TAP_DEINT: r.n_rs_items * 1632, TAP_RS: r.n_rs_bytes,
+                 TAP_TS: r.n_ts_bytes, TAP_CP_START: r.n_symbols * 4, TAP_SYMBOL_INDEX: max(r.n_symbols - 1, 0) * 4}
+        nbytes = max(int(sizes[tap]), 0)
+        buf = np.zeros(nbytes, np.uint8)
+        if nbytes:
+            n = _chk(self.L.dvbt_rx_read_tap(self.h, tap, buf.ctypes.data_as(C.c_void_p), nbytes))
+            buf = buf[:n]
+        out = buf.view(self._TAP_DTYPE.get(tap, np.uint8))
+        if tap in (TAP_ACQ, TAP_FFT):
+            out = out.reshape(-1, d.fft_length)
+        elif tap in (TAP_EQ, TAP_DEMAP, TAP_SYMDEINT, TAP_BITDEINT):
+            out = out.reshape(-1, d.payload_length)
+        return out
+
+    def tap_device_ptr(self, tap):
+        return self.L.dvbt_rx_tap_device_ptr(self.h, tap)
+
+    def enable_timing(self, on=True):
+        _chk(self.L.dvbt_rx_enable_timing(self.h, 1 if on else 0))
+
+    def stage_ms(self, name):
+        return self.L.dvbt_rx_stage_ms(self.h, name.encode())
+
+    def close(self):
+        if self.h:
+            self.L.dvbt_rx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

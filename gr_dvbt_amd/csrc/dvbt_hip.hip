@@ -1,0 +1,400 @@
+// dvbt_hip.hip -- C ABI (include/dvbt_hip.h) over the gfx950 kernels.  There is no CPU path:
+// every entry point fails with DVBT_ERR_NO_DEVICE when no HIP device is usable.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <map>
+#include "../../include/dvbt_hip.h"
+#include "dvbt_tables.hpp"
+#include "k_frontend.hpp"
+#include "k_backend.hpp"
+
+using namespace dvbt;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(DVBT_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+#define HIPCHKV(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_err = std::string(#x) + ": " + hipGetErrorString(e_); } } while (0)
+
+extern "C" const char *dvbt_last_error(void) { return g_err.c_str(); }
+extern "C" const char *dvbt_version(void) { return "dvbt_hip 0.1 (gfx950)"; }
+extern "C" int dvbt_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+static int need_device()
+{
+  if (dvbt_device_count() <= 0) return fail(DVBT_ERR_NO_DEVICE, "no HIP device visible: libdvbt_hip has no CPU fallback");
+  return DVBT_OK;
+}
+
+extern "C" int dvbt_get_dims(int constellation, int hierarchy, int code_rate, int guard, int mode, dvbt_dims *o)
+{
+  Dims d = make_dims(constellation, hierarchy, code_rate, guard, mode);
+  if (!d.valid || !o) return fail(DVBT_ERR_INVALID, "bad DVB-T parameters");
+  o->fft_length = d.N; o->cp_length = d.cp; o->Kmax = d.Kmax; o->payload_length = d.payload; o->zeros_on_left = d.zl;
+  o->m = d.m; o->cr_k = d.k; o->cr_n = d.n; o->norm = d.norm; o->ntraceback = d.ntb; o->info_bits_per_symbol = d.info_bits_per_symbol;
+  return DVBT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ helpers
+template <class T> static int upload(const std::vector<T> &v, T **dptr)
+{
+  HIPCHK(hipMalloc((void **)dptr, v.size() * sizeof(T) + 16));
+  HIPCHK(hipMemcpy(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return DVBT_OK;
+}
+
+struct DevBuf {          // growable device scratch
+  void *p = nullptr; size_t cap = 0;
+  int reserve(size_t n) { if (n <= cap) return DVBT_OK; if (p) (void)hipFree(p); p = nullptr; cap = 0; HIPCHK(hipMalloc(&p, n + 64)); cap = n; return DVBT_OK; }
+  ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+struct Tables {          // device lookup tables for one configuration
+  Dims d;
+  float2 *tw = nullptr; uint16_t *perm = nullptr;
+  int16_t *cpilot = nullptr, *tps = nullptr; float *known = nullptr, *pref = nullptr;
+  uint16_t *pay_c = nullptr, *pay_L = nullptr, *pay_R = nullptr, *tps_L = nullptr, *tps_R = nullptr;
+  uint16_t *H = nullptr; float2 *points = nullptr;
+  uint8_t *mul_alpha = nullptr, *gexp = nullptr, *glog = nullptr, *prbs = nullptr;
+  bool front = false, inner = false, rs = false;
+
+  int build_fft(int N)
+  {
+    std::vector<float> tw_h = fft_twiddles(N);
+    std::vector<float2> t2(N);
+    for (int i = 0; i < N; i++) t2[i] = make_float2(tw_h[2 * i], tw_h[2 * i + 1]);
+    int r = upload(t2, &tw); if (r) return r;
+    return upload(fft_out_perm(N), &perm);
+  }
+  int build_front()
+  {
+    std::vector<int> c = cpilot_table(d), t = tps_table(d);
+    std::vector<int16_t> c16(c.begin(), c.end()), t16(t.begin(), t.end());
+    std::vector<float> pr = pilot_ref_table(d), kn(d.n_cp - 1);
+    for (int i = 0; i + 1 < d.n_cp; i++) { float df = pr[c[i + 1]] - pr[c[i]]; kn[i] = df * df; }
+    int r;
+    if ((r = upload(c16, &cpilot)) || (r = upload(t16, &tps)) || (r = upload(pr, &pref)) || (r = upload(kn, &known))) return r;
+    std::vector<uint16_t> pc, pl, prr, tl, trr;
+    for (int s = 0; s < 4; s++) {
+      PatternTables pt = pattern_tables(d, s);
+      if ((int)pt.pay_c.size() != d.payload) return fail(DVBT_ERR_INVALID, "payload carrier table size mismatch");
+      pc.insert(pc.end(), pt.pay_c.begin(), pt.pay_c.end()); pl.insert(pl.end(), pt.pay_L.begin(), pt.pay_L.end());
+      prr.insert(prr.end(), pt.pay_R.begin(), pt.pay_R.end()); tl.insert(tl.end(), pt.tps_L.begin(), pt.tps_L.end());
+      trr.insert(trr.end(), pt.tps_R.begin(), pt.tps_R.end());
+    }
+    if ((r = upload(pc, &pay_c)) || (r = upload(pl, &pay_L)) || (r = upload(prr, &pay_R)) || (r = upload(tl, &tps_L)) || (r = upload(trr, &tps_R))) return r;
+    front = true;
+    return DVBT_OK;
+  }
+  int build_inner(float gain)
+  {
+    int r;
+    if (!H && (r = upload(symbol_H(d), &H))) return r;
+    std::vector<float> p = constellation_points(d, gain);
+    std::vector<float2> p2(d.csize);
+    for (int i = 0; i < d.csize; i++) p2[i] = make_float2(p[2 * i], p[2 * i + 1]);
+    if (points) { (void)hipFree(points); points = nullptr; }
+    if ((r = upload(p2, &points))) return r;
+    inner = true;
+    return DVBT_OK;
+  }
+  int build_rs()
+  {
+    std::vector<uint8_t> ex(512), lg(256), mul(16 * 256);
+    gf_tables(ex.data(), lg.data());
+    for (int i = 0; i < 16; i++) for (int b = 0; b < 256; b++) mul[i * 256 + b] = b ? ex[lg[b] + i] : 0;
+    int r;
+    if ((r = upload(ex, &gexp)) || (r = upload(lg, &glog)) || (r = upload(mul, &mul_alpha)) || (r = upload(energy_prbs(), &prbs))) return r;
+    rs = true;
+    return DVBT_OK;
+  }
+  DemodTables demod_tables() const { DemodTables T; T.cpilot = cpilot; T.known_diff = known; T.tps = tps; T.pilot_ref = pref;
+    T.pay_c = pay_c; T.pay_L = pay_L; T.pay_R = pay_R; T.tps_L = tps_L; T.tps_R = tps_R; return T; }
+  RsTables rs_tables() const { RsTables T; T.mul_alpha = mul_alpha; T.gexp = gexp; T.glog = glog; return T; }
+  ~Tables()
+  {
+    void *all[] = {tw, perm, cpilot, tps, known, pref, pay_c, pay_L, pay_R, tps_L, tps_R, H, points, mul_alpha, gexp, glog, prbs};
+    for (void *q : all) if (q) (void)hipFree(q);
+  }
+};
+
+static VitParams make_vit_params(const Dims &d, int bsize, int chunk_bytes)
+{
+  VitParams v; memset(&v, 0, sizeof v);
+  v.m = d.m; v.k = d.k; v.n = d.n; v.plen = d.plen; v.ntb = d.ntb; v.bsize = bsize;
+  v.d_nsymbols = bsize * d.n / d.m; v.d_nbits = 2 * d.k * bsize;
+  v.chunk_bytes = chunk_bytes > 0 ? chunk_bytes : 1024; v.payload = d.payload;
+  memcpy(v.punct, d.punct, 16); memcpy(v.prefix, d.prefix, 16);
+  return v;
+}
+static FrontParams make_front_params(const Dims &d, float snr_db)
+{
+  FrontParams p; memset(&p, 0, sizeof p);
+  p.N = d.N; p.cp = d.cp; p.K = d.K; p.zl = d.zl; p.payload = d.payload; p.n_cp = d.n_cp; p.n_tps = d.n_tps; p.fi_start = d.fi_start;
+  p.R = ACQ_R;
+  float snr = (float)pow(10, snr_db / 10.0);               // ofdm_sym_acquisition_impl.cc:390-391
+  float rho = (float)(snr / (snr + 1.0));
+  p.half_rho = (float)(rho / 2.0);
+  return p;
+}
+static int set_lds(const void *fn, size_t bytes)
+{
+  if (bytes > 48 * 1024) HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return DVBT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ segment API
+enum { ST_ACQ = 0, ST_FFT, ST_DEMOD, ST_INNER, ST_VIT, ST_RS, ST_END, ST_COUNT };
+static const char *kStageNames[] = {"acq", "fft", "demod", "inner", "viterbi", "rs"};
+
+struct dvbt_rx {
+  dvbt_rx_params prm; Dims d; Tables T; FrontParams fp; VitParams vp;
+  hipStream_t own_stream = nullptr, cur_stream = nullptr;
+  size_t max_samples = 0; int max_calls = 0;
+  float2 *d_iq = nullptr;              // only when input comes from the host
+  float2 *g_init = nullptr; float *l_init = nullptr; float2 *g_trk = nullptr; float *l_trk = nullptr;
+  SymMeta *meta = nullptr; RxState *st = nullptr, *st_host = nullptr; TpsState *tps_state = nullptr;
+  float2 *acq_tap = nullptr, *fft_out = nullptr, *eq = nullptr, *tpsval = nullptr; SymInfo *info = nullptr; int *maj = nullptr, *sym_index = nullptr;
+  uint8_t *demap_tap = nullptr, *symdeint_tap = nullptr, *bitdeint = nullptr, *vit = nullptr, *deint_tap = nullptr, *rs_out = nullptr, *ts_out = nullptr;
+  size_t vit_cap = 0;
+  bool timing = false, pending = false;
+  hipEvent_t ev[ST_COUNT]; double acc_ms[ST_COUNT] = {0}; long n_timed = 0; bool ev_ready = false, ev_recorded = false;
+  dvbt_rx_report last; bool have_last = false;
+};
+
+static void rx_free(dvbt_rx *h)
+{
+  void *all[] = {h->d_iq, h->g_init, h->l_init, h->g_trk, h->l_trk, h->meta, h->st, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
+                 h->info, h->maj, h->sym_index, h->demap_tap, h->symdeint_tap, h->bitdeint, h->vit, h->deint_tap, h->rs_out, h->ts_out};
+  for (void *q : all) if (q) (void)hipFree(q);
+  if (h->st_host) (void)hipHostFree(h->st_host);
+  if (h->ev_ready) for (int i = 0; i < ST_COUNT; i++) (void)hipEventDestroy(h->ev[i]);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+}
+
+extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
+{
+  if (!p || !out) return fail(DVBT_ERR_INVALID, "null argument");
+  int r = need_device(); if (r) return r;
+  Dims d = make_dims(p->constellation, p->hierarchy, p->code_rate, p->guard_interval, p->transmission_mode);
+  if (!d.valid) return fail(DVBT_ERR_INVALID, "bad DVB-T parameters");
+  if (p->viterbi_bsize <= 0 || (2 * d.k * p->viterbi_bsize) % 16 != 0 || (p->viterbi_bsize * d.n) % d.m != 0)
+    return fail(DVBT_ERR_INVALID, "viterbi_bsize must make bsize*n/m integral and 2*k*bsize a multiple of 16");
+  if (p->max_samples < (size_t)(2 * d.N + d.cp + 16)) return fail(DVBT_ERR_INVALID, "max_samples smaller than one acquisition window");
+  HIPCHK(hipSetDevice(p->device));
+  dvbt_rx *h = new dvbt_rx();
+  h->prm = *p; h->d = d; h->T.d = d;
+  h->fp = make_front_params(d, p->snr_db);
+  int cb = p->viterbi_chunk_bytes > 0 ? p->viterbi_chunk_bytes : 1024;
+  h->vp = make_vit_params(d, p->viterbi_bsize, cb);
+  h->max_samples = p->max_samples;
+  h->max_calls = (int)((p->max_samples - (2 * d.N + d.cp + 16)) / (d.N + d.cp) + 1);
+#define RXCHK(x) do { int r_ = (x); if (r_) { rx_free(h); return r_; } } while (0)
+#define RXHIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_err = std::string(#x) + ": " + hipGetErrorString(e_); rx_free(h); return DVBT_ERR_HIP; } } while (0)
+  RXCHK(h->T.build_fft(d.N)); RXCHK(h->T.build_front()); RXCHK(h->T.build_inner(1.0f)); RXCHK(h->T.build_rs());
+  RXHIP(hipStreamCreate(&h->own_stream));
+  const size_t C = (size_t)h->max_calls, N = d.N, P = d.payload;
+  RXHIP(hipMalloc((void **)&h->g_init, sizeof(float2) * ACQ_INIT_TRIES * N)); RXHIP(hipMalloc((void **)&h->l_init, sizeof(float) * ACQ_INIT_TRIES * N));
+  RXHIP(hipMalloc((void **)&h->g_trk, sizeof(float2) * C * 2 * ACQ_R)); RXHIP(hipMalloc((void **)&h->l_trk, sizeof(float) * C * 2 * ACQ_R));
+  RXHIP(hipMalloc((void **)&h->meta, sizeof(SymMeta) * C)); RXHIP(hipMalloc((void **)&h->st, sizeof(RxState)));
+  RXHIP(hipHostMalloc((void **)&h->st_host, sizeof(RxState))); RXHIP(hipMalloc((void **)&h->tps_state, sizeof(TpsState)));
+  RXHIP(hipMalloc((void **)&h->fft_out, sizeof(float2) * C * N)); RXHIP(hipMalloc((void **)&h->eq, sizeof(float2) * C * P));
+  RXHIP(hipMalloc((void **)&h->tpsval, sizeof(float2) * C * d.n_tps)); RXHIP(hipMalloc((void **)&h->info, sizeof(SymInfo) * C));
+  RXHIP(hipMalloc((void **)&h->maj, sizeof(int) * C)); RXHIP(hipMalloc((void **)&h->sym_index, sizeof(int) * C));
+  RXHIP(hipMalloc((void **)&h->bitdeint, C * P + 64));
+  h->vit_cap = C * P * d.m * d.k / (8 * d.n) + 4096;
+  RXHIP(hipMalloc((void **)&h->vit, h->vit_cap)); RXHIP(hipMalloc((void **)&h->rs_out, h->vit_cap)); RXHIP(hipMalloc((void **)&h->ts_out, h->vit_cap));
+  RXHIP(hipMemset(h->st, 0, sizeof(RxState)));
+  for (int i = 0; i < ST_COUNT; i++) RXHIP(hipEventCreate(&h->ev[i]));
+  h->ev_ready = true;
+  RXCHK(set_lds((const void *)derot_fft_kernel, (size_t)N * 8));
+  RXCHK(set_lds((const void *)inner_kernel, ((P + 15) & ~(size_t)15) + d.csize * 8));
+  *out = h;
+  return DVBT_OK;
+}
+
+extern "C" int dvbt_rx_enable_timing(dvbt_rx *h, int enable) { if (!h) return DVBT_ERR_INVALID; h->timing = enable != 0; return DVBT_OK; }
+
+// debug taps that are not pipeline buffers are allocated on first request
+static int ensure_taps(dvbt_rx *h)
+{
+  const size_t C = (size_t)h->max_calls, N = h->d.N, P = h->d.payload;
+  if (!h->acq_tap) HIPCHK(hipMalloc((void **)&h->acq_tap, sizeof(float2) * C * N));
+  if (!h->demap_tap) HIPCHK(hipMalloc((void **)&h->demap_tap, C * P + 64));
+  if (!h->symdeint_tap) HIPCHK(hipMalloc((void **)&h->symdeint_tap, C * P + 64));
+  if (!h->deint_tap) HIPCHK(hipMalloc((void **)&h->deint_tap, h->vit_cap));
+  return DVBT_OK;
+}
+extern "C" int dvbt_rx_enable_taps(dvbt_rx *h, int enable)
+{
+  if (!h) return DVBT_ERR_INVALID;
+  if (enable) return ensure_taps(h);
+  void **all[] = {(void **)&h->acq_tap, (void **)&h->demap_tap, (void **)&h->symdeint_tap, (void **)&h->deint_tap};
+  for (void **q : all) if (*q) { (void)hipFree(*q); *q = nullptr; }
+  return DVBT_OK;
+}
+
+static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s)
+{
+  const Dims &d = h->d;
+  if (nsamples > h->max_samples) return fail(DVBT_ERR_CAPACITY, "segment longer than max_samples");
+  if (nsamples < (size_t)(2 * d.N + d.cp + 16)) return fail(DVBT_ERR_INVALID, "segment shorter than one acquisition window");
+  FrontParams fp = h->fp;
+  fp.ncalls = (int)((nsamples - (2 * d.N + d.cp + 16)) / (d.N + d.cp) + 1);
+  const int C = fp.ncalls, N = d.N;
+  h->cur_stream = s;
+  const bool tm = h->timing;
+  if (tm) HIPCHK(hipEventRecord(h->ev[ST_ACQ], s));
+  HIPCHK(hipMemsetAsync(h->tps_state, 0, sizeof(TpsState), s));
+  int tries = C < ACQ_INIT_TRIES ? C : ACQ_INIT_TRIES;
+  hipLaunchKernelGGL(acq_metric_kernel, dim3((N + 255) / 256, tries), dim3(256), 0, s, iq, fp, (const RxState *)h->st, 0, h->g_init, h->l_init);
+  hipLaunchKernelGGL(acq_init_fsm_kernel, dim3(1), dim3(64), 0, s, fp, h->st, (const float2 *)h->g_init, (const float *)h->l_init);
+  hipLaunchKernelGGL(acq_metric_kernel, dim3((C * 2 * ACQ_R + 255) / 256), dim3(256), 0, s, iq, fp, (const RxState *)h->st, 1, h->g_trk, h->l_trk);
+  hipLaunchKernelGGL(acq_track_kernel, dim3(1), dim3(64), 0, s, fp, h->st, (const float2 *)h->g_trk, (const float *)h->l_trk, h->meta);
+  if (tm) HIPCHK(hipEventRecord(h->ev[ST_FFT], s));
+  hipLaunchKernelGGL(derot_fft_kernel, dim3(C), dim3(256), (size_t)N * 8, s, iq, fp, (const RxState *)h->st, (const SymMeta *)h->meta,
+                     (const float2 *)h->T.tw, (const uint16_t *)h->T.perm, h->acq_tap, h->fft_out);
+  if (tm) HIPCHK(hipEventRecord(h->ev[ST_DEMOD], s));
+  hipLaunchKernelGGL(demod_kernel, dim3(C), dim3(256), 0, s, (const float2 *)h->fft_out, fp, (const RxState *)h->st, 0, h->T.demod_tables(),
+                     h->eq, h->tpsval, h->info);
+  hipLaunchKernelGGL(tps_vote_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float2 *)h->tpsval, d.n_tps, (const RxState *)h->st, 0,
+                     (const float2 *)nullptr, h->maj);
+  hipLaunchKernelGGL(tps_fsm_kernel, dim3(1), dim3(64), 0, s, fp, h->st, 0, (const SymInfo *)h->info, (const int *)h->maj, h->tps_state,
+                     h->sym_index, (int *)nullptr);
+  hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(64), 0, s, h->st, h->vp, h->prm.descramble);
+  if (tm) HIPCHK(hipEventRecord(h->ev[ST_INNER], s));
+  InnerParams ip; ip.payload = d.payload; ip.m = d.m; ip.csize = d.csize;
+  hipLaunchKernelGGL(inner_kernel, dim3(C), dim3(256), ((d.payload + 15) & ~15) + d.csize * 8, s, (const float2 *)h->eq, (const uint8_t *)nullptr, ip,
+                     (const RxState *)h->st, 0, 7, (const int *)h->sym_index, (const float2 *)h->T.points, (const uint16_t *)h->T.H,
+                     h->demap_tap, h->symdeint_tap, h->bitdeint);
+  if (tm) HIPCHK(hipEventRecord(h->ev[ST_VIT], s));
+  long long max_vit = (long long)C * d.payload * d.m * d.k / (8 * d.n) + 1;
+  long long max_chunks = (max_vit + h->vp.chunk_bytes - 1) / h->vp.chunk_bytes;
+  hipLaunchKernelGGL(viterbi_kernel, dim3((unsigned)((max_chunks + 3) / 4)), dim3(256), 0, s, (const uint8_t *)h->bitdeint, h->vit,
+                     (const RxState *)h->st, 0ll, h->vp);
+  if (tm) HIPCHK(hipEventRecord(h->ev[ST_RS], s));
+  long long max_words = max_vit / 204 + 1;
+  hipLaunchKernelGGL(deint_rs_kernel, dim3((unsigned)((max_words + 63) / 64)), dim3(64), 0, s, (const uint8_t *)h->vit, h->deint_tap, h->rs_out,
+                     h->st, 0ll, 0, 0ll, h->T.rs_tables(), h->prm.rs_oracle_compat, &h->st->rs_fail, &h->st->rs_corr);
+  if (h->prm.descramble) {
+    hipLaunchKernelGGL(descramble_find_kernel, dim3(1), dim3(64), 0, s, (const uint8_t *)h->rs_out, h->st);
+    hipLaunchKernelGGL(descramble_apply_kernel, dim3(1024), dim3(256), 0, s, (const uint8_t *)h->rs_out, (const uint8_t *)h->T.prbs,
+                       (const RxState *)h->st, h->ts_out);
+  }
+  if (tm) { HIPCHK(hipEventRecord(h->ev[ST_END], s)); h->ev_recorded = true; }
+  HIPCHK(hipMemcpyAsync(h->st_host, h->st, sizeof(RxState), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipGetLastError());
+  h->pending = true;
+  return DVBT_OK;
+}
+
+extern "C" int dvbt_rx_segment_enqueue_device(dvbt_rx *h, const void *iq_device, size_t nsamples, void *stream)
+{
+  if (!h || !iq_device) return fail(DVBT_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(h->prm.device));
+  return enqueue(h, (const float2 *)iq_device, nsamples, stream ? (hipStream_t)stream : h->own_stream);
+}
+
+extern "C" int dvbt_rx_segment_finish(dvbt_rx *h, dvbt_rx_report *rep)
+{
+  if (!h) return fail(DVBT_ERR_INVALID, "null handle");
+  if (!h->pending) return fail(DVBT_ERR_STATE, "no segment enqueued");
+  HIPCHK(hipStreamSynchronize(h->cur_stream));
+  h->pending = false;
+  if (h->timing && h->ev_recorded) {
+    for (int i = 0; i < ST_END; i++) { float ms = 0; if (hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]) == hipSuccess) h->acc_ms[i] += ms; }
+    float ms = 0; if (hipEventElapsedTime(&ms, h->ev[0], h->ev[ST_END]) == hipSuccess) h->acc_ms[ST_END] += ms;
+    h->n_timed++; h->ev_recorded = false;
+  }
+  const RxState &s = *h->st_host;
+  dvbt_rx_report r; memset(&r, 0, sizeof r);
+  r.status = s.status; r.n_symbols = s.n_symbols; r.first_out_symbol = s.first_out; r.n_out_symbols = s.n_out_symbols;
+  r.cp_start0 = s.cp_start0; r.n_viterbi_bytes = s.n_vit_bytes; r.n_rs_items = s.n_rs_items; r.n_rs_bytes = s.n_rs_items * 1504;
+  r.n_ts_bytes = s.n_ts_bytes; r.rs_fail_words = s.rs_fail; r.rs_corrected_symbols = s.rs_corr;
+  h->last = r; h->have_last = true;
+  if (rep) *rep = r;
+  return DVBT_OK;
+}
+
+extern "C" int dvbt_rx_segment_run(dvbt_rx *h, const void *iq_host, size_t nsamples, dvbt_rx_report *rep)
+{
+  if (!h || !iq_host) return fail(DVBT_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(h->prm.device));
+  if (nsamples > h->max_samples) return fail(DVBT_ERR_CAPACITY, "segment longer than max_samples");
+  if (!h->d_iq) HIPCHK(hipMalloc((void **)&h->d_iq, sizeof(float2) * h->max_samples));
+  HIPCHK(hipMemcpyAsync(h->d_iq, iq_host, sizeof(float2) * nsamples, hipMemcpyHostToDevice, h->own_stream));
+  int r = enqueue(h, h->d_iq, nsamples, h->own_stream); if (r) return r;
+  return dvbt_rx_segment_finish(h, rep);
+}
+
+static int tap_info(dvbt_rx *h, int tap, void **ptr, size_t *bytes)
+{
+  if (!h->have_last) return fail(DVBT_ERR_STATE, "no finished segment");
+  const dvbt_rx_report &r = h->last; const Dims &d = h->d;
+  size_t ns = r.n_symbols > 0 ? (size_t)r.n_symbols : 0, no = r.n_out_symbols > 0 ? (size_t)r.n_out_symbols : 0;
+  size_t fo = r.first_out_symbol > 0 ? (size_t)r.first_out_symbol : 0;
+  switch (tap) {
+    case DVBT_TAP_ACQ: *ptr = h->acq_tap; *bytes = ns * d.N * 8; break;
+    case DVBT_TAP_FFT: *ptr = h->fft_out; *bytes = ns * d.N * 8; break;
+    case DVBT_TAP_EQ: *ptr = h->eq ? (void *)(h->eq + fo * d.payload) : nullptr; *bytes = no * d.payload * 8; break;
+    case DVBT_TAP_DEMAP: *ptr = h->demap_tap; *bytes = no * d.payload; break;
+    case DVBT_TAP_SYMDEINT: *ptr = h->symdeint_tap; *bytes = no * d.payload; break;
+    case DVBT_TAP_BITDEINT: *ptr = h->bitdeint; *bytes = no * d.payload; break;
+    case DVBT_TAP_VITERBI: *ptr = h->vit; *bytes = (size_t)r.n_viterbi_bytes; break;
+    case DVBT_TAP_DEINT: *ptr = h->deint_tap; *bytes = (size_t)r.n_rs_items * 1632; break;
+    case DVBT_TAP_RS: *ptr = h->rs_out; *bytes = (size_t)r.n_rs_bytes; break;
+    case DVBT_TAP_TS: *ptr = h->ts_out; *bytes = (size_t)r.n_ts_bytes; break;
+    case DVBT_TAP_SYMBOL_INDEX: *ptr = h->sym_index; *bytes = (ns > 0 ? ns - 1 : 0) * 4; break;
+    default: return fail(DVBT_ERR_INVALID, "unknown tap");
+  }
+  return DVBT_OK;
+}
+
+extern "C" int64_t dvbt_rx_read_tap(dvbt_rx *h, int tap, void *dst, size_t cap)
+{
+  if (!h || !dst) return fail(DVBT_ERR_INVALID, "null argument");
+  if (tap == DVBT_TAP_CP_START) {
+    size_t ns = h->have_last && h->last.n_symbols > 0 ? (size_t)h->last.n_symbols : 0;
+    std::vector<SymMeta> m(ns);
+    if (ns) HIPCHK(hipMemcpy(m.data(), h->meta, ns * sizeof(SymMeta), hipMemcpyDeviceToHost));
+    size_t n = ns * 4 <= cap ? ns : cap / 4;
+    for (size_t i = 0; i < n; i++) ((int32_t *)dst)[i] = m[i].cp_start;
+    return (int64_t)(n * 4);
+  }
+  void *p = nullptr; size_t bytes = 0;
+  int r = tap_info(h, tap, &p, &bytes); if (r) return r;
+  if (!p) return fail(DVBT_ERR_STATE, "tap not enabled (call dvbt_rx_enable_taps before the segment)");
+  if (bytes > cap) bytes = cap;
+  if (bytes) HIPCHK(hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost));
+  return (int64_t)bytes;
+}
+
+extern "C" void *dvbt_rx_tap_device_ptr(dvbt_rx *h, int tap)
+{
+  if (!h) return nullptr;
+  switch (tap) {
+    case DVBT_TAP_RS: return h->rs_out; case DVBT_TAP_TS: return h->ts_out; case DVBT_TAP_VITERBI: return h->vit;
+    case DVBT_TAP_FFT: return h->fft_out; case DVBT_TAP_EQ: return h->eq; case DVBT_TAP_BITDEINT: return h->bitdeint;
+    default: return nullptr;
+  }
+}
+
+extern "C" double dvbt_rx_stage_ms(dvbt_rx *h, const char *stage)
+{
+  if (!h || !stage || h->n_timed == 0) return -1.0;
+  if (!strcmp(stage, "total")) return h->acc_ms[ST_END] / h->n_timed;
+  for (int i = 0; i < ST_END; i++) if (!strcmp(stage, kStageNames[i])) return h->acc_ms[i] / h->n_timed;
+  return -1.0;
+}
+
+extern "C" void dvbt_rx_destroy(dvbt_rx *h) { if (h) rx_free(h); }
+
+#include "dvbt_blocks.inc"

@@ -1,0 +1,369 @@
+// k_backend.hpp -- gfx950 kernels for A4..A9 (+ energy_descramble): integer/byte stages,
+// bit-exact against the reference.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "k_frontend.hpp"
+
+namespace dvbt {
+
+// ---------------------------------------------------------------- A4+A5+A6 fused: demap -> symbol de-interleave -> bit de-interleave
+// One workgroup per OFDM symbol, the 6048 (1512) labels staged in LDS.
+//   A4 dvbt_demap_impl.cc:167-203  : first strict minimum of (dr*dr + di*di) over the label table
+//   A5 symbol_inner_interleaver_impl.cc:202-208 : even symbol out[q]=in[H(q)], odd out[H(q)]=in[q]
+//   A6 bit_inner_deinterleaver_impl.cc:138-157 : out[i] bit k = bit (v-1-e) of in[(i-off_e) mod 126], e = perm(k)
+struct InnerParams { int payload, m, csize; };
+
+__device__ __forceinline__ int demap_one(float2 v, const float2 *pts, int csize)
+{
+  float dr = v.x - pts[0].x, di = v.y - pts[0].y;
+  float best = dr * dr + di * di; int idx = 0;
+  for (int j = 1; j < csize; j++) {
+    dr = v.x - pts[j].x; di = v.y - pts[j].y;
+    float d = dr * dr + di * di;
+    if (d < best) { best = d; idx = j; }
+  }
+  return idx;
+}
+
+// mode bits: 1 = demap, 2 = symbol de-interleave, 4 = bit de-interleave (7 = fused chain path)
+__global__ __launch_bounds__(256) void inner_kernel(const float2 *__restrict__ eq, const uint8_t *__restrict__ in_bytes, InnerParams p,
+                                                   const RxState *st, int nitems_fixed, int mode, const int *__restrict__ sym_index,
+                                                   const float2 *__restrict__ points, const uint16_t *__restrict__ H,
+                                                   uint8_t *__restrict__ tap_demap, uint8_t *__restrict__ tap_symdeint,
+                                                   uint8_t *__restrict__ out)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint8_t *v = smem_raw;                                       // payload bytes
+  float2 *pts = reinterpret_cast<float2 *>(smem_raw + ((p.payload + 15) & ~15));
+  const int u = blockIdx.x, tid = threadIdx.x;
+  int first = 0, nout = nitems_fixed;
+  if (st) { first = st->first_out; nout = st->n_out_symbols; if (first < 0) return; }
+  if (u >= nout) return;
+  const int s = first + u;
+  if (mode & 1) { for (int j = tid; j < p.csize; j += 256) pts[j] = points[j]; }
+  __syncthreads();
+  const bool odd = (mode & 2) ? (sym_index[s] & 1) : false;
+  const float2 *e = eq ? eq + (size_t)s * p.payload : nullptr;
+  const uint8_t *ib = in_bytes ? in_bytes + (size_t)s * p.payload : nullptr;
+  for (int q = tid; q < p.payload; q += 256) {
+    int src = q, dst = q;
+    if (mode & 2) { if (odd) dst = H[q]; else src = H[q]; }
+    int lab = (mode & 1) ? demap_one(e[src], pts, p.csize) : ib[src];
+    v[dst] = (uint8_t)lab;
+    if (tap_demap && (mode & 1)) tap_demap[(size_t)u * p.payload + src] = (uint8_t)lab;
+  }
+  __syncthreads();
+  uint8_t *o = out + (size_t)u * p.payload;
+  if (tap_symdeint) for (int q = tid; q < p.payload; q += 256) tap_symdeint[(size_t)u * p.payload + q] = v[q];
+  if (!(mode & 4)) { for (int q = tid; q < p.payload; q += 256) o[q] = v[q]; return; }
+  const int vb = p.m, hv = vb >> 1;
+  const int off[6] = {0, 63, 105, 42, 21, 84};
+  for (int q = tid; q < p.payload; q += 256) {
+    int blk = q / 126, i = q - blk * 126;
+    int val = 0;
+    for (int k = 0; k < vb; k++) {
+      int eidx = k / hv + 2 * (k % hv);                         // d_perm, non-hierarchical (:91-99)
+      int w = i - off[eidx]; if (w < 0) w += 126;
+      val = (val << 1) | ((v[blk * 126 + w] >> (vb - 1 - eidx)) & 1);
+    }
+    o[q] = (uint8_t)val;
+  }
+}
+
+// ---------------------------------------------------------------- sizes derived on the device (no host sync)
+struct VitParams {
+  int m, k, n, plen, ntb, bsize;
+  int d_nsymbols;        // input bytes per reference block  (viterbi_decoder_impl.cc:149)
+  int d_nbits;           // depunctured bits per block       (:151)
+  int chunk_bytes;       // decoded bytes per wavefront chunk
+  int payload;
+  uint8_t punct[16], prefix[16];
+};
+
+__global__ void plan_kernel(RxState *st, VitParams vp, int descramble)
+{
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  long long nin = (long long)st->n_out_symbols * vp.payload;
+  long long nblocks = nin / vp.d_nsymbols;
+  st->n_vit_in = nblocks * vp.d_nsymbols;
+  st->n_vit_steps = nblocks * (vp.d_nbits / 2);
+  long long nb = st->n_vit_steps / 8 - vp.ntb;
+  if (nb < 0) nb = 0;
+  st->n_vit_bytes = nb;
+  st->n_rs_items = (nb / 1632) & ~1ll;                          // convolutional_deinterleaver set_output_multiple(2)
+  st->n_ts_bytes = 0; st->rs_fail = 0; st->rs_corr = 0;
+  (void)descramble;
+}
+
+// ---------------------------------------------------------------- A7: depuncture + K=7 Viterbi, one wavefront per chunk
+// Lane s holds the metric of trellis state s (state = last 6 input bits, newest at LSB;
+// d_viterbi.c:272-277,503-524).  Per step: predecessors s>>1 and (s>>1)+32 via ds_bpermute,
+// branch metrics as "number of agreeing non-erased symbols", decision bit = (hi >= lo) exactly as
+// decision0/decision1 of the SSE2 butterfly, ballot -> one 64-bit decision word per step in LDS.
+// Every 8 steps (the reference's get_output cadence, viterbi_decoder_impl.cc:263-268): first-index
+// arg-max of the metrics, subtract the minimum.  Traceback runs with lanes = output bytes:
+// (ntraceback-1) hops of 8 decisions from the window's best state, then the 8 decisions of the
+// next-older window are the decoded byte (d_viterbi.c:699-724).
+//
+// Stream-parallel decode: chunk c produces decoded bytes [c*B, (c+1)*B).  It starts VIT_WARM
+// windows early from all-zero metrics (exactly the reference's state only at the stream start) and
+// runs ntraceback windows past its end.  The extended step index g counts two leading null steps
+// (both symbols erased) so that every window, including the reference's 6-step first one, is 8 steps.
+constexpr int VIT_WARM = 64;        // windows of warm-up before the first wanted byte
+constexpr int VIT_RING = 128;       // windows kept in LDS (>= 64 + ntraceback)
+
+__device__ __forceinline__ int parity6(int x) { return __popc(x) & 1; }
+
+__global__ __launch_bounds__(256) void viterbi_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const RxState *st,
+                                                     long long steps_fixed, VitParams vp)
+{
+  __shared__ unsigned long long s_dec[4][VIT_RING * 8];
+  __shared__ unsigned char s_best[4][VIT_RING];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  unsigned long long *dec = s_dec[wv];
+  unsigned char *bestw = s_best[wv];
+  const long long total_steps = st ? st->n_vit_steps : steps_fixed;
+  const long long total_out = total_steps / 8 - vp.ntb;
+  const long long chunk = (long long)blockIdx.x * 4 + wv;
+  const long long b0 = chunk * vp.chunk_bytes;
+  if (b0 >= total_out) return;
+  long long b1 = b0 + vp.chunk_bytes; if (b1 > total_out) b1 = total_out;
+  const int ntb = vp.ntb;
+  long long w_start = b0 + 2 - VIT_WARM; if (w_start < 1) w_start = 1;
+  const long long w_end = b1 + ntb;                   // last window needed (inclusive)
+  const long long c_first = b0 + ntb + 1;             // get_output call that emits byte b0
+
+  // lane constants: butterfly i = lane>>1, appended bit x = lane&1
+  const int bi = lane >> 1, xb = lane & 1;
+  const int e0 = parity6((2 * bi) & 0x4f) ^ xb, e1 = parity6((2 * bi) & 0x6d) ^ xb;
+  const int cls_shift = 8 * (e0 | (e1 << 1));
+  const int pred0 = bi, pred1 = bi + 32;
+  int M = 0;
+
+  for (long long wb = w_start; wb <= w_end; wb += 64) {
+    // ---- depuncture (viterbi_decoder_impl.cc:241-256) for the 64 windows of this block: lane = window
+    unsigned codes = 0;
+    {
+      long long w = wb + lane;
+      long long g0 = 8 * (w - 1);
+      for (int k = 0; k < 8; k++) {
+        long long g = g0 + k;
+        unsigned code = 2u | (2u << 2);                                     // both erased (null step)
+        if (g >= 2 && (g - 2) < total_steps && w <= w_end) {
+          unsigned long long pbit = 2ull * (unsigned long long)(g - 2);
+          unsigned long long q = pbit / (unsigned)vp.plen; int ph = (int)(pbit - q * vp.plen);
+          unsigned r[2];
+          for (int h = 0; h < 2; h++) {
+            int phh = ph + h;                                                // plen is even: no wrap inside a step
+            if (vp.punct[phh]) {
+              unsigned long long rb = q * (unsigned)vp.n + vp.prefix[phh];
+              unsigned long long byte = rb / (unsigned)vp.m; int bo = (int)(rb - byte * vp.m);
+              r[h] = (in[byte] >> (vp.m - 1 - bo)) & 1u;
+            } else r[h] = 2u;
+          }
+          code = r[0] | (r[1] << 2);
+        }
+        codes |= code << (4 * k);
+      }
+    }
+    // ---- forward ACS over up to 64 windows
+    long long nwin = w_end - wb + 1; if (nwin > 64) nwin = 64;
+    for (int wi = 0; wi < (int)nwin; wi++) {
+      const unsigned wc = __shfl(codes, wi);
+      const long long w = wb + wi;
+      const int ring = (int)(w & (VIT_RING - 1));
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const unsigned r0 = (wc >> (4 * k)) & 3u, r1 = (wc >> (4 * k + 2)) & 3u;
+        const unsigned w0 = r0 != 2u, w1 = r1 != 2u;
+        // disagreement count for the 4 label classes (e0,e1), one byte each
+        unsigned packed = 0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) packed |= ((w0 & ((c & 1u) ^ r0)) + (w1 & ((c >> 1) ^ r1))) << (8 * c);
+        const int hi_add = (packed >> cls_shift) & 0xff;
+        const int lo_add = (int)(w0 + w1) - hi_add;
+        const int lo = __shfl(M, pred0) + lo_add;
+        const int hi = __shfl(M, pred1) + hi_add;
+        const bool bit = hi >= lo;
+        M = bit ? hi : lo;
+        const unsigned long long d = __ballot(bit);
+        if (lane == 0) dec[ring * 8 + k] = d;
+      }
+      // get_output cadence: best state (first index of the maximum) and min-renormalisation
+      int key = (M << 6) | (63 - lane), mn = M;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { key = max(key, __shfl_xor(key, o)); mn = min(mn, __shfl_xor(mn, o)); }
+      M -= mn;
+      if (lane == 0) bestw[ring] = (unsigned char)(63 - (key & 63));
+    }
+    // ---- traceback for the calls completed in this block: lane = call
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // lane 0's decision/best stores -> all lanes
+    {
+      long long c = wb + lane;
+      bool active = (lane < nwin) && c >= c_first && c <= w_end && (c - ntb - 1) < b1;
+      if (active) {
+        int s = bestw[c & (VIT_RING - 1)];
+        long long w = c;
+        for (int hop = 0; hop < ntb - 1; hop++, w--) {
+          const unsigned long long *dw = dec + (w & (VIT_RING - 1)) * 8;
+#pragma unroll
+          for (int k = 7; k >= 0; k--) { unsigned b = (unsigned)(dw[k] >> s) & 1u; s = (s >> 1) | (b << 5); }
+        }
+        const unsigned long long *dw = dec + (w & (VIT_RING - 1)) * 8;
+        unsigned byte = 0;
+#pragma unroll
+        for (int k = 7; k >= 0; k--) { unsigned b = (unsigned)(dw[k] >> s) & 1u; byte |= b << (7 - k); s = (s >> 1) | (b << 5); }
+        out[c - ntb - 1] = (unsigned char)byte;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- A8+A9 fused: Forney de-interleave gather + RS(204,188) decode
+// out word w, byte p  <-  viterbi stream word (w - 11 + p%12), byte p   (zeros before the start)
+// (convolutional_deinterleaver_impl.cc:64-65,133-138 in closed form).  64 words per workgroup; the
+// 75 source words are staged in LDS with coalesced loads, each thread then owns one codeword.
+// RS: reed_solomon.cc:246-489.  Syndromes by table T_i[b] = b*alpha^i; error path on exp/log tables.
+struct RsTables { const uint8_t *mul_alpha; /* [16][256] */ const uint8_t *gexp; /* 512 */ const uint8_t *glog; /* 256 */ };
+
+__device__ inline int rs_decode_word(uint8_t *d /* 204 bytes, index 0 = codeword index 51 */, const uint8_t *syn,
+                                     const uint8_t *gexp, const uint8_t *glog, int compat)
+{
+  auto gmul = [&](int a, int b) -> int { return (a == 0 || b == 0) ? 0 : gexp[glog[a] + glog[b]]; };
+  auto gdiv = [&](int a, int b) -> int { return (a == 0 || b == 0) ? 0 : gexp[255 + glog[a] - glog[b]]; };
+  auto gpow = [&](int a, int pw) -> int { return a == 0 ? 0 : gexp[(glog[a] + pw) % 255]; };
+  uint8_t sigma[17], b[17], T[17], reg[17], root[17], loc[17], omega[17];
+  for (int i = 0; i < 17; i++) { sigma[i] = 0; b[i] = 0; }
+  sigma[0] = 1; b[0] = 1;
+  int r = 0, el = 0;
+  while (++r <= 16) {                                             // Berlekamp-Massey :315-354
+    int discr = 0;
+    for (int i = 0; i < r; i++) discr ^= gmul(sigma[i], syn[r - i - 1]);
+    if (discr == 0) { for (int i = 16; i > 0; i--) b[i] = b[i - 1]; b[0] = 0; }
+    else {
+      T[0] = sigma[0];
+      for (int i = 0; i < 16; i++) T[i + 1] = sigma[i + 1] ^ gmul(discr, b[i]);
+      if (2 * el <= r - 1) { el = r - el; for (int i = 0; i <= 16; i++) b[i] = (uint8_t)gdiv(sigma[i], discr); }
+      else { for (int i = 16; i > 0; i--) b[i] = b[i - 1]; b[0] = 0; }
+      for (int i = 0; i <= 16; i++) sigma[i] = T[i];
+    }
+  }
+  int deg_sigma = 0;
+  for (int i = 0; i <= 16; i++) if (sigma[i]) deg_sigma = i;
+  int no_roots = 0;                                               // Chien :376-403
+  for (int i = 1; i <= 16; i++) reg[i] = sigma[i];
+  for (int i = 1; i <= 255; i++) {
+    int q = 1;
+    for (int j = deg_sigma; j > 0; j--) { reg[j] = (uint8_t)gpow(reg[j], j); q ^= reg[j]; }
+    if (q != 0) continue;
+    root[no_roots] = (uint8_t)i; loc[no_roots] = (uint8_t)(i - 1);
+    if (++no_roots == deg_sigma) break;
+  }
+  if (no_roots != deg_sigma) return -1;
+  int deg_omega = 0;                                              // omega :419-434
+  for (int i = 0; i < 16; i++) {
+    int tmp = 0, j = deg_sigma < i ? deg_sigma : i;
+    for (; j >= 0; j--) tmp ^= gmul(syn[i - j], sigma[j]);
+    if (tmp) deg_omega = i;
+    omega[i] = (uint8_t)tmp;
+  }
+  if (compat) loc[0] = 0;                                         // the as-compiled omega[2t] overflow (SURVEY B-1)
+  for (int j = no_roots - 1; j >= 0; j--) {                       // Forney :445-486
+    int num1 = 0;
+    for (int i = deg_omega; i >= 0; i--) num1 ^= gpow(omega[i], i * root[j]);
+    int num2 = gexp[(255 - root[j]) % 255];
+    int den = 0, deg_max = deg_sigma < 15 ? deg_sigma : 15;
+    for (int i = 1; i <= deg_max; i += 2) if (sigma[i]) den ^= gexp[(glog[sigma[i]] + (i - 1) * root[j]) % 255];
+    if (den == 0) return -1;
+    int err = gdiv(gmul(num1, num2), den);
+    int l = loc[j];
+    if (l >= 51) d[l - 51] ^= (uint8_t)err;                        // corrections inside the zero padding are not output
+  }
+  return no_roots;
+}
+
+// standalone = 1: input is already de-interleaved items (A9 block alone); 0: gather from the Viterbi stream (A8+A9)
+__global__ __launch_bounds__(64) void deint_rs_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ deint_tap,
+                                                     uint8_t *__restrict__ out, RxState *st, long long words_fixed, int standalone,
+                                                     long long hist_words /* words of real history before word 0 (block API) */,
+                                                     RsTables T, int compat, int *fail_cnt, int *corr_cnt)
+{
+  __shared__ __attribute__((aligned(16))) uint8_t s_src[75 * 204 + 12];
+  __shared__ __attribute__((aligned(16))) uint8_t s_cw[64 * 204];
+  __shared__ uint8_t s_mul[16 * 256];
+  __shared__ uint8_t s_exp[512], s_log[256];
+  const int tid = threadIdx.x;
+  const long long nwords = st ? st->n_rs_items * 8 : words_fixed;
+  const long long w0 = (long long)blockIdx.x * 64;
+  if (w0 >= nwords) return;
+  for (int i = tid; i < 4096; i += 64) s_mul[i] = T.mul_alpha[i];
+  for (int i = tid; i < 512; i += 64) s_exp[i] = T.gexp[i];
+  for (int i = tid; i < 256; i += 64) s_log[i] = T.glog[i];
+  const int nw = (int)((nwords - w0) < 64 ? (nwords - w0) : 64);
+  if (!standalone) {
+    // source words w0-11 .. w0+63 ; dword copies (204 = 51 dwords; base is 4-byte aligned: word index*204)
+    const long long first = w0 - 11;
+    for (int i = tid; i < 75 * 51; i += 64) {
+      long long word = first + i / 51;
+      unsigned v = 0;
+      if (word >= -hist_words && word < nwords + 0 && (word - first) < (nw + 11)) v = reinterpret_cast<const unsigned *>(in + word * 204)[i % 51];
+      reinterpret_cast<unsigned *>(s_src)[i] = v;
+    }
+  }
+  __syncthreads();
+  uint8_t *cw = s_cw + tid * 204;
+  const long long w = w0 + tid;
+  if (tid < nw) {
+    if (standalone) { for (int p = 0; p < 204; p++) cw[p] = in[w * 204 + p]; }
+    else            { for (int p = 0; p < 204; p++) cw[p] = s_src[(tid + p % 12) * 204 + p]; }
+    if (deint_tap) for (int p = 0; p < 204; p++) deint_tap[w * 204 + p] = cw[p];
+    uint8_t syn[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) syn[i] = 0;
+    for (int p = 0; p < 204; p++) {                               // :281-288 (the 51 leading zeros leave syn at 0)
+      uint8_t dd = cw[p];
+#pragma unroll
+      for (int i = 0; i < 16; i++) syn[i] = dd ^ s_mul[i * 256 + syn[i]];
+    }
+    int any = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) any |= syn[i];
+    if (any) {
+      int r = rs_decode_word(cw, syn, s_exp, s_log, compat);
+      if (r < 0) atomicAdd(fail_cnt, 1); else atomicAdd(corr_cnt, r);
+    }
+  }
+  __syncthreads();
+  // coalesced store of 64 x 188 payload bytes (reed_solomon_dec_impl.cc:102: output regardless of success)
+  for (int i = tid; i < nw * 188; i += 64) { int ww = i / 188, p = i - ww * 188; out[(w0 + ww) * 188 + p] = s_cw[ww * 204 + p]; }
+}
+
+// ---------------------------------------------------------------- next row: energy_descramble (energy_descramble_impl.cc:108-174)
+__global__ void descramble_find_kernel(const uint8_t *__restrict__ in, RxState *st)
+{
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  long long nitems = st->n_rs_items, base = 0; int d_index = 0;
+  st->n_ts_bytes = 0; st->descr_base = 0; st->descr_index = 0;
+  while (nitems - base >= 4) {
+    const uint8_t *p = in + base * 1504;
+    while (d_index < 2 * 1504 && p[d_index] != 0xB8) d_index += 188;
+    if (d_index >= 2 * 1504) { d_index = 0; base += 2; continue; }
+    st->descr_base = (int)base; st->descr_index = d_index;
+    st->n_ts_bytes = (nitems - base - 2) * 1504;
+    return;
+  }
+}
+
+__global__ __launch_bounds__(256) void descramble_apply_kernel(const uint8_t *__restrict__ in, const uint8_t *__restrict__ seq,
+                                                              const RxState *st, uint8_t *__restrict__ out)
+{
+  long long n = st->n_ts_bytes;
+  const uint8_t *p = in + (long long)st->descr_base * 1504 + st->descr_index;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    int k = (int)(i % 1504);
+    out[i] = (k % 188 == 0) ? 0x47 : (p[i] ^ seq[k]);
+  }
+}
+
+}  // namespace dvbt

@@ -1,0 +1,488 @@
+// k_frontend.hpp -- gfx950 kernels for A1 (ofdm_sym_acquisition), A2 (forward FFT) and A3
+// (demod_reference_signals).  Float stages: parity with the reference is "within the stated
+// tolerance at the equalised-carrier tap" (SURVEY 8a); the integer decisions they feed
+// (cp position, integer CFO, symbol index mod 4, TPS bits, superframe start) must be identical.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dvbt {
+
+// ---------------------------------------------------------------- device-resident run state
+struct RxState {
+  int status;            // bit0 init-acq failed, bit1 tracking lost, bit2 no superframe start, bit3 lag range exceeded
+  int call0;             // general_work call (window index) in which initial acquisition succeeded
+  int cp_start0;         // d_cp_start returned by the initial ml_sync
+  int n_symbols;         // items produced by A1
+  int first_out;         // symbol at which superframe_start fired (-1: none)
+  int n_out_symbols;     // items passed downstream of A3
+  float avg;             // peak detector IIR state d_avg after the initial search
+  float eps_init;
+  long long n_vit_in;    // bytes entering A7
+  long long n_vit_steps; // trellis steps (real)
+  long long n_vit_bytes; // bytes leaving A7
+  long long n_rs_items;
+  long long n_ts_bytes;
+  int descr_base, descr_index;
+  int rs_fail, rs_corr;
+};
+
+struct FrontParams {
+  int N, cp, K, zl, payload, n_cp, n_tps, fi_start;
+  int ncalls;            // windows available: (ncalls-1)*(N+cp) + 2N+cp+16 <= nsamples
+  int R;                 // half-width of the precomputed lag range around cp_start0
+  float half_rho;        // (float)(rho/2)
+};
+
+constexpr int ACQ_R = 16;
+constexpr int ACQ_INIT_TRIES = 4;
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a*conj(b)
+__device__ __forceinline__ float2 cdiv(float2 a, float2 b)
+{ float den = b.x * b.x + b.y * b.y; return make_float2((a.x * b.x + a.y * b.y) / den, (a.y * b.x - a.x * b.y) / den); }
+
+// ---------------------------------------------------------------- A1: CP correlation metric
+// ml_sync (ofdm_sym_acquisition_impl.cc:148-250): gamma(i) = sum_{j<cp} x[i-j] conj(x[i-j-N]),
+// phi(i) = sum |x[i-j]|^2 + |x[i-j-N]|^2, lambda = |gamma| - rho/2 * phi.
+// One thread per lag.  mode 0: initial search, lags N+cp-1 .. 2N+cp-2 of window `try`;
+// mode 1: tracking, lags cp_start0-R .. cp_start0+R-1 of every window.
+__global__ __launch_bounds__(256) void acq_metric_kernel(const float2 *__restrict__ iq, FrontParams p, const RxState *st,
+                                                        int mode, float2 *__restrict__ gamma, float *__restrict__ lambda)
+{
+  const int N = p.N, cp = p.cp;
+  long long wbase; int lag, oidx;
+  if (mode == 0) {
+    int t = blockIdx.y;
+    if (t >= p.ncalls) return;
+    int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= N) return;
+    wbase = (long long)t * (N + cp); lag = N + cp - 1 + q; oidx = t * N + q;
+  } else {
+    int idx = blockIdx.x * 256 + threadIdx.x;
+    int call = idx / (2 * p.R), q = idx % (2 * p.R);
+    if (call >= p.ncalls || call < st->call0 || (st->status & 1)) return;
+    lag = st->cp_start0 - p.R + q;
+    wbase = (long long)call * (N + cp); oidx = idx;
+    if (lag - cp + 1 - N < 0) { gamma[oidx] = make_float2(0.f, 0.f); lambda[oidx] = -3.0e38f; return; }
+  }
+  const float2 *x = iq + wbase + lag;
+  float gr = 0.f, gi = 0.f, phi = 0.f;
+  for (int j = 0; j < cp; j++) {
+    float2 a = x[-j], b = x[-j - N];
+    gr += a.x * b.x + a.y * b.y; gi += a.y * b.x - a.x * b.y;
+    phi += (a.x * a.x + a.y * a.y) + (b.x * b.x + b.y * b.y);
+  }
+  gamma[oidx] = make_float2(gr, gi);
+  lambda[oidx] = sqrtf(gr * gr + gi * gi) - phi * p.half_rho;
+}
+
+// peak_detect_process (ofdm_sym_acquisition_impl.cc:72-146); avg persists across calls
+__device__ inline int peak_detect(const float *d, int n, float &avg, int &best_pos)
+{
+  const float rise = 0.8f, fall = 0.9f, alpha = 0.9f;
+  int state = 0, peak_index = 0, npk = 0, i = 0;
+  float peak_val = -INFINITY, best_val = 0.f;
+  while (i < n) {
+    float v = d[i];
+    if (state == 0) {
+      if (v > avg * rise) state = 1;
+      else { avg = alpha * v + (1 - alpha) * avg; i++; }
+    } else {
+      if (v > peak_val) { peak_val = v; peak_index = i; avg = alpha * v + (1 - alpha) * avg; i++; }
+      else if (v > avg * fall) { avg = alpha * v + (1 - alpha) * avg; i++; }
+      else {                         // falling edge: record the peak; keep the largest (first wins ties)
+        if (npk == 0 || d[peak_index] > best_val) { best_val = d[peak_index]; best_pos = peak_index; }
+        npk++; state = 0; peak_val = -INFINITY;
+      }
+    }
+  }
+  return npk;
+}
+
+__device__ __forceinline__ float wrap_pi(double ph)
+{
+  const double twopi = 6.283185307179586;
+  ph = ph - twopi * floor((ph + 3.141592653589793) / twopi);
+  return (float)ph;
+}
+
+// initial acquisition FSM (general_work :498-510): sequential by nature (IIR + state machine)
+__global__ void acq_init_fsm_kernel(FrontParams p, RxState *st, const float2 *gamma, const float *lambda)
+{
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float avg = 0.f;
+  int tries = p.ncalls < ACQ_INIT_TRIES ? p.ncalls : ACQ_INIT_TRIES;
+  st->status = 1; st->call0 = 0; st->cp_start0 = 0; st->n_symbols = 0; st->first_out = -1; st->n_out_symbols = 0;
+  st->n_vit_in = st->n_vit_steps = st->n_vit_bytes = st->n_rs_items = st->n_ts_bytes = 0; st->rs_fail = st->rs_corr = 0;
+  for (int t = 0; t < tries; t++) {
+    int pos = 0;
+    int npk = peak_detect(lambda + (size_t)t * p.N, p.N, avg, pos);
+    if (npk) {
+      float2 g = gamma[(size_t)t * p.N + pos];
+      st->status = 0; st->call0 = t; st->cp_start0 = pos + p.N + p.cp - 1;
+      st->eps_init = atan2f(g.y, g.x); st->avg = avg;
+      return;
+    }
+  }
+  st->avg = avg;
+}
+
+// tracking FSM over all windows (general_work :512-560 + the phase bookkeeping of ml_sync :285-313).
+// Sequential reference version: one thread walks the calls.
+struct SymMeta { int cp_start; int sw; float eps; float ph_base; double incA, incB; };
+
+__global__ void acq_track_kernel(FrontParams p, RxState *st, const float2 *gamma, const float *lambda, SymMeta *meta)
+{
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (st->status & 1) return;
+  const int N = p.N, cp = p.cp, R = p.R, c0 = st->cp_start0;
+  float avg = st->avg, phase = 0.f;
+  double phaseinc = 0.0, nextphaseinc = (-1.0 / (double)N) * (double)st->eps_init;
+  int nextpos = c0 - (N + cp), cur = c0, s = 0;
+  for (int call = st->call0; call < p.ncalls; call++, s++) {
+    int rel0 = (cur - 8) - (c0 - R);
+    if (rel0 < 0 || rel0 + 16 > 2 * R) { st->status |= 8; break; }
+    const float *lam = lambda + (size_t)call * 2 * R + rel0;
+    int pos = 0;
+    int npk = peak_detect(lam, 16, avg, pos);
+    if (!npk) { st->status |= 2; break; }       // the reference would drop lock and re-acquire (:545-559)
+    float2 g = gamma[(size_t)call * 2 * R + rel0 + pos];
+    float eps = atan2f(g.y, g.x);
+    int peak = pos + cur - 8;
+    SymMeta m; m.cp_start = peak; m.eps = eps; m.ph_base = phase; m.incA = phaseinc; m.incB = nextphaseinc; m.sw = nextpos;
+    meta[s] = m;
+    double total;
+    if (nextpos >= 0 && nextpos < N + cp) { total = nextpos * phaseinc + (N + cp - nextpos) * nextphaseinc; phaseinc = nextphaseinc; }
+    else total = (double)(N + cp) * phaseinc;
+    phase = wrap_pi((double)phase + total);
+    nextphaseinc = (-1.0 / (double)N) * (double)eps;
+    nextpos = peak - (N + cp);
+    cur = peak;
+  }
+  st->n_symbols = s;
+}
+
+// ---------------------------------------------------------------- A1 tail + A2: derotate, strip CP, forward FFT with shift
+// One workgroup per OFDM symbol; the symbol lives in LDS (N*8 bytes) through all stages.
+// DIF radix-4 stages (+ one radix-2 when log2 N is odd), in place; the digit-reversed result is
+// written out in natural, fft-shifted order through the host-built permutation.
+__global__ __launch_bounds__(256) void derot_fft_kernel(const float2 *__restrict__ iq, FrontParams p, const RxState *st,
+                                                       const SymMeta *__restrict__ meta, const float2 *__restrict__ tw,
+                                                       const uint16_t *__restrict__ perm, float2 *__restrict__ acq_tap,
+                                                       float2 *__restrict__ out)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float2 *x = reinterpret_cast<float2 *>(smem_raw);
+  const int s = blockIdx.x;
+  if (s >= st->n_symbols) return;
+  const int N = p.N, cp = p.cp, tid = threadIdx.x;
+  const SymMeta m = meta[s];
+  const long long low = (long long)(st->call0 + s) * (N + cp) + m.cp_start - N + 1;
+  const bool rot = (m.incA != 0.0) || (m.incB != 0.0) || (m.ph_base != 0.f);
+  for (int n = tid; n < N; n += 256) {
+    float2 v = iq[low + n];
+    if (rot) {                                   // derot[n] = expj(phase after n+1 increments)  (:285-309,:527-534)
+      int a = n + 1, b = 0;
+      if (m.sw >= 0 && m.sw < N + cp && a > m.sw) { b = a - m.sw; a = m.sw; }
+      float ph = wrap_pi((double)m.ph_base + a * m.incA + b * m.incB);
+      float sn, cs; sincosf(ph, &sn, &cs);
+      v = cmul(make_float2(cs, sn), v);
+    }
+    x[n] = v;
+    if (acq_tap) acq_tap[(size_t)s * N + n] = v;
+  }
+  __syncthreads();
+  int L = N;
+  while (L >= 4) {
+    const int Q = L >> 2, tstep = N / L;
+    for (int bf = tid; bf < (N >> 2); bf += 256) {
+      int r = bf % Q, base = (bf / Q) * L + r;
+      float2 a0 = x[base], a1 = x[base + Q], a2 = x[base + 2 * Q], a3 = x[base + 3 * Q];
+      float2 s02 = make_float2(a0.x + a2.x, a0.y + a2.y), d02 = make_float2(a0.x - a2.x, a0.y - a2.y);
+      float2 s13 = make_float2(a1.x + a3.x, a1.y + a3.y), d13 = make_float2(a1.x - a3.x, a1.y - a3.y);
+      float2 y0 = make_float2(s02.x + s13.x, s02.y + s13.y);
+      float2 y2 = make_float2(s02.x - s13.x, s02.y - s13.y);
+      float2 y1 = make_float2(d02.x + d13.y, d02.y - d13.x);       // d02 - i*d13
+      float2 y3 = make_float2(d02.x - d13.y, d02.y + d13.x);       // d02 + i*d13
+      x[base] = y0;
+      if (r == 0) { x[base + Q] = y1; x[base + 2 * Q] = y2; x[base + 3 * Q] = y3; }
+      else {
+        x[base + Q] = cmul(y1, tw[r * tstep]);
+        x[base + 2 * Q] = cmul(y2, tw[2 * r * tstep]);
+        x[base + 3 * Q] = cmul(y3, tw[3 * r * tstep]);
+      }
+    }
+    __syncthreads();
+    L = Q;
+  }
+  if (L == 2) {
+    for (int bf = tid; bf < (N >> 1); bf += 256) {
+      float2 a0 = x[2 * bf], a1 = x[2 * bf + 1];
+      x[2 * bf] = make_float2(a0.x + a1.x, a0.y + a1.y);
+      x[2 * bf + 1] = make_float2(a0.x - a1.x, a0.y - a1.y);
+    }
+    __syncthreads();
+  }
+  float2 *o = out + (size_t)s * N;
+  for (int b = tid; b < N; b += 256) o[b] = x[perm[b]];
+}
+
+// plain FFT for the standalone A2 block: items already CP-stripped
+__global__ __launch_bounds__(256) void fft_items_kernel(const float2 *__restrict__ in, int N, int nitems,
+                                                       const float2 *__restrict__ tw, const uint16_t *__restrict__ perm,
+                                                       float2 *__restrict__ out)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float2 *x = reinterpret_cast<float2 *>(smem_raw);
+  const int s = blockIdx.x, tid = threadIdx.x;
+  if (s >= nitems) return;
+  for (int n = tid; n < N; n += 256) x[n] = in[(size_t)s * N + n];
+  __syncthreads();
+  int L = N;
+  while (L >= 4) {
+    const int Q = L >> 2, tstep = N / L;
+    for (int bf = tid; bf < (N >> 2); bf += 256) {
+      int r = bf % Q, base = (bf / Q) * L + r;
+      float2 a0 = x[base], a1 = x[base + Q], a2 = x[base + 2 * Q], a3 = x[base + 3 * Q];
+      float2 s02 = make_float2(a0.x + a2.x, a0.y + a2.y), d02 = make_float2(a0.x - a2.x, a0.y - a2.y);
+      float2 s13 = make_float2(a1.x + a3.x, a1.y + a3.y), d13 = make_float2(a1.x - a3.x, a1.y - a3.y);
+      x[base] = make_float2(s02.x + s13.x, s02.y + s13.y);
+      float2 y2 = make_float2(s02.x - s13.x, s02.y - s13.y);
+      float2 y1 = make_float2(d02.x + d13.y, d02.y - d13.x);
+      float2 y3 = make_float2(d02.x - d13.y, d02.y + d13.x);
+      x[base + Q] = cmul(y1, tw[r * tstep]);
+      x[base + 2 * Q] = cmul(y2, tw[2 * r * tstep]);
+      x[base + 3 * Q] = cmul(y3, tw[3 * r * tstep]);
+    }
+    __syncthreads();
+    L = Q;
+  }
+  if (L == 2) {
+    for (int bf = tid; bf < (N >> 1); bf += 256) {
+      float2 a0 = x[2 * bf], a1 = x[2 * bf + 1];
+      x[2 * bf] = make_float2(a0.x + a1.x, a0.y + a1.y);
+      x[2 * bf + 1] = make_float2(a0.x - a1.x, a0.y - a1.y);
+    }
+    __syncthreads();
+  }
+  for (int b = tid; b < N; b += 256) out[(size_t)s * N + b] = x[perm[b]];
+}
+
+// ---------------------------------------------------------------- A3: pilot engine, one workgroup per OFDM symbol
+struct DemodTables {
+  const int16_t *cpilot;        // n_cp
+  const float *known_diff;      // n_cp-1  |ref(c[j+1])-ref(c[j])|^2  (reference_signals_impl.cc:224-228)
+  const int16_t *tps;           // n_tps
+  const float *pilot_ref;       // K  (+-4/3)
+  const uint16_t *pay_c, *pay_L, *pay_R;   // [4][payload]
+  const uint16_t *tps_L, *tps_R;           // [4][n_tps]
+};
+struct SymInfo { int freq_offset; int mod_index; float cfc; int pad; };
+
+__device__ __forceinline__ float wave_sum(float v)
+{ for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
+
+// parse_input (reference_signals_impl.cc:1189-1248) minus the sequential TPS/frame bookkeeping,
+// which only needs mod_index and the per-carrier TPS values produced here.
+// in: fft items [n_symbols][N]; symbol s needs item s+1 too (compute_oneshot_csft :747-790).
+__global__ __launch_bounds__(256) void demod_kernel(const float2 *__restrict__ fft, FrontParams p, const RxState *st, int nitems_fixed,
+                                                   DemodTables T, float2 *__restrict__ eq, float2 *__restrict__ tpsval,
+                                                   SymInfo *__restrict__ info)
+{
+  __shared__ float s_sum[16];
+  __shared__ float s_red[8][4];
+  __shared__ int s_fo, s_mod;
+  __shared__ float2 s_ph;
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nsym = st ? st->n_symbols : nitems_fixed;
+  if (s + 1 >= nsym) return;
+  const int N = p.N, zl = p.zl;
+  const float2 *in = fft + (size_t)s * N;
+
+  // integer CFO: process_cpilot_data :715-744 -- 16 candidate shifts x (n_cp-1) pilot pairs
+  {
+    int cand = tid >> 4, sub = tid & 15;
+    int i = zl - 8 + cand;
+    float sum = 0.f;
+    for (int j = sub; j < p.n_cp - 1; j += 16) {
+      float2 a = in[i + T.cpilot[j + 1]], b = in[i + T.cpilot[j]];
+      float dx = a.x - b.x, dy = a.y - b.y;
+      sum += T.known_diff[j] * (dx * dx + dy * dy);
+    }
+    for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (sub == 0) s_sum[cand] = sum;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float mx = 0.f; int start = 0;
+    for (int c = 0; c < 16; c++) if (s_sum[c] > mx) { mx = s_sum[c]; start = zl - 8 + c; }
+    s_fo = start - zl;
+  }
+  __syncthreads();
+  const int fo = s_fo;
+
+  // compute_oneshot_csft :747-790 -- left/right continual-pilot correlation with the next symbol
+  {
+    int half = (p.n_cp - 1) / 2;
+    float lr = 0.f, li = 0.f, rr = 0.f, ri = 0.f;
+    for (int j = tid; j < p.n_cp; j += 256) {
+      if (j == half) continue;
+      int idx = fo + zl + T.cpilot[j];
+      float2 c = cmulc(in[idx], in[idx + N]);
+      if (j < half) { lr += c.x; li += c.y; } else { rr += c.x; ri += c.y; }
+    }
+    lr = wave_sum(lr); li = wave_sum(li); rr = wave_sum(rr); ri = wave_sum(ri);
+    if (lane == 0) { s_red[wave][0] = lr; s_red[wave][1] = li; s_red[wave][2] = rr; s_red[wave][3] = ri; }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float lr = 0, li = 0, rr = 0, ri = 0;
+    for (int w = 0; w < 4; w++) { lr += s_red[w][0]; li += s_red[w][1]; rr += s_red[w][2]; ri += s_red[w][3]; }
+    float la = atan2f(li, lr), ra = atan2f(ri, rr);
+    float carrier_coeff = (float)(1.0 / (2 * M_PI * (1 + (float)p.cp / (float)N) * 2));
+    float cfc = (ra + la) * carrier_coeff;
+    // frequency_correction :793-819: one constant phasor for the whole symbol
+    float correction = (float)fo + cfc;
+    float ph = (float)(-2 * M_PI * correction * (N + p.cp) / N);
+    float sn, cs; sincosf(ph, &sn, &cs);
+    s_ph = make_float2(cs, sn);
+    info[s].freq_offset = fo; info[s].cfc = cfc;
+  }
+  __syncthreads();
+  const float2 cph = s_ph;
+  const float2 *xin = in + zl + fo;               // derot_in[zl + k] = cph * in[zl + k + fo]
+
+  // symbol index mod 4: process_spilot_data :549-582 -- first 10 scattered pilots of each pattern
+  if (tid < 64) {
+    int pat = tid >> 4, j = tid & 15;
+    float cr = 0.f, ci = 0.f;
+    if (j < 10) {
+      int k = 3 * pat + 12 * j;
+      float2 v = cmul(cph, xin[k]);
+      float r = T.pilot_ref[k];
+      cr = r * v.x; ci = -r * v.y;                // ref * conj(v)
+    }
+    for (int o = 8; o > 0; o >>= 1) { cr += __shfl_xor(cr, o); ci += __shfl_xor(ci, o); }
+    if (j == 0) s_sum[pat] = cr * cr + ci * ci;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    // `max` starts at 0 and d_mod_symbol_index keeps its previous value when nothing exceeds it;
+    // with any signal present one pattern always does, so the previous value is never needed.
+    float mx = 0.f; int mod = 0;
+    for (int c = 0; c < 4; c++) if (s_sum[c] > mx) { mx = s_sum[c]; mod = c; }
+    s_mod = mod; info[s].mod_index = mod;
+  }
+  __syncthreads();
+  const int mod = s_mod;
+
+  // channel gains (set_channel_gain :486-490, interpolation :617-642) + equalise (:1111-1114)
+  auto gain_at = [&](int c, int L, int Rr) -> float2 {
+    float2 gl = cdiv(make_float2(T.pilot_ref[L], 0.f), cmul(cph, xin[L]));
+    if (L == c) return gl;
+    float2 gr = cdiv(make_float2(T.pilot_ref[Rr], 0.f), cmul(cph, xin[Rr]));
+    float j = (float)(c - L);
+    float tx = (gr.x - gl.x) / 11.0f, ty = (gr.y - gl.y) / 11.0f;       // the constant 11 (:625)
+    return make_float2(gl.x + tx * j, gl.y + ty * j);
+  };
+  const uint16_t *pc = T.pay_c + (size_t)mod * p.payload, *pL = T.pay_L + (size_t)mod * p.payload, *pR = T.pay_R + (size_t)mod * p.payload;
+  float2 *o = eq + (size_t)s * p.payload;
+  for (int i = tid; i < p.payload; i += 256) {
+    int c = pc[i];
+    float2 g = gain_at(c, pL[i], pR[i]);
+    o[i] = cmul(cmul(cph, xin[c]), g);
+  }
+  // equalised TPS carriers (process_tps_data :929-931)
+  if (tid < p.n_tps) {
+    int c = T.tps[tid];
+    float2 g = gain_at(c, T.tps_L[mod * p.n_tps + tid], T.tps_R[mod * p.n_tps + tid]);
+    tpsval[(size_t)s * p.n_tps + tid] = cmul(cmul(cph, xin[c]), g);
+  }
+}
+
+// DBPSK majority vote per symbol (process_tps_data :929-950): parallel over symbols
+__global__ __launch_bounds__(256) void tps_vote_kernel(const float2 *__restrict__ tpsval, int n_tps, const RxState *st, int nitems_fixed,
+                                                      const float2 *__restrict__ prev0, int *__restrict__ maj)
+{
+  int s = blockIdx.x * 256 + threadIdx.x;
+  int nsym = st ? st->n_symbols : nitems_fixed;
+  if (s + 1 >= nsym) return;
+  int m = 0;
+  for (int k = 0; k < n_tps; k++) {
+    float2 v = tpsval[(size_t)s * n_tps + k];
+    float2 pv = s > 0 ? tpsval[(size_t)(s - 1) * n_tps + k] : (prev0 ? prev0[k] : make_float2(0.f, 0.f));
+    float re = v.x * pv.x + v.y * pv.y;
+    m += (re >= 0.0f) ? 1 : -1;
+  }
+  maj[s] = m;
+}
+
+// persistent TPS / frame-sync state (pilot_gen members + demod block members)
+struct TpsState {
+  unsigned long long fifo_lo;   // fifo[0..63], bit i = fifo[i]
+  unsigned fifo_hi;             // fifo[64..67]
+  int symbol_index, symbol_index_known, frame_index, prev_mod, d_init;
+};
+
+__device__ inline int bch_check(unsigned long long lo, unsigned hi)
+{ // verify_bch_code :385-425
+  auto bit = [&](int i) -> unsigned { return i < 64 ? (unsigned)((lo >> i) & 1ull) : ((hi >> (i - 64)) & 1u); };
+  unsigned reg = 0;
+  for (int i = 0; i < 113; i++) {
+    unsigned d = i < 60 ? 0u : bit(1 + (i - 60));
+    unsigned fb = 1u & (d ^ reg);
+    reg >>= 1; reg |= fb << 13;
+    reg ^= (fb << 12) ^ (fb << 11) ^ (fb << 9) ^ (fb << 8) ^ (fb << 7) ^ (fb << 5) ^ (fb << 4);
+  }
+  for (int i = 0; i < 14; i++) if (bit(54 + i) != (1u & (reg >> i))) return -1;
+  return 0;
+}
+
+// symbol/frame bookkeeping: parse_input :1228-1241, process_tps_data :952-1028,
+// demod_reference_signals_impl.cc:108-143 (one item per call regime).  Sequential over symbols.
+__global__ void tps_fsm_kernel(FrontParams p, RxState *st, int nitems_fixed, const SymInfo *info, const int *maj,
+                               TpsState *ts, int *sym_index, int *superframe_flag)
+{
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int nsym = st ? st->n_symbols : nitems_fixed;
+  TpsState t = *ts;
+  // sync words s1..s15 as fifo bits 1..15 (only 15 of the 16 are compared: B-11)
+  static const unsigned char se[15] = {0, 0, 1, 1, 0, 1, 0, 1, 1, 1, 1, 0, 1, 1, 1};
+  unsigned mask_even = 0, mask_odd = 0;
+  for (int i = 0; i < 15; i++) { mask_even |= (unsigned)se[i] << (1 + i); mask_odd |= (unsigned)(1 - se[i]) << (1 + i); }
+  int first_out = -1;
+  for (int s = 0; s + 1 < nsym; s++) {
+    int mod = info[s].mod_index;
+    int diff = (mod - t.prev_mod + 4) % 4;
+    t.prev_mod = mod;
+    t.symbol_index = (t.symbol_index + diff) % 68;
+    int si = t.symbol_index, fi = t.frame_index;
+    int use = (!t.symbol_index_known || t.symbol_index != 0);
+    unsigned bitv = use ? (maj[s] >= 0 ? 0u : 1u) : 0u;
+    for (int i = 0; i < diff; i++) {
+      t.fifo_lo = (t.fifo_lo >> 1) | ((unsigned long long)(t.fifo_hi & 1u) << 63);
+      t.fifo_hi = (t.fifo_hi >> 1) | (bitv << 3);
+    }
+    unsigned low16 = (unsigned)(t.fifo_lo & 0xFFFEull);
+    if (low16 == mask_even || low16 == mask_odd) {
+      if (bch_check(t.fifo_lo, t.fifo_hi) == 0) {
+        t.frame_index = (int)(((t.fifo_lo >> 23) & 1ull) << 1 | ((t.fifo_lo >> 24) & 1ull));
+        t.symbol_index_known = 1; t.symbol_index = 67;
+      } else t.symbol_index_known = 0;
+      t.fifo_lo = 0; t.fifo_hi = 0;
+    }
+    sym_index[s] = si;
+    int sf = 0;
+    if (!t.d_init && (si % 68) == 0 && (fi % 4) == p.fi_start) { t.d_init = 1; sf = 1; if (first_out < 0) first_out = s; }
+    if (superframe_flag) superframe_flag[s] = t.d_init ? (sf ? 2 : 1) : 0;   // 0 dropped, 1 produced, 2 produced + superframe_start
+  }
+  *ts = t;
+  if (st) {
+    st->first_out = first_out;
+    if (first_out < 0) { st->status |= 4; st->n_out_symbols = 0; }
+    else st->n_out_symbols = nsym - 1 - first_out;
+  }
+}
+
+}  // namespace dvbt

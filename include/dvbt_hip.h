@@ -1,0 +1,264 @@
+/*
+ * dvbt_hip.h -- C ABI of libdvbt_hip.so: the MI355X (gfx950) DVB-T receive hot path
+ * behind the gr::dvbt block interfaces of BogdanDIA/gr-dvbt.
+ *
+ * Plain C: opaque handles, POD parameter structs that carry exactly the arguments of the
+ * reference's X::make(...), caller-owned in/out buffers (host memory unless a function
+ * says "_device"), explicit sideband struct instead of GNU Radio stream tags.
+ *
+ * One triple per reference block (create / forecast / work / destroy) + the segment API
+ * that runs the whole chain device-resident.  Each entry cites the reference interface
+ * it replaces (paths relative to the gr-dvbt tree).
+ *
+ * Threading: like a GNU Radio block, a handle must not be used from two threads at once.
+ * Errors: functions return >= 0 (items produced / DVBT_OK) or a negative dvbt_status.
+ * The reference never reports errors (SURVEY 8b "Error conventions"); RS failures are
+ * likewise silent here (bytes pass through), and are only counted in the report.
+ */
+#ifndef DVBT_HIP_H
+#define DVBT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  DVBT_OK = 0,
+  DVBT_ERR_INVALID = -1,      /* bad parameter */
+  DVBT_ERR_NO_DEVICE = -2,    /* no HIP device / kernel image not loadable: there is NO CPU fallback */
+  DVBT_ERR_HIP = -3,          /* a HIP runtime call failed (message via dvbt_last_error) */
+  DVBT_ERR_CAPACITY = -4,     /* caller buffer or handle capacity too small */
+  DVBT_ERR_STATE = -5         /* call sequence violates the block's contract */
+} dvbt_status;
+
+/* enums: include/dvbt/dvbt_config.h:34-75 (values double as TPS field encodings) */
+typedef enum { DVBT_QPSK = 0, DVBT_QAM16 = 1, DVBT_QAM64 = 2 } dvbt_constellation_t;
+typedef enum { DVBT_NH = 0, DVBT_ALPHA1, DVBT_ALPHA2, DVBT_ALPHA4 } dvbt_hierarchy_t;
+typedef enum { DVBT_C1_2 = 0, DVBT_C2_3, DVBT_C3_4, DVBT_C5_6, DVBT_C7_8 } dvbt_code_rate_t;
+typedef enum { DVBT_T2k = 0, DVBT_T8k = 1 } dvbt_transmission_mode_t;
+typedef enum { DVBT_G1_32 = 0, DVBT_G1_16, DVBT_G1_8, DVBT_G1_4 } dvbt_guard_interval_t;
+
+/* sideband: replaces the stream tags of SURVEY Appendix D */
+typedef enum { DVBT_TAG_SYNC_START = 1, DVBT_TAG_SUPERFRAME_START = 2, DVBT_TAG_SYMBOL_INDEX = 3 } dvbt_tag_key;
+typedef struct { int64_t rel_offset; int32_t key; int32_t value; } dvbt_tag;   /* offset in items, relative to the call's first item */
+typedef struct {
+  const dvbt_tag *in_tags; int n_in_tags;      /* tags visible in the input window */
+  dvbt_tag *out_tags; int out_cap; int n_out_tags;  /* tags the block attaches to its output */
+  int n_consumed;                              /* what the block would pass to consume_each() */
+} dvbt_sideband;
+
+const char *dvbt_last_error(void);
+int dvbt_device_count(void);                   /* HIP devices visible; <=0 means the library cannot run */
+const char *dvbt_version(void);
+
+/* ------------------------------------------------------------------ derived constants
+ * replaces dvbt_config::dvbt_config (lib/dvbt_config.cc:94-250, include/dvbt/dvbt_config.h:95-139) */
+typedef struct {
+  int fft_length, cp_length, Kmax, payload_length, zeros_on_left, m, cr_k, cr_n;
+  float norm;
+  int ntraceback;                              /* lib/viterbi_decoder_impl.cc:95-124 */
+  int info_bits_per_symbol;
+} dvbt_dims;
+int dvbt_get_dims(int constellation, int hierarchy, int code_rate, int guard_interval,
+                  int transmission_mode, dvbt_dims *out);
+
+/* ------------------------------------------------------------------ A1 ofdm_sym_acquisition
+ * replaces ofdm_sym_acquisition::make(blocks, fft_length, occupied_tones, cp_length, snr)
+ * (include/dvbt/ofdm_sym_acquisition.h:49) and general_work/forecast
+ * (lib/ofdm_sym_acquisition_impl.cc:474-481,489-568).  in: cfloat stream; out: items of N cfloat.
+ * Unlike the reference (<=1 item per call) a call may produce up to noutput_items items;
+ * n_consumed = (N+cp) per symbol attempted. */
+typedef struct { int blocks, fft_length, occupied_tones, cp_length; float snr; } dvbt_ofdm_sym_acquisition_params;
+typedef struct dvbt_ofdm_sym_acquisition dvbt_ofdm_sym_acquisition;
+int  dvbt_ofdm_sym_acquisition_create(const dvbt_ofdm_sym_acquisition_params *p, dvbt_ofdm_sym_acquisition **out);
+int  dvbt_ofdm_sym_acquisition_forecast(const dvbt_ofdm_sym_acquisition *h, int noutput_items, int *ninput_required);
+int  dvbt_ofdm_sym_acquisition_work(dvbt_ofdm_sym_acquisition *h, int noutput_items, int ninput_items,
+                                    const void *in, void *out, dvbt_sideband *sb);
+void dvbt_ofdm_sym_acquisition_destroy(dvbt_ofdm_sym_acquisition *h);
+
+/* ------------------------------------------------------------------ A2 forward FFT (stock fft_vxx in the flowgraph)
+ * replaces gr::fft::fft_vcc(fft_size, forward=True, rectangular, shift=True)
+ * (apps/dvbt_rx_demo*.grc block fft_vxx_0). items of N cfloat in and out. */
+typedef struct { int fft_size; int forward; int shift; } dvbt_fft_params;
+typedef struct dvbt_fft dvbt_fft;
+int  dvbt_fft_create(const dvbt_fft_params *p, dvbt_fft **out);
+int  dvbt_fft_forecast(const dvbt_fft *h, int noutput_items, int *ninput_required);
+int  dvbt_fft_work(dvbt_fft *h, int noutput_items, int ninput_items, const void *in, void *out, dvbt_sideband *sb);
+void dvbt_fft_destroy(dvbt_fft *h);
+
+/* ------------------------------------------------------------------ A3 demod_reference_signals
+ * replaces demod_reference_signals::make(itemsize, ninput, noutput, constellation, hierarchy,
+ * code_rate_HP, code_rate_LP, guard_interval, transmission_mode, include_cell_id, cell_id)
+ * (include/dvbt/demod_reference_signals.h:50-54); general_work lib/demod_reference_signals_impl.cc:97-150.
+ * in: items of ninput cfloat (needs noutput_items+1 visible); out: items of noutput cfloat.
+ * Emits SUPERFRAME_START once and SYMBOL_INDEX per produced item. */
+typedef struct { int itemsize, ninput, noutput, constellation, hierarchy, code_rate_hp, code_rate_lp,
+                 guard_interval, transmission_mode, include_cell_id, cell_id; } dvbt_demod_reference_signals_params;
+typedef struct dvbt_demod_reference_signals dvbt_demod_reference_signals;
+int  dvbt_demod_reference_signals_create(const dvbt_demod_reference_signals_params *p, dvbt_demod_reference_signals **out);
+int  dvbt_demod_reference_signals_forecast(const dvbt_demod_reference_signals *h, int noutput_items, int *ninput_required);
+int  dvbt_demod_reference_signals_work(dvbt_demod_reference_signals *h, int noutput_items, int ninput_items,
+                                       const void *in, void *out, dvbt_sideband *sb);
+void dvbt_demod_reference_signals_destroy(dvbt_demod_reference_signals *h);
+
+/* ------------------------------------------------------------------ A4 dvbt_demap
+ * replaces dvbt_demap::make(nsize, constellation, hierarchy, transmission, gain)
+ * (include/dvbt/dvbt_demap.h:50); general_work lib/dvbt_demap_impl.cc:217-240. cfloat x nsize -> u8 x nsize */
+typedef struct { int nsize, constellation, hierarchy, transmission_mode; float gain; } dvbt_demap_params;
+typedef struct dvbt_demap dvbt_demap;
+int  dvbt_demap_create(const dvbt_demap_params *p, dvbt_demap **out);
+int  dvbt_demap_forecast(const dvbt_demap *h, int noutput_items, int *ninput_required);
+int  dvbt_demap_work(dvbt_demap *h, int noutput_items, int ninput_items, const void *in, void *out, dvbt_sideband *sb);
+void dvbt_demap_destroy(dvbt_demap *h);
+
+/* ------------------------------------------------------------------ A5 symbol_inner_interleaver
+ * replaces symbol_inner_interleaver::make(ninput, transmission, direction)
+ * (include/dvbt/symbol_inner_interleaver.h:50-51); general_work lib/symbol_inner_interleaver_impl.cc:161-219.
+ * direction 0 (RX) needs one SYMBOL_INDEX tag per item; direction 1 (TX) counts internally. */
+typedef struct { int nsize, transmission_mode, direction; } dvbt_symbol_inner_interleaver_params;
+typedef struct dvbt_symbol_inner_interleaver dvbt_symbol_inner_interleaver;
+int  dvbt_symbol_inner_interleaver_create(const dvbt_symbol_inner_interleaver_params *p, dvbt_symbol_inner_interleaver **out);
+int  dvbt_symbol_inner_interleaver_forecast(const dvbt_symbol_inner_interleaver *h, int noutput_items, int *ninput_required);
+int  dvbt_symbol_inner_interleaver_work(dvbt_symbol_inner_interleaver *h, int noutput_items, int ninput_items,
+                                        const void *in, void *out, dvbt_sideband *sb);
+void dvbt_symbol_inner_interleaver_destroy(dvbt_symbol_inner_interleaver *h);
+
+/* ------------------------------------------------------------------ A6 bit_inner_deinterleaver
+ * replaces bit_inner_deinterleaver::make(nsize, constellation, hierarchy, transmission)
+ * (include/dvbt/bit_inner_deinterleaver.h:50-51); general_work lib/bit_inner_deinterleaver_impl.cc:120-184
+ * (non-hierarchical: one output stream). */
+typedef struct { int nsize, constellation, hierarchy, transmission_mode; } dvbt_bit_inner_deinterleaver_params;
+typedef struct dvbt_bit_inner_deinterleaver dvbt_bit_inner_deinterleaver;
+int  dvbt_bit_inner_deinterleaver_create(const dvbt_bit_inner_deinterleaver_params *p, dvbt_bit_inner_deinterleaver **out);
+int  dvbt_bit_inner_deinterleaver_forecast(const dvbt_bit_inner_deinterleaver *h, int noutput_items, int *ninput_required);
+int  dvbt_bit_inner_deinterleaver_work(dvbt_bit_inner_deinterleaver *h, int noutput_items, int ninput_items,
+                                       const void *in, void *out, dvbt_sideband *sb);
+void dvbt_bit_inner_deinterleaver_destroy(dvbt_bit_inner_deinterleaver *h);
+
+/* ------------------------------------------------------------------ A7 viterbi_decoder
+ * replaces viterbi_decoder::make(constellation, hierarchy, coderate, bsize, S0, SK)
+ * (include/dvbt/viterbi_decoder.h:51-52); general_work lib/viterbi_decoder_impl.cc:192-324 and the
+ * SSE2 kernels lib/d_viterbi.c:461-576,680-735.  u8 stream (m bits per byte) -> u8 stream.
+ * noutput_items must be a multiple of bsize*k/8 (set_output_multiple, :141). A SUPERFRAME_START tag
+ * at rel_offset 0 resets the decoder; at rel_offset>0 the call consumes up to the tag and returns 0 (:213-229).
+ * Unlike the reference (file-scope static state) any number of instances may coexist. */
+typedef struct { int constellation, hierarchy, code_rate, bsize, S0, SK; } dvbt_viterbi_decoder_params;
+typedef struct dvbt_viterbi_decoder dvbt_viterbi_decoder;
+int  dvbt_viterbi_decoder_create(const dvbt_viterbi_decoder_params *p, dvbt_viterbi_decoder **out);
+int  dvbt_viterbi_decoder_forecast(const dvbt_viterbi_decoder *h, int noutput_items, int *ninput_required);
+int  dvbt_viterbi_decoder_work(dvbt_viterbi_decoder *h, int noutput_items, int ninput_items,
+                               const void *in, void *out, dvbt_sideband *sb);
+void dvbt_viterbi_decoder_destroy(dvbt_viterbi_decoder *h);
+
+/* ------------------------------------------------------------------ A8 convolutional_deinterleaver
+ * replaces convolutional_deinterleaver::make(nsize(blocks), I, M)
+ * (include/dvbt/convolutional_deinterleaver.h:49); general_work lib/convolutional_deinterleaver_impl.cc:93-150.
+ * u8 stream -> items of I*blocks bytes; noutput_items must be even (set_output_multiple(2)). */
+typedef struct { int blocks, I, M; } dvbt_convolutional_deinterleaver_params;
+typedef struct dvbt_convolutional_deinterleaver dvbt_convolutional_deinterleaver;
+int  dvbt_convolutional_deinterleaver_create(const dvbt_convolutional_deinterleaver_params *p, dvbt_convolutional_deinterleaver **out);
+int  dvbt_convolutional_deinterleaver_forecast(const dvbt_convolutional_deinterleaver *h, int noutput_items, int *ninput_required);
+int  dvbt_convolutional_deinterleaver_work(dvbt_convolutional_deinterleaver *h, int noutput_items, int ninput_items,
+                                           const void *in, void *out, dvbt_sideband *sb);
+void dvbt_convolutional_deinterleaver_destroy(dvbt_convolutional_deinterleaver *h);
+
+/* ------------------------------------------------------------------ A9 reed_solomon_dec
+ * replaces reed_solomon_dec::make(p, m, gfpoly, n, k, t, s, blocks)
+ * (include/dvbt/reed_solomon_dec.h:49); general_work lib/reed_solomon_dec_impl.cc:77-116 and
+ * reed_solomon::rs_decode lib/reed_solomon.cc:246-489. items of blocks*(n-s) -> blocks*(k-s) bytes.
+ * Only the DVB parameter set (2,8,0x11d,255,239,8,51) is accepted.
+ * oracle_compat = 1 reproduces the as-compiled reference quirk (SURVEY 8c last row / B-1). */
+typedef struct { int p, m, gfpoly, n, k, t, s, blocks; int oracle_compat; } dvbt_reed_solomon_dec_params;
+typedef struct dvbt_reed_solomon_dec dvbt_reed_solomon_dec;
+int  dvbt_reed_solomon_dec_create(const dvbt_reed_solomon_dec_params *p, dvbt_reed_solomon_dec **out);
+int  dvbt_reed_solomon_dec_forecast(const dvbt_reed_solomon_dec *h, int noutput_items, int *ninput_required);
+int  dvbt_reed_solomon_dec_work(dvbt_reed_solomon_dec *h, int noutput_items, int ninput_items,
+                                const void *in, void *out, dvbt_sideband *sb);
+void dvbt_reed_solomon_dec_destroy(dvbt_reed_solomon_dec *h);
+
+/* ------------------------------------------------------------------ next row: energy_descramble
+ * replaces energy_descramble::make(nblocks) (lib/energy_descramble_impl.cc:108-174).
+ * items of 8*188 bytes -> u8 stream. */
+typedef struct { int nblocks; } dvbt_energy_descramble_params;
+typedef struct dvbt_energy_descramble dvbt_energy_descramble;
+int  dvbt_energy_descramble_create(const dvbt_energy_descramble_params *p, dvbt_energy_descramble **out);
+int  dvbt_energy_descramble_forecast(const dvbt_energy_descramble *h, int noutput_items, int *ninput_required);
+int  dvbt_energy_descramble_work(dvbt_energy_descramble *h, int noutput_items, int ninput_items,
+                                 const void *in, void *out, dvbt_sideband *sb);
+void dvbt_energy_descramble_destroy(dvbt_energy_descramble *h);
+
+/* ------------------------------------------------------------------ segment API: the whole chain, device resident
+ * One segment = a contiguous run of baseband samples (complex64 at the OFDM elementary rate,
+ * i.e. the input of ofdm_sym_acquisition in apps/dvbt_rx_demo*.grc).  The segment is processed
+ * exactly as the flowgraph would process it from a cold start (acquire, hunt the superframe
+ * start, decode), every stage in HBM; the only host<->device traffic is the input (unless
+ * already on the device) and the decoded bytes + report. */
+typedef struct {
+  int constellation, hierarchy, code_rate, guard_interval, transmission_mode, include_cell_id, cell_id;
+  float snr_db;            /* ofdm_sym_acquisition snr, 30 in every demo flowgraph */
+  int viterbi_bsize;       /* 768 in every demo flowgraph */
+  int rs_oracle_compat;    /* see dvbt_reed_solomon_dec_params */
+  int descramble;          /* 1: also run energy_descramble and return TS */
+  size_t max_samples;      /* capacity: device buffers are sized for this many input samples */
+  int device;              /* HIP device ordinal */
+  int viterbi_chunk_bytes; /* 0 = default; decoded bytes per wavefront-chunk */
+} dvbt_rx_params;
+
+typedef struct {
+  int32_t status;              /* 0 ok; bit0: initial acquisition failed; bit1: CP tracking lost;
+                                  bit2: no superframe start found; bit3: tracking left the precomputed lag range */
+  int32_t n_symbols;           /* OFDM symbols acquired */
+  int32_t first_out_symbol;    /* symbol at which superframe_start fired, -1 if none */
+  int32_t n_out_symbols;       /* symbols passed downstream */
+  int32_t cp_start0;           /* d_cp_start after initial acquisition */
+  int32_t reserved0;
+  int64_t n_viterbi_bytes;
+  int64_t n_rs_items;          /* items of 8 codewords */
+  int64_t n_rs_bytes;          /* = n_rs_items*1504 */
+  int64_t n_ts_bytes;          /* after energy_descramble (0 when descramble==0) */
+  int32_t rs_fail_words, rs_corrected_symbols;
+} dvbt_rx_report;
+
+typedef enum {
+  DVBT_TAP_ACQ = 0,        /* cfloat[n_symbols][N]     output of A1 */
+  DVBT_TAP_FFT = 1,        /* cfloat[n_symbols][N]     output of A2 */
+  DVBT_TAP_EQ = 2,         /* cfloat[n_out_symbols][payload]  output of A3 (the float-tolerance tap) */
+  DVBT_TAP_DEMAP = 3,      /* u8[n_out_symbols][payload] */
+  DVBT_TAP_SYMDEINT = 4,
+  DVBT_TAP_BITDEINT = 5,
+  DVBT_TAP_VITERBI = 6,    /* u8[n_viterbi_bytes] */
+  DVBT_TAP_DEINT = 7,      /* u8[n_rs_items*1632] */
+  DVBT_TAP_RS = 8,         /* u8[n_rs_bytes] */
+  DVBT_TAP_TS = 9,         /* u8[n_ts_bytes] */
+  DVBT_TAP_CP_START = 10,  /* i32[n_symbols] */
+  DVBT_TAP_SYMBOL_INDEX = 11 /* i32[n_symbols] */
+} dvbt_tap;
+
+typedef struct dvbt_rx dvbt_rx;
+int  dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out);
+/* iq: host pointer to nsamples complex64 (copied to the device first) */
+int  dvbt_rx_segment_run(dvbt_rx *h, const void *iq_host, size_t nsamples, dvbt_rx_report *report);
+/* iq_device: device pointer (hipMalloc'd, e.g. a torch tensor's data_ptr). stream: a hipStream_t or NULL.
+ * Asynchronous w.r.t. the host: enqueue only.  Use dvbt_rx_segment_finish to wait and fetch the report. */
+int  dvbt_rx_segment_enqueue_device(dvbt_rx *h, const void *iq_device, size_t nsamples, void *stream);
+int  dvbt_rx_segment_finish(dvbt_rx *h, dvbt_rx_report *report);
+/* copy a tap of the last finished segment to host memory; returns bytes written */
+int64_t dvbt_rx_read_tap(dvbt_rx *h, int tap, void *dst_host, size_t cap_bytes);
+/* device pointer of a tap's buffer (for RCCL gathers of the decoded packets) */
+void *dvbt_rx_tap_device_ptr(dvbt_rx *h, int tap);
+/* average device time in ms of the named stage over all enqueues since create (HIP events on the
+ * segment's stream); stage names: "acq","fft","demod","inner","viterbi","rs","total" */
+double dvbt_rx_stage_ms(dvbt_rx *h, const char *stage);
+int  dvbt_rx_enable_timing(dvbt_rx *h, int enable);
+/* allocate (1) / free (0) the debug-only taps ACQ, DEMAP, SYMDEINT, DEINT; the other taps are
+ * pipeline buffers and always readable.  Call before the segment whose taps are wanted. */
+int  dvbt_rx_enable_taps(dvbt_rx *h, int enable);
+void dvbt_rx_destroy(dvbt_rx *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVBT_HIP_H */
