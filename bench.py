@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""bench.py -- RX Msamples/s of the DVB-T receive hot path on MI355X (BASELINE.json metric).
+
+One step = one pass of the whole chain (ofdm_sym_acquisition -> FFT -> demod_reference_signals ->
+dvbt_demap -> symbol/bit de-interleave -> viterbi_decoder -> convolutional_deinterleaver ->
+reed_solomon_dec -> energy_descramble) over one batch of synthetic loopback baseband that is already
+resident in HBM.  N>1: one process per GPU (torch.distributed / RCCL), every rank decodes its own
+independent segment (weak scaling) and the decoded TS bytes are gathered on rank 0 once per step.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md)
+REALTIME_MSPS = 64.0 / 7.0       # OFDM elementary rate at the input of ofdm_sym_acquisition
+
+
+class _DevView:
+    """Zero-copy torch view of a library-owned device buffer."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def make_input(cfg_name, n_superframes, seed):
+    """Synthetic loopback baseband from the test-utility TX generator: seeded random TS,
+    one extra lead-in superframe so the superframe hunt locks before the payload region."""
+    from oracle import pyoracle as po
+    const, cr, mode = {"8k_qam64_7_8": (po.QAM64, po.C7_8, po.T8k), "2k_qam16_1_2": (po.QAM16, po.C1_2, po.T2k),
+                       "8k_qpsk_7_8": (po.QPSK, po.C7_8, po.T8k)}[cfg_name]
+    c = po.cfg(const, cr, mode)
+    ibits = c.payload * c.m * c.k // c.n
+    npk = (272 * ibits * (n_superframes + 1)) // (204 * 8)
+    ts = po.make_ts(npk, seed)
+    iq = po.tx(c, ts, lead_in=1000, tail=3 * c.N)
+    return (const, cr, mode), c, iq
+
+
+def cpu_baseline(cfg_name, n_superframes=3):
+    """The oracle port (oracle/o_chain.c, single thread, -O3 -funroll-loops -msse2) timed on a bounded
+    sample of the same workload on this box's host cores."""
+    from oracle import pyoracle as po
+    (_, _, _), c, iq = make_input(cfg_name, n_superframes, 99)
+    t0 = time.time()
+    r = po.rx(c, iq, want=("ts",))
+    dt = time.time() - t0
+    return {"value": round(len(iq) / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": f"{n_superframes + 1} superframes of {cfg_name} ({len(iq)} samples, {dt:.1f} s), oracle/o_chain.c end to end",
+            "stage_seconds": [round(x, 3) for x in r["t_stage"]]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="8k_qam64_7_8")
+    ap.add_argument("--superframes", type=int, default=32, help="payload superframes per GPU per step")
+    ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-superframes", type=int, default=3)
+    a = ap.parse_args()
+
+    import torch
+    import gr_dvbt_amd as g
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    (const, cr, mode), c, iq = make_input(a.workload, a.superframes, 20240607 + rank)
+    nsamp = len(iq)
+    d_iq = torch.from_numpy(iq.view(np.float32)).cuda()
+    rx = g.Rx(const, cr, mode, max_samples=nsamp, device=local, viterbi_chunk_bytes=a.chunk)
+    stream = torch.cuda.current_stream().cuda_stream
+    ts_cap = int(nsamp * 0.45) + 4096
+    ts_view = torch.as_tensor(_DevView(rx.tap_device_ptr(g.TAP_TS), ts_cap), device=f"cuda:{local}")
+    gathered = [torch.empty(ts_cap, dtype=torch.uint8, device=f"cuda:{local}") for _ in range(world)] if (dist and rank == 0) else None
+
+    def step():
+        rx.enqueue_device(d_iq.data_ptr(), nsamp, stream)
+        rep = rx.finish()
+        if dist:                                   # the single exchange step: TS packets -> rank 0 over xGMI
+            dist.gather(ts_view, gathered, dst=0)
+        return rep
+
+    for _ in range(a.warmup):
+        rep = step()
+    rx.enable_timing(True)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        rep = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        msps = world * nsamp * a.steps / dt / 1e6
+        vit_ms = rx.stage_ms("viterbi")
+        # dominant kernel = viterbi_kernel: algorithmic bytes per launch = bytes in (one per m coded bits)
+        # + decoded bytes out (6048 + 3969 B per 8k QAM64 7/8 OFDM symbol)
+        d = rx.dims
+        vit_in = rep.n_out_symbols * d.payload_length
+        alg_bytes = vit_in + rep.n_viterbi_bytes
+        achieved = alg_bytes / (vit_ms * 1e-3) / 1e9 if vit_ms > 0 else 0.0
+        out = {
+            "metric": "RX Msamples/s (baseband in -> TS out)", "value": round(msps, 2), "unit": "Msamples/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 (Viterbi/RS) + f32 (front end)",
+            "data": "synthetic", "x_realtime": round(msps / REALTIME_MSPS / world, 1),
+            "config": {"workload": f"{a.workload} GI 1/32 RX chain, clean TX->RX loopback", "superframes_per_gpu": a.superframes + 1,
+                       "samples_per_gpu_per_step": nsamp, "parallelism": f"segments x{world}" + (" + RCCL gather of TS" if world > 1 else ""),
+                       "ts_bytes_per_step": int(rep.n_ts_bytes), "status": int(rep.status), "rs_fail_words": int(rep.rs_fail_words)},
+            "roofline": {"bound": "hbm", "kernel": "viterbi_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(vit_ms, 4),
+                         "chain_frac": round(msps / world * 1e6 * (8 + rep.n_ts_bytes / nsamp) / 1e9 / HBM_PEAK_GBS, 6)},
+            "stage_ms": {k: round(rx.stage_ms(k), 4) for k in ("acq", "fft", "demod", "inner", "viterbi", "rs", "total")},
+        }
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_superframes)
+        print(json.dumps(out))
+    rx.close()
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -183,3 +183,75 @@ class Rx:
             self.close()
         except Exception:
             pass
+
+
+# ------------------------------------------------------------------ per-block C ABI (one triple per reference block)
+TAG_SYNC_START, TAG_SUPERFRAME_START, TAG_SYMBOL_INDEX = 1, 2, 3
+
+
+class Tag(C.Structure):
+    _fields_ = [("rel_offset", C.c_int64), ("key", C.c_int32), ("value", C.c_int32)]
+
+
+class Sideband(C.Structure):
+    _fields_ = [("in_tags", C.POINTER(Tag)), ("n_in_tags", C.c_int), ("out_tags", C.POINTER(Tag)), ("out_cap", C.c_int),
+                ("n_out_tags", C.c_int), ("n_consumed", C.c_int)]
+
+
+def _params(fields):
+    return type("P", (C.Structure,), {"_fields_": fields})
+
+
+_I = C.c_int
+BLOCK_PARAMS = {
+    "ofdm_sym_acquisition": _params([("blocks", _I), ("fft_length", _I), ("occupied_tones", _I), ("cp_length", _I), ("snr", C.c_float)]),
+    "fft": _params([("fft_size", _I), ("forward", _I), ("shift", _I)]),
+    "demod_reference_signals": _params([(n, _I) for n in ("itemsize", "ninput", "noutput", "constellation", "hierarchy", "code_rate_hp",
+                                                          "code_rate_lp", "guard_interval", "transmission_mode", "include_cell_id", "cell_id")]),
+    "demap": _params([("nsize", _I), ("constellation", _I), ("hierarchy", _I), ("transmission_mode", _I), ("gain", C.c_float)]),
+    "symbol_inner_interleaver": _params([("nsize", _I), ("transmission_mode", _I), ("direction", _I)]),
+    "bit_inner_deinterleaver": _params([("nsize", _I), ("constellation", _I), ("hierarchy", _I), ("transmission_mode", _I)]),
+    "viterbi_decoder": _params([("constellation", _I), ("hierarchy", _I), ("code_rate", _I), ("bsize", _I), ("S0", _I), ("SK", _I)]),
+    "convolutional_deinterleaver": _params([("blocks", _I), ("I", _I), ("M", _I)]),
+    "reed_solomon_dec": _params([(n, _I) for n in ("p", "m", "gfpoly", "n", "k", "t", "s", "blocks", "oracle_compat")]),
+    "energy_descramble": _params([("nblocks", _I)]),
+}
+
+
+class Block:
+    """Generic driver of dvbt_<name>_{create,forecast,work,destroy}; mirrors gr::dvbt::<name>::make(...)."""
+
+    def __init__(self, name, *args):
+        self.L = lib()
+        self.name = name
+        self.params = BLOCK_PARAMS[name](*args)
+        self.h = C.c_void_p()
+        _chk(getattr(self.L, f"dvbt_{name}_create")(C.byref(self.params), C.byref(self.h)))
+        self._work = getattr(self.L, f"dvbt_{name}_work")
+        self._work.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(Sideband)]
+
+    def forecast(self, noutput_items):
+        n = C.c_int()
+        _chk(getattr(self.L, f"dvbt_{self.name}_forecast")(self.h, noutput_items, C.byref(n)))
+        return n.value
+
+    def work(self, noutput_items, ninput_items, inp, out, tags=()):
+        """returns (items produced, items consumed, [(rel_offset, key, value)] attached to the output)"""
+        tin = (Tag * max(len(tags), 1))(*[Tag(*t) for t in tags])
+        tout = (Tag * 4096)()
+        sb = Sideband(tin, len(tags), tout, 4096, 0, 0)
+        r = _chk(self._work(self.h, noutput_items, ninput_items, inp.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.byref(sb)))
+        return r, sb.n_consumed, [(tout[i].rel_offset, tout[i].key, tout[i].value) for i in range(min(sb.n_out_tags, 4096))]
+
+    def close(self):
+        if self.h:
+            fn = getattr(self.L, f"dvbt_{self.name}_destroy")
+            fn.argtypes = [C.c_void_p]
+            fn(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

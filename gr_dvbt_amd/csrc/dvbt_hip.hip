@@ -161,6 +161,7 @@ struct dvbt_rx {
   float2 *d_iq = nullptr;              // only when input comes from the host
   float2 *g_init = nullptr; float *l_init = nullptr; float2 *g_trk = nullptr; float *l_trk = nullptr;
   SymMeta *meta = nullptr; RxState *st = nullptr, *st_host = nullptr; TpsState *tps_state = nullptr;
+  int *trk_cp_a = nullptr, *trk_cp_b = nullptr, *trk_flags = nullptr; float *trk_eps = nullptr;
   float2 *acq_tap = nullptr, *fft_out = nullptr, *eq = nullptr, *tpsval = nullptr; SymInfo *info = nullptr; int *maj = nullptr, *sym_index = nullptr;
   uint8_t *demap_tap = nullptr, *symdeint_tap = nullptr, *bitdeint = nullptr, *vit = nullptr, *deint_tap = nullptr, *rs_out = nullptr, *ts_out = nullptr;
   size_t vit_cap = 0;
@@ -171,7 +172,7 @@ struct dvbt_rx {
 
 static void rx_free(dvbt_rx *h)
 {
-  void *all[] = {h->d_iq, h->g_init, h->l_init, h->g_trk, h->l_trk, h->meta, h->st, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
+  void *all[] = {h->trk_cp_a, h->trk_cp_b, h->trk_flags, h->trk_eps, h->d_iq, h->g_init, h->l_init, h->g_trk, h->l_trk, h->meta, h->st, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
                  h->info, h->maj, h->sym_index, h->demap_tap, h->symdeint_tap, h->bitdeint, h->vit, h->deint_tap, h->rs_out, h->ts_out};
   for (void *q : all) if (q) (void)hipFree(q);
   if (h->st_host) (void)hipHostFree(h->st_host);
@@ -204,7 +205,9 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   const size_t C = (size_t)h->max_calls, N = d.N, P = d.payload;
   RXHIP(hipMalloc((void **)&h->g_init, sizeof(float2) * ACQ_INIT_TRIES * N)); RXHIP(hipMalloc((void **)&h->l_init, sizeof(float) * ACQ_INIT_TRIES * N));
   RXHIP(hipMalloc((void **)&h->g_trk, sizeof(float2) * C * 2 * ACQ_R)); RXHIP(hipMalloc((void **)&h->l_trk, sizeof(float) * C * 2 * ACQ_R));
-  RXHIP(hipMalloc((void **)&h->meta, sizeof(SymMeta) * C)); RXHIP(hipMalloc((void **)&h->st, sizeof(RxState)));
+  RXHIP(hipMalloc((void **)&h->meta, sizeof(SymMeta) * C));
+  RXHIP(hipMalloc((void **)&h->trk_cp_a, sizeof(int) * C)); RXHIP(hipMalloc((void **)&h->trk_cp_b, sizeof(int) * C));
+  RXHIP(hipMalloc((void **)&h->trk_eps, sizeof(float) * C)); RXHIP(hipMalloc((void **)&h->trk_flags, sizeof(int) * 16)); RXHIP(hipMalloc((void **)&h->st, sizeof(RxState)));
   RXHIP(hipHostMalloc((void **)&h->st_host, sizeof(RxState))); RXHIP(hipMalloc((void **)&h->tps_state, sizeof(TpsState)));
   RXHIP(hipMalloc((void **)&h->fft_out, sizeof(float2) * C * N)); RXHIP(hipMalloc((void **)&h->eq, sizeof(float2) * C * P));
   RXHIP(hipMalloc((void **)&h->tpsval, sizeof(float2) * C * d.n_tps)); RXHIP(hipMalloc((void **)&h->info, sizeof(SymInfo) * C));
@@ -256,9 +259,19 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s)
   HIPCHK(hipMemsetAsync(h->tps_state, 0, sizeof(TpsState), s));
   int tries = C < ACQ_INIT_TRIES ? C : ACQ_INIT_TRIES;
   hipLaunchKernelGGL(acq_metric_kernel, dim3((N + 255) / 256, tries), dim3(256), 0, s, iq, fp, (const RxState *)h->st, 0, h->g_init, h->l_init);
-  hipLaunchKernelGGL(acq_init_fsm_kernel, dim3(1), dim3(64), 0, s, fp, h->st, (const float2 *)h->g_init, (const float *)h->l_init);
+  hipLaunchKernelGGL(acq_init_fsm_kernel, dim3(1), dim3(256), (size_t)N * 4, s, fp, h->st, (const float2 *)h->g_init, (const float *)h->l_init, (const AcqState *)nullptr);
+  HIPCHK(hipMemsetAsync(h->trk_flags, 0, sizeof(int) * 16, s));
   hipLaunchKernelGGL(acq_metric_kernel, dim3((C * 2 * ACQ_R + 255) / 256), dim3(256), 0, s, iq, fp, (const RxState *)h->st, 1, h->g_trk, h->l_trk);
-  hipLaunchKernelGGL(acq_track_kernel, dim3(1), dim3(64), 0, s, fp, h->st, (const float2 *)h->g_trk, (const float *)h->l_trk, h->meta);
+  constexpr int kIters = 4;                     // Jacobi iterations of the window placement; flags[kIters] = need_seq
+  for (int it = 0; it < kIters; it++) {
+    int *cin = (it & 1) ? h->trk_cp_a : h->trk_cp_b, *cout = (it & 1) ? h->trk_cp_b : h->trk_cp_a;
+    hipLaunchKernelGGL(acq_track_par_kernel, dim3((C + 255) / 256), dim3(256), 0, s, fp, (const RxState *)h->st, (const float2 *)h->g_trk,
+                       (const float *)h->l_trk, (const int *)cin, cout, h->trk_eps, h->trk_flags, it);
+  }
+  hipLaunchKernelGGL(acq_finalize_kernel, dim3(1), dim3(1024), 0, s, fp, h->st, (const int *)h->trk_cp_a, (const float *)h->trk_eps,
+                     (const int *)h->trk_flags, kIters - 1, h->meta, h->trk_flags + kIters);
+  hipLaunchKernelGGL(acq_track_kernel, dim3(1), dim3(64), 0, s, fp, h->st, (const float2 *)h->g_trk, (const float *)h->l_trk, h->meta,
+                     (const int *)(h->trk_flags + kIters), (AcqState *)nullptr);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_FFT], s));
   hipLaunchKernelGGL(derot_fft_kernel, dim3(C), dim3(256), (size_t)N * 8, s, iq, fp, (const RxState *)h->st, (const SymMeta *)h->meta,
                      (const float2 *)h->T.tw, (const uint16_t *)h->T.perm, h->acq_tap, h->fft_out);
@@ -268,7 +281,7 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s)
   hipLaunchKernelGGL(tps_vote_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float2 *)h->tpsval, d.n_tps, (const RxState *)h->st, 0,
                      (const float2 *)nullptr, h->maj);
   hipLaunchKernelGGL(tps_fsm_kernel, dim3(1), dim3(64), 0, s, fp, h->st, 0, (const SymInfo *)h->info, (const int *)h->maj, h->tps_state,
-                     h->sym_index, (int *)nullptr);
+                     h->sym_index, (int *)nullptr, (const unsigned char *)nullptr);
   hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(64), 0, s, h->st, h->vp, h->prm.descramble);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_INNER], s));
   InnerParams ip; ip.payload = d.payload; ip.m = d.m; ip.csize = d.csize;
@@ -279,7 +292,7 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s)
   long long max_vit = (long long)C * d.payload * d.m * d.k / (8 * d.n) + 1;
   long long max_chunks = (max_vit + h->vp.chunk_bytes - 1) / h->vp.chunk_bytes;
   hipLaunchKernelGGL(viterbi_kernel, dim3((unsigned)((max_chunks + 3) / 4)), dim3(256), 0, s, (const uint8_t *)h->bitdeint, h->vit,
-                     (const RxState *)h->st, 0ll, h->vp);
+                     (const RxState *)h->st, 0ll, h->vp, 0ll, 0ll);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_RS], s));
   long long max_words = max_vit / 204 + 1;
   hipLaunchKernelGGL(deint_rs_kernel, dim3((unsigned)((max_words + 63) / 64)), dim3(64), 0, s, (const uint8_t *)h->vit, h->deint_tap, h->rs_out,

@@ -115,8 +115,10 @@ constexpr int VIT_RING = 128;       // windows kept in LDS (>= 64 + ntraceback)
 
 __device__ __forceinline__ int parity6(int x) { return __popc(x) & 1; }
 
+// in_base: stream index of in[0]; out_lo: first decoded byte this launch has to produce (out[0] is
+// that byte).  Both 0 for a whole segment; non-zero only for the streaming block API.
 __global__ __launch_bounds__(256) void viterbi_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const RxState *st,
-                                                     long long steps_fixed, VitParams vp)
+                                                     long long steps_fixed, VitParams vp, long long in_base, long long out_lo)
 {
   __shared__ unsigned long long s_dec[4][VIT_RING * 8];
   __shared__ unsigned char s_best[4][VIT_RING];
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(256) void viterbi_kernel(const uint8_t *__restrict_
   const long long total_steps = st ? st->n_vit_steps : steps_fixed;
   const long long total_out = total_steps / 8 - vp.ntb;
   const long long chunk = (long long)blockIdx.x * 4 + wv;
-  const long long b0 = chunk * vp.chunk_bytes;
+  const long long b0 = out_lo + chunk * vp.chunk_bytes;
   if (b0 >= total_out) return;
   long long b1 = b0 + vp.chunk_bytes; if (b1 > total_out) b1 = total_out;
   const int ntb = vp.ntb;
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256) void viterbi_kernel(const uint8_t *__restrict_
             if (vp.punct[phh]) {
               unsigned long long rb = q * (unsigned)vp.n + vp.prefix[phh];
               unsigned long long byte = rb / (unsigned)vp.m; int bo = (int)(rb - byte * vp.m);
-              r[h] = (in[byte] >> (vp.m - 1 - bo)) & 1u;
+              r[h] = (in[byte - in_base] >> (vp.m - 1 - bo)) & 1u;
             } else r[h] = 2u;
           }
           code = r[0] | (r[1] << 2);
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(256) void viterbi_kernel(const uint8_t *__restrict_
         unsigned byte = 0;
 #pragma unroll
         for (int k = 7; k >= 0; k--) { unsigned b = (unsigned)(dw[k] >> s) & 1u; byte |= b << (7 - k); s = (s >> 1) | (b << 5); }
-        out[c - ntb - 1] = (unsigned char)byte;
+        out[c - ntb - 1 - out_lo] = (unsigned char)byte;
       }
     }
   }
@@ -233,7 +235,7 @@ __device__ inline int rs_decode_word(uint8_t *d /* 204 bytes, index 0 = codeword
   auto gmul = [&](int a, int b) -> int { return (a == 0 || b == 0) ? 0 : gexp[glog[a] + glog[b]]; };
   auto gdiv = [&](int a, int b) -> int { return (a == 0 || b == 0) ? 0 : gexp[255 + glog[a] - glog[b]]; };
   auto gpow = [&](int a, int pw) -> int { return a == 0 ? 0 : gexp[(glog[a] + pw) % 255]; };
-  uint8_t sigma[17], b[17], T[17], reg[17], root[17], loc[17], omega[17];
+  uint8_t sigma[17], b[17], T[17], root[17], loc[17], omega[17];
   for (int i = 0; i < 17; i++) { sigma[i] = 0; b[i] = 0; }
   sigma[0] = 1; b[0] = 1;
   int r = 0, el = 0;
@@ -251,11 +253,13 @@ __device__ inline int rs_decode_word(uint8_t *d /* 204 bytes, index 0 = codeword
   }
   int deg_sigma = 0;
   for (int i = 0; i <= 16; i++) if (sigma[i]) deg_sigma = i;
-  int no_roots = 0;                                               // Chien :376-403
-  for (int i = 1; i <= 16; i++) reg[i] = sigma[i];
+  int no_roots = 0;                                               // Chien :376-403, registers kept in the log domain
+  int lr[17];
+  for (int i = 1; i <= 16; i++) lr[i] = sigma[i] ? glog[sigma[i]] : -1;
   for (int i = 1; i <= 255; i++) {
     int q = 1;
-    for (int j = deg_sigma; j > 0; j--) { reg[j] = (uint8_t)gpow(reg[j], j); q ^= reg[j]; }
+    for (int j = deg_sigma; j > 0; j--)
+      if (lr[j] >= 0) { lr[j] += j; if (lr[j] >= 255) lr[j] -= 255; q ^= gexp[lr[j]]; }
     if (q != 0) continue;
     root[no_roots] = (uint8_t)i; loc[no_roots] = (uint8_t)(i - 1);
     if (++no_roots == deg_sigma) break;
@@ -337,6 +341,17 @@ __global__ __launch_bounds__(64) void deint_rs_kernel(const uint8_t *__restrict_
   __syncthreads();
   // coalesced store of 64 x 188 payload bytes (reed_solomon_dec_impl.cc:102: output regardless of success)
   for (int i = tid; i < nw * 188; i += 64) { int ww = i / 188, p = i - ww * 188; out[(w0 + ww) * 188 + p] = s_cw[ww * 204 + p]; }
+}
+
+// A8 alone (block API): buf holds `hist` bytes of history followed by the call's n input bytes;
+// stream index of buf[hist] is `pos0`.  out[i] = stream[pos0+i - 204*(11-(pos0+i)%12)], 0 before the start.
+__global__ __launch_bounds__(256) void conv_deint_kernel(const uint8_t *__restrict__ buf, long long hist, long long pos0, long long n,
+                                                        uint8_t *__restrict__ out)
+{
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    long long g = pos0 + i, d = 204ll * (11 - (g % 12)), src = g - d;
+    out[i] = (src >= 0 && i - d + hist >= 0) ? buf[hist + i - d] : 0;
+  }
 }
 
 // ---------------------------------------------------------------- next row: energy_descramble (energy_descramble_impl.cc:108-174)

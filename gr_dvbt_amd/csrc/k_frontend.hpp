@@ -34,6 +34,9 @@ struct FrontParams {
   float half_rho;        // (float)(rho/2)
 };
 
+// persistent members of the acquisition block between work() calls (block API only)
+struct AcqState { int acquired; int cp_start; float avg; float phase; double phaseinc, nextphaseinc; int nextpos; int lost; };
+
 constexpr int ACQ_R = 16;
 constexpr int ACQ_INIT_TRIES = 4;
 
@@ -107,46 +110,79 @@ __device__ __forceinline__ float wrap_pi(double ph)
   return (float)ph;
 }
 
-// initial acquisition FSM (general_work :498-510): sequential by nature (IIR + state machine)
-__global__ void acq_init_fsm_kernel(FrontParams p, RxState *st, const float2 *gamma, const float *lambda)
+// initial acquisition FSM (general_work :498-510): sequential by nature (IIR + state machine).
+// The N metric values of one try are staged in LDS by the whole workgroup so that the single
+// walking lane pays LDS, not HBM, latency per step.
+__global__ __launch_bounds__(256) void acq_init_fsm_kernel(FrontParams p, RxState *st, const float2 *gamma, const float *lambda, const AcqState *as)
 {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  float avg = 0.f;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float *lam = reinterpret_cast<float *>(smem_raw);
+  __shared__ int s_done;
+  __shared__ float s_avg;
+  const int tid = threadIdx.x;
   int tries = p.ncalls < ACQ_INIT_TRIES ? p.ncalls : ACQ_INIT_TRIES;
-  st->status = 1; st->call0 = 0; st->cp_start0 = 0; st->n_symbols = 0; st->first_out = -1; st->n_out_symbols = 0;
-  st->n_vit_in = st->n_vit_steps = st->n_vit_bytes = st->n_rs_items = st->n_ts_bytes = 0; st->rs_fail = st->rs_corr = 0;
-  for (int t = 0; t < tries; t++) {
-    int pos = 0;
-    int npk = peak_detect(lambda + (size_t)t * p.N, p.N, avg, pos);
-    if (npk) {
-      float2 g = gamma[(size_t)t * p.N + pos];
-      st->status = 0; st->call0 = t; st->cp_start0 = pos + p.N + p.cp - 1;
-      st->eps_init = atan2f(g.y, g.x); st->avg = avg;
-      return;
+  if (tid == 0) {
+    st->status = 1; st->call0 = 0; st->cp_start0 = 0; st->n_symbols = 0; st->first_out = -1; st->n_out_symbols = 0;
+    st->n_vit_in = st->n_vit_steps = st->n_vit_bytes = st->n_rs_items = st->n_ts_bytes = 0; st->rs_fail = st->rs_corr = 0;
+    s_done = 0; s_avg = as ? as->avg : 0.f;
+    if (as && as->acquired) {          // block API: still locked from the previous work() call, nothing to search
+      st->status = 0; st->cp_start0 = as->cp_start; st->eps_init = 0.f; s_done = 2;
     }
   }
-  st->avg = avg;
+  __syncthreads();
+  if (s_done == 2) { if (tid == 0) st->avg = s_avg; return; }
+  for (int t = 0; t < tries; t++) {
+    for (int i = tid; i < p.N; i += 256) lam[i] = lambda[(size_t)t * p.N + i];
+    __syncthreads();
+    if (tid == 0) {
+      float avg = s_avg; int pos = 0;
+      int npk = peak_detect(lam, p.N, avg, pos);
+      s_avg = avg;
+      if (npk) {
+        float2 g = gamma[(size_t)t * p.N + pos];
+        st->status = 0; st->call0 = t; st->cp_start0 = pos + p.N + p.cp - 1;
+        st->eps_init = atan2f(g.y, g.x); s_done = 1;
+      }
+    }
+    __syncthreads();
+    if (s_done) break;
+  }
+  if (tid == 0) st->avg = s_avg;
 }
 
 // tracking FSM over all windows (general_work :512-560 + the phase bookkeeping of ml_sync :285-313).
 // Sequential reference version: one thread walks the calls.
 struct SymMeta { int cp_start; int sw; float eps; float ph_base; double incA, incB; };
 
-__global__ void acq_track_kernel(FrontParams p, RxState *st, const float2 *gamma, const float *lambda, SymMeta *meta)
+__global__ void acq_track_kernel(FrontParams p, RxState *st, const float2 *gamma, const float *lambda, SymMeta *meta, const int *need_seq,
+                                 AcqState *as)
 {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (st->status & 1) return;
+  if (st->status & 1) { if (as) { as->avg = st->avg; as->lost = 0; } return; }
+  if (need_seq && *need_seq == 0) return;
   const int N = p.N, cp = p.cp, R = p.R, c0 = st->cp_start0;
   float avg = st->avg, phase = 0.f;
   double phaseinc = 0.0, nextphaseinc = (-1.0 / (double)N) * (double)st->eps_init;
   int nextpos = c0 - (N + cp), cur = c0, s = 0;
+  if (as) {
+    phase = as->phase; phaseinc = as->phaseinc;
+    if (as->acquired) { nextphaseinc = as->nextphaseinc; nextpos = as->nextpos; }
+    else {
+      // the initial ml_sync of this call ran the phase loop once with the carried increments (:285-313)
+      double tot = (as->nextpos >= 0 && as->nextpos < N + cp) ? as->nextpos * as->phaseinc + (N + cp - as->nextpos) * as->nextphaseinc
+                                                              : (double)(N + cp) * as->phaseinc;
+      if (as->nextpos >= 0 && as->nextpos < N + cp) phaseinc = as->nextphaseinc;
+      phase = wrap_pi((double)phase + tot);
+    }
+  }
+  bool lost = false;
   for (int call = st->call0; call < p.ncalls; call++, s++) {
     int rel0 = (cur - 8) - (c0 - R);
     if (rel0 < 0 || rel0 + 16 > 2 * R) { st->status |= 8; break; }
     const float *lam = lambda + (size_t)call * 2 * R + rel0;
     int pos = 0;
     int npk = peak_detect(lam, 16, avg, pos);
-    if (!npk) { st->status |= 2; break; }       // the reference would drop lock and re-acquire (:545-559)
+    if (!npk) { st->status |= 2; lost = true; break; }   // the reference drops lock and re-acquires (:545-559)
     float2 g = gamma[(size_t)call * 2 * R + rel0 + pos];
     float eps = atan2f(g.y, g.x);
     int peak = pos + cur - 8;
@@ -161,6 +197,128 @@ __global__ void acq_track_kernel(FrontParams p, RxState *st, const float2 *gamma
     cur = peak;
   }
   st->n_symbols = s;
+  if (as) {
+    if (lost) {   // the failing call still advanced the phase by N+cp steps without switching (:336-345)
+      phase = wrap_pi((double)phase + (double)(N + cp) * phaseinc);
+    }
+    as->acquired = lost ? 0 : 1; as->lost = lost ? 1 : 0; as->cp_start = cur; as->avg = avg; as->phase = phase;
+    as->phaseinc = phaseinc; as->nextphaseinc = nextphaseinc; as->nextpos = nextpos;
+  }
+}
+
+// ---- parallel tracking.  Two facts make the per-call FSM independent of its predecessors:
+//  (1) every sample of a window updates d_avg with the same expression whatever the FSM state,
+//      so d_avg entering call j is a plain IIR (x0.1 per sample) over the earlier windows; after
+//      the 32 samples of the two previous calls the older history weighs 1e-32 -- far below half
+//      an ulp -- so restarting the IIR two calls back reproduces the float value;
+//  (2) the window position only depends on the previous call's peak.
+// Jacobi iteration on (2): iteration k places call j's window with iteration k-1's peak of call
+// j-1 (iteration 0: cp_start0 everywhere) until nothing changes; the fixed point is the
+// sequential trajectory by induction from call0.  If it has not converged after the last
+// iteration the sequential kernel above is run instead (flag checked on the device).
+struct TrackWork { int *cp_a; int *cp_b; float *eps; int *changed; /* [iters+1] */ };
+
+__global__ __launch_bounds__(256) void acq_track_par_kernel(FrontParams p, const RxState *st, const float2 *__restrict__ gamma,
+                                                           const float *__restrict__ lambda, const int *__restrict__ cp_in,
+                                                           int *__restrict__ cp_out, float *__restrict__ eps_out, int *changed, int iter)
+{
+  if (st->status & 1) return;
+  if (iter > 0 && changed[iter - 1] == 0) return;               // already at the fixed point
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  const int call = st->call0 + s;
+  if (call >= p.ncalls) return;
+  const int R = p.R, c0 = st->cp_start0;
+  auto prev_cp = [&](int ss) -> int { return ss <= 0 ? c0 : (iter == 0 ? c0 : cp_in[ss - 1]); };   // peak of call ss-1
+  float avg;
+  int first_warm;
+  if (s <= 2) { avg = st->avg; first_warm = 0; } else { avg = 0.f; first_warm = s - 2; }
+  bool bad = false;
+  for (int ws = first_warm; ws < s; ws++) {                      // IIR over the earlier windows (fact 1)
+    int cur = prev_cp(ws);
+    if (cur < 0) { bad = true; break; }
+    int rel0 = (cur - 8) - (c0 - R);
+    if (rel0 < 0 || rel0 + 16 > 2 * R) { bad = true; break; }
+    const float *lam = lambda + (size_t)(st->call0 + ws) * 2 * R + rel0;
+    for (int i = 0; i < 16; i++) avg = 0.9f * lam[i] + (1 - 0.9f) * avg;
+  }
+  int cur = prev_cp(s), res = -1; float eps = 0.f;
+  if (!bad && cur >= 0) {
+    int rel0 = (cur - 8) - (c0 - R);
+    if (rel0 < 0 || rel0 + 16 > 2 * R) res = -2;                // left the precomputed lag range
+    else {
+      float lam[16];
+      const float *lp = lambda + (size_t)call * 2 * R + rel0;
+      for (int i = 0; i < 16; i++) lam[i] = lp[i];
+      int pos = 0;
+      int npk = peak_detect(lam, 16, avg, pos);
+      if (npk) { res = pos + cur - 8; float2 g = gamma[(size_t)call * 2 * R + rel0 + pos]; eps = atan2f(g.y, g.x); }
+    }
+  }
+  cp_out[s] = res; eps_out[s] = eps;
+  int old = iter == 0 ? c0 : cp_in[s];
+  if (res != old) atomicOr(&changed[iter], 1);
+}
+
+// bookkeeping after the fixed point: n_symbols = calls before the first miss; derotation phase
+// parameters per symbol (ml_sync :285-313).  One workgroup; prefix sum of the per-call phase
+// advance in double.  Falls back to nothing when the Jacobi iteration did not converge
+// (acq_track_kernel then overwrites everything).
+__global__ __launch_bounds__(1024) void acq_finalize_kernel(FrontParams p, RxState *st, const int *__restrict__ cp, const float *__restrict__ eps,
+                                                           const int *changed, int last_iter, SymMeta *__restrict__ meta, int *need_seq)
+{
+  __shared__ double s_tot[1024];
+  __shared__ int s_first_bad, s_viol;
+  const int tid = threadIdx.x;
+  if (st->status & 1) { if (tid == 0) *need_seq = 0; return; }
+  bool converged = false;
+  for (int i = 0; i <= last_iter; i++) if (changed[i] == 0) converged = true;
+  if (!converged) { if (tid == 0) *need_seq = 1; return; }
+  if (tid == 0) { *need_seq = 0; s_first_bad = p.ncalls - st->call0; s_viol = 0; }
+  __syncthreads();
+  const int ntot = p.ncalls - st->call0, N = p.N, cpl = p.cp, c0 = st->cp_start0;
+  for (int s = tid; s < ntot; s += 1024) if (cp[s] < 0) atomicMin(&s_first_bad, s);
+  __syncthreads();
+  const int nsym = s_first_bad;
+  // the closed form below needs every phase-increment switch to fall inside its call
+  for (int s = tid; s < nsym; s += 1024) { int sw = (s == 0 ? c0 : cp[s - 1]) - (N + cpl); if (sw < 0 || sw >= N + cpl) s_viol = 1; }
+  __syncthreads();
+  if (s_viol) { if (tid == 0) *need_seq = 1; return; }
+  // per-call quantities: entering call s: nextpos = cp[s-1]-(N+cp), incB = -eps[s-1]/N, incA = -eps[s-2]/N
+  // (valid when every switch position lies inside the call, i.e. N+cp <= cp < 2N+2cp: always true
+  //  for a tracked peak, which lives in [N+cp-1+8, 2N+cp-2]; cp == N+cp-1.. is guarded below)
+  auto epsm = [&](int s) -> double { return s < 0 ? (s == -1 ? (double)st->eps_init : 0.0) : (double)eps[s]; };
+  auto cpm = [&](int s) -> int { return s < 0 ? c0 : cp[s]; };
+  const int per = (nsym + 1023) / 1024;
+  double local = 0.0;
+  for (int i = 0; i < per; i++) {
+    int s = tid * per + i;
+    if (s >= nsym) break;
+    int sw = cpm(s - 1) - (N + cpl);
+    double A = s == 0 ? 0.0 : (-1.0 / N) * epsm(s - 2), B = (-1.0 / N) * epsm(s - 1);
+    local += (sw >= 0 && sw < N + cpl) ? sw * A + (N + cpl - sw) * B : (double)(N + cpl) * A;
+  }
+  s_tot[tid] = local;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {                     // inclusive scan
+    double v = tid >= off ? s_tot[tid - off] : 0.0;
+    __syncthreads();
+    s_tot[tid] += v;
+    __syncthreads();
+  }
+  double base = tid == 0 ? 0.0 : s_tot[tid - 1];
+  for (int i = 0; i < per; i++) {
+    int s = tid * per + i;
+    if (s >= nsym) break;
+    int sw = cpm(s - 1) - (N + cpl);
+    double A = s == 0 ? 0.0 : (-1.0 / N) * epsm(s - 2), B = (-1.0 / N) * epsm(s - 1);
+    SymMeta m; m.cp_start = cp[s]; m.eps = eps[s]; m.sw = sw; m.incA = A; m.incB = B; m.ph_base = wrap_pi(base);
+    meta[s] = m;
+    base += (sw >= 0 && sw < N + cpl) ? sw * A + (N + cpl - sw) * B : (double)(N + cpl) * A;
+  }
+  if (tid == 0) {
+    st->n_symbols = nsym;
+    if (nsym < ntot) st->status |= (cp[nsym] == -2) ? 8 : 2;
+  }
 }
 
 // ---------------------------------------------------------------- A1 tail + A2: derotate, strip CP, forward FFT with shift
@@ -192,6 +350,7 @@ __global__ __launch_bounds__(256) void derot_fft_kernel(const float2 *__restrict
     x[n] = v;
     if (acq_tap) acq_tap[(size_t)s * N + n] = v;
   }
+  if (!out) return;                              // A1 alone (block API): derotated, CP-stripped item only
   __syncthreads();
   int L = N;
   while (L >= 4) {
@@ -442,7 +601,7 @@ __device__ inline int bch_check(unsigned long long lo, unsigned hi)
 // symbol/frame bookkeeping: parse_input :1228-1241, process_tps_data :952-1028,
 // demod_reference_signals_impl.cc:108-143 (one item per call regime).  Sequential over symbols.
 __global__ void tps_fsm_kernel(FrontParams p, RxState *st, int nitems_fixed, const SymInfo *info, const int *maj,
-                               TpsState *ts, int *sym_index, int *superframe_flag)
+                               TpsState *ts, int *sym_index, int *superframe_flag, const unsigned char *sync_flags)
 {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const int nsym = st ? st->n_symbols : nitems_fixed;
@@ -473,6 +632,7 @@ __global__ void tps_fsm_kernel(FrontParams p, RxState *st, int nitems_fixed, con
       t.fifo_lo = 0; t.fifo_hi = 0;
     }
     sym_index[s] = si;
+    if (sync_flags && sync_flags[s]) t.d_init = 0;               // sync_start tag: hunt the superframe start again (:115-116)
     int sf = 0;
     if (!t.d_init && (si % 68) == 0 && (fi % 4) == p.fi_start) { t.d_init = 1; sf = 1; if (first_out < 0) first_out = s; }
     if (superframe_flag) superframe_flag[s] = t.d_init ? (sf ? 2 : 1) : 0;   // 0 dropped, 1 produced, 2 produced + superframe_start

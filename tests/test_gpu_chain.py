@@ -1,0 +1,156 @@
+"""GPU parity of the whole RX chain (segment API of the C ABI) against the oracle, tap by tap.
+
+Integer taps (demapper decisions onward) must be bit-exact on a clean TX->RX loopback; the float
+taps are compared within the stated tolerance: |delta| <= 1e-3 of the constellation unit spacing
+(2*d_norm) per component at the equalised-carrier tap, and <= 1e-5 of the symbol's peak
+magnitude at the FFT tap.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+WANT = ("acq", "fft", "eq", "demap", "symdeint", "bitdeint", "vit", "deint", "rs", "ts")
+
+
+def _make(po, const, cr, mode, nsf, seed, lead=1000, snr=None):
+    c = po.cfg(const, cr, mode)
+    ibits = c.payload * c.m * c.k // c.n
+    npk = (272 * ibits * nsf) // (204 * 8)
+    ts = po.make_ts(npk, seed)
+    iq = po.tx(c, ts, lead_in=lead, tail=3 * c.N)
+    if snr is not None:
+        rng = np.random.RandomState(5)
+        p = np.mean(np.abs(iq[lead:lead + 100000]) ** 2)
+        sig = np.sqrt(p / (10 ** (snr / 10)) / 2)
+        iq = (iq + sig * (rng.randn(len(iq)) + 1j * rng.randn(len(iq)))).astype(np.complex64)
+    return c, iq
+
+
+@pytest.fixture(scope="module")
+def g():
+    import gr_dvbt_amd
+    assert gr_dvbt_amd.device_count() > 0, "GPU tests need a GPU; the product path has no fallback"
+    return gr_dvbt_amd
+
+
+# BASELINE.json configs 2 and 3 (+ a non byte-aligned one and an odd chunk size)
+@pytest.mark.parametrize("const,cr,mode,nsf,chunk,lead", [
+    (1, 0, 0, 3, 0, 1000),        # 2k QAM16 1/2
+    (2, 4, 1, 2, 0, 1000),        # 8k QAM64 7/8
+    (0, 4, 1, 2, 0, 4000),        # 8k QPSK 7/8
+    (2, 2, 0, 3, 200, 333),       # 2k QAM64 3/4: OFDM symbols not byte aligned; chunk not a multiple of 64
+    (1, 3, 1, 2, 4096, 1000),     # 8k QAM16 5/6
+])
+def test_clean_loopback_every_tap(po, g, const, cr, mode, nsf, chunk, lead):
+    c, iq = _make(po, const, cr, mode, nsf, 11, lead)
+    o = po.rx(c, iq, want=WANT)
+    rx = g.Rx(const, cr, mode, max_samples=len(iq), taps=True, viterbi_chunk_bytes=chunk)
+    rep = rx.run(iq)
+    assert rep.n_symbols == o["n_acquired"] and rep.first_out_symbol == o["first_out_symbol"] >= 0
+    assert (rx.tap(g.TAP_CP_START) == o["cp_start"]).all()
+    assert (rx.tap(g.TAP_SYMBOL_INDEX) == o["sym_index"][:rep.n_symbols - 1]).all()
+    # float taps
+    acq, fft, eq = rx.tap(g.TAP_ACQ), rx.tap(g.TAP_FFT), rx.tap(g.TAP_EQ)
+    assert acq.shape == o["acq"].shape and fft.shape == o["fft"].shape and eq.shape == o["eq"].shape
+    assert np.abs(acq - o["acq"]).max() <= 1e-6 * np.abs(o["acq"]).max()
+    assert np.abs(fft - o["fft"]).max() <= 1e-5 * np.abs(o["fft"]).max()
+    tol = 1e-3 * 2 * c.norm
+    d = eq - o["eq"]
+    assert max(np.abs(d.real).max(), np.abs(d.imag).max()) <= tol
+    # integer taps: bit exact, same lengths (same start offset and same end)
+    for name, tap in (("demap", g.TAP_DEMAP), ("symdeint", g.TAP_SYMDEINT), ("bitdeint", g.TAP_BITDEINT),
+                      ("vit", g.TAP_VITERBI), ("deint", g.TAP_DEINT), ("rs", g.TAP_RS), ("ts", g.TAP_TS)):
+        a, b = rx.tap(tap), o[name]
+        assert a.size == b.size > 0, name
+        assert (a.reshape(-1) == b.reshape(-1)).all(), name
+    assert rep.rs_fail_words == o["rs_fail"] == 11 and rep.rs_corrected_symbols == o["rs_corr"] == 0
+    # re-running the same handle gives the same bytes (no state leaks between segments)
+    rx.run(iq)
+    assert (rx.tap(g.TAP_TS) == o["ts"]).all()
+    rx.close()
+
+
+def test_awgn_config5_qpsk_7_8(po, g):
+    """BASELINE config 5: 8k QPSK 7/8 + AWGN.  SNR = 14 dB (acquisition snr parameter set to the same
+    value): the lowest at which the reference's CP tracker holds lock over the run -- below ~13 dB it
+    drops lock and re-acquires, which is outside the steady-state comparison.  The CP position jitters
+    from symbol to symbol here, so this also exercises the parallel tracker against the sequential FSM."""
+    c, iq = _make(po, 0, 4, 1, 3, 21, snr=14.0)
+    o = po.rx(c, iq, snr_db=14.0, want=("bitdeint", "vit", "rs", "ts", "eq"))
+    rx = g.Rx(0, 4, 1, max_samples=len(iq), snr_db=14.0)
+    rep = rx.run(iq)
+    assert len(np.unique(o["cp_start"])) > 1                       # jitter present
+    assert (rx.tap(g.TAP_CP_START) == o["cp_start"]).all()
+    assert rep.first_out_symbol == o["first_out_symbol"] >= 0
+    bd = rx.tap(g.TAP_BITDEINT)
+    assert bd.shape == o["bitdeint"].shape
+    # hard decisions may differ only where a noisy point sits within float rounding of a boundary
+    assert (bd != o["bitdeint"]).mean() < 1e-5
+    assert rx.tap(g.TAP_RS).size == o["rs"].size and (rx.tap(g.TAP_RS) == o["rs"]).all()
+    assert (rx.tap(g.TAP_TS) == o["ts"]).all()
+    rx.close()
+
+
+def test_awgn_qam64_post_rs_equal(po, g):
+    """8k QAM64 7/8 at 22 dB: pre-Viterbi BER ~1e-2, Viterbi and RS both busy. Post-RS output and the
+    failure count must match the oracle; corrected-symbol counts agree statistically."""
+    c, iq = _make(po, 2, 4, 1, 3, 31, snr=22.0)
+    o = po.rx(c, iq, snr_db=22.0, want=("bitdeint", "vit", "rs"))
+    rx = g.Rx(2, 4, 1, max_samples=len(iq), snr_db=22.0)
+    rep = rx.run(iq)
+    assert (rx.tap(g.TAP_CP_START) == o["cp_start"]).all()
+    bd, vit = rx.tap(g.TAP_BITDEINT), rx.tap(g.TAP_VITERBI)
+    assert (bd != o["bitdeint"]).mean() < 2e-5
+    assert (vit != o["vit"]).mean() < 2e-5
+    assert o["rs_corr"] > 1000 and abs(rep.rs_corrected_symbols - o["rs_corr"]) <= 0.01 * o["rs_corr"] + 20
+    assert rep.rs_fail_words == o["rs_fail"]
+    assert (rx.tap(g.TAP_RS) == o["rs"]).all()
+    rx.close()
+
+
+def test_size_independent_properties_full_size(po, g):
+    """BASELINE-size segment (8k QAM64 7/8, 9 superframes ~ 20.7 M samples): too long to diff every tap
+    against the CPU oracle quickly, so check properties: every decoded packet after the 11 start-up
+    words equals the transmitted (energy-dispersed) packet, packet count and alignment are what the
+    superframe-start rule predicts, and the TS carries 0x47 sync bytes every 188."""
+    import ctypes as C
+    const, cr, mode, nsf = 2, 4, 1, 9
+    c = po.cfg(const, cr, mode)
+    ibits = c.payload * c.m * c.k // c.n
+    npk = (272 * ibits * nsf) // (204 * 8)
+    ts = po.make_ts(npk, 77)
+    iq = po.tx(c, ts, lead_in=1000, tail=3 * c.N)
+    rx = g.Rx(const, cr, mode, max_samples=len(iq))
+    rep = rx.run(iq)
+    assert rep.first_out_symbol == 204 and rep.rs_fail_words == 11 and rep.rs_corrected_symbols == 0
+    disp = np.zeros(npk * 188, np.uint8)
+    po.lib().o_energy_dispersal(ts.ctypes.data_as(C.c_void_p), disp.ctypes.data_as(C.c_void_p), C.c_size_t(npk))
+    rs = rx.tap(g.TAP_RS)
+    n = len(rs) // 188
+    p0 = rep.first_out_symbol * ibits // (204 * 8) - 11
+    assert n == rep.n_rs_items * 8 and n > 40000
+    a = rs.reshape(n, 188)
+    b = disp[p0 * 188:(p0 + n) * 188].reshape(-1, 188)
+    assert (a[11:] == b[11:]).all()
+    tso = rx.tap(g.TAP_TS).reshape(-1, 188)
+    assert (tso[:, 0] == 0x47).all() and len(tso) == n - 16
+    orig = ts.reshape(-1, 188)
+    k = next(q for q in range(p0 + 11, p0 + 40) if (orig[q] == tso[0]).all())
+    assert (tso == orig[k:k + len(tso)]).all()
+    rx.close()
+
+
+def test_short_and_degenerate_segments(po, g):
+    c, iq = _make(po, 1, 0, 0, 3, 5)
+    rx = g.Rx(1, 0, 0, max_samples=len(iq))
+    with pytest.raises(g.DvbtError):
+        rx.run(iq[:1000])                                     # shorter than one acquisition window
+    rep = rx.run(np.zeros(20000, np.complex64))               # no signal: initial acquisition fails, nothing decoded
+    assert rep.status & 1 and rep.n_symbols == 0 and rep.n_rs_bytes == 0
+    rep = rx.run(iq[:100 * (c.N + c.cp)])                     # less than one frame: no superframe start
+    o = po.rx(c, iq[:100 * (c.N + c.cp)], want=("rs",))
+    assert rep.first_out_symbol == o["first_out_symbol"] == -1 and rep.n_rs_bytes == 0 and rep.status & 4
+    rep = rx.run(iq)                                          # and the handle still works afterwards
+    assert rep.first_out_symbol == 272
+    rx.close()

@@ -5,7 +5,7 @@ import numpy as np
 from oracle import pyoracle as po
 import gr_dvbt_amd as g
 
-def one(const, cr, mode, nsf, lead=1000, seed=11, chunk=0, snr=None):
+def one(const, cr, mode, nsf, lead=1000, seed=11, chunk=0, snr=None, snr_param=30.0):
     c = po.cfg(const, cr, mode)
     ibits = c.payload * c.m * c.k // c.n
     npk = (272 * ibits * nsf) // (204 * 8)
@@ -17,9 +17,9 @@ def one(const, cr, mode, nsf, lead=1000, seed=11, chunk=0, snr=None):
         sig = np.sqrt(p / (10 ** (snr / 10)) / 2)
         iq = (iq + sig * (rng.randn(len(iq)) + 1j * rng.randn(len(iq)))).astype(np.complex64)
     t0 = time.time()
-    o = po.rx(c, iq, want=("acq", "fft", "eq", "demap", "symdeint", "bitdeint", "vit", "deint", "rs", "ts"))
+    o = po.rx(c, iq, snr_db=snr_param, want=("acq", "fft", "eq", "demap", "symdeint", "bitdeint", "vit", "deint", "rs", "ts"))
     t_or = time.time() - t0
-    rx = g.Rx(const, cr, mode, max_samples=len(iq), taps=True, viterbi_chunk_bytes=chunk)
+    rx = g.Rx(const, cr, mode, max_samples=len(iq), taps=True, viterbi_chunk_bytes=chunk, snr_db=snr_param)
     t0 = time.time()
     rep = rx.run(iq)
     t_gpu = time.time() - t0
@@ -64,6 +64,8 @@ if __name__ == "__main__":
     print("devices", g.device_count())
     r = [one(po.QAM16, po.C1_2, po.T2k, 3),
          one(po.QAM64, po.C7_8, po.T8k, 2),
-         one(po.QPSK, po.C7_8, po.T8k, 2, snr=6.0),
+         one(po.QPSK, po.C7_8, po.T8k, 3, snr=14.0, snr_param=14.0),
+         one(po.QAM64, po.C7_8, po.T8k, 3, snr=22.0, snr_param=22.0),
+         one(po.QAM16, po.C2_3, po.T2k, 4, snr=18.0, snr_param=18.0, lead=777),
          one(po.QAM64, po.C3_4, po.T2k, 3, chunk=128)]
     print("ALL OK" if all(r) else "MISMATCH")
