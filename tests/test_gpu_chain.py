@@ -134,7 +134,8 @@ def test_size_independent_properties_full_size(po, g):
     b = disp[p0 * 188:(p0 + n) * 188].reshape(-1, 188)
     assert (a[11:] == b[11:]).all()
     tso = rx.tap(g.TAP_TS).reshape(-1, 188)
-    assert (tso[:, 0] == 0x47).all() and len(tso) == n - 16
+    # energy_descramble holds back 2 items, +2 more when no NSYNC lies in the first search window (:121-135)
+    assert (tso[:, 0] == 0x47).all() and len(tso) in (n - 16, n - 32)
     orig = ts.reshape(-1, 188)
     k = next(q for q in range(p0 + 11, p0 + 40) if (orig[q] == tso[0]).all())
     assert (tso == orig[k:k + len(tso)]).all()
