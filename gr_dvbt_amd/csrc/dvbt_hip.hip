@@ -11,6 +11,7 @@
 #include "dvbt_tables.hpp"
 #include "k_frontend.hpp"
 #include "k_backend.hpp"
+#include "k_viterbi2.hpp"
 
 using namespace dvbt;
 
@@ -125,13 +126,34 @@ struct Tables {          // device lookup tables for one configuration
   }
 };
 
+// A7 kernel generation: 2 = DPP butterflies, 4 chunks per wavefront (default); 1 = one chunk per
+// wavefront on ds_bpermute (kept for A/B runs: DVBT_VITERBI_KERNEL=1)
+static int viterbi_kernel_version()
+{
+  const char *e = getenv("DVBT_VITERBI_KERNEL");
+  return (e && e[0] == '1') ? 1 : 2;
+}
+static void launch_viterbi(hipStream_t s, const uint8_t *in, uint8_t *out, const RxState *st, long long steps_fixed, const VitParams &vp,
+                           long long in_base, long long out_lo, long long max_out_bytes)
+{
+  long long chunks = (max_out_bytes + vp.chunk_bytes - 1) / vp.chunk_bytes;
+  if (chunks < 1) chunks = 1;
+  if (viterbi_kernel_version() == 1)
+    hipLaunchKernelGGL(viterbi_kernel, dim3((unsigned)((chunks + 3) / 4)), dim3(256), 0, s, in, out, st, steps_fixed, vp, in_base, out_lo);
+  else {
+    const long long per_wg = 4 * V2_WAVES;
+    hipLaunchKernelGGL(viterbi2_kernel, dim3((unsigned)((chunks + per_wg - 1) / per_wg)), dim3(64 * V2_WAVES), 0, s, in, out, st, steps_fixed, vp, in_base, out_lo);
+  }
+}
+
 static VitParams make_vit_params(const Dims &d, int bsize, int chunk_bytes)
 {
   VitParams v; memset(&v, 0, sizeof v);
   v.m = d.m; v.k = d.k; v.n = d.n; v.plen = d.plen; v.ntb = d.ntb; v.bsize = bsize;
   v.d_nsymbols = bsize * d.n / d.m; v.d_nbits = 2 * d.k * bsize;
-  v.chunk_bytes = chunk_bytes > 0 ? chunk_bytes : 1024; v.payload = d.payload;
+  v.chunk_bytes = chunk_bytes > 0 ? chunk_bytes : 768; v.payload = d.payload;
   memcpy(v.punct, d.punct, 16); memcpy(v.prefix, d.prefix, 16);
+  { const char *e = getenv("DVBT_VITERBI_DBG"); v.dbg = e ? atoi(e) : 0; }
   return v;
 }
 static FrontParams make_front_params(const Dims &d, float snr_db)
@@ -194,7 +216,7 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   dvbt_rx *h = new dvbt_rx();
   h->prm = *p; h->d = d; h->T.d = d;
   h->fp = make_front_params(d, p->snr_db);
-  int cb = p->viterbi_chunk_bytes > 0 ? p->viterbi_chunk_bytes : 1024;
+  int cb = p->viterbi_chunk_bytes > 0 ? p->viterbi_chunk_bytes : 768;
   h->vp = make_vit_params(d, p->viterbi_bsize, cb);
   h->max_samples = p->max_samples;
   h->max_calls = (int)((p->max_samples - (2 * d.N + d.cp + 16)) / (d.N + d.cp) + 1);
@@ -280,7 +302,7 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s)
                      h->eq, h->tpsval, h->info);
   hipLaunchKernelGGL(tps_vote_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float2 *)h->tpsval, d.n_tps, (const RxState *)h->st, 0,
                      (const float2 *)nullptr, h->maj);
-  hipLaunchKernelGGL(tps_fsm_kernel, dim3(1), dim3(64), 0, s, fp, h->st, 0, (const SymInfo *)h->info, (const int *)h->maj, h->tps_state,
+  hipLaunchKernelGGL(tps_fsm_kernel, dim3(1), dim3(256), 0, s, fp, h->st, 0, (const SymInfo *)h->info, (const int *)h->maj, h->tps_state,
                      h->sym_index, (int *)nullptr, (const unsigned char *)nullptr);
   hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(64), 0, s, h->st, h->vp, h->prm.descramble);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_INNER], s));
@@ -290,9 +312,7 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s)
                      h->demap_tap, h->symdeint_tap, h->bitdeint);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_VIT], s));
   long long max_vit = (long long)C * d.payload * d.m * d.k / (8 * d.n) + 1;
-  long long max_chunks = (max_vit + h->vp.chunk_bytes - 1) / h->vp.chunk_bytes;
-  hipLaunchKernelGGL(viterbi_kernel, dim3((unsigned)((max_chunks + 3) / 4)), dim3(256), 0, s, (const uint8_t *)h->bitdeint, h->vit,
-                     (const RxState *)h->st, 0ll, h->vp, 0ll, 0ll);
+  launch_viterbi(s, (const uint8_t *)h->bitdeint, h->vit, (const RxState *)h->st, 0ll, h->vp, 0ll, 0ll, max_vit);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_RS], s));
   long long max_words = max_vit / 204 + 1;
   hipLaunchKernelGGL(deint_rs_kernel, dim3((unsigned)((max_words + 63) / 64)), dim3(64), 0, s, (const uint8_t *)h->vit, h->deint_tap, h->rs_out,

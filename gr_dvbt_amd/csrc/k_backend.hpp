@@ -78,6 +78,7 @@ struct VitParams {
   int d_nbits;           // depunctured bits per block       (:151)
   int chunk_bytes;       // decoded bytes per wavefront chunk
   int payload;
+  int dbg;               // experiment switches (DVBT_VITERBI_DBG): 1 skip traceback, 2 skip forward, 4 skip staging
   uint8_t punct[16], prefix[16];
 };
 

@@ -599,49 +599,80 @@ __device__ inline int bch_check(unsigned long long lo, unsigned hi)
 }
 
 // symbol/frame bookkeeping: parse_input :1228-1241, process_tps_data :952-1028,
-// demod_reference_signals_impl.cc:108-143 (one item per call regime).  Sequential over symbols.
-__global__ void tps_fsm_kernel(FrontParams p, RxState *st, int nitems_fixed, const SymInfo *info, const int *maj,
+// demod_reference_signals_impl.cc:108-143 (one item per call regime).  Sequential over symbols by
+// nature (68-bit FIFO + counters); the per-symbol inputs are staged through LDS in tiles by the
+// whole workgroup so the walking lane never waits on HBM.
+constexpr int TPS_TILE = 2048;
+__global__ __launch_bounds__(256) void tps_fsm_kernel(FrontParams p, RxState *st, int nitems_fixed, const SymInfo *info, const int *maj,
                                TpsState *ts, int *sym_index, int *superframe_flag, const unsigned char *sync_flags)
 {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  __shared__ signed char s_mod[TPS_TILE];
+  __shared__ short s_maj[TPS_TILE];
+  __shared__ unsigned char s_sync[TPS_TILE], s_si[TPS_TILE], s_flag[TPS_TILE];
+  __shared__ TpsState s_t;
+  __shared__ int s_first_out;
+  const int tid = threadIdx.x;
   const int nsym = st ? st->n_symbols : nitems_fixed;
-  TpsState t = *ts;
+  const int ntot = nsym > 0 ? nsym - 1 : 0;
+  if (tid == 0) { s_t = *ts; s_first_out = -1; }
   // sync words s1..s15 as fifo bits 1..15 (only 15 of the 16 are compared: B-11)
-  static const unsigned char se[15] = {0, 0, 1, 1, 0, 1, 0, 1, 1, 1, 1, 0, 1, 1, 1};
   unsigned mask_even = 0, mask_odd = 0;
-  for (int i = 0; i < 15; i++) { mask_even |= (unsigned)se[i] << (1 + i); mask_odd |= (unsigned)(1 - se[i]) << (1 + i); }
-  int first_out = -1;
-  for (int s = 0; s + 1 < nsym; s++) {
-    int mod = info[s].mod_index;
-    int diff = (mod - t.prev_mod + 4) % 4;
-    t.prev_mod = mod;
-    t.symbol_index = (t.symbol_index + diff) % 68;
-    int si = t.symbol_index, fi = t.frame_index;
-    int use = (!t.symbol_index_known || t.symbol_index != 0);
-    unsigned bitv = use ? (maj[s] >= 0 ? 0u : 1u) : 0u;
-    for (int i = 0; i < diff; i++) {
-      t.fifo_lo = (t.fifo_lo >> 1) | ((unsigned long long)(t.fifo_hi & 1u) << 63);
-      t.fifo_hi = (t.fifo_hi >> 1) | (bitv << 3);
-    }
-    unsigned low16 = (unsigned)(t.fifo_lo & 0xFFFEull);
-    if (low16 == mask_even || low16 == mask_odd) {
-      if (bch_check(t.fifo_lo, t.fifo_hi) == 0) {
-        t.frame_index = (int)(((t.fifo_lo >> 23) & 1ull) << 1 | ((t.fifo_lo >> 24) & 1ull));
-        t.symbol_index_known = 1; t.symbol_index = 67;
-      } else t.symbol_index_known = 0;
-      t.fifo_lo = 0; t.fifo_hi = 0;
-    }
-    sym_index[s] = si;
-    if (sync_flags && sync_flags[s]) t.d_init = 0;               // sync_start tag: hunt the superframe start again (:115-116)
-    int sf = 0;
-    if (!t.d_init && (si % 68) == 0 && (fi % 4) == p.fi_start) { t.d_init = 1; sf = 1; if (first_out < 0) first_out = s; }
-    if (superframe_flag) superframe_flag[s] = t.d_init ? (sf ? 2 : 1) : 0;   // 0 dropped, 1 produced, 2 produced + superframe_start
+  {
+    const unsigned char se[15] = {0, 0, 1, 1, 0, 1, 0, 1, 1, 1, 1, 0, 1, 1, 1};
+    for (int i = 0; i < 15; i++) { mask_even |= (unsigned)se[i] << (1 + i); mask_odd |= (unsigned)(1 - se[i]) << (1 + i); }
   }
-  *ts = t;
-  if (st) {
-    st->first_out = first_out;
-    if (first_out < 0) { st->status |= 4; st->n_out_symbols = 0; }
-    else st->n_out_symbols = nsym - 1 - first_out;
+  for (int base = 0; base < ntot; base += TPS_TILE) {
+    const int n = ntot - base < TPS_TILE ? ntot - base : TPS_TILE;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+      s_mod[i] = (signed char)info[base + i].mod_index; s_maj[i] = (short)maj[base + i];
+      s_sync[i] = sync_flags ? sync_flags[base + i] : 0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      TpsState t = s_t;
+      for (int i = 0; i < n; i++) {
+        int mod = s_mod[i];
+        int diff = (mod - t.prev_mod + 4) % 4;
+        t.prev_mod = mod;
+        t.symbol_index = (t.symbol_index + diff) % 68;
+        int si = t.symbol_index, fi = t.frame_index;
+        int use = (!t.symbol_index_known || t.symbol_index != 0);
+        unsigned bitv = use ? (s_maj[i] >= 0 ? 0u : 1u) : 0u;
+        for (int k = 0; k < diff; k++) {
+          t.fifo_lo = (t.fifo_lo >> 1) | ((unsigned long long)(t.fifo_hi & 1u) << 63);
+          t.fifo_hi = (t.fifo_hi >> 1) | (bitv << 3);
+        }
+        unsigned low16 = (unsigned)(t.fifo_lo & 0xFFFEull);
+        if (low16 == mask_even || low16 == mask_odd) {
+          if (bch_check(t.fifo_lo, t.fifo_hi) == 0) {
+            t.frame_index = (int)(((t.fifo_lo >> 23) & 1ull) << 1 | ((t.fifo_lo >> 24) & 1ull));
+            t.symbol_index_known = 1; t.symbol_index = 67;
+          } else t.symbol_index_known = 0;
+          t.fifo_lo = 0; t.fifo_hi = 0;
+        }
+        s_si[i] = (unsigned char)si;
+        if (s_sync[i]) t.d_init = 0;                             // sync_start tag: hunt the superframe start again (:115-116)
+        int sf = 0;
+        if (!t.d_init && (si % 68) == 0 && (fi % 4) == p.fi_start) { t.d_init = 1; sf = 1; if (s_first_out < 0) s_first_out = base + i; }
+        s_flag[i] = t.d_init ? (sf ? 2 : 1) : 0;                 // 0 dropped, 1 produced, 2 produced + superframe_start
+      }
+      s_t = t;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+      sym_index[base + i] = s_si[i];
+      if (superframe_flag) superframe_flag[base + i] = s_flag[i];
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    *ts = s_t;
+    if (st) {
+      st->first_out = s_first_out;
+      if (s_first_out < 0) { st->status |= 4; st->n_out_symbols = 0; }
+      else st->n_out_symbols = nsym - 1 - s_first_out;
+    }
   }
 }
 
