@@ -154,6 +154,9 @@ static VitParams make_vit_params(const Dims &d, int bsize, int chunk_bytes)
   v.chunk_bytes = chunk_bytes > 0 ? chunk_bytes : 768; v.payload = d.payload;
   memcpy(v.punct, d.punct, 16); memcpy(v.prefix, d.prefix, 16);
   { const char *e = getenv("DVBT_VITERBI_DBG"); v.dbg = e ? atoi(e) : 0; }
+  v.punct_mask = 0; v.prefix_nib = 0;
+  for (int i = 0; i < d.plen; i++) { v.punct_mask |= (unsigned)d.punct[i] << i; v.prefix_nib |= (unsigned long long)d.prefix[i] << (4 * i); }
+  v.magic_plen = ~0ull / (unsigned)d.plen + 1; v.magic_m = ~0ull / (unsigned)d.m + 1;
   return v;
 }
 static FrontParams make_front_params(const Dims &d, float snr_db)
@@ -183,7 +186,7 @@ struct dvbt_rx {
   float2 *d_iq = nullptr;              // only when input comes from the host
   float2 *g_init = nullptr; float *l_init = nullptr; float2 *g_trk = nullptr; float *l_trk = nullptr;
   SymMeta *meta = nullptr; RxState *st = nullptr, *st_host = nullptr; TpsState *tps_state = nullptr;
-  int *trk_cp_a = nullptr, *trk_cp_b = nullptr, *trk_flags = nullptr; float *trk_eps = nullptr;
+  int *trk_cp_a = nullptr, *trk_cp_b = nullptr, *trk_flags = nullptr; float *trk_eps = nullptr; TpsEdge *tps_edges = nullptr;
   float2 *acq_tap = nullptr, *fft_out = nullptr, *eq = nullptr, *tpsval = nullptr; SymInfo *info = nullptr; int *maj = nullptr, *sym_index = nullptr;
   uint8_t *demap_tap = nullptr, *symdeint_tap = nullptr, *bitdeint = nullptr, *vit = nullptr, *deint_tap = nullptr, *rs_out = nullptr, *ts_out = nullptr;
   size_t vit_cap = 0;
@@ -194,7 +197,7 @@ struct dvbt_rx {
 
 static void rx_free(dvbt_rx *h)
 {
-  void *all[] = {h->trk_cp_a, h->trk_cp_b, h->trk_flags, h->trk_eps, h->d_iq, h->g_init, h->l_init, h->g_trk, h->l_trk, h->meta, h->st, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
+  void *all[] = {h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags, h->trk_eps, h->d_iq, h->g_init, h->l_init, h->g_trk, h->l_trk, h->meta, h->st, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
                  h->info, h->maj, h->sym_index, h->demap_tap, h->symdeint_tap, h->bitdeint, h->vit, h->deint_tap, h->rs_out, h->ts_out};
   for (void *q : all) if (q) (void)hipFree(q);
   if (h->st_host) (void)hipHostFree(h->st_host);
@@ -229,7 +232,8 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   RXHIP(hipMalloc((void **)&h->g_trk, sizeof(float2) * C * 2 * ACQ_R)); RXHIP(hipMalloc((void **)&h->l_trk, sizeof(float) * C * 2 * ACQ_R));
   RXHIP(hipMalloc((void **)&h->meta, sizeof(SymMeta) * C));
   RXHIP(hipMalloc((void **)&h->trk_cp_a, sizeof(int) * C)); RXHIP(hipMalloc((void **)&h->trk_cp_b, sizeof(int) * C));
-  RXHIP(hipMalloc((void **)&h->trk_eps, sizeof(float) * C)); RXHIP(hipMalloc((void **)&h->trk_flags, sizeof(int) * 16)); RXHIP(hipMalloc((void **)&h->st, sizeof(RxState)));
+  RXHIP(hipMalloc((void **)&h->trk_eps, sizeof(float) * C)); RXHIP(hipMalloc((void **)&h->trk_flags, sizeof(int) * 16));
+  RXHIP(hipMalloc((void **)&h->tps_edges, sizeof(TpsEdge) * (C / TPS_SEG + 2))); RXHIP(hipMalloc((void **)&h->st, sizeof(RxState)));
   RXHIP(hipHostMalloc((void **)&h->st_host, sizeof(RxState))); RXHIP(hipMalloc((void **)&h->tps_state, sizeof(TpsState)));
   RXHIP(hipMalloc((void **)&h->fft_out, sizeof(float2) * C * N)); RXHIP(hipMalloc((void **)&h->eq, sizeof(float2) * C * P));
   RXHIP(hipMalloc((void **)&h->tpsval, sizeof(float2) * C * d.n_tps)); RXHIP(hipMalloc((void **)&h->info, sizeof(SymInfo) * C));
@@ -302,8 +306,15 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s)
                      h->eq, h->tpsval, h->info);
   hipLaunchKernelGGL(tps_vote_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float2 *)h->tpsval, d.n_tps, (const RxState *)h->st, 0,
                      (const float2 *)nullptr, h->maj);
-  hipLaunchKernelGGL(tps_fsm_kernel, dim3(1), dim3(256), 0, s, fp, h->st, 0, (const SymInfo *)h->info, (const int *)h->maj, h->tps_state,
-                     h->sym_index, (int *)nullptr, (const unsigned char *)nullptr);
+  {   // flags[8] = first superframe-start candidate (min), flags[9] = need_seq for the TPS bookkeeping
+    static const int kInit[2] = {0x7fffffff, 0};
+    HIPCHK(hipMemcpyAsync(h->trk_flags + 8, kInit, sizeof kInit, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(tps_fsm_par_kernel, dim3((C + 64 * TPS_SEG - 1) / (64 * TPS_SEG)), dim3(64), 0, s, fp, (const RxState *)h->st, (const SymInfo *)h->info,
+                       (const int *)h->maj, h->sym_index, h->tps_edges, h->trk_flags + 8);
+    hipLaunchKernelGGL(tps_finalize_kernel, dim3(1), dim3(256), 0, s, h->st, (const TpsEdge *)h->tps_edges, (const int *)(h->trk_flags + 8), h->trk_flags + 9);
+    hipLaunchKernelGGL(tps_fsm_kernel, dim3(1), dim3(256), 0, s, fp, h->st, 0, (const SymInfo *)h->info, (const int *)h->maj, h->tps_state,
+                       h->sym_index, (int *)nullptr, (const unsigned char *)nullptr, (const int *)(h->trk_flags + 9));
+  }
   hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(64), 0, s, h->st, h->vp, h->prm.descramble);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_INNER], s));
   InnerParams ip; ip.payload = d.payload; ip.m = d.m; ip.csize = d.csize;

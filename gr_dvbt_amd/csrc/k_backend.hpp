@@ -79,6 +79,9 @@ struct VitParams {
   int chunk_bytes;       // decoded bytes per wavefront chunk
   int payload;
   int dbg;               // experiment switches (DVBT_VITERBI_DBG): 1 skip traceback, 2 skip forward, 4 skip staging
+  unsigned punct_mask;            // bit p = puncture vector entry p
+  unsigned long long prefix_nib;  // nibble p = kept bits before phase p
+  unsigned long long magic_plen, magic_m;   // ceil(2^64/d): x/d == umul64hi(x, magic) for x < 2^56
   uint8_t punct[16], prefix[16];
 };
 
@@ -230,13 +233,14 @@ __global__ __launch_bounds__(256) void viterbi_kernel(const uint8_t *__restrict_
 // RS: reed_solomon.cc:246-489.  Syndromes by table T_i[b] = b*alpha^i; error path on exp/log tables.
 struct RsTables { const uint8_t *mul_alpha; /* [16][256] */ const uint8_t *gexp; /* 512 */ const uint8_t *glog; /* 256 */ };
 
+// scr: 128 bytes of per-thread LDS scratch (the polynomial arrays are indexed at run time)
 __device__ inline int rs_decode_word(uint8_t *d /* 204 bytes, index 0 = codeword index 51 */, const uint8_t *syn,
-                                     const uint8_t *gexp, const uint8_t *glog, int compat)
+                                     const uint8_t *gexp, const uint8_t *glog, int compat, uint8_t *scr)
 {
   auto gmul = [&](int a, int b) -> int { return (a == 0 || b == 0) ? 0 : gexp[glog[a] + glog[b]]; };
   auto gdiv = [&](int a, int b) -> int { return (a == 0 || b == 0) ? 0 : gexp[255 + glog[a] - glog[b]]; };
   auto gpow = [&](int a, int pw) -> int { return a == 0 ? 0 : gexp[(glog[a] + pw) % 255]; };
-  uint8_t sigma[17], b[17], T[17], root[17], loc[17], omega[17];
+  uint8_t *sigma = scr, *b = scr + 17, *T = scr + 34, *root = scr + 51, *loc = scr + 68, *omega = scr + 85, *lr = scr + 102;
   for (int i = 0; i < 17; i++) { sigma[i] = 0; b[i] = 0; }
   sigma[0] = 1; b[0] = 1;
   int r = 0, el = 0;
@@ -255,12 +259,11 @@ __device__ inline int rs_decode_word(uint8_t *d /* 204 bytes, index 0 = codeword
   int deg_sigma = 0;
   for (int i = 0; i <= 16; i++) if (sigma[i]) deg_sigma = i;
   int no_roots = 0;                                               // Chien :376-403, registers kept in the log domain
-  int lr[17];
-  for (int i = 1; i <= 16; i++) lr[i] = sigma[i] ? glog[sigma[i]] : -1;
+  for (int i = 1; i <= 16; i++) lr[i] = sigma[i] ? glog[sigma[i]] : 255;          // 255 = log of zero
   for (int i = 1; i <= 255; i++) {
     int q = 1;
     for (int j = deg_sigma; j > 0; j--)
-      if (lr[j] >= 0) { lr[j] += j; if (lr[j] >= 255) lr[j] -= 255; q ^= gexp[lr[j]]; }
+      if (lr[j] != 255) { int x = lr[j] + j; if (x >= 255) x -= 255; lr[j] = (uint8_t)x; q ^= gexp[x]; }
     if (q != 0) continue;
     root[no_roots] = (uint8_t)i; loc[no_roots] = (uint8_t)(i - 1);
     if (++no_roots == deg_sigma) break;
@@ -298,6 +301,7 @@ __global__ __launch_bounds__(64) void deint_rs_kernel(const uint8_t *__restrict_
   __shared__ __attribute__((aligned(16))) uint8_t s_cw[64 * 204];
   __shared__ uint8_t s_mul[16 * 256];
   __shared__ uint8_t s_exp[512], s_log[256];
+  __shared__ uint8_t s_scr[64 * 128];
   const int tid = threadIdx.x;
   const long long nwords = st ? st->n_rs_items * 8 : words_fixed;
   const long long w0 = (long long)blockIdx.x * 64;
@@ -335,7 +339,7 @@ __global__ __launch_bounds__(64) void deint_rs_kernel(const uint8_t *__restrict_
 #pragma unroll
     for (int i = 0; i < 16; i++) any |= syn[i];
     if (any) {
-      int r = rs_decode_word(cw, syn, s_exp, s_log, compat);
+      int r = rs_decode_word(cw, syn, s_exp, s_log, compat, s_scr + tid * 128);
       if (r < 0) atomicAdd(fail_cnt, 1); else atomicAdd(corr_cnt, r);
     }
   }

@@ -80,25 +80,30 @@ __global__ __launch_bounds__(256) void acq_metric_kernel(const float2 *__restric
   lambda[oidx] = sqrtf(gr * gr + gi * gi) - phi * p.half_rho;
 }
 
-// peak_detect_process (ofdm_sym_acquisition_impl.cc:72-146); avg persists across calls
+// peak_detect_process (ofdm_sym_acquisition_impl.cc:72-146); avg persists across calls.
+// Same state machine written one sample per iteration (the reference's non-consuming transitions
+// -- rise detection, peak completion -- are folded into the sample that triggers them), so the
+// loop body is straight-line and the metric reads can be pipelined:
+//   state 1: new maximum -> keep going; else still above avg*fall -> keep going; else the peak is
+//            complete (largest one wins, first wins ties) and the sample is re-examined in state 0;
+//   state 0: above avg*rise -> enter state 1 with this sample as the running maximum;
+//   every sample then updates the IIR average exactly once.
 __device__ inline int peak_detect(const float *d, int n, float &avg, int &best_pos)
 {
   const float rise = 0.8f, fall = 0.9f, alpha = 0.9f;
-  int state = 0, peak_index = 0, npk = 0, i = 0;
+  int state = 0, peak_index = 0, npk = 0;
   float peak_val = -INFINITY, best_val = 0.f;
-  while (i < n) {
-    float v = d[i];
-    if (state == 0) {
-      if (v > avg * rise) state = 1;
-      else { avg = alpha * v + (1 - alpha) * avg; i++; }
-    } else {
-      if (v > peak_val) { peak_val = v; peak_index = i; avg = alpha * v + (1 - alpha) * avg; i++; }
-      else if (v > avg * fall) { avg = alpha * v + (1 - alpha) * avg; i++; }
-      else {                         // falling edge: record the peak; keep the largest (first wins ties)
-        if (npk == 0 || d[peak_index] > best_val) { best_val = d[peak_index]; best_pos = peak_index; }
+  for (int i = 0; i < n; i++) {
+    const float v = d[i];
+    if (state == 1) {
+      if (v > peak_val) { peak_val = v; peak_index = i; }
+      else if (!(v > avg * fall)) {
+        if (npk == 0 || peak_val > best_val) { best_val = peak_val; best_pos = peak_index; }
         npk++; state = 0; peak_val = -INFINITY;
       }
     }
+    if (state == 0 && v > avg * rise) { state = 1; peak_val = v; peak_index = i; }
+    avg = alpha * v + (1 - alpha) * avg;
   }
   return npk;
 }
@@ -604,8 +609,9 @@ __device__ inline int bch_check(unsigned long long lo, unsigned hi)
 // whole workgroup so the walking lane never waits on HBM.
 constexpr int TPS_TILE = 2048;
 __global__ __launch_bounds__(256) void tps_fsm_kernel(FrontParams p, RxState *st, int nitems_fixed, const SymInfo *info, const int *maj,
-                               TpsState *ts, int *sym_index, int *superframe_flag, const unsigned char *sync_flags)
+                               TpsState *ts, int *sym_index, int *superframe_flag, const unsigned char *sync_flags, const int *need_seq)
 {
+  if (need_seq && *need_seq == 0) return;
   __shared__ signed char s_mod[TPS_TILE];
   __shared__ short s_maj[TPS_TILE];
   __shared__ unsigned char s_sync[TPS_TILE], s_si[TPS_TILE], s_flag[TPS_TILE];
@@ -672,6 +678,104 @@ __global__ __launch_bounds__(256) void tps_fsm_kernel(FrontParams p, RxState *st
       st->first_out = s_first_out;
       if (s_first_out < 0) { st->status |= 4; st->n_out_symbols = 0; }
       else st->n_out_symbols = nsym - 1 - s_first_out;
+    }
+  }
+}
+
+
+// ---- the same bookkeeping, segment-parallel (segment path only: no sync_start tags, fresh state).
+// The state is fully re-derived at every frame end (symbol_index forced to 67, frame number read
+// from the TPS bits, FIFO cleared: :978-1028,1240-1241), so a lane that starts TPS_WARM symbols
+// early from a blank state holds the sequential state when it reaches its own segment, provided
+// a frame end with an intact TPS word lies in the warm-up.  Every lane records its state at the
+// start and at the end of its segment; tps_finalize_kernel checks that neighbours agree and
+// otherwise requests the sequential kernel (need_seq), so the result is always the sequential one.
+constexpr int TPS_SEG = 128;          // symbols per lane
+constexpr int TPS_WARM = 204;         // three frames
+struct TpsEdge { TpsState start, end; };
+
+__device__ __forceinline__ void tps_advance(TpsState &t, int mod, int majv, int fi_start, unsigned mask_even, unsigned mask_odd,
+                                            int &si_out, int &cand)
+{
+  int diff = (mod - t.prev_mod + 4) & 3;
+  t.prev_mod = mod;
+  t.symbol_index += diff; if (t.symbol_index >= 68) t.symbol_index -= 68;
+  const int si = t.symbol_index, fi = t.frame_index;
+  const int use = (!t.symbol_index_known || t.symbol_index != 0);
+  const unsigned bitv = use ? (majv >= 0 ? 0u : 1u) : 0u;
+  for (int k = 0; k < diff; k++) {
+    t.fifo_lo = (t.fifo_lo >> 1) | ((unsigned long long)(t.fifo_hi & 1u) << 63);
+    t.fifo_hi = (t.fifo_hi >> 1) | (bitv << 3);
+  }
+  const unsigned low16 = (unsigned)(t.fifo_lo & 0xFFFEull);
+  if (low16 == mask_even || low16 == mask_odd) {
+    if (bch_check(t.fifo_lo, t.fifo_hi) == 0) {
+      t.frame_index = (int)(((t.fifo_lo >> 23) & 1ull) << 1 | ((t.fifo_lo >> 24) & 1ull));
+      t.symbol_index_known = 1; t.symbol_index = 67;
+    } else t.symbol_index_known = 0;
+    t.fifo_lo = 0; t.fifo_hi = 0;
+  }
+  si_out = si;
+  cand = (si == 0) && ((fi & 3) == fi_start);
+}
+
+__global__ __launch_bounds__(64) void tps_fsm_par_kernel(FrontParams p, const RxState *st, const SymInfo *__restrict__ info, const int *__restrict__ maj,
+                                                        int *__restrict__ sym_index, TpsEdge *__restrict__ edges, int *first_cand)
+{
+  __shared__ signed char s_mod[64 * TPS_SEG + TPS_WARM];
+  __shared__ short s_maj[64 * TPS_SEG + TPS_WARM];
+  const int tid = threadIdx.x;
+  const int nsym = st->n_symbols, ntot = nsym > 0 ? nsym - 1 : 0;
+  const int blk0 = blockIdx.x * 64 * TPS_SEG;
+  if (blk0 >= ntot) return;
+  const int lo = blk0 - TPS_WARM < 0 ? 0 : blk0 - TPS_WARM;
+  const int hi = blk0 + 64 * TPS_SEG < ntot ? blk0 + 64 * TPS_SEG : ntot;
+  for (int i = lo + tid; i < hi; i += 64) { s_mod[i - lo] = (signed char)info[i].mod_index; s_maj[i - lo] = (short)maj[i]; }
+  __syncthreads();
+  unsigned mask_even = 0, mask_odd = 0;
+  {
+    const unsigned char se[15] = {0, 0, 1, 1, 0, 1, 0, 1, 1, 1, 1, 0, 1, 1, 1};
+    for (int i = 0; i < 15; i++) { mask_even |= (unsigned)se[i] << (1 + i); mask_odd |= (unsigned)(1 - se[i]) << (1 + i); }
+  }
+  const int s0 = blk0 + tid * TPS_SEG;
+  if (s0 >= ntot) return;
+  const int s1 = s0 + TPS_SEG < ntot ? s0 + TPS_SEG : ntot;
+  int sw = s0 - TPS_WARM; if (sw < 0) sw = 0;
+  TpsState t; t.fifo_lo = 0; t.fifo_hi = 0; t.symbol_index = 0; t.symbol_index_known = 0; t.frame_index = 0; t.prev_mod = 0; t.d_init = 0;
+  int si, cand;
+  for (int s = sw; s < s0; s++) tps_advance(t, s_mod[s - lo], s_maj[s - lo], p.fi_start, mask_even, mask_odd, si, cand);
+  const int seg = s0 / TPS_SEG;
+  edges[seg].start = t;
+  int first = 0x7fffffff;
+  for (int s = s0; s < s1; s++) {
+    tps_advance(t, s_mod[s - lo], s_maj[s - lo], p.fi_start, mask_even, mask_odd, si, cand);
+    sym_index[s] = si;
+    if (cand && first == 0x7fffffff) first = s;
+  }
+  edges[seg].end = t;
+  if (first != 0x7fffffff) atomicMin(first_cand, first);
+}
+
+__global__ __launch_bounds__(256) void tps_finalize_kernel(RxState *st, const TpsEdge *edges, const int *first_cand, int *need_seq)
+{
+  __shared__ int s_bad;
+  const int tid = threadIdx.x;
+  const int nsym = st->n_symbols, ntot = nsym > 0 ? nsym - 1 : 0;
+  const int nseg = (ntot + TPS_SEG - 1) / TPS_SEG;
+  if (tid == 0) s_bad = 0;
+  __syncthreads();
+  for (int k = tid; k + 1 < nseg; k += 256) {
+    const TpsState &a = edges[k].end, &b = edges[k + 1].start;
+    if (a.fifo_lo != b.fifo_lo || a.fifo_hi != b.fifo_hi || a.symbol_index != b.symbol_index || a.symbol_index_known != b.symbol_index_known ||
+        a.frame_index != b.frame_index || a.prev_mod != b.prev_mod) s_bad = 1;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    *need_seq = s_bad;
+    if (!s_bad) {
+      int fo = *first_cand;
+      if (fo == 0x7fffffff) { st->first_out = -1; st->status |= 4; st->n_out_symbols = 0; }
+      else { st->first_out = fo; st->n_out_symbols = nsym - 1 - fo; }
     }
   }
 }

@@ -171,49 +171,54 @@ __global__ __launch_bounds__(64 * V2_WAVES) void viterbi2_kernel(const uint8_t *
   for (int jb = 0; jb < J; jb += V2_BLK) {
     // ---- depuncture (viterbi_decoder_impl.cc:241-256) + delta packing for 192 steps x 4 decoders
     if (!(vp.dbg & 4)) {
-      // first real step of this decoder's block and the input byte it starts in
+      // position of a real step t: depunctured bit 2t -> (period q, phase ph) -> received-bit index rb
+      // -> (input byte, bit offset).  Divisions by the small run-time constants 2k and m use
+      // host-made magic multipliers (exact far beyond any segment length).
+      auto locate = [&](long long t, int &ph, long long &byte, int &bo) {
+        const unsigned long long pbit = 2ull * (unsigned long long)t;
+        const unsigned long long q = __umul64hi(pbit, vp.magic_plen);
+        ph = (int)(pbit - q * (unsigned)vp.plen);
+        const unsigned long long rb = q * (unsigned)vp.n + ((vp.prefix_nib >> (4 * ph)) & 15ull);
+        const unsigned long long by = __umul64hi(rb, vp.magic_m);
+        byte = (long long)by; bo = (int)(rb - by * (unsigned)vp.m);
+      };
       const long long tb = 8 * (w0 - 1) + (long long)jb * 8 - 2;   // real step index of block step 0 (may be < 0)
-      const long long tfirst = tb > 0 ? tb : 0;
-      const unsigned long long pb0 = 2ull * (unsigned long long)tfirst;
-      const unsigned long long q0 = pb0 / (unsigned)vp.plen;
-      const unsigned long long rb0 = q0 * (unsigned)vp.n + vp.prefix[(int)(pb0 - q0 * vp.plen)];
-      const long long byte0 = (long long)(rb0 / (unsigned)vp.m);   // same value in the 16 lanes of the row
-      // cooperative load of V2_INBYTES bytes per decoder (16 per lane)
-      {
+      int ph0, bo0; long long byte0;
+      locate(tb > 0 ? tb : 0, ph0, byte0, bo0);                    // same value in the 16 lanes of the row
+      {   // cooperative load of V2_INBYTES input bytes per decoder (16 per lane)
         const long long src = byte0 + pl * 16;
         unsigned char tmp[16];
 #pragma unroll
-        for (int i = 0; i < 16; i++) { long long b = src + i; tmp[i] = (dec_active && b < n_in_bytes) ? in[b - in_base] : 0; }
+        for (int i = 0; i < 16; i++) { long long bb = src + i; tmp[i] = (dec_active && bb < n_in_bytes) ? in[bb - in_base] : 0; }
 #pragma unroll
         for (int i = 0; i < 16; i++) inb[dd * V2_INBYTES + pl * 16 + i] = tmp[i];
       }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      // 12 steps per lane, incremental depuncture state
+      // 12 steps per lane, branch-free incremental depuncture
       const int ub0 = pl * 12;
       long long t = tb + ub0;
-      const long long tpos = t > 0 ? t : 0;
-      unsigned long long pbit = 2ull * (unsigned long long)tpos;
-      unsigned long long q = pbit / (unsigned)vp.plen; int ph = (int)(pbit - q * vp.plen);
-      unsigned long long rb = q * (unsigned)vp.n + vp.prefix[ph];
-      unsigned long long byte = rb / (unsigned)vp.m; int bo = (int)(rb - byte * vp.m);
-      int boff = (int)((long long)byte - byte0);                   // offset into the staged bytes
+      int ph, bo; long long byte;
+      locate(t > 0 ? t : 0, ph, byte, bo);
+      int boff = (int)(byte - byte0);
+      const unsigned char *ib = inb + dd * V2_INBYTES;
+#pragma unroll
       for (int i = 0; i < 12; i++, t++) {
-        unsigned Wd = 0;
-        if (dec_active && t >= 0 && t < total_steps) {
-          int u[2];
-          for (int hh = 0; hh < 2; hh++) {
-            if (vp.punct[ph]) {
-              int bit = (inb[dd * V2_INBYTES + boff] >> (vp.m - 1 - bo)) & 1;
-              u[hh] = 1 - 2 * bit;
-              if (++bo == vp.m) { bo = 0; boff++; }
-            } else u[hh] = 0;
-            if (++ph == vp.plen) ph = 0;
-          }
-          // bytes: class 0 (c0=0,c1=0): u0+u1 | class 1 (c0=1): -u0+u1 | class 2 (c1=1): u0-u1 | class 3: -u0-u1,
-          // times 2 so that a step with one punctured symbol (odd agreement difference) keeps the LSB free for the bias
-          Wd = ((unsigned)(2 * (u[0] + u[1])) & 0xff) | (((unsigned)(2 * (-u[0] + u[1])) & 0xff) << 8) |
-               (((unsigned)(2 * (u[0] - u[1])) & 0xff) << 16) | (((unsigned)(2 * (-u[0] - u[1])) & 0xff) << 24);
+        const bool real = dec_active && t >= 0 && t < total_steps;
+        int u[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) {
+          const int kept = real ? (int)((vp.punct_mask >> ph) & 1u) : 0;
+          const int bit = (ib[boff & (V2_INBYTES - 1)] >> (vp.m - 1 - bo)) & 1;
+          u[hh] = kept * (1 - 2 * bit);
+          bo += kept;
+          const int wrap = bo == vp.m;
+          bo = wrap ? 0 : bo; boff += wrap;
+          if (real) { ph++; ph = ph == vp.plen ? 0 : ph; }
         }
+        // bytes: class 0 (c0=0,c1=0): u0+u1 | class 1 (c0=1): -u0+u1 | class 2 (c1=1): u0-u1 | class 3: -u0-u1,
+        // times 2 so that a step with one punctured symbol (odd agreement difference) keeps the LSB free for the bias
+        const unsigned Wd = ((unsigned)(2 * (u[0] + u[1])) & 0xff) | (((unsigned)(2 * (-u[0] + u[1])) & 0xff) << 8) |
+                            (((unsigned)(2 * (u[0] - u[1])) & 0xff) << 16) | (((unsigned)(2 * (-u[0] - u[1])) & 0xff) << 24);
         wbuf[dd * (V2_BLK * 8) + ub0 + i] = Wd;
       }
     }
