@@ -1,0 +1,112 @@
+// dvbt_blocks.hpp -- C++ host-side mirror of the gr::dvbt block interface over the C ABI.
+//
+// GNU Radio is not available where this repository is built, so these classes do not derive
+// from gr::block; they keep the reference's names, make() argument lists and the
+// forecast()/general_work() contract (include/dvbt/*.h) so that the real block
+// shells are a few lines each: general_work() gathers the visible tags into a
+// dvbt_sideband, calls work(), re-emits the returned tags and calls consume_each(n_consumed).
+//
+// Header-only; link with libdvbt_hip.so.  All computation happens on the GPU behind the C ABI.
+#pragma once
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/dvbt_hip.h"
+
+namespace gr { namespace dvbt_amd {
+
+typedef dvbt_constellation_t dvbt_constellation_t;
+typedef dvbt_hierarchy_t dvbt_hierarchy_t;
+typedef dvbt_code_rate_t dvbt_code_rate_t;
+typedef dvbt_guard_interval_t dvbt_guard_interval_t;
+typedef dvbt_transmission_mode_t dvbt_transmission_mode_t;
+
+struct tag_t { long long offset; int key; int value; };
+
+inline void check(int r) { if (r < 0) throw std::runtime_error(std::string("libdvbt_hip: ") + dvbt_last_error()); }
+
+// CRTP-free helper: every block is (handle, forecast fn, work fn, destroy fn)
+template <class H, class P> class block_base {
+ public:
+  typedef std::shared_ptr<block_base> sptr;
+  typedef int (*create_fn)(const P *, H **);
+  typedef int (*forecast_fn)(const H *, int, int *);
+  typedef int (*work_fn)(H *, int, int, const void *, void *, dvbt_sideband *);
+  typedef void (*destroy_fn)(H *);
+  block_base(const P &p, create_fn c, forecast_fn f, work_fn w, destroy_fn d) : d_forecast(f), d_work(w), d_destroy(d)
+  { check(c(&p, &d_h)); }
+  ~block_base() { if (d_h) d_destroy(d_h); }
+  block_base(const block_base &) = delete;
+  // gr::block::forecast
+  void forecast(int noutput_items, std::vector<int> &ninput_items_required)
+  { int n = 0; check(d_forecast(d_h, noutput_items, &n)); for (auto &x : ninput_items_required) x = n; }
+  // gr::block::general_work for one input and one output stream.  tags_in: tags visible in the input
+  // window (offsets relative to its first item); tags_out: tags to attach (relative to the first output
+  // item); n_consumed: argument for consume_each().  Returns the number of items produced.
+  int general_work(int noutput_items, int ninput_items, const void *in, void *out, const std::vector<tag_t> &tags_in,
+                   std::vector<tag_t> &tags_out, int &n_consumed)
+  {
+    std::vector<dvbt_tag> ti(tags_in.size()), to(4096);
+    for (size_t i = 0; i < tags_in.size(); i++) { ti[i].rel_offset = tags_in[i].offset; ti[i].key = tags_in[i].key; ti[i].value = tags_in[i].value; }
+    dvbt_sideband sb; sb.in_tags = ti.data(); sb.n_in_tags = (int)ti.size(); sb.out_tags = to.data(); sb.out_cap = (int)to.size();
+    sb.n_out_tags = 0; sb.n_consumed = 0;
+    int r = d_work(d_h, noutput_items, ninput_items, in, out, &sb);
+    check(r);
+    tags_out.clear();
+    for (int i = 0; i < sb.n_out_tags && i < sb.out_cap; i++) tags_out.push_back(tag_t{to[i].rel_offset, to[i].key, to[i].value});
+    n_consumed = sb.n_consumed;
+    return r;
+  }
+ private:
+  H *d_h = nullptr; forecast_fn d_forecast; work_fn d_work; destroy_fn d_destroy;
+};
+
+#define DVBT_AMD_BLOCK(NAME, PARAMS, MAKE_ARGS, PARAM_INIT)                                                     \
+  class NAME : public block_base<::dvbt_##NAME, PARAMS> {                                                       \
+   public:                                                                                                      \
+    typedef std::shared_ptr<NAME> sptr;                                                                         \
+    static sptr make MAKE_ARGS { PARAMS prm__ = PARAM_INIT; return sptr(new NAME(prm__)); }                             \
+   private:                                                                                                     \
+    explicit NAME(const PARAMS &p)                                                                              \
+        : block_base<::dvbt_##NAME, PARAMS>(p, dvbt_##NAME##_create, dvbt_##NAME##_forecast, dvbt_##NAME##_work, dvbt_##NAME##_destroy) {} \
+  };
+
+// include/dvbt/ofdm_sym_acquisition.h:49
+DVBT_AMD_BLOCK(ofdm_sym_acquisition, dvbt_ofdm_sym_acquisition_params, (int blocks, int fft_length, int occupied_tones, int cp_length, float snr),
+               (dvbt_ofdm_sym_acquisition_params{blocks, fft_length, occupied_tones, cp_length, snr}))
+// gr::fft::fft_vcc(fft_size, forward, window, shift) as used by apps/dvbt_rx_demo*.grc
+DVBT_AMD_BLOCK(fft, dvbt_fft_params, (int fft_size, bool forward, bool shift), (dvbt_fft_params{fft_size, forward ? 1 : 0, shift ? 1 : 0}))
+// include/dvbt/demod_reference_signals.h:50-54
+DVBT_AMD_BLOCK(demod_reference_signals, dvbt_demod_reference_signals_params,
+               (int itemsize, int ninput, int noutput, dvbt_constellation_t constellation, dvbt_hierarchy_t hierarchy, dvbt_code_rate_t code_rate_HP,
+                dvbt_code_rate_t code_rate_LP, dvbt_guard_interval_t guard_interval, dvbt_transmission_mode_t transmission_mode,
+                int include_cell_id, int cell_id),
+               (dvbt_demod_reference_signals_params{itemsize, ninput, noutput, constellation, hierarchy, code_rate_HP, code_rate_LP, guard_interval,
+                                                    transmission_mode, include_cell_id, cell_id}))
+// include/dvbt/dvbt_demap.h:50
+DVBT_AMD_BLOCK(demap, dvbt_demap_params, (int nsize, dvbt_constellation_t constellation, dvbt_hierarchy_t hierarchy, dvbt_transmission_mode_t transmission, float gain),
+               (dvbt_demap_params{nsize, constellation, hierarchy, transmission, gain}))
+typedef demap dvbt_demap;   // reference class name
+// include/dvbt/symbol_inner_interleaver.h:50-51
+DVBT_AMD_BLOCK(symbol_inner_interleaver, dvbt_symbol_inner_interleaver_params, (int ninput, dvbt_transmission_mode_t transmission, int direction),
+               (dvbt_symbol_inner_interleaver_params{ninput, transmission, direction}))
+// include/dvbt/bit_inner_deinterleaver.h:50-51
+DVBT_AMD_BLOCK(bit_inner_deinterleaver, dvbt_bit_inner_deinterleaver_params,
+               (int nsize, dvbt_constellation_t constellation, dvbt_hierarchy_t hierarchy, dvbt_transmission_mode_t transmission),
+               (dvbt_bit_inner_deinterleaver_params{nsize, constellation, hierarchy, transmission}))
+// include/dvbt/viterbi_decoder.h:51-52
+DVBT_AMD_BLOCK(viterbi_decoder, dvbt_viterbi_decoder_params,
+               (dvbt_constellation_t constellation, dvbt_hierarchy_t hierarchy, dvbt_code_rate_t coderate, int bsize, int S0, int SK),
+               (dvbt_viterbi_decoder_params{constellation, hierarchy, coderate, bsize, S0, SK}))
+// include/dvbt/convolutional_deinterleaver.h:49
+DVBT_AMD_BLOCK(convolutional_deinterleaver, dvbt_convolutional_deinterleaver_params, (int nsize, int I, int M),
+               (dvbt_convolutional_deinterleaver_params{nsize, I, M}))
+// include/dvbt/reed_solomon_dec.h:49
+DVBT_AMD_BLOCK(reed_solomon_dec, dvbt_reed_solomon_dec_params, (int p, int m, int gfpoly, int n, int k, int t, int s, int blocks),
+               (dvbt_reed_solomon_dec_params{p, m, gfpoly, n, k, t, s, blocks, 0}))
+// include/dvbt/energy_descramble.h
+DVBT_AMD_BLOCK(energy_descramble, dvbt_energy_descramble_params, (int nblocks), (dvbt_energy_descramble_params{nblocks}))
+
+#undef DVBT_AMD_BLOCK
+}}  // namespace gr::dvbt_amd
