@@ -130,6 +130,15 @@ def main():
         vit_in = rep.n_out_symbols * d.payload_length
         alg_bytes = vit_in + rep.n_viterbi_bytes
         achieved = alg_bytes / (vit_ms * 1e-3) / 1e9 if vit_ms > 0 else 0.0
+        # HBM bytes of that kernel from the committed rocprofv3 PMC passes (tools/pmc.sh; FETCH_SIZE doubled per the
+        # gfx950 note in MI355X_MICROARCH.md), valid only for the batch size they were taken on
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary_8k_qam64_7_8_33sf.json")))
+            if pm["workload"]["samples_per_gpu_per_step"] == nsamp and a.workload == "8k_qam64_7_8":
+                traffic = int(pm["kernels"]["viterbi2_kernel"]["hbm_bytes_corrected"])
+        except Exception:
+            traffic = None
         out = {
             "metric": "RX Msamples/s (baseband in -> TS out)", "value": round(msps, 2), "unit": "Msamples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
@@ -138,8 +147,8 @@ def main():
             "config": {"workload": f"{a.workload} GI 1/32 RX chain, clean TX->RX loopback", "superframes_per_gpu": a.superframes + 1,
                        "samples_per_gpu_per_step": nsamp, "parallelism": f"segments x{world}" + (" + RCCL gather of TS" if world > 1 else ""),
                        "ts_bytes_per_step": int(rep.n_ts_bytes), "status": int(rep.status), "rs_fail_words": int(rep.rs_fail_words)},
-            "roofline": {"bound": "hbm", "kernel": "viterbi_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "viterbi2_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(vit_ms, 4),
                          "chain_frac": round(msps / world * 1e6 * (8 + rep.n_ts_bytes / nsamp) / 1e9 / HBM_PEAK_GBS, 6)},
             "stage_ms": {k: round(rx.stage_ms(k), 4) for k in ("acq", "fft", "demod", "inner", "viterbi", "rs", "total")},
