@@ -25,10 +25,14 @@
 //
 // Survivors.  Like the reference, which carries one path byte per state through each 8-step window
 // and keeps a ring of the last `ntraceback` path arrays (ppresult, d_viterbi.c:68-77,690-693), every
-// cell carries a tracking byte through the window: the cell its survivor occupied at the window
-// start (6 bits) and the raw decisions of the window's last two steps (2 bits).  That is the same
-// information: the reference hops with `state = path_byte >> 2` (:717), i.e. the state 8 steps
-// back, and the decoded byte is (state 8 steps back) << 2 | the last two appended bits.
+// cell carries survivor tracking through the window -- in the LOW 16 bits of the metric register
+// (metric in the high 16): the cell the survivor occupied at the window start, and the cell it
+// occupied after the window's 6th step.  Because the bias makes the two candidates of a compare
+// never equal in the metric field, max(X, Y_partner) on the whole register selects metric AND
+// tracking of the winner in one instruction (and the DPP exchange folds into it).
+// At the window end these give the reference's path byte: the reference hops with
+// `state = path_byte >> 2` (:717), i.e. the state 8 steps back, and the byte's low two bits are the
+// inputs of steps 7 and 8 = the top two bits of the state after step 6.
 // The 64 tracking bytes per decoder per window go to an LDS ring; traceback = ntraceback-1 table
 // hops from the window's best state (first index of the maximum, :699-711) + one decode.
 #pragma once
@@ -55,8 +59,8 @@ template <int CTRL> __device__ __forceinline__ int dpp(int v) { return __builtin
 __device__ __forceinline__ int rotl6(int c, int p) { return ((c << p) | (c >> (6 - p))) & 63; }
 
 struct V2Lane {                     // per-lane constants of the layout
-  unsigned sel[6];                  // v_perm selectors: byte r = label class of slot r's butterfly at phase P
-  int abit[4];                      // logical lane bits a0..a3
+  unsigned sel[6][4];               // v_perm selectors: delta<<16 (sign extended) of slot r's butterfly label at phase P
+  int abit[4];                      // logical lane bits a0..a3, pre-shifted to the bias position (bit 16)
   unsigned kc[3][4];                // best-state key constants at window ends (phase 0,2,4): (63-state)<<6 | z
 };
 
@@ -64,57 +68,60 @@ __device__ inline void v2_init_lane(int pl, V2Lane &L)
 {
   int q = pl & 7, a2 = (q >> 2) & 1;
   int a = ((q ^ (a2 ? 7 : 0)) & 3) | (a2 << 2) | (pl & 8);
-  for (int k = 0; k < 4; k++) L.abit[k] = (a >> k) & 1;
-  for (int P = 0; P < 6; P++) {
-    unsigned s = 0;
+  for (int k = 0; k < 4; k++) L.abit[k] = ((a >> k) & 1) << 16;
+  // the step's two delta words hold the four label classes at byte positions 1 and 3:
+  //   W0 = [0, d(class0), 0, d(class1)],  W1 = [0, d(class2), 0, d(class3)]
+  // v_perm_b32(W1, W0, sel) with sel = {0x0c, 0x0c, byte index, sign-extension code} yields d << 16
+  for (int P = 0; P < 6; P++)
     for (int r = 0; r < 4; r++) {
       int c = r * 16 + a, st = rotl6(c, P), i = st & 31;
       int c0 = ((i >> 2) ^ (i >> 1) ^ i) & 1;                 // parity(2i & 0x4f)
       int c1 = ((i >> 4) ^ (i >> 2) ^ (i >> 1)) & 1;          // parity(2i & 0x6d)
-      s |= (unsigned)(c0 | (c1 << 1)) << (8 * r);
+      int cls = c0 | (c1 << 1);
+      unsigned idx = 1 + 2 * cls, code = 8 + cls;              // in[] = {W0 bytes 0..3, W1 bytes 0..3}
+      L.sel[P][r] = 0x0c | (0x0c << 8) | (idx << 16) | (code << 24);
     }
-    L.sel[P] = s;
-  }
   for (int e = 0; e < 3; e++)
     for (int r = 0; r < 4; r++) { int c = r * 16 + a; L.kc[e][r] = ((unsigned)(63 - rotl6(c, 2 * e)) << 6) | (unsigned)(r * 16 + pl); }
 }
 
-// one trellis step at compile-time phase P.  m[]: metrics 2M+bias, trk[]: survivor tracking byte, W: packed deltas.
-// APPEND: the window's last two steps also shift the raw decision into the tracking byte.
-template <int P, bool APPEND> __device__ __forceinline__ void v2_step(int (&m)[4], int (&trk)[4], unsigned W, const V2Lane &L)
+// one trellis step at compile-time phase P.  v[]: (2M+bias) << 16 | tracking, W0/W1: the step's delta words
+template <int P> __device__ __forceinline__ void v2_step(int (&v)[4], unsigned W0, unsigned W1, const V2Lane &L)
 {
-  const unsigned E = __builtin_amdgcn_perm(W, W, L.sel[P]);
-  int d[4], X[4], Y[4], Yp[4], Tp[4];
+  int X[4], Y[4], Yp[4];
 #pragma unroll
-  for (int r = 0; r < 4; r++) { d[r] = (int)(E << (24 - 8 * r)) >> 24; X[r] = m[r] + d[r]; Y[r] = m[r] - d[r]; }
-  if (P == 0) { Yp[0] = Y[2]; Yp[2] = Y[0]; Yp[1] = Y[3]; Yp[3] = Y[1]; Tp[0] = trk[2]; Tp[2] = trk[0]; Tp[1] = trk[3]; Tp[3] = trk[1]; }
-  else if (P == 1) { Yp[0] = Y[1]; Yp[1] = Y[0]; Yp[2] = Y[3]; Yp[3] = Y[2]; Tp[0] = trk[1]; Tp[1] = trk[0]; Tp[2] = trk[3]; Tp[3] = trk[2]; }
+  for (int r = 0; r < 4; r++) {
+    const int D = (int)__builtin_amdgcn_perm(W1, W0, L.sel[P][r]);     // delta << 16
+    X[r] = v[r] + D; Y[r] = v[r] - D;
+  }
+  if (P == 0) { Yp[0] = Y[2]; Yp[2] = Y[0]; Yp[1] = Y[3]; Yp[3] = Y[1]; }
+  else if (P == 1) { Yp[0] = Y[1]; Yp[1] = Y[0]; Yp[2] = Y[3]; Yp[3] = Y[2]; }
   else {
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
+    for (int r = 0; r < 4; r++)
       Yp[r] = P == 2 ? dpp<DPP_ROR8>(Y[r]) : P == 3 ? dpp<DPP_HALF_MIRROR>(Y[r]) : P == 4 ? dpp<DPP_XOR2>(Y[r]) : dpp<DPP_XOR1>(Y[r]);
-      Tp[r] = P == 2 ? dpp<DPP_ROR8>(trk[r]) : P == 3 ? dpp<DPP_HALF_MIRROR>(trk[r]) : P == 4 ? dpp<DPP_XOR2>(trk[r]) : dpp<DPP_XOR1>(trk[r]);
-    }
   }
   constexpr int PN = (P + 1) % 6;                               // bias for the next phase
 #pragma unroll
   for (int r = 0; r < 4; r++) {
-    const bool from_partner = X[r] < Yp[r];                     // sign(T), T = X - Yp (never 0 when it matters: bias)
-    const int sel = from_partner ? Tp[r] : trk[r];
-    trk[r] = APPEND ? ((sel << 1) | (int)from_partner) : sel;
-    const int mx = max(X[r], Yp[r]);
-    const int nb = PN == 0 ? (r >> 1) : PN == 1 ? (r & 1) : PN == 2 ? L.abit[3] : PN == 3 ? L.abit[2] : PN == 4 ? L.abit[1] : L.abit[0];
-    m[r] = (mx & ~1) | nb;
+    const int mx = max(X[r], Yp[r]);                            // metric fields never tie (bias): tracking rides along
+    const int nb = PN == 0 ? ((r >> 1) << 16) : PN == 1 ? ((r & 1) << 16) : PN == 2 ? L.abit[3] : PN == 3 ? L.abit[2] : PN == 4 ? L.abit[1] : L.abit[0];
+    v[r] = (mx & ~0x10000) | nb;
   }
 }
 
-// 8 steps of one window; P0 = phase of its first step (0, 2 or 4)
-template <int P0> __device__ __forceinline__ void v2_window(int (&m)[4], int (&trk)[4], const unsigned (&W)[8], const V2Lane &L)
+// 8 steps of one window; P0 = phase of its first step (0, 2 or 4).  Tracking: byte 1 = cell at the window
+// start, byte 0 = cell after the 6th step.
+template <int P0> __device__ __forceinline__ void v2_window(int (&v)[4], const unsigned (&W)[16], const V2Lane &L, int pl)
 {
-  v2_step<(P0 + 0) % 6, false>(m, trk, W[0], L); v2_step<(P0 + 1) % 6, false>(m, trk, W[1], L);
-  v2_step<(P0 + 2) % 6, false>(m, trk, W[2], L); v2_step<(P0 + 3) % 6, false>(m, trk, W[3], L);
-  v2_step<(P0 + 4) % 6, false>(m, trk, W[4], L); v2_step<(P0 + 5) % 6, false>(m, trk, W[5], L);
-  v2_step<(P0 + 6) % 6, true>(m, trk, W[6], L);  v2_step<(P0 + 7) % 6, true>(m, trk, W[7], L);
+#pragma unroll
+  for (int r = 0; r < 4; r++) v[r] = (v[r] & 0xffff0000) | ((r * 16 + pl) << 8);
+  v2_step<(P0 + 0) % 6>(v, W[0], W[1], L); v2_step<(P0 + 1) % 6>(v, W[2], W[3], L);
+  v2_step<(P0 + 2) % 6>(v, W[4], W[5], L); v2_step<(P0 + 3) % 6>(v, W[6], W[7], L);
+  v2_step<(P0 + 4) % 6>(v, W[8], W[9], L); v2_step<(P0 + 5) % 6>(v, W[10], W[11], L);
+#pragma unroll
+  for (int r = 0; r < 4; r++) v[r] = (v[r] & 0xffffff00) | (r * 16 + pl);
+  v2_step<(P0 + 6) % 6>(v, W[12], W[13], L); v2_step<(P0 + 7) % 6>(v, W[14], W[15], L);
 }
 
 template <int CTRL> __device__ __forceinline__ int row_min_step(int v) { return min(v, dpp<CTRL>(v)); }
@@ -122,16 +129,29 @@ template <int CTRL> __device__ __forceinline__ unsigned row_max_step(unsigned v)
 
 // end of a window: min-renormalise, best state.  PE = phase after the window (0,2,4) -> kc index PE/2.
 // returns the winning cell's storage index z (slot*16 + physical lane) in every lane of the row
-template <int PE> __device__ __forceinline__ int v2_window_end(int (&m)[4], const V2Lane &L)
+template <int PE> __device__ __forceinline__ int v2_window_end(int (&v)[4], const V2Lane &L)
 {
-  int mn = min(min(m[0], m[1]), min(m[2], m[3]));
+  int mn = min(min(v[0], v[1]), min(v[2], v[3]));               // ordering is decided by the metric field
   mn = row_min_step<DPP_XOR1>(mn); mn = row_min_step<DPP_XOR2>(mn); mn = row_min_step<DPP_HALF_MIRROR>(mn); mn = row_min_step<DPP_MIRROR>(mn);
-  mn &= ~1;
+  mn &= 0xfffe0000;                                             // metric without bias, tracking cleared
   unsigned key = 0;
 #pragma unroll
-  for (int r = 0; r < 4; r++) { m[r] -= mn; key = max(key, ((unsigned)(m[r] >> 1) << 12) | L.kc[PE / 2][r]); }
+  for (int r = 0; r < 4; r++) { v[r] -= mn; key = max(key, ((unsigned)(v[r] >> 17) << 12) | L.kc[PE / 2][r]); }
   key = row_max_step<DPP_XOR1>(key); key = row_max_step<DPP_XOR2>(key); key = row_max_step<DPP_HALF_MIRROR>(key); key = row_max_step<DPP_MIRROR>(key);
   return (int)(key & 63);
+}
+
+// the reference's path byte from the tracking field: (cell at window start) << 2 | top two bits of the state after
+// step 6.  After 6 steps of a window that began at phase P0 the phase is P0 again, so that state is
+// rotl6(logical(z6), P0): its bits 5,4 are cell-index bits (5-P0, 4-P0).
+template <int P0> __device__ __forceinline__ unsigned v2_track_byte(int v)
+{
+  const unsigned z6 = (unsigned)v & 0x3f, org = ((unsigned)v >> 8) & 0x3f;
+  unsigned b;
+  if (P0 == 0) b = z6 >> 4;                                     // slot bits
+  else if (P0 == 2) b = (z6 >> 2) & 3;                          // a3 a2 = physical bits 3,2
+  else b = (z6 & 3) ^ (((z6 >> 2) & 1) * 3);                    // a1 a0 = physical bits 1,0 ^ a2
+  return (org << 2) | b;
 }
 
 // logical cell index (slot : a3..a0) of a storage index z (slot : physical lane)
@@ -146,7 +166,7 @@ __global__ __launch_bounds__(64 * V2_WAVES) void viterbi2_kernel(const uint8_t *
                                                                 long long steps_fixed, VitParams vp, long long in_base, long long out_lo)
 {
   __shared__ unsigned char s_tab[V2_WAVES][V2_RINGW * 4 * 64];     // tracking bytes: [window][decoder][cell z]  (the ppresult ring)
-  __shared__ __attribute__((aligned(16))) unsigned s_w[V2_WAVES][4 * V2_BLK * 8];   // packed deltas: [decoder][step in block]
+  __shared__ __attribute__((aligned(16))) unsigned s_w[V2_WAVES][4 * V2_BLK * 16];  // delta words W0,W1: [decoder][step in block][2]
   __shared__ __attribute__((aligned(16))) unsigned char s_in[V2_WAVES][4 * V2_INBYTES];   // staged input bytes per decoder
   __shared__ unsigned char s_best[V2_WAVES][4 * V2_RINGW];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, dd = lane >> 4, pl = lane & 15;
@@ -165,8 +185,7 @@ __global__ __launch_bounds__(64 * V2_WAVES) void viterbi2_kernel(const uint8_t *
   const long long n_in_bytes = (total_steps * 2 / vp.plen * vp.n + vp.m - 1) / vp.m;   // input bytes that exist
 
   V2Lane L; v2_init_lane(pl, L);
-  int m[4] = {0, 0, 1, 1};                                         // phase 0: slots 2,3 hold upper states
-  int trk[4];
+  int v[4] = {0, 0, 1 << 16, 1 << 16};                             // phase 0: slots 2,3 hold upper states
 
   for (int jb = 0; jb < J; jb += V2_BLK) {
     // ---- depuncture (viterbi_decoder_impl.cc:241-256) + delta packing for 192 steps x 4 decoders
@@ -215,11 +234,12 @@ __global__ __launch_bounds__(64 * V2_WAVES) void viterbi2_kernel(const uint8_t *
           bo = wrap ? 0 : bo; boff += wrap;
           if (real) { ph++; ph = ph == vp.plen ? 0 : ph; }
         }
-        // bytes: class 0 (c0=0,c1=0): u0+u1 | class 1 (c0=1): -u0+u1 | class 2 (c1=1): u0-u1 | class 3: -u0-u1,
-        // times 2 so that a step with one punctured symbol (odd agreement difference) keeps the LSB free for the bias
-        const unsigned Wd = ((unsigned)(2 * (u[0] + u[1])) & 0xff) | (((unsigned)(2 * (-u[0] + u[1])) & 0xff) << 8) |
-                            (((unsigned)(2 * (u[0] - u[1])) & 0xff) << 16) | (((unsigned)(2 * (-u[0] - u[1])) & 0xff) << 24);
-        wbuf[dd * (V2_BLK * 8) + ub0 + i] = Wd;
+        // class 0 (c0=0,c1=0): u0+u1 | class 1 (c0=1): -u0+u1 | class 2 (c1=1): u0-u1 | class 3: -u0-u1, times 2 so
+        // that a step with one punctured symbol (odd agreement difference) keeps the LSB free for the bias;
+        // stored at byte positions 1 and 3 (the ones v_perm can sign-extend)
+        const unsigned Wa = (((unsigned)(2 * (u[0] + u[1])) & 0xff) << 8) | (((unsigned)(2 * (-u[0] + u[1])) & 0xff) << 24);
+        const unsigned Wb = (((unsigned)(2 * (u[0] - u[1])) & 0xff) << 8) | (((unsigned)(2 * (-u[0] - u[1])) & 0xff) << 24);
+        *reinterpret_cast<uint2 *>(wbuf + (dd * (V2_BLK * 8) + ub0 + i) * 2) = make_uint2(Wa, Wb);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -229,21 +249,32 @@ __global__ __launch_bounds__(64 * V2_WAVES) void viterbi2_kernel(const uint8_t *
       for (int v3 = 0; v3 < 3; v3++) {
         const int j = jb + wi + v3;                                // relative window
         const int jr = j % V2_RINGW;
-        unsigned W[8];
+        unsigned W[16];
         {
-          const uint4 *wp = reinterpret_cast<const uint4 *>(wbuf + dd * (V2_BLK * 8) + (wi + v3) * 8);
-          uint4 lo = wp[0], hi = wp[1];
-          W[0] = lo.x; W[1] = lo.y; W[2] = lo.z; W[3] = lo.w; W[4] = hi.x; W[5] = hi.y; W[6] = hi.z; W[7] = hi.w;
-        }
+          const uint4 *wp = reinterpret_cast<const uint4 *>(wbuf + (dd * (V2_BLK * 8) + (wi + v3) * 8) * 2);
 #pragma unroll
-        for (int r = 0; r < 4; r++) trk[r] = r * 16 + pl;          // survivors start in their own cell
-        int z;
-        if (v3 == 0) { v2_window<0>(m, trk, W, L); z = v2_window_end<2>(m, L); }     // steps 8j..8j+7 with 8j%6==0 -> ends at phase 2
-        else if (v3 == 1) { v2_window<2>(m, trk, W, L); z = v2_window_end<4>(m, L); }
-        else { v2_window<4>(m, trk, W, L); z = v2_window_end<0>(m, L); }
+          for (int q4 = 0; q4 < 4; q4++) { uint4 t4 = wp[q4]; W[4 * q4] = t4.x; W[4 * q4 + 1] = t4.y; W[4 * q4 + 2] = t4.z; W[4 * q4 + 3] = t4.w; }
+        }
+        int z; unsigned tb[4];
+        if (v3 == 0) {            // steps 8j..8j+7 with 8j%6==0 -> ends at phase 2
+          v2_window<0>(v, W, L, pl);
+#pragma unroll
+          for (int r = 0; r < 4; r++) tb[r] = v2_track_byte<0>(v[r]);
+          z = v2_window_end<2>(v, L);
+        } else if (v3 == 1) {
+          v2_window<2>(v, W, L, pl);
+#pragma unroll
+          for (int r = 0; r < 4; r++) tb[r] = v2_track_byte<2>(v[r]);
+          z = v2_window_end<4>(v, L);
+        } else {
+          v2_window<4>(v, W, L, pl);
+#pragma unroll
+          for (int r = 0; r < 4; r++) tb[r] = v2_track_byte<4>(v[r]);
+          z = v2_window_end<0>(v, L);
+        }
         if (pl == 0) bestz[dd * V2_RINGW + jr] = (unsigned char)z;
 #pragma unroll
-        for (int r = 0; r < 4; r++) tab[(jr * 4 + dd) * 64 + r * 16 + pl] = (unsigned char)trk[r];
+        for (int r = 0; r < 4; r++) tab[(jr * 4 + dd) * 64 + r * 16 + pl] = (unsigned char)tb[r];
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -257,15 +288,10 @@ __global__ __launch_bounds__(64 * V2_WAVES) void viterbi2_kernel(const uint8_t *
       int z = bestz[dd * V2_RINGW + (j % V2_RINGW)];
       int w = j;
       for (int hop = 0; hop < ntb - 1; hop++, w--) z = tab[((w % V2_RINGW) * 4 + dd) * 64 + z] >> 2;   // state = path_byte >> 2 (:717)
-      // decode window w: byte = (state at its start) << 2 | the two bits appended by its last two steps
+      // decode window w: byte = (state at its start) << 2 | inputs of its steps 7 and 8 (already in the table byte)
       const unsigned t = tab[((w % V2_RINGW) * 4 + dd) * 64 + z];
-      const int P0 = (8 * w) % 6, P6 = (P0 + 6) % 6, P7 = (P0 + 7) % 6;
-      const int origin = (int)(t >> 2), s7 = (int)((t >> 1) & 1u), s8 = (int)(t & 1u);
-      const int z7 = z ^ (s8 ? v2_xmask(P7) : 0);                 // cell the survivor occupied before the last step
-      const int b8 = s8 ^ ((v2_logical(z) >> (5 - P7)) & 1);      // appended bit = decision ^ "own cell is an upper state"
-      const int b7 = s7 ^ ((v2_logical(z7) >> (5 - P6)) & 1);
-      const int sstart = rotl6(v2_logical(origin), P0);
-      out[ob - out_lo] = (unsigned char)((sstart << 2) | (b7 << 1) | b8);
+      const int sstart = rotl6(v2_logical((int)(t >> 2)), (8 * w) % 6);
+      out[ob - out_lo] = (unsigned char)((sstart << 2) | (t & 3u));
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   }
