@@ -62,7 +62,7 @@ struct Tables {          // device lookup tables for one configuration
   float2 *tw = nullptr; uint16_t *perm = nullptr;
   int16_t *cpilot = nullptr, *tps = nullptr; float *known = nullptr, *pref = nullptr;
   uint16_t *pay_c = nullptr, *pay_L = nullptr, *pay_R = nullptr, *tps_L = nullptr, *tps_R = nullptr;
-  uint16_t *H = nullptr; float2 *points = nullptr;
+  uint16_t *H = nullptr, *Hinv = nullptr; float2 *points = nullptr; uint8_t *label_tab = nullptr; int nlev = 0; float inv_step = 0.f, guard = 0.f;
   uint8_t *mul_alpha = nullptr, *gexp = nullptr, *glog = nullptr, *prbs = nullptr;
   bool front = false, inner = false, rs = false;
 
@@ -97,15 +97,36 @@ struct Tables {          // device lookup tables for one configuration
   int build_inner(float gain)
   {
     int r;
-    if (!H && (r = upload(symbol_H(d), &H))) return r;
+    if (!H) {
+      std::vector<uint16_t> h = symbol_H(d), hi(h.size());
+      for (size_t q = 0; q < h.size(); q++) hi[h[q]] = (uint16_t)q;
+      if ((r = upload(h, &H)) || (r = upload(hi, &Hinv))) return r;
+    }
     std::vector<float> p = constellation_points(d, gain);
-    std::vector<float2> p2(d.csize);
+    std::vector<float2> p2(64, make_float2(0.f, 0.f));
     for (int i = 0; i < d.csize; i++) p2[i] = make_float2(p[2 * i], p[2 * i + 1]);
+    // level grid for the candidate search (uniform only when alpha == 1): label_of[i_re * 8 + i_im]
+    std::vector<uint8_t> lab(64, 0);
+    nlev = 0;
+    if (d.alpha == 1 && gain > 0.f) {
+      int n = 1 << (d.m / 2);
+      float step = 2.0f * gain * d.norm;                       // spacing between adjacent levels
+      bool ok = true;
+      for (int i = 0; i < d.csize && ok; i++) {
+        float fi = p2[i].x / step + 0.5f * (n - 1), fq = p2[i].y / step + 0.5f * (n - 1);
+        int ii = (int)std::lround(fi), qq = (int)std::lround(fq);
+        if (ii < 0 || ii >= n || qq < 0 || qq >= n || std::fabs(fi - ii) > 1e-3f || std::fabs(fq - qq) > 1e-3f) ok = false;
+        else lab[ii * 8 + qq] = (uint8_t)i;
+      }
+      if (ok) { nlev = n; inv_step = 1.0f / step; guard = 1.0e4f * step; }
+    }
     if (points) { (void)hipFree(points); points = nullptr; }
-    if ((r = upload(p2, &points))) return r;
+    if (label_tab) { (void)hipFree(label_tab); label_tab = nullptr; }
+    if ((r = upload(p2, &points)) || (r = upload(lab, &label_tab))) return r;
     inner = true;
     return DVBT_OK;
   }
+  InnerParams inner_params(int payload) const { InnerParams ip; ip.payload = payload; ip.m = d.m; ip.csize = d.csize; ip.nlev = nlev; ip.inv_step = inv_step; ip.guard = guard; return ip; }
   int build_rs()
   {
     std::vector<uint8_t> ex(512), lg(256), mul(16 * 256);
@@ -121,7 +142,7 @@ struct Tables {          // device lookup tables for one configuration
   RsTables rs_tables() const { RsTables T; T.mul_alpha = mul_alpha; T.gexp = gexp; T.glog = glog; return T; }
   ~Tables()
   {
-    void *all[] = {tw, perm, cpilot, tps, known, pref, pay_c, pay_L, pay_R, tps_L, tps_R, H, points, mul_alpha, gexp, glog, prbs};
+    void *all[] = {tw, perm, cpilot, tps, known, pref, pay_c, pay_L, pay_R, tps_L, tps_R, H, Hinv, points, label_tab, mul_alpha, gexp, glog, prbs};
     for (void *q : all) if (q) (void)hipFree(q);
   }
 };
@@ -244,8 +265,8 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   RXHIP(hipMemset(h->st, 0, sizeof(RxState)));
   for (int i = 0; i < ST_COUNT; i++) RXHIP(hipEventCreate(&h->ev[i]));
   h->ev_ready = true;
-  RXCHK(set_lds((const void *)derot_fft_kernel, (size_t)N * 8));
-  RXCHK(set_lds((const void *)inner_kernel, ((P + 15) & ~(size_t)15) + d.csize * 8));
+  RXCHK(set_lds((const void *)derot_fft_kernel, (size_t)(N + N / 32 + N / 128 + 128) * 8));
+  RXCHK(set_lds((const void *)inner_kernel, ((P + 15) & ~(size_t)15) + 64 * 8 + 64));
   *out = h;
   return DVBT_OK;
 }
@@ -299,7 +320,7 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s)
   hipLaunchKernelGGL(acq_track_kernel, dim3(1), dim3(64), 0, s, fp, h->st, (const float2 *)h->g_trk, (const float *)h->l_trk, h->meta,
                      (const int *)(h->trk_flags + kIters), (AcqState *)nullptr);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_FFT], s));
-  hipLaunchKernelGGL(derot_fft_kernel, dim3(C), dim3(256), (size_t)N * 8, s, iq, fp, (const RxState *)h->st, (const SymMeta *)h->meta,
+  hipLaunchKernelGGL(derot_fft_kernel, dim3(C), dim3(256), (size_t)(N + N / 32 + N / 128 + 128) * 8, s, iq, fp, (const RxState *)h->st, (const SymMeta *)h->meta,
                      (const float2 *)h->T.tw, (const uint16_t *)h->T.perm, h->acq_tap, h->fft_out);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_DEMOD], s));
   hipLaunchKernelGGL(demod_kernel, dim3(C), dim3(256), 0, s, (const float2 *)h->fft_out, fp, (const RxState *)h->st, 0, h->T.demod_tables(),
@@ -317,10 +338,10 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s)
   }
   hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(64), 0, s, h->st, h->vp, h->prm.descramble);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_INNER], s));
-  InnerParams ip; ip.payload = d.payload; ip.m = d.m; ip.csize = d.csize;
-  hipLaunchKernelGGL(inner_kernel, dim3(C), dim3(256), ((d.payload + 15) & ~15) + d.csize * 8, s, (const float2 *)h->eq, (const uint8_t *)nullptr, ip,
-                     (const RxState *)h->st, 0, 7, (const int *)h->sym_index, (const float2 *)h->T.points, (const uint16_t *)h->T.H,
-                     h->demap_tap, h->symdeint_tap, h->bitdeint);
+  InnerParams ip = h->T.inner_params(d.payload);
+  hipLaunchKernelGGL(inner_kernel, dim3(C), dim3(256), ((d.payload + 15) & ~15) + 64 * 8 + 64, s, (const float2 *)h->eq, (const uint8_t *)nullptr, ip,
+                     (const RxState *)h->st, 0, 7, (const int *)h->sym_index, (const float2 *)h->T.points, (const unsigned char *)h->T.label_tab,
+                     (const uint16_t *)h->T.H, (const uint16_t *)h->T.Hinv, h->demap_tap, h->symdeint_tap, h->bitdeint);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_VIT], s));
   long long max_vit = (long long)C * d.payload * d.m * d.k / (8 * d.n) + 1;
   launch_viterbi(s, (const uint8_t *)h->bitdeint, h->vit, (const RxState *)h->st, 0ll, h->vp, 0ll, 0ll, max_vit);

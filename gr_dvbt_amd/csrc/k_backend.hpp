@@ -12,9 +12,12 @@ namespace dvbt {
 //   A4 dvbt_demap_impl.cc:167-203  : first strict minimum of (dr*dr + di*di) over the label table
 //   A5 symbol_inner_interleaver_impl.cc:202-208 : even symbol out[q]=in[H(q)], odd out[H(q)]=in[q]
 //   A6 bit_inner_deinterleaver_impl.cc:138-157 : out[i] bit k = bit (v-1-e) of in[(i-off_e) mod 126], e = perm(k)
-struct InnerParams { int payload, m, csize; };
+struct InnerParams { int payload, m, csize; int nlev; float inv_step, guard; };
+// nlev: levels per axis when the constellation is a uniform square grid (non-hierarchical), else 0;
+// inv_step = 1/(level spacing); guard: |component| above which the exhaustive search is used
 
-__device__ __forceinline__ int demap_one(float2 v, const float2 *pts, int csize)
+// exhaustive search: literally dvbt_demap_impl.cc:167-203
+__device__ __forceinline__ int demap_all(float2 v, const float2 *pts, int csize)
 {
   float dr = v.x - pts[0].x, di = v.y - pts[0].y;
   float best = dr * dr + di * di; int idx = 0;
@@ -26,32 +29,65 @@ __device__ __forceinline__ int demap_one(float2 v, const float2 *pts, int csize)
   return idx;
 }
 
-// mode bits: 1 = demap, 2 = symbol de-interleave, 4 = bit de-interleave (7 = fused chain path)
+// Same result from 9 candidates: the float sum dr*dr + di*di is monotone in each addend, so its
+// minimum over the table is attained on the per-axis nearest levels; a tie with any point outside the
+// 3x3 neighbourhood would need two distances that differ by >= one level spacing squared to round
+// equal, impossible below the guard magnitude.  "First strict minimum" = smallest label among equals.
+__device__ __forceinline__ int demap_one(float2 v, const float2 *pts, const unsigned char *label_of, const InnerParams &p)
+{
+  if (p.nlev == 0 || !(fabsf(v.x) < p.guard) || !(fabsf(v.y) < p.guard)) return demap_all(v, pts, p.csize);
+  const int n = p.nlev;
+  int ji = (int)floorf(v.x * p.inv_step + 0.5f * (float)n), jq = (int)floorf(v.y * p.inv_step + 0.5f * (float)n);
+  ji = ji < 0 ? 0 : ji > n - 1 ? n - 1 : ji; jq = jq < 0 ? 0 : jq > n - 1 ? n - 1 : jq;
+  float best = 3.0e38f; int idx = 255;
+#pragma unroll
+  for (int a = -1; a <= 1; a++) {
+    int i1 = ji + a; if (i1 < 0 || i1 >= n) continue;
+#pragma unroll
+    for (int b = -1; b <= 1; b++) {
+      int q1 = jq + b; if (q1 < 0 || q1 >= n) continue;
+      const int lab = label_of[i1 * 8 + q1];
+      const float dr = v.x - pts[lab].x, di = v.y - pts[lab].y;
+      const float d = dr * dr + di * di;
+      if (d < best || (d == best && lab < idx)) { best = d; idx = lab; }
+    }
+  }
+  return idx;
+}
+
+// mode bits: 1 = demap, 2 = symbol de-interleave, 4 = bit de-interleave (7 = fused chain path).
+// Reads are in carrier order (coalesced); the symbol permutation is applied on the LDS store:
+// even symbol out[q] = in[H(q)]  <=>  label of source p lands at Hinv[p];  odd: at H[p].
 __global__ __launch_bounds__(256) void inner_kernel(const float2 *__restrict__ eq, const uint8_t *__restrict__ in_bytes, InnerParams p,
                                                    const RxState *st, int nitems_fixed, int mode, const int *__restrict__ sym_index,
-                                                   const float2 *__restrict__ points, const uint16_t *__restrict__ H,
+                                                   const float2 *__restrict__ points, const unsigned char *__restrict__ label_tab,
+                                                   const uint16_t *__restrict__ H, const uint16_t *__restrict__ Hinv,
                                                    uint8_t *__restrict__ tap_demap, uint8_t *__restrict__ tap_symdeint,
                                                    uint8_t *__restrict__ out)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint8_t *v = smem_raw;                                       // payload bytes
   float2 *pts = reinterpret_cast<float2 *>(smem_raw + ((p.payload + 15) & ~15));
+  unsigned char *label_of = reinterpret_cast<unsigned char *>(pts + 64);
   const int u = blockIdx.x, tid = threadIdx.x;
   int first = 0, nout = nitems_fixed;
   if (st) { first = st->first_out; nout = st->n_out_symbols; if (first < 0) return; }
   if (u >= nout) return;
   const int s = first + u;
-  if (mode & 1) { for (int j = tid; j < p.csize; j += 256) pts[j] = points[j]; }
+  if (mode & 1) {
+    for (int j = tid; j < p.csize; j += 256) pts[j] = points[j];
+    if (tid < 64) label_of[tid] = label_tab[tid];
+  }
   __syncthreads();
   const bool odd = (mode & 2) ? (sym_index[s] & 1) : false;
   const float2 *e = eq ? eq + (size_t)s * p.payload : nullptr;
   const uint8_t *ib = in_bytes ? in_bytes + (size_t)s * p.payload : nullptr;
   for (int q = tid; q < p.payload; q += 256) {
-    int src = q, dst = q;
-    if (mode & 2) { if (odd) dst = H[q]; else src = H[q]; }
-    int lab = (mode & 1) ? demap_one(e[src], pts, p.csize) : ib[src];
+    int dst = q;
+    if (mode & 2) dst = odd ? H[q] : Hinv[q];
+    int lab = (mode & 1) ? demap_one(e[q], pts, label_of, p) : ib[q];
     v[dst] = (uint8_t)lab;
-    if (tap_demap && (mode & 1)) tap_demap[(size_t)u * p.payload + src] = (uint8_t)lab;
+    if (tap_demap && (mode & 1)) tap_demap[(size_t)u * p.payload + q] = (uint8_t)lab;
   }
   __syncthreads();
   uint8_t *o = out + (size_t)u * p.payload;

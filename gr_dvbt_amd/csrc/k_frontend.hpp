@@ -88,23 +88,34 @@ __global__ __launch_bounds__(256) void acq_metric_kernel(const float2 *__restric
 //            complete (largest one wins, first wins ties) and the sample is re-examined in state 0;
 //   state 0: above avg*rise -> enter state 1 with this sample as the running maximum;
 //   every sample then updates the IIR average exactly once.
-__device__ inline int peak_detect(const float *d, int n, float &avg, int &best_pos)
+__device__ __forceinline__ void peak_step(float v, int i, int &state, float &peak_val, int &peak_index, int &npk, float &best_val,
+                                          int &best_pos, float &avg)
 {
   const float rise = 0.8f, fall = 0.9f, alpha = 0.9f;
+  if (state == 1) {
+    if (v > peak_val) { peak_val = v; peak_index = i; }
+    else if (!(v > avg * fall)) {
+      if (npk == 0 || peak_val > best_val) { best_val = peak_val; best_pos = peak_index; }
+      npk++; state = 0; peak_val = -INFINITY;
+    }
+  }
+  if (state == 0 && v > avg * rise) { state = 1; peak_val = v; peak_index = i; }
+  avg = alpha * v + (1 - alpha) * avg;
+}
+
+__device__ inline int peak_detect(const float *d, int n, float &avg, int &best_pos)
+{
   int state = 0, peak_index = 0, npk = 0;
   float peak_val = -INFINITY, best_val = 0.f;
-  for (int i = 0; i < n; i++) {
-    const float v = d[i];
-    if (state == 1) {
-      if (v > peak_val) { peak_val = v; peak_index = i; }
-      else if (!(v > avg * fall)) {
-        if (npk == 0 || peak_val > best_val) { best_val = peak_val; best_pos = peak_index; }
-        npk++; state = 0; peak_val = -INFINITY;
-      }
-    }
-    if (state == 0 && v > avg * rise) { state = 1; peak_val = v; peak_index = i; }
-    avg = alpha * v + (1 - alpha) * avg;
+  int i = 0;
+  for (; i + 8 <= n; i += 8) {            // 8 metric values per trip in registers: the recurrence never waits on a load
+    float x[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) x[k] = d[i + k];
+#pragma unroll
+    for (int k = 0; k < 8; k++) peak_step(x[k], i + k, state, peak_val, peak_index, npk, best_val, best_pos, avg);
   }
+  for (; i < n; i++) peak_step(d[i], i, state, peak_val, peak_index, npk, best_val, best_pos, avg);
   return npk;
 }
 
@@ -326,6 +337,13 @@ __global__ __launch_bounds__(1024) void acq_finalize_kernel(FrontParams p, RxSta
   }
 }
 
+// LDS image of a symbol: one float2 of padding after every 32 keeps the stride-4/16/64 accesses of the
+// late radix-4 stages conflict-free (bank = float2 index mod 32 for ds_read_b64)
+__device__ __forceinline__ int fpad(int a) { return a + (a >> 5); }
+// twiddle W_N^t from a two-level table held in LDS: coarse[t >> 7] * fine[t & 127] (one complex multiply instead of
+// an L2 round trip per twiddle; relative error ~1.2e-7)
+__device__ __forceinline__ float2 twid(const float2 *coarse, const float2 *fine, int t) { return cmul(coarse[t >> 7], fine[t & 127]); }
+
 // ---------------------------------------------------------------- A1 tail + A2: derotate, strip CP, forward FFT with shift
 // One workgroup per OFDM symbol; the symbol lives in LDS (N*8 bytes) through all stages.
 // DIF radix-4 stages (+ one radix-2 when log2 N is odd), in place; the digit-reversed result is
@@ -340,6 +358,8 @@ __global__ __launch_bounds__(256) void derot_fft_kernel(const float2 *__restrict
   const int s = blockIdx.x;
   if (s >= st->n_symbols) return;
   const int N = p.N, cp = p.cp, tid = threadIdx.x;
+  float2 *tw_c = x + (N + N / 32), *tw_f = tw_c + N / 128;
+  if (out) { for (int i = tid; i < N / 128; i += 256) tw_c[i] = tw[i * 128]; if (tid < 128) tw_f[tid] = tw[tid]; }   // N >= 2048 here
   const SymMeta m = meta[s];
   const long long low = (long long)(st->call0 + s) * (N + cp) + m.cp_start - N + 1;
   const bool rot = (m.incA != 0.0) || (m.incB != 0.0) || (m.ph_base != 0.f);
@@ -352,7 +372,7 @@ __global__ __launch_bounds__(256) void derot_fft_kernel(const float2 *__restrict
       float sn, cs; sincosf(ph, &sn, &cs);
       v = cmul(make_float2(cs, sn), v);
     }
-    x[n] = v;
+    x[fpad(n)] = v;
     if (acq_tap) acq_tap[(size_t)s * N + n] = v;
   }
   if (!out) return;                              // A1 alone (block API): derotated, CP-stripped item only
@@ -362,19 +382,20 @@ __global__ __launch_bounds__(256) void derot_fft_kernel(const float2 *__restrict
     const int Q = L >> 2, tstep = N / L;
     for (int bf = tid; bf < (N >> 2); bf += 256) {
       int r = bf % Q, base = (bf / Q) * L + r;
-      float2 a0 = x[base], a1 = x[base + Q], a2 = x[base + 2 * Q], a3 = x[base + 3 * Q];
+      const int i0 = fpad(base), i1 = fpad(base + Q), i2 = fpad(base + 2 * Q), i3 = fpad(base + 3 * Q);
+      float2 a0 = x[i0], a1 = x[i1], a2 = x[i2], a3 = x[i3];
       float2 s02 = make_float2(a0.x + a2.x, a0.y + a2.y), d02 = make_float2(a0.x - a2.x, a0.y - a2.y);
       float2 s13 = make_float2(a1.x + a3.x, a1.y + a3.y), d13 = make_float2(a1.x - a3.x, a1.y - a3.y);
       float2 y0 = make_float2(s02.x + s13.x, s02.y + s13.y);
       float2 y2 = make_float2(s02.x - s13.x, s02.y - s13.y);
       float2 y1 = make_float2(d02.x + d13.y, d02.y - d13.x);       // d02 - i*d13
       float2 y3 = make_float2(d02.x - d13.y, d02.y + d13.x);       // d02 + i*d13
-      x[base] = y0;
-      if (r == 0) { x[base + Q] = y1; x[base + 2 * Q] = y2; x[base + 3 * Q] = y3; }
+      x[i0] = y0;
+      if (r == 0) { x[i1] = y1; x[i2] = y2; x[i3] = y3; }
       else {
-        x[base + Q] = cmul(y1, tw[r * tstep]);
-        x[base + 2 * Q] = cmul(y2, tw[2 * r * tstep]);
-        x[base + 3 * Q] = cmul(y3, tw[3 * r * tstep]);
+        x[i1] = cmul(y1, twid(tw_c, tw_f, r * tstep));
+        x[i2] = cmul(y2, twid(tw_c, tw_f, 2 * r * tstep));
+        x[i3] = cmul(y3, twid(tw_c, tw_f, 3 * r * tstep));
       }
     }
     __syncthreads();
@@ -382,14 +403,15 @@ __global__ __launch_bounds__(256) void derot_fft_kernel(const float2 *__restrict
   }
   if (L == 2) {
     for (int bf = tid; bf < (N >> 1); bf += 256) {
-      float2 a0 = x[2 * bf], a1 = x[2 * bf + 1];
-      x[2 * bf] = make_float2(a0.x + a1.x, a0.y + a1.y);
-      x[2 * bf + 1] = make_float2(a0.x - a1.x, a0.y - a1.y);
+      const int j0 = fpad(2 * bf), j1 = fpad(2 * bf + 1);
+      float2 a0 = x[j0], a1 = x[j1];
+      x[j0] = make_float2(a0.x + a1.x, a0.y + a1.y);
+      x[j1] = make_float2(a0.x - a1.x, a0.y - a1.y);
     }
     __syncthreads();
   }
   float2 *o = out + (size_t)s * N;
-  for (int b = tid; b < N; b += 256) o[b] = x[perm[b]];
+  for (int b = tid; b < N; b += 256) o[b] = x[fpad(perm[b])];
 }
 
 // plain FFT for the standalone A2 block: items already CP-stripped
@@ -401,36 +423,42 @@ __global__ __launch_bounds__(256) void fft_items_kernel(const float2 *__restrict
   float2 *x = reinterpret_cast<float2 *>(smem_raw);
   const int s = blockIdx.x, tid = threadIdx.x;
   if (s >= nitems) return;
-  for (int n = tid; n < N; n += 256) x[n] = in[(size_t)s * N + n];
+  const int nc = N >= 128 ? N / 128 : 1;
+  float2 *tw_c = x + (N + N / 32), *tw_f = tw_c + nc;
+  for (int i = tid; i < nc; i += 256) tw_c[i] = tw[i * 128 < N ? i * 128 : 0];
+  if (tid < 128 && tid < N) tw_f[tid] = tw[tid];
+  for (int n = tid; n < N; n += 256) x[fpad(n)] = in[(size_t)s * N + n];
   __syncthreads();
   int L = N;
   while (L >= 4) {
     const int Q = L >> 2, tstep = N / L;
     for (int bf = tid; bf < (N >> 2); bf += 256) {
       int r = bf % Q, base = (bf / Q) * L + r;
-      float2 a0 = x[base], a1 = x[base + Q], a2 = x[base + 2 * Q], a3 = x[base + 3 * Q];
+      const int i0 = fpad(base), i1 = fpad(base + Q), i2 = fpad(base + 2 * Q), i3 = fpad(base + 3 * Q);
+      float2 a0 = x[i0], a1 = x[i1], a2 = x[i2], a3 = x[i3];
       float2 s02 = make_float2(a0.x + a2.x, a0.y + a2.y), d02 = make_float2(a0.x - a2.x, a0.y - a2.y);
       float2 s13 = make_float2(a1.x + a3.x, a1.y + a3.y), d13 = make_float2(a1.x - a3.x, a1.y - a3.y);
-      x[base] = make_float2(s02.x + s13.x, s02.y + s13.y);
+      x[i0] = make_float2(s02.x + s13.x, s02.y + s13.y);
       float2 y2 = make_float2(s02.x - s13.x, s02.y - s13.y);
       float2 y1 = make_float2(d02.x + d13.y, d02.y - d13.x);
       float2 y3 = make_float2(d02.x - d13.y, d02.y + d13.x);
-      x[base + Q] = cmul(y1, tw[r * tstep]);
-      x[base + 2 * Q] = cmul(y2, tw[2 * r * tstep]);
-      x[base + 3 * Q] = cmul(y3, tw[3 * r * tstep]);
+      x[i1] = cmul(y1, twid(tw_c, tw_f, r * tstep));
+      x[i2] = cmul(y2, twid(tw_c, tw_f, 2 * r * tstep));
+      x[i3] = cmul(y3, twid(tw_c, tw_f, 3 * r * tstep));
     }
     __syncthreads();
     L = Q;
   }
   if (L == 2) {
     for (int bf = tid; bf < (N >> 1); bf += 256) {
-      float2 a0 = x[2 * bf], a1 = x[2 * bf + 1];
-      x[2 * bf] = make_float2(a0.x + a1.x, a0.y + a1.y);
-      x[2 * bf + 1] = make_float2(a0.x - a1.x, a0.y - a1.y);
+      const int j0 = fpad(2 * bf), j1 = fpad(2 * bf + 1);
+      float2 a0 = x[j0], a1 = x[j1];
+      x[j0] = make_float2(a0.x + a1.x, a0.y + a1.y);
+      x[j1] = make_float2(a0.x - a1.x, a0.y - a1.y);
     }
     __syncthreads();
   }
-  for (int b = tid; b < N; b += 256) out[(size_t)s * N + b] = x[perm[b]];
+  for (int b = tid; b < N; b += 256) out[(size_t)s * N + b] = x[fpad(perm[b])];
 }
 
 // ---------------------------------------------------------------- A3: pilot engine, one workgroup per OFDM symbol
