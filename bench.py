@@ -19,6 +19,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# independent segments run on separate HIP streams; give the runtime enough hardware queues that two
+# streams of one process do not share one (the ROCm default maps them onto 4 queues round-robin)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md)
 REALTIME_MSPS = 64.0 / 7.0       # OFDM elementary rate at the input of ofdm_sym_acquisition
@@ -66,6 +69,8 @@ def main():
     ap.add_argument("--workload", default="8k_qam64_7_8")
     ap.add_argument("--superframes", type=int, default=32, help="payload superframes per GPU per step")
     ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--segments", type=int, default=4,
+                    help="independent baseband segments per GPU per step, each on its own HIP stream (each gets its own lead-in superframe)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-superframes", type=int, default=3)
     a = ap.parse_args()
@@ -80,37 +85,52 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
-    (const, cr, mode), c, iq = make_input(a.workload, a.superframes, 20240607 + rank)
-    nsamp = len(iq)
-    d_iq = torch.from_numpy(iq.view(np.float32)).cuda()
-    rx = g.Rx(const, cr, mode, max_samples=nsamp, device=local, viterbi_chunk_bytes=a.chunk)
-    stream = torch.cuda.current_stream().cuda_stream
+    # the per-GPU batch is cut into `segments` independent segments (whole superframes + one lead-in each); they are
+    # enqueued on separate streams so that the short sequential kernels of one overlap the Viterbi kernel of another
+    nseg = max(1, a.segments)
+    per = [a.superframes // nseg + (1 if i < a.superframes % nseg else 0) for i in range(nseg)]
+    segs = []
+    for i, nsf in enumerate(per):
+        (const, cr, mode), c, iq = make_input(a.workload, nsf, 20240607 + 100 * rank + i)
+        d_iq = torch.from_numpy(iq.view(np.float32)).cuda()
+        rxi = g.Rx(const, cr, mode, max_samples=len(iq), device=local, viterbi_chunk_bytes=a.chunk)
+        segs.append({"iq": d_iq, "n": len(iq), "rx": rxi, "stream": torch.cuda.Stream()})
+    nsamp = sum(sg["n"] for sg in segs)
+    rx = segs[0]["rx"]
     ts_cap = int(nsamp * 0.45) + 4096
-    ts_view = torch.as_tensor(_DevView(rx.tap_device_ptr(g.TAP_TS), ts_cap), device=f"cuda:{local}")
+    ts_views = [torch.as_tensor(_DevView(sg["rx"].tap_device_ptr(g.TAP_TS), int(sg["n"] * 0.45) + 4096), device=f"cuda:{local}") for sg in segs]
+    ts_send = torch.zeros(ts_cap, dtype=torch.uint8, device=f"cuda:{local}") if dist else None
     gathered = [torch.empty(ts_cap, dtype=torch.uint8, device=f"cuda:{local}") for _ in range(world)] if (dist and rank == 0) else None
 
     def step():
-        rx.enqueue_device(d_iq.data_ptr(), nsamp, stream)
-        rep = rx.finish()
+        for sg in segs:
+            sg["rx"].enqueue_device(sg["iq"].data_ptr(), sg["n"], sg["stream"].cuda_stream)
+        reps = [sg["rx"].finish() for sg in segs]
         if dist:                                   # the single exchange step: TS packets -> rank 0 over xGMI
-            dist.gather(ts_view, gathered, dst=0)
-        return rep
+            off = 0
+            for v, r in zip(ts_views, reps):
+                n = int(r.n_ts_bytes)
+                ts_send[off:off + n].copy_(v[:n])
+                off += n
+            dist.gather(ts_send, gathered, dst=0)
+        return reps
 
     for _ in range(a.warmup):
-        rep = step()
-    rx.enable_timing(True)
+        reps = step()
+    for sg in segs:
+        sg["rx"].enable_timing(True)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        rep = step()
+        reps = step()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -123,20 +143,22 @@ def main():
 
     if rank == 0:
         msps = world * nsamp * a.steps / dt / 1e6
-        vit_ms = rx.stage_ms("viterbi")
-        # dominant kernel = viterbi_kernel: algorithmic bytes per launch = bytes in (one per m coded bits)
-        # + decoded bytes out (6048 + 3969 B per 8k QAM64 7/8 OFDM symbol)
+        # dominant kernel = viterbi2_kernel: per launch, algorithmic bytes = bytes in (one per m coded bits) + decoded
+        # bytes out (6048 + 3969 B per 8k QAM64 7/8 OFDM symbol); launch duration from HIP events
+        # recorded on the segment's own stream; averages over the segments' launches
         d = rx.dims
-        vit_in = rep.n_out_symbols * d.payload_length
-        alg_bytes = vit_in + rep.n_viterbi_bytes
+        vit_ms = sum(sg["rx"].stage_ms("viterbi") for sg in segs) / nseg
+        alg_bytes = sum(r.n_out_symbols * d.payload_length + r.n_viterbi_bytes for r in reps) / nseg
+        rep = reps[0]
+        n_ts = sum(int(r.n_ts_bytes) for r in reps)
         achieved = alg_bytes / (vit_ms * 1e-3) / 1e9 if vit_ms > 0 else 0.0
         # HBM bytes of that kernel from the committed rocprofv3 PMC passes (tools/pmc.sh; FETCH_SIZE doubled per the
-        # gfx950 note in MI355X_MICROARCH.md), valid only for the batch size they were taken on
+        # gfx950 note in MI355X_MICROARCH.md), scaled per algorithmic byte of the profiled launch
         traffic = None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary_8k_qam64_7_8_33sf.json")))
-            if pm["workload"]["samples_per_gpu_per_step"] == nsamp and a.workload == "8k_qam64_7_8":
-                traffic = int(pm["kernels"]["viterbi2_kernel"]["hbm_bytes_corrected"])
+            if a.workload == "8k_qam64_7_8":
+                traffic = int(pm["kernels"]["viterbi2_kernel"]["hbm_bytes_corrected"] / pm["viterbi_algorithmic_bytes"] * alg_bytes)
         except Exception:
             traffic = None
         out = {
@@ -144,19 +166,20 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 (Viterbi/RS) + f32 (front end)",
             "data": "synthetic", "x_realtime": round(msps / REALTIME_MSPS / world, 1),
-            "config": {"workload": f"{a.workload} GI 1/32 RX chain, clean TX->RX loopback", "superframes_per_gpu": a.superframes + 1,
+            "config": {"workload": f"{a.workload} GI 1/32 RX chain, clean TX->RX loopback", "superframes_per_gpu": a.superframes + nseg, "segments_per_gpu": nseg,
                        "samples_per_gpu_per_step": nsamp, "parallelism": f"segments x{world}" + (" + RCCL gather of TS" if world > 1 else ""),
-                       "ts_bytes_per_step": int(rep.n_ts_bytes), "status": int(rep.status), "rs_fail_words": int(rep.rs_fail_words)},
+                       "ts_bytes_per_step": n_ts, "status": [int(r.status) for r in reps], "rs_fail_words": [int(r.rs_fail_words) for r in reps]},
             "roofline": {"bound": "hbm", "kernel": "viterbi2_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(vit_ms, 4),
-                         "chain_frac": round(msps / world * 1e6 * (8 + rep.n_ts_bytes / nsamp) / 1e9 / HBM_PEAK_GBS, 6)},
-            "stage_ms": {k: round(rx.stage_ms(k), 4) for k in ("acq", "fft", "demod", "inner", "viterbi", "rs", "total")},
+                         "chain_frac": round(msps / world * 1e6 * (8 + n_ts / nsamp) / 1e9 / HBM_PEAK_GBS, 6)},
+            "stage_ms_per_segment": {k: round(sum(sg["rx"].stage_ms(k) for sg in segs) / nseg, 4) for k in ("acq", "fft", "demod", "inner", "viterbi", "rs", "total")},
         }
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_superframes)
         print(json.dumps(out))
-    rx.close()
+    for sg in segs:
+        sg["rx"].close()
     if dist:
         dist.destroy_process_group()
 

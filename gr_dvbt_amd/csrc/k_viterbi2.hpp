@@ -45,7 +45,7 @@ namespace dvbt {
 constexpr int V2_WARM = 72;        // warm-up windows before a chunk's first byte
 constexpr int V2_BLK = 24;         // windows per forward block (multiple of 3: the phase cycle of 6 steps vs 8-step windows)
 constexpr int V2_RINGW = 48;       // windows kept in the LDS ring (>= V2_BLK + max ntraceback - 1)
-constexpr int V2_WAVES = 2;        // wavefronts per workgroup
+constexpr int V2_WAVES = 1;        // wavefronts per workgroup
 constexpr int V2_INBYTES = 256;    // input bytes staged per decoder per block (192 steps need <= 192 + slack)
 
 #define DPP_XOR1 0xB1              /* quad_perm [1,0,3,2] */

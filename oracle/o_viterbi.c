@@ -34,30 +34,32 @@ void o_vit_core_init(o_vit_core *v, int ntraceback)
   v->ntraceback = ntraceback;
 }
 
-/* one trellis step; d_viterbi.c:483-524 (and its copy :533-575) */
+/* one trellis step; d_viterbi.c:483-524 (and its copy :533-575).  Written as the SSE2 code is
+ * organised (branch metrics for the 32 butterflies first, then the ACS, then the interleave of
+ * even/odd successors) with every loop over plain uint8 arrays so that gcc -O3 -msse2 vectorises it. */
 static void step(const unsigned char *metric0, const unsigned char *path0,
                  unsigned char *metric1, unsigned char *path1,
                  unsigned char s0, unsigned char s1)
 {
+  unsigned char metsvm[32], metsv[32], sv0[32], sv1[32], pt0[32], pt1[32];
+  if (s0 == 2)      for (int b = 0; b < 32; b++) { metsvm[b] = branchtab[1][b] ^ s1; metsv[b] = (unsigned char)(1 - metsvm[b]); }
+  else if (s1 == 2) for (int b = 0; b < 32; b++) { metsvm[b] = branchtab[0][b] ^ s0; metsv[b] = (unsigned char)(1 - metsvm[b]); }
+  else for (int b = 0; b < 32; b++) { metsvm[b] = (unsigned char)((branchtab[0][b] ^ s0) + (branchtab[1][b] ^ s1)); metsv[b] = (unsigned char)(2 - metsvm[b]); }
   for (int b = 0; b < 32; b++) {
-    unsigned char metsvm, metsv;
-    if (s0 == 2)      { metsvm = branchtab[1][b] ^ s1; metsv = (unsigned char)(1 - metsvm); }
-    else if (s1 == 2) { metsvm = branchtab[0][b] ^ s0; metsv = (unsigned char)(1 - metsvm); }
-    else { metsvm = (unsigned char)((branchtab[0][b] ^ s0) + (branchtab[1][b] ^ s1));
-           metsv = (unsigned char)(2 - metsvm); }
-    unsigned char m0 = (unsigned char)(metric0[b] + metsv);
-    unsigned char m1 = (unsigned char)(metric0[b + 32] + metsvm);
-    unsigned char m2 = (unsigned char)(metric0[b] + metsvm);
-    unsigned char m3 = (unsigned char)(metric0[b + 32] + metsv);
-    int d0 = (signed char)(unsigned char)(m0 - m1) > 0;
-    int d1 = (signed char)(unsigned char)(m2 - m3) > 0;
+    unsigned char m0 = (unsigned char)(metric0[b] + metsv[b]);
+    unsigned char m1 = (unsigned char)(metric0[b + 32] + metsvm[b]);
+    unsigned char m2 = (unsigned char)(metric0[b] + metsvm[b]);
+    unsigned char m3 = (unsigned char)(metric0[b + 32] + metsv[b]);
+    unsigned char d0 = (signed char)(unsigned char)(m0 - m1) > 0 ? 0xff : 0;
+    unsigned char d1 = (signed char)(unsigned char)(m2 - m3) > 0 ? 0xff : 0;
     unsigned char sh0 = (unsigned char)(path0[b] << 1);
     unsigned char sh1 = (unsigned char)((path0[b + 32] << 1) + 1);
-    metric1[2 * b]     = d0 ? m0 : m1;
-    metric1[2 * b + 1] = d1 ? m2 : m3;
-    path1[2 * b]       = d0 ? sh0 : sh1;
-    path1[2 * b + 1]   = d1 ? sh0 : sh1;
+    sv0[b] = (unsigned char)((d0 & m0) | (~d0 & m1));
+    sv1[b] = (unsigned char)((d1 & m2) | (~d1 & m3));
+    pt0[b] = (unsigned char)((d0 & sh0) | (~d0 & sh1));
+    pt1[b] = (unsigned char)((d1 & sh0) | (~d1 & sh1));
   }
+  for (int b = 0; b < 32; b++) { metric1[2 * b] = sv0[b]; metric1[2 * b + 1] = sv1[b]; path1[2 * b] = pt0[b]; path1[2 * b + 1] = pt1[b]; }
 }
 
 /* d_viterbi_butterfly2_sse2: two trellis steps on 4 depunctured symbols */

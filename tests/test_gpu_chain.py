@@ -155,3 +155,27 @@ def test_short_and_degenerate_segments(po, g):
     rep = rx.run(iq)                                          # and the handle still works afterwards
     assert rep.first_out_symbol == 272
     rx.close()
+
+
+def test_concurrent_segments_on_separate_streams(po, g):
+    """Several independent segments in flight at once (one handle + one HIP stream each, as bench.py and the
+    multi-GPU path use them): results equal the one-at-a-time results, whatever the interleaving."""
+    import torch
+    cfgs = [(1, 0, 0, 3, 41), (2, 4, 1, 2, 42), (1, 0, 0, 4, 43), (0, 4, 1, 2, 44)]
+    items = []
+    for const, cr, mode, nsf, seed in cfgs:
+        c, iq = _make(po, const, cr, mode, nsf, seed)
+        ref = po.rx(c, iq, want=("ts",))["ts"]
+        d_iq = torch.from_numpy(iq.view(np.float32)).cuda()
+        items.append({"rx": g.Rx(const, cr, mode, max_samples=len(iq)), "iq": d_iq, "n": len(iq), "ref": ref,
+                      "stream": torch.cuda.Stream()})
+    for _ in range(3):
+        for it in items:
+            it["rx"].enqueue_device(it["iq"].data_ptr(), it["n"], it["stream"].cuda_stream)
+        for it in reversed(items):
+            it["rx"].finish()
+        for it in items:
+            tso = it["rx"].tap(g.TAP_TS)
+            assert tso.size == it["ref"].size > 0 and (tso == it["ref"]).all()
+    for it in items:
+        it["rx"].close()
