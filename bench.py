@@ -67,9 +67,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="8k_qam64_7_8")
-    ap.add_argument("--superframes", type=int, default=32, help="payload superframes per GPU per step")
+    ap.add_argument("--superframes", type=int, default=64, help="payload superframes per GPU per step")
     ap.add_argument("--chunk", type=int, default=0)
-    ap.add_argument("--segments", type=int, default=4,
+    ap.add_argument("--segments", type=int, default=1,
                     help="independent baseband segments per GPU per step, each on its own HIP stream (each gets its own lead-in superframe)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-superframes", type=int, default=3)
@@ -101,6 +101,7 @@ def main():
         rxi = g.Rx(const, cr, mode, max_samples=len(iq), device=local, viterbi_chunk_bytes=a.chunk)
         segs.append({"iq": d_iq, "n": len(iq), "rx": rxi, "stream": torch.cuda.Stream()})
     nsamp = sum(sg["n"] for sg in segs)
+    torch.cuda.synchronize()                       # uploads done before any segment stream reads them
     rx = segs[0]["rx"]
     ts_cap = int(nsamp * 0.45) + 4096
     ts_views = [torch.as_tensor(_DevView(sg["rx"].tap_device_ptr(g.TAP_TS), int(sg["n"] * 0.45) + 4096), device=f"cuda:{local}") for sg in segs]

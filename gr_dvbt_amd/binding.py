@@ -66,7 +66,10 @@ _lib = None
 
 
 def lib():
-    """Load libdvbt_hip.so. Fails loudly when the extension is missing: there is no fallback."""
+    """Load libdvbt_hip.so. Fails loudly when the extension is missing: there is no fallback.
+
+    Note for processes that also use PyTorch: import torch BEFORE the first call of this function, so that
+    both share torch's bundled HIP runtime (two HIP runtimes in one process cannot both open the GPU)."""
     global _lib
     if _lib is None:
         if not os.path.exists(_SO):

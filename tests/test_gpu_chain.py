@@ -169,6 +169,7 @@ def test_concurrent_segments_on_separate_streams(po, g):
         d_iq = torch.from_numpy(iq.view(np.float32)).cuda()
         items.append({"rx": g.Rx(const, cr, mode, max_samples=len(iq)), "iq": d_iq, "n": len(iq), "ref": ref,
                       "stream": torch.cuda.Stream()})
+    torch.cuda.synchronize()                      # uploads were enqueued on torch's current stream
     for _ in range(3):
         for it in items:
             it["rx"].enqueue_device(it["iq"].data_ptr(), it["n"], it["stream"].cuda_stream)
