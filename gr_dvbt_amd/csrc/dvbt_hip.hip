@@ -344,7 +344,21 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s)
                      (const uint16_t *)h->T.H, (const uint16_t *)h->T.Hinv, h->demap_tap, h->symdeint_tap, h->bitdeint);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_VIT], s));
   long long max_vit = (long long)C * d.payload * d.m * d.k / (8 * d.n) + 1;
-  launch_viterbi(s, (const uint8_t *)h->bitdeint, h->vit, (const RxState *)h->st, 0ll, h->vp, 0ll, 0ll, max_vit);
+  VitParams vp = h->vp;
+  if (h->prm.viterbi_chunk_bytes <= 0 && viterbi_kernel_version() == 2) {
+    // chunk size chosen per segment so that the wavefront count is a whole number of "rounds" of the resident
+    // wavefront slots (4 chunks per wavefront, V2 kernel: 8 one-wave workgroups per CU by LDS): equal-length
+    // chunks then finish together instead of leaving a partial last round, and longer chunks amortise the
+    // warm-up + traceback overlap (V2_WARM + ntraceback - 1 windows per chunk)
+    int ncu = 256; (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->prm.device);
+    const long long slots = (long long)ncu * 8 * 4;             // chunks resident at once
+    long long rounds = (max_vit + slots * 1792 - 1) / (slots * 1792);
+    if (rounds < 1) rounds = 1;
+    long long B = (max_vit + slots * rounds - 1) / (slots * rounds);
+    if (B < 256) B = 256;
+    vp.chunk_bytes = (int)B;
+  }
+  launch_viterbi(s, (const uint8_t *)h->bitdeint, h->vit, (const RxState *)h->st, 0ll, vp, 0ll, 0ll, max_vit);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_RS], s));
   long long max_words = max_vit / 204 + 1;
   hipLaunchKernelGGL(deint_rs_kernel, dim3((unsigned)((max_words + 63) / 64)), dim3(64), 0, s, (const uint8_t *)h->vit, h->deint_tap, h->rs_out,

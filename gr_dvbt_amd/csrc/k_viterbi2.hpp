@@ -38,6 +38,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <limits.h>
 #include "k_backend.hpp"
 
 namespace dvbt {
@@ -127,18 +128,25 @@ template <int P0> __device__ __forceinline__ void v2_window(int (&v)[4], const u
 template <int CTRL> __device__ __forceinline__ int row_min_step(int v) { return min(v, dpp<CTRL>(v)); }
 template <int CTRL> __device__ __forceinline__ unsigned row_max_step(unsigned v) { return max(v, (unsigned)dpp<CTRL>((int)v)); }
 
-// end of a window: min-renormalise, best state.  PE = phase after the window (0,2,4) -> kc index PE/2.
+// end of a window: best state (signed keys: the metric field may be negative between renormalisations) and, every
+// fourth window, min-renormalisation (the reference subtracts the minimum at every output, d_viterbi.c:728-732; that
+// only keeps its 8-bit metrics from wrapping -- decisions depend on differences -- and the 16-bit field here has room
+// for 4 windows of drift).  PE = phase after the window (0,2,4) -> kc index PE/2.
 // returns the winning cell's storage index z (slot*16 + physical lane) in every lane of the row
-template <int PE> __device__ __forceinline__ int v2_window_end(int (&v)[4], const V2Lane &L)
+template <int PE> __device__ __forceinline__ int v2_window_end(int (&v)[4], const V2Lane &L, bool renorm)
 {
-  int mn = min(min(v[0], v[1]), min(v[2], v[3]));               // ordering is decided by the metric field
-  mn = row_min_step<DPP_XOR1>(mn); mn = row_min_step<DPP_XOR2>(mn); mn = row_min_step<DPP_HALF_MIRROR>(mn); mn = row_min_step<DPP_MIRROR>(mn);
-  mn &= 0xfffe0000;                                             // metric without bias, tracking cleared
-  unsigned key = 0;
+  int key = INT_MIN;
 #pragma unroll
-  for (int r = 0; r < 4; r++) { v[r] -= mn; key = max(key, ((unsigned)(v[r] >> 17) << 12) | L.kc[PE / 2][r]); }
-  key = row_max_step<DPP_XOR1>(key); key = row_max_step<DPP_XOR2>(key); key = row_max_step<DPP_HALF_MIRROR>(key); key = row_max_step<DPP_MIRROR>(key);
-  return (int)(key & 63);
+  for (int r = 0; r < 4; r++) key = max(key, (int)(((unsigned)(v[r] >> 17) << 12) | L.kc[PE / 2][r]));
+  key = max(key, dpp<DPP_XOR1>(key)); key = max(key, dpp<DPP_XOR2>(key)); key = max(key, dpp<DPP_HALF_MIRROR>(key)); key = max(key, dpp<DPP_MIRROR>(key));
+  if (renorm) {
+    int mn = min(min(v[0], v[1]), min(v[2], v[3]));             // ordering is decided by the metric field
+    mn = row_min_step<DPP_XOR1>(mn); mn = row_min_step<DPP_XOR2>(mn); mn = row_min_step<DPP_HALF_MIRROR>(mn); mn = row_min_step<DPP_MIRROR>(mn);
+    mn &= 0xfffe0000;                                           // metric without bias, tracking cleared
+#pragma unroll
+    for (int r = 0; r < 4; r++) v[r] -= mn;
+  }
+  return key & 63;
 }
 
 // the reference's path byte from the tracking field: (cell at window start) << 2 | top two bits of the state after
@@ -260,17 +268,17 @@ __global__ __launch_bounds__(64 * V2_WAVES) void viterbi2_kernel(const uint8_t *
           v2_window<0>(v, W, L, pl);
 #pragma unroll
           for (int r = 0; r < 4; r++) tb[r] = v2_track_byte<0>(v[r]);
-          z = v2_window_end<2>(v, L);
+          z = v2_window_end<2>(v, L, (j & 3) == 3);
         } else if (v3 == 1) {
           v2_window<2>(v, W, L, pl);
 #pragma unroll
           for (int r = 0; r < 4; r++) tb[r] = v2_track_byte<2>(v[r]);
-          z = v2_window_end<4>(v, L);
+          z = v2_window_end<4>(v, L, (j & 3) == 3);
         } else {
           v2_window<4>(v, W, L, pl);
 #pragma unroll
           for (int r = 0; r < 4; r++) tb[r] = v2_track_byte<4>(v[r]);
-          z = v2_window_end<0>(v, L);
+          z = v2_window_end<0>(v, L, (j & 3) == 3);
         }
         if (pl == 0) bestz[dd * V2_RINGW + jr] = (unsigned char)z;
 #pragma unroll
