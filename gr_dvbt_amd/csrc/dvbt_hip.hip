@@ -320,7 +320,7 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s)
   hipLaunchKernelGGL(acq_track_kernel, dim3(1), dim3(64), 0, s, fp, h->st, (const float2 *)h->g_trk, (const float *)h->l_trk, h->meta,
                      (const int *)(h->trk_flags + kIters), (AcqState *)nullptr);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_FFT], s));
-  hipLaunchKernelGGL(derot_fft_kernel, dim3(C), dim3(256), (size_t)(N + N / 32 + N / 128 + 128) * 8, s, iq, fp, (const RxState *)h->st, (const SymMeta *)h->meta,
+  hipLaunchKernelGGL(derot_fft_kernel, dim3(C), dim3(FFT_THREADS), (size_t)(N + N / 32 + N / 128 + 128) * 8, s, iq, fp, (const RxState *)h->st, (const SymMeta *)h->meta,
                      (const float2 *)h->T.tw, (const uint16_t *)h->T.perm, h->acq_tap, h->fft_out);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_DEMOD], s));
   hipLaunchKernelGGL(demod_kernel, dim3(C), dim3(256), 0, s, (const float2 *)h->fft_out, fp, (const RxState *)h->st, 0, h->T.demod_tables(),

@@ -176,16 +176,17 @@ inline PatternTables pattern_tables(const Dims &d, int s)
   return t;
 }
 
-// FFT plan: DIF stages of radix 4 (and one radix 2 when log2 N is odd), in place, natural-order
+// FFT plan: DIF passes of radix 16 (then 4 and/or 2), in place, natural-order
 // input.  After the last stage position p holds X[k(p)] with k the digit reversal of p.
 // perm[b] = position holding the bin that the shifted output index b must receive:
 // out[b] = X[(b - N/2) mod N]   (gr::fft::fft_vcc forward, shift=True; SURVEY C-2).
 inline std::vector<int> fft_radices(int N)
-{
+{ // the pass sequence of k_frontend.hpp::fft_dif_lds: radix 16 while the span allows, then 4 and/or 2
   std::vector<int> r;
-  int l = 0; while ((1 << l) < N) l++;
-  for (int i = 0; i + 1 < l; i += 2) r.push_back(4);
-  if (l & 1) r.push_back(2);
+  int L = N;
+  while (L >= 16) { r.push_back(16); L /= 16; }
+  if (L >= 4) { r.push_back(4); L /= 4; }
+  if (L == 2) r.push_back(2);
   return r;
 }
 inline std::vector<uint16_t> fft_out_perm(int N)

@@ -339,16 +339,106 @@ __global__ __launch_bounds__(1024) void acq_finalize_kernel(FrontParams p, RxSta
 
 // LDS image of a symbol: one float2 of padding after every 32 keeps the stride-4/16/64 accesses of the
 // late radix-4 stages conflict-free (bank = float2 index mod 32 for ds_read_b64)
+constexpr int FFT_THREADS = 256;
 __device__ __forceinline__ int fpad(int a) { return a + (a >> 5); }
 // twiddle W_N^t from a two-level table held in LDS: coarse[t >> 7] * fine[t & 127] (one complex multiply instead of
 // an L2 round trip per twiddle; relative error ~1.2e-7)
 __device__ __forceinline__ float2 twid(const float2 *coarse, const float2 *fine, int t) { return cmul(coarse[t >> 7], fine[t & 127]); }
 
+// LDS position that holds bin k after fft_dif_lds: digit reversal over the pass radices (16.. then 4 and/or 2)
+__device__ __forceinline__ int fft_pos_of_bin(int k, int N)
+{
+  int L = N, p = 0;
+  while (L >= 16) { L >>= 4; p += (k & 15) * L; k >>= 4; }
+  if (L >= 4) { L >>= 2; p += (k & 3) * L; k >>= 2; }
+  if (L == 2) p += k & 1;
+  return p;
+}
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// forward radix-4 butterfly: y_k = sum_j a_j (-i)^(jk)
+__device__ __forceinline__ void bfly4(float2 a0, float2 a1, float2 a2, float2 a3, float2 &y0, float2 &y1, float2 &y2, float2 &y3)
+{
+  const float2 s02 = cadd(a0, a2), d02 = csub(a0, a2), s13 = cadd(a1, a3), d13 = csub(a1, a3);
+  y0 = cadd(s02, s13); y2 = csub(s02, s13);
+  y1 = make_float2(d02.x + d13.y, d02.y - d13.x);               // d02 - i*d13
+  y3 = make_float2(d02.x - d13.y, d02.y + d13.x);               // d02 + i*d13
+}
+
+// In-place decimation-in-frequency FFT of the padded LDS image x (N points, natural order in, digit-reversed
+// out; the host-built permutation undoes the reversal).  Radix-16 passes with the 16-point transform held in
+// registers (two radix-4 levels), then a radix-4 and/or radix-2 tail: 8192 = 16.16.16.2, 2048 = 16.16.4.2
+// (dvbt_tables.hpp::fft_radices lists the same sequence).  One __syncthreads per pass.
+__device__ inline void fft_dif_lds(float2 *x, int N, const float2 *tw_c, const float2 *tw_f, int tid)
+{
+  // W16^m = exp(-2 pi i m / 16), m = 0..9 (products r'*k1 with r',k1 <= 3)
+  const float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, h = 0.70710678118654752f;
+  const float2 w16[10] = {{1.f, 0.f}, {c1, -s1}, {h, -h}, {s1, -c1}, {0.f, -1.f}, {-s1, -c1}, {-h, -h}, {-c1, -s1}, {-1.f, 0.f}, {-c1, s1}};
+  int L = N;
+  while (L >= 16) {
+    const int Q = L >> 4, tstep = N / L;
+    for (int bf = tid; bf < (N >> 4); bf += FFT_THREADS) {
+      const int r = bf % Q, base = (bf / Q) * L + r;
+      float2 a[16], t[16];
+#pragma unroll
+      for (int j = 0; j < 16; j++) a[j] = x[fpad(base + j * Q)];
+#pragma unroll
+      for (int rp = 0; rp < 4; rp++) {                          // level 1: span 16
+        float2 y0, y1, y2, y3;
+        bfly4(a[rp], a[rp + 4], a[rp + 8], a[rp + 12], y0, y1, y2, y3);
+        t[0 * 4 + rp] = y0;
+        t[1 * 4 + rp] = rp ? cmul(y1, w16[rp]) : y1;
+        t[2 * 4 + rp] = rp ? cmul(y2, w16[2 * rp]) : y2;
+        t[3 * 4 + rp] = rp ? cmul(y3, w16[3 * rp]) : y3;
+      }
+#pragma unroll
+      for (int k1 = 0; k1 < 4; k1++) {                          // level 2: span 4 -> Y[k1 + 4*k2]
+        float2 y0, y1, y2, y3;
+        bfly4(t[k1 * 4], t[k1 * 4 + 1], t[k1 * 4 + 2], t[k1 * 4 + 3], y0, y1, y2, y3);
+        a[k1] = y0; a[k1 + 4] = y1; a[k1 + 8] = y2; a[k1 + 12] = y3;
+      }
+      x[fpad(base)] = a[0];
+      if (r == 0) {
+#pragma unroll
+        for (int k = 1; k < 16; k++) x[fpad(base + k * Q)] = a[k];
+      } else {
+#pragma unroll
+        for (int k = 1; k < 16; k++) x[fpad(base + k * Q)] = cmul(a[k], twid(tw_c, tw_f, r * k * tstep));
+      }
+    }
+    __syncthreads();
+    L = Q;
+  }
+  if (L >= 4) {
+    const int Q = L >> 2, tstep = N / L;
+    for (int bf = tid; bf < (N >> 2); bf += FFT_THREADS) {
+      const int r = bf % Q, base = (bf / Q) * L + r;
+      const int i0 = fpad(base), i1 = fpad(base + Q), i2 = fpad(base + 2 * Q), i3 = fpad(base + 3 * Q);
+      float2 y0, y1, y2, y3;
+      bfly4(x[i0], x[i1], x[i2], x[i3], y0, y1, y2, y3);
+      x[i0] = y0;
+      if (r == 0) { x[i1] = y1; x[i2] = y2; x[i3] = y3; }
+      else { x[i1] = cmul(y1, twid(tw_c, tw_f, r * tstep)); x[i2] = cmul(y2, twid(tw_c, tw_f, 2 * r * tstep)); x[i3] = cmul(y3, twid(tw_c, tw_f, 3 * r * tstep)); }
+    }
+    __syncthreads();
+    L = Q;
+  }
+  if (L == 2) {
+    for (int bf = tid; bf < (N >> 1); bf += FFT_THREADS) {
+      const int j0 = fpad(2 * bf), j1 = fpad(2 * bf + 1);
+      const float2 a0 = x[j0], a1 = x[j1];
+      x[j0] = cadd(a0, a1); x[j1] = csub(a0, a1);
+    }
+    __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------- A1 tail + A2: derotate, strip CP, forward FFT with shift
 // One workgroup per OFDM symbol; the symbol lives in LDS (N*8 bytes) through all stages.
 // DIF radix-4 stages (+ one radix-2 when log2 N is odd), in place; the digit-reversed result is
 // written out in natural, fft-shifted order through the host-built permutation.
-__global__ __launch_bounds__(256) void derot_fft_kernel(const float2 *__restrict__ iq, FrontParams p, const RxState *st,
+__global__ __launch_bounds__(FFT_THREADS) void derot_fft_kernel(const float2 *__restrict__ iq, FrontParams p, const RxState *st,
                                                        const SymMeta *__restrict__ meta, const float2 *__restrict__ tw,
                                                        const uint16_t *__restrict__ perm, float2 *__restrict__ acq_tap,
                                                        float2 *__restrict__ out)
@@ -359,11 +449,11 @@ __global__ __launch_bounds__(256) void derot_fft_kernel(const float2 *__restrict
   if (s >= st->n_symbols) return;
   const int N = p.N, cp = p.cp, tid = threadIdx.x;
   float2 *tw_c = x + (N + N / 32), *tw_f = tw_c + N / 128;
-  if (out) { for (int i = tid; i < N / 128; i += 256) tw_c[i] = tw[i * 128]; if (tid < 128) tw_f[tid] = tw[tid]; }   // N >= 2048 here
+  if (out) { for (int i = tid; i < N / 128; i += FFT_THREADS) tw_c[i] = tw[i * 128]; if (tid < 128) tw_f[tid] = tw[tid]; }   // N >= 2048 here
   const SymMeta m = meta[s];
   const long long low = (long long)(st->call0 + s) * (N + cp) + m.cp_start - N + 1;
   const bool rot = (m.incA != 0.0) || (m.incB != 0.0) || (m.ph_base != 0.f);
-  for (int n = tid; n < N; n += 256) {
+  for (int n = tid; n < N; n += FFT_THREADS) {
     float2 v = iq[low + n];
     if (rot) {                                   // derot[n] = expj(phase after n+1 increments)  (:285-309,:527-534)
       int a = n + 1, b = 0;
@@ -377,45 +467,13 @@ __global__ __launch_bounds__(256) void derot_fft_kernel(const float2 *__restrict
   }
   if (!out) return;                              // A1 alone (block API): derotated, CP-stripped item only
   __syncthreads();
-  int L = N;
-  while (L >= 4) {
-    const int Q = L >> 2, tstep = N / L;
-    for (int bf = tid; bf < (N >> 2); bf += 256) {
-      int r = bf % Q, base = (bf / Q) * L + r;
-      const int i0 = fpad(base), i1 = fpad(base + Q), i2 = fpad(base + 2 * Q), i3 = fpad(base + 3 * Q);
-      float2 a0 = x[i0], a1 = x[i1], a2 = x[i2], a3 = x[i3];
-      float2 s02 = make_float2(a0.x + a2.x, a0.y + a2.y), d02 = make_float2(a0.x - a2.x, a0.y - a2.y);
-      float2 s13 = make_float2(a1.x + a3.x, a1.y + a3.y), d13 = make_float2(a1.x - a3.x, a1.y - a3.y);
-      float2 y0 = make_float2(s02.x + s13.x, s02.y + s13.y);
-      float2 y2 = make_float2(s02.x - s13.x, s02.y - s13.y);
-      float2 y1 = make_float2(d02.x + d13.y, d02.y - d13.x);       // d02 - i*d13
-      float2 y3 = make_float2(d02.x - d13.y, d02.y + d13.x);       // d02 + i*d13
-      x[i0] = y0;
-      if (r == 0) { x[i1] = y1; x[i2] = y2; x[i3] = y3; }
-      else {
-        x[i1] = cmul(y1, twid(tw_c, tw_f, r * tstep));
-        x[i2] = cmul(y2, twid(tw_c, tw_f, 2 * r * tstep));
-        x[i3] = cmul(y3, twid(tw_c, tw_f, 3 * r * tstep));
-      }
-    }
-    __syncthreads();
-    L = Q;
-  }
-  if (L == 2) {
-    for (int bf = tid; bf < (N >> 1); bf += 256) {
-      const int j0 = fpad(2 * bf), j1 = fpad(2 * bf + 1);
-      float2 a0 = x[j0], a1 = x[j1];
-      x[j0] = make_float2(a0.x + a1.x, a0.y + a1.y);
-      x[j1] = make_float2(a0.x - a1.x, a0.y - a1.y);
-    }
-    __syncthreads();
-  }
+  fft_dif_lds(x, N, tw_c, tw_f, tid);
   float2 *o = out + (size_t)s * N;
-  for (int b = tid; b < N; b += 256) o[b] = x[fpad(perm[b])];
+  for (int b = tid; b < N; b += FFT_THREADS) o[b] = x[fpad(fft_pos_of_bin((b + (N >> 1)) & (N - 1), N))];   // shifted: out[b] = X[(b - N/2) mod N]
 }
 
 // plain FFT for the standalone A2 block: items already CP-stripped
-__global__ __launch_bounds__(256) void fft_items_kernel(const float2 *__restrict__ in, int N, int nitems,
+__global__ __launch_bounds__(FFT_THREADS) void fft_items_kernel(const float2 *__restrict__ in, int N, int nitems,
                                                        const float2 *__restrict__ tw, const uint16_t *__restrict__ perm,
                                                        float2 *__restrict__ out)
 {
@@ -425,40 +483,12 @@ __global__ __launch_bounds__(256) void fft_items_kernel(const float2 *__restrict
   if (s >= nitems) return;
   const int nc = N >= 128 ? N / 128 : 1;
   float2 *tw_c = x + (N + N / 32), *tw_f = tw_c + nc;
-  for (int i = tid; i < nc; i += 256) tw_c[i] = tw[i * 128 < N ? i * 128 : 0];
+  for (int i = tid; i < nc; i += FFT_THREADS) tw_c[i] = tw[i * 128 < N ? i * 128 : 0];
   if (tid < 128 && tid < N) tw_f[tid] = tw[tid];
-  for (int n = tid; n < N; n += 256) x[fpad(n)] = in[(size_t)s * N + n];
+  for (int n = tid; n < N; n += FFT_THREADS) x[fpad(n)] = in[(size_t)s * N + n];
   __syncthreads();
-  int L = N;
-  while (L >= 4) {
-    const int Q = L >> 2, tstep = N / L;
-    for (int bf = tid; bf < (N >> 2); bf += 256) {
-      int r = bf % Q, base = (bf / Q) * L + r;
-      const int i0 = fpad(base), i1 = fpad(base + Q), i2 = fpad(base + 2 * Q), i3 = fpad(base + 3 * Q);
-      float2 a0 = x[i0], a1 = x[i1], a2 = x[i2], a3 = x[i3];
-      float2 s02 = make_float2(a0.x + a2.x, a0.y + a2.y), d02 = make_float2(a0.x - a2.x, a0.y - a2.y);
-      float2 s13 = make_float2(a1.x + a3.x, a1.y + a3.y), d13 = make_float2(a1.x - a3.x, a1.y - a3.y);
-      x[i0] = make_float2(s02.x + s13.x, s02.y + s13.y);
-      float2 y2 = make_float2(s02.x - s13.x, s02.y - s13.y);
-      float2 y1 = make_float2(d02.x + d13.y, d02.y - d13.x);
-      float2 y3 = make_float2(d02.x - d13.y, d02.y + d13.x);
-      x[i1] = cmul(y1, twid(tw_c, tw_f, r * tstep));
-      x[i2] = cmul(y2, twid(tw_c, tw_f, 2 * r * tstep));
-      x[i3] = cmul(y3, twid(tw_c, tw_f, 3 * r * tstep));
-    }
-    __syncthreads();
-    L = Q;
-  }
-  if (L == 2) {
-    for (int bf = tid; bf < (N >> 1); bf += 256) {
-      const int j0 = fpad(2 * bf), j1 = fpad(2 * bf + 1);
-      float2 a0 = x[j0], a1 = x[j1];
-      x[j0] = make_float2(a0.x + a1.x, a0.y + a1.y);
-      x[j1] = make_float2(a0.x - a1.x, a0.y - a1.y);
-    }
-    __syncthreads();
-  }
-  for (int b = tid; b < N; b += 256) out[(size_t)s * N + b] = x[fpad(perm[b])];
+  fft_dif_lds(x, N, tw_c, tw_f, tid);
+  for (int b = tid; b < N; b += FFT_THREADS) out[(size_t)s * N + b] = x[fpad(fft_pos_of_bin((b + (N >> 1)) & (N - 1), N))];
 }
 
 // ---------------------------------------------------------------- A3: pilot engine, one workgroup per OFDM symbol
