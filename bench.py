@@ -157,7 +157,7 @@ def main():
         # gfx950 note in MI355X_MICROARCH.md), scaled per algorithmic byte of the profiled launch
         traffic = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary_8k_qam64_7_8_33sf.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary_8k_qam64_7_8_65sf.json")))
             if a.workload == "8k_qam64_7_8":
                 traffic = int(pm["kernels"]["viterbi2_kernel"]["hbm_bytes_corrected"] / pm["viterbi_algorithmic_bytes"] * alg_bytes)
         except Exception:

@@ -269,62 +269,86 @@ __global__ __launch_bounds__(256) void viterbi_kernel(const uint8_t *__restrict_
 // RS: reed_solomon.cc:246-489.  Syndromes by table T_i[b] = b*alpha^i; error path on exp/log tables.
 struct RsTables { const uint8_t *mul_alpha; /* [16][256] */ const uint8_t *gexp; /* 512 */ const uint8_t *glog; /* 256 */ };
 
-// scr: 128 bytes of per-thread LDS scratch (the polynomial arrays are indexed at run time)
-__device__ inline int rs_decode_word(uint8_t *d /* 204 bytes, index 0 = codeword index 51 */, const uint8_t *syn,
-                                     const uint8_t *gexp, const uint8_t *glog, int compat, uint8_t *scr)
+// Error path of rs_decode (reed_solomon.cc:315-486) for ONE codeword, executed by the whole
+// wavefront: Berlekamp-Massey with one lane per polynomial coefficient, Chien search with four
+// trial positions per lane, Forney with one lane per root.  Same results as the sequential code,
+// including its order-dependent behaviours: roots are taken in ascending position and the search
+// stops at deg(sigma) roots (:376-403); a zero Forney denominator aborts after the higher-indexed
+// roots have already been patched (:445-486); compat reproduces the as-compiled omega[2t] overflow
+// that redirects the lowest root's correction into the zero padding (SURVEY B-1).
+// syn: 16 syndromes (LDS), cw: the 204 received bytes (LDS, index 0 = codeword index 51),
+// scr: >= 64 bytes of LDS scratch.  Returns rs_decode's return value in every lane.
+__device__ inline int rs_decode_word_wave(uint8_t *cw, const uint8_t *syn, const uint8_t *gexp, const uint8_t *glog,
+                                          int compat, uint8_t *scr, int lane)
 {
   auto gmul = [&](int a, int b) -> int { return (a == 0 || b == 0) ? 0 : gexp[glog[a] + glog[b]]; };
   auto gdiv = [&](int a, int b) -> int { return (a == 0 || b == 0) ? 0 : gexp[255 + glog[a] - glog[b]]; };
-  auto gpow = [&](int a, int pw) -> int { return a == 0 ? 0 : gexp[(glog[a] + pw) % 255]; };
-  uint8_t *sigma = scr, *b = scr + 17, *T = scr + 34, *root = scr + 51, *loc = scr + 68, *omega = scr + 85, *lr = scr + 102;
-  for (int i = 0; i < 17; i++) { sigma[i] = 0; b[i] = 0; }
-  sigma[0] = 1; b[0] = 1;
-  int r = 0, el = 0;
-  while (++r <= 16) {                                             // Berlekamp-Massey :315-354
-    int discr = 0;
-    for (int i = 0; i < r; i++) discr ^= gmul(sigma[i], syn[r - i - 1]);
-    if (discr == 0) { for (int i = 16; i > 0; i--) b[i] = b[i - 1]; b[0] = 0; }
+  auto wxor = [&](int v) -> int { for (int o = 16; o > 0; o >>= 1) v ^= __shfl_xor(v, o); return v; };   // over lanes 0..31
+  // ---- Berlekamp-Massey: lane i (0..16) holds sigma[i] and b[i]
+  int sig = lane == 0 ? 1 : 0, bb = sig, el = 0;
+  for (int r = 1; r <= 16; r++) {
+    int term = (lane < r && lane <= 16) ? gmul(sig, syn[r - 1 - lane]) : 0;
+    const int discr = __shfl(wxor(term), 0);
+    int bup = __shfl_up(bb, 1); if (lane == 0) bup = 0;
+    if (discr == 0) bb = bup;
     else {
-      T[0] = sigma[0];
-      for (int i = 0; i < 16; i++) T[i + 1] = sigma[i + 1] ^ gmul(discr, b[i]);
-      if (2 * el <= r - 1) { el = r - el; for (int i = 0; i <= 16; i++) b[i] = (uint8_t)gdiv(sigma[i], discr); }
-      else { for (int i = 16; i > 0; i--) b[i] = b[i - 1]; b[0] = 0; }
-      for (int i = 0; i <= 16; i++) sigma[i] = T[i];
+      const int T = sig ^ gmul(discr, bup);
+      if (2 * el <= r - 1) { el = r - el; bb = gdiv(sig, discr); } else bb = bup;
+      sig = lane <= 16 ? T : 0;
     }
   }
-  int deg_sigma = 0;
-  for (int i = 0; i <= 16; i++) if (sigma[i]) deg_sigma = i;
-  int no_roots = 0;                                               // Chien :376-403, registers kept in the log domain
-  for (int i = 1; i <= 16; i++) lr[i] = sigma[i] ? glog[sigma[i]] : 255;          // 255 = log of zero
-  for (int i = 1; i <= 255; i++) {
+  const unsigned long long nz = __ballot(sig != 0 && lane <= 16);
+  const int deg_sigma = nz ? 63 - __clzll(nz) : 0;
+  uint8_t *s_sig = scr, *s_root = scr + 17, *s_om = scr + 34;
+  if (lane <= 16) s_sig[lane] = (uint8_t)sig;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  // ---- Chien: q(i) = 1 + sum_j sigma[j] alpha^(j*i), i = 1..255; lane tests i = lane+1 + 64k
+  int found[4]; int nroots = 0;
+  unsigned long long bal[4];
+  for (int k = 0; k < 4; k++) {
+    const int i = lane + 1 + 64 * k;
     int q = 1;
-    for (int j = deg_sigma; j > 0; j--)
-      if (lr[j] != 255) { int x = lr[j] + j; if (x >= 255) x -= 255; lr[j] = (uint8_t)x; q ^= gexp[x]; }
-    if (q != 0) continue;
-    root[no_roots] = (uint8_t)i; loc[no_roots] = (uint8_t)(i - 1);
-    if (++no_roots == deg_sigma) break;
+    if (i <= 255) {
+      for (int j = 1; j <= deg_sigma; j++) { int sg = s_sig[j]; if (sg) q ^= gexp[(glog[sg] + (j * i) % 255) % 255]; }
+    }
+    found[k] = (i <= 255) && (q == 0);
+    bal[k] = __ballot(found[k]);
   }
-  if (no_roots != deg_sigma) return -1;
-  int deg_omega = 0;                                              // omega :419-434
-  for (int i = 0; i < 16; i++) {
-    int tmp = 0, j = deg_sigma < i ? deg_sigma : i;
-    for (; j >= 0; j--) tmp ^= gmul(syn[i - j], sigma[j]);
-    if (tmp) deg_omega = i;
-    omega[i] = (uint8_t)tmp;
+  {
+    int before = 0;
+    for (int k = 0; k < 4; k++) {
+      if (found[k]) { int rank = before + __popcll(bal[k] & ((1ull << lane) - 1)); if (rank < 17 && rank < deg_sigma) s_root[rank] = (uint8_t)(lane + 1 + 64 * k); }
+      before += __popcll(bal[k]);
+    }
+    nroots = before < deg_sigma ? before : deg_sigma;             // the reference stops searching at deg_sigma roots
   }
-  if (compat) loc[0] = 0;                                         // the as-compiled omega[2t] overflow (SURVEY B-1)
-  for (int j = no_roots - 1; j >= 0; j--) {                       // Forney :445-486
-    int num1 = 0;
-    for (int i = deg_omega; i >= 0; i--) num1 ^= gpow(omega[i], i * root[j]);
-    int num2 = gexp[(255 - root[j]) % 255];
-    int den = 0, deg_max = deg_sigma < 15 ? deg_sigma : 15;
-    for (int i = 1; i <= deg_max; i += 2) if (sigma[i]) den ^= gexp[(glog[sigma[i]] + (i - 1) * root[j]) % 255];
-    if (den == 0) return -1;
-    int err = gdiv(gmul(num1, num2), den);
-    int l = loc[j];
-    if (l >= 51) d[l - 51] ^= (uint8_t)err;                        // corrections inside the zero padding are not output
+  if (nroots != deg_sigma) return -1;
+  // ---- omega = sigma * S mod x^16 (lane i computes omega[i])
+  {
+    int tmp = 0;
+    if (lane < 16) { int jm = deg_sigma < lane ? deg_sigma : lane; for (int j = jm; j >= 0; j--) tmp ^= gmul(syn[lane - j], s_sig[j]); s_om[lane] = (uint8_t)tmp; }
+    const unsigned long long oz = __ballot(lane < 16 && tmp != 0);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    const int deg_omega = oz ? 63 - __clzll(oz) : 0;
+    // ---- Forney: lane k handles root k
+    int err = 0, den = 1, loc = 0;
+    if (lane < nroots) {
+      const int root = s_root[lane];
+      int num1 = 0;
+      for (int i = deg_omega; i >= 0; i--) { int om = s_om[i]; if (om) num1 ^= gexp[(glog[om] + (i * root) % 255) % 255]; }
+      const int num2 = gexp[(255 - root) % 255];
+      den = 0;
+      const int deg_max = deg_sigma < 15 ? deg_sigma : 15;
+      for (int i = 1; i <= deg_max; i += 2) { int sg = s_sig[i]; if (sg) den ^= gexp[(glog[sg] + ((i - 1) * root) % 255) % 255]; }
+      err = gdiv(gmul(num1, num2), den);
+      loc = (compat && lane == 0) ? 0 : root - 1;
+    }
+    const unsigned long long dz = __ballot(lane < nroots && den == 0);
+    const int kz = dz ? 63 - __clzll(dz) : -1;                    // the reference walks roots from the highest index down
+    if (lane < nroots && lane > kz && loc >= 51) cw[loc - 51] ^= (uint8_t)err;   // patches inside the zero padding are not output
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    return kz >= 0 ? -1 : nroots;
   }
-  return no_roots;
 }
 
 // standalone = 1: input is already de-interleaved items (A9 block alone); 0: gather from the Viterbi stream (A8+A9)
@@ -337,7 +361,8 @@ __global__ __launch_bounds__(64) void deint_rs_kernel(const uint8_t *__restrict_
   __shared__ __attribute__((aligned(16))) uint8_t s_cw[64 * 204];
   __shared__ uint8_t s_mul[16 * 256];
   __shared__ uint8_t s_exp[512], s_log[256];
-  __shared__ uint8_t s_scr[64 * 128];
+  __shared__ uint8_t s_scr[64];
+  __shared__ uint8_t s_syn[64 * 16];
   const int tid = threadIdx.x;
   const long long nwords = st ? st->n_rs_items * 8 : words_fixed;
   const long long w0 = (long long)blockIdx.x * 64;
@@ -359,6 +384,7 @@ __global__ __launch_bounds__(64) void deint_rs_kernel(const uint8_t *__restrict_
   __syncthreads();
   uint8_t *cw = s_cw + tid * 204;
   const long long w = w0 + tid;
+  bool bad = false;
   if (tid < nw) {
     if (standalone) { for (int p = 0; p < 204; p++) cw[p] = in[w * 204 + p]; }
     else            { for (int p = 0; p < 204; p++) cw[p] = s_src[(tid + p % 12) * 204 + p]; }
@@ -373,11 +399,21 @@ __global__ __launch_bounds__(64) void deint_rs_kernel(const uint8_t *__restrict_
     }
     int any = 0;
 #pragma unroll
-    for (int i = 0; i < 16; i++) any |= syn[i];
-    if (any) {
-      int r = rs_decode_word(cw, syn, s_exp, s_log, compat, s_scr + tid * 128);
-      if (r < 0) atomicAdd(fail_cnt, 1); else atomicAdd(corr_cnt, r);
+    for (int i = 0; i < 16; i++) { any |= syn[i]; s_syn[tid * 16 + i] = syn[i]; }
+    bad = any != 0;
+  }
+  // words with a non-zero syndrome (reed_solomon.cc:299-305 returns early otherwise) are decoded one at a time
+  // by the whole wavefront
+  {
+    unsigned long long mask = __ballot(bad);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    int nf = 0, nc = 0;
+    while (mask) {
+      const int wl = __ffsll((long long)mask) - 1; mask &= mask - 1;
+      const int r = rs_decode_word_wave(s_cw + wl * 204, s_syn + wl * 16, s_exp, s_log, compat, s_scr, tid);
+      if (r < 0) nf++; else nc += r;
     }
+    if (tid == 0) { if (nf) atomicAdd(fail_cnt, nf); if (nc) atomicAdd(corr_cnt, nc); }
   }
   __syncthreads();
   // coalesced store of 64 x 188 payload bytes (reed_solomon_dec_impl.cc:102: output regardless of success)

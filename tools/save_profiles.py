@@ -1,0 +1,32 @@
+"""Copy the rocprofv3 outputs of the last gpurun (gpurun_out/) into profiles/ as judged artefacts."""
+import csv, glob, collections, json, os, shutil, sys
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+prof = sorted(glob.glob(os.path.join(root, "gpurun_out", "prof*", "*kernel_stats.csv")), key=os.path.getmtime)[-1]
+shutil.copy(prof, os.path.join(root, "profiles", f"{tag}_kernel_stats_8k_qam64_7_8_65sf.csv"))
+b = json.load(open(os.path.join(root, "gpurun_out", "bench_final.json")))
+json.dump(b, open(os.path.join(root, "profiles", f"{tag}_bench_n1.json"), "w"), indent=1)
+out = {}
+for f in sorted(glob.glob(os.path.join(root, "gpurun_out", "pmc", "*", "*counter_collection.csv"))):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("dvbt::", "")
+        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k in acc:
+        for c, v in acc[k].items():
+            out.setdefault(k, {})[c] = sum(v) / len(v)
+pb = json.load(open(os.path.join(root, "gpurun_out", "pmc", "FETCH_SIZE.json")))
+summary = {"command": "tools/pmc.sh: rocprofv3 --pmc <group> --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --superframes 64 (one pass per counter group: FETCH_SIZE | WRITE_SIZE | SQ issue counters | LDS counters)",
+           "workload": pb["config"],
+           "note": "FETCH_SIZE/WRITE_SIZE in KB per dispatch (average over dispatches). gfx950: FETCH_SIZE counts 64 B per 128 B request on coalesced streams, so it is doubled in hbm_bytes_corrected (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported.",
+           "viterbi_algorithmic_bytes": pb["roofline"]["algorithmic_bytes_per_launch"], "kernels": {}}
+for k, c in out.items():
+    e = dict(c)
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        e["hbm_bytes_corrected"] = 2 * c["FETCH_SIZE"] * 1024 + c["WRITE_SIZE"] * 1024
+    summary["kernels"][k] = e
+json.dump(summary, open(os.path.join(root, "profiles", f"{tag}_pmc_summary_8k_qam64_7_8_65sf.json"), "w"), indent=1)
+v = summary["kernels"]["viterbi2_kernel"]
+print("viterbi2: hbm", v["hbm_bytes_corrected"] / 1e6, "MB; algorithmic", summary["viterbi_algorithmic_bytes"] / 1e6, "MB")
+for r in list(csv.DictReader(open(prof)))[:14]:
+    print(r["Name"].split("(")[0][6:36].ljust(30), r["Calls"].rjust(4), f"{float(r['AverageNs'])/1e3:10.1f} us", r["Percentage"])
