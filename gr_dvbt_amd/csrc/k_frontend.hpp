@@ -126,16 +126,21 @@ __device__ __forceinline__ float wrap_pi(double ph)
   return (float)ph;
 }
 
-// initial acquisition FSM (general_work :498-510): sequential by nature (IIR + state machine).
-// The N metric values of one try are staged in LDS by the whole workgroup so that the single
-// walking lane pays LDS, not HBM, latency per step.
+// initial acquisition FSM (general_work :498-510).  Two phases per try:
+//  (1) all lanes: the IIR average seen by every sample.  Every sample updates d_avg with the same expression in
+//      every FSM state, so avg_i is a plain recursion over lambda; restarted 48 samples back its older history
+//      weighs 1e-48, i.e. it reproduces the float value (the first 48 samples start from the carried average and
+//      are exact by construction).  From it the two threshold tests of sample i (rise: > 0.8 avg, keep: > 0.9 avg).
+//  (2) one lane walks the state machine on the precomputed flags; its only remaining recurrence is the running
+//      maximum of the open peak, so a step costs a few cycles instead of a dependent float chain.
 __global__ __launch_bounds__(256) void acq_init_fsm_kernel(FrontParams p, RxState *st, const float2 *gamma, const float *lambda, const AcqState *as)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float *lam = reinterpret_cast<float *>(smem_raw);
+  unsigned char *flg = smem_raw + (size_t)p.N * 4;
   __shared__ int s_done;
   __shared__ float s_avg;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, N = p.N;
   int tries = p.ncalls < ACQ_INIT_TRIES ? p.ncalls : ACQ_INIT_TRIES;
   if (tid == 0) {
     st->status = 1; st->call0 = 0; st->cp_start0 = 0; st->n_symbols = 0; st->first_out = -1; st->n_out_symbols = 0;
@@ -147,16 +152,43 @@ __global__ __launch_bounds__(256) void acq_init_fsm_kernel(FrontParams p, RxStat
   }
   __syncthreads();
   if (s_done == 2) { if (tid == 0) st->avg = s_avg; return; }
+  const float rise = 0.8f, fall = 0.9f, alpha = 0.9f;
+  constexpr int HIST = 48;
   for (int t = 0; t < tries; t++) {
-    for (int i = tid; i < p.N; i += 256) lam[i] = lambda[(size_t)t * p.N + i];
+    for (int i = tid; i < N; i += 256) lam[i] = lambda[(size_t)t * N + i];
+    __syncthreads();
+    const float avg0 = s_avg;
+    for (int i = tid; i <= N; i += 256) {                          // avg before sample i (i == N: the carried value)
+      int j0 = i > HIST ? i - HIST : 0;
+      float avg = i > HIST ? 0.f : avg0;
+      for (int j = j0; j < i; j++) avg = alpha * lam[j] + (1 - alpha) * avg;
+      if (i < N) { const float v = lam[i]; flg[i] = (unsigned char)((v > avg * rise ? 1 : 0) | (v > avg * fall ? 2 : 0)); }
+      else s_avg = avg;
+    }
     __syncthreads();
     if (tid == 0) {
-      float avg = s_avg; int pos = 0;
-      int npk = peak_detect(lam, p.N, avg, pos);
-      s_avg = avg;
+      int state = 0, peak_index = 0, npk = 0, best_pos = 0;
+      float peak_val = -INFINITY, best_val = 0.f;
+      for (int i0 = 0; i0 < N; i0 += 8) {
+        float x[8]; unsigned char f[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { x[k] = lam[i0 + k]; f[k] = flg[i0 + k]; }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const float v = x[k];
+          if (state == 1) {
+            if (v > peak_val) { peak_val = v; peak_index = i0 + k; }
+            else if (!(f[k] & 2)) {
+              if (npk == 0 || peak_val > best_val) { best_val = peak_val; best_pos = peak_index; }
+              npk++; state = 0; peak_val = -INFINITY;
+            }
+          }
+          if (state == 0 && (f[k] & 1)) { state = 1; peak_val = v; peak_index = i0 + k; }
+        }
+      }
       if (npk) {
-        float2 g = gamma[(size_t)t * p.N + pos];
-        st->status = 0; st->call0 = t; st->cp_start0 = pos + p.N + p.cp - 1;
+        float2 g = gamma[(size_t)t * N + best_pos];
+        st->status = 0; st->call0 = t; st->cp_start0 = best_pos + N + p.cp - 1;
         st->eps_init = atan2f(g.y, g.x); s_done = 1;
       }
     }
