@@ -129,9 +129,8 @@ struct Tables {          // device lookup tables for one configuration
   InnerParams inner_params(int payload) const { InnerParams ip; ip.payload = payload; ip.m = d.m; ip.csize = d.csize; ip.nlev = nlev; ip.inv_step = inv_step; ip.guard = guard; return ip; }
   int build_rs()
   {
-    std::vector<uint8_t> ex(512), lg(256), mul(16 * 256);
+    std::vector<uint8_t> ex(512), lg(256), mul = rs_division_table();
     gf_tables(ex.data(), lg.data());
-    for (int i = 0; i < 16; i++) for (int b = 0; b < 256; b++) mul[i * 256 + b] = b ? ex[lg[b] + i] : 0;
     int r;
     if ((r = upload(ex, &gexp)) || (r = upload(lg, &glog)) || (r = upload(mul, &mul_alpha)) || (r = upload(energy_prbs(), &prbs))) return r;
     rs = true;
@@ -139,7 +138,7 @@ struct Tables {          // device lookup tables for one configuration
   }
   DemodTables demod_tables() const { DemodTables T; T.cpilot = cpilot; T.known_diff = known; T.tps = tps; T.pilot_ref = pref;
     T.pay_c = pay_c; T.pay_L = pay_L; T.pay_R = pay_R; T.tps_L = tps_L; T.tps_R = tps_R; return T; }
-  RsTables rs_tables() const { RsTables T; T.mul_alpha = mul_alpha; T.gexp = gexp; T.glog = glog; return T; }
+  RsTables rs_tables() const { RsTables T; T.div_tab = mul_alpha; T.gexp = gexp; T.glog = glog; return T; }
   ~Tables()
   {
     void *all[] = {tw, perm, cpilot, tps, known, pref, pay_c, pay_L, pay_R, tps_L, tps_R, H, Hinv, points, label_tab, mul_alpha, gexp, glog, prbs};

@@ -232,4 +232,23 @@ inline void gf_tables(uint8_t *exp512, uint8_t *log256)
   exp512[510] = exp512[0]; exp512[511] = exp512[1];
 }
 
+// RS(255,239) generator g(x) = prod_{i<16} (x - alpha^i) (reed_solomon.cc:168-192) and the division table
+// T[b] = b * (g_15 .. g_0): one row is XORed into the running remainder per input byte
+// (R <- R*x + c mod g, with x^16 = sum g_k x^k).  Row layout: byte k = coefficient of x^k.
+inline std::vector<uint8_t> rs_division_table()
+{
+  uint8_t ex[512], lg[256];
+  gf_tables(ex, lg);
+  auto mul = [&](int a, int b) -> int { return (a && b) ? ex[lg[a] + lg[b]] : 0; };
+  int g[17] = {0}; g[0] = 1;                                   // g[k] = coefficient of x^k, built root by root
+  for (int i = 0; i < 16; i++) {
+    int root = ex[i];
+    for (int k = 16; k > 0; k--) g[k] = g[k - 1] ^ mul(g[k], root);
+    g[0] = mul(g[0], root);
+  }
+  std::vector<uint8_t> T(256 * 16);
+  for (int b = 0; b < 256; b++) for (int k = 0; k < 16; k++) T[b * 16 + k] = (uint8_t)mul(b, g[k]);
+  return T;
+}
+
 }  // namespace dvbt

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void viterbi_kernel(const uint8_t *__restrict_
 // (convolutional_deinterleaver_impl.cc:64-65,133-138 in closed form).  64 words per workgroup; the
 // 75 source words are staged in LDS with coalesced loads, each thread then owns one codeword.
 // RS: reed_solomon.cc:246-489.  Syndromes by table T_i[b] = b*alpha^i; error path on exp/log tables.
-struct RsTables { const uint8_t *mul_alpha; /* [16][256] */ const uint8_t *gexp; /* 512 */ const uint8_t *glog; /* 256 */ };
+struct RsTables { const uint8_t *div_tab; /* [256][16]: b * g(x) */ const uint8_t *gexp; /* 512 */ const uint8_t *glog; /* 256 */ };
 
 // Error path of rs_decode (reed_solomon.cc:315-486) for ONE codeword, executed by the whole
 // wavefront: Berlekamp-Massey with one lane per polynomial coefficient, Chien search with four
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(64) void deint_rs_kernel(const uint8_t *__restrict_
 {
   __shared__ __attribute__((aligned(16))) uint8_t s_src[75 * 204 + 12];
   __shared__ __attribute__((aligned(16))) uint8_t s_cw[64 * 204];
-  __shared__ uint8_t s_mul[16 * 256];
+  __shared__ __attribute__((aligned(16))) uint8_t s_div[256 * 16];
   __shared__ uint8_t s_exp[512], s_log[256];
   __shared__ uint8_t s_scr[64];
   __shared__ uint8_t s_syn[64 * 16];
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(64) void deint_rs_kernel(const uint8_t *__restrict_
   const long long nwords = st ? st->n_rs_items * 8 : words_fixed;
   const long long w0 = (long long)blockIdx.x * 64;
   if (w0 >= nwords) return;
-  for (int i = tid; i < 4096; i += 64) s_mul[i] = T.mul_alpha[i];
+  for (int i = tid; i < 1024; i += 64) reinterpret_cast<unsigned *>(s_div)[i] = reinterpret_cast<const unsigned *>(T.div_tab)[i];
   for (int i = tid; i < 512; i += 64) s_exp[i] = T.gexp[i];
   for (int i = tid; i < 256; i += 64) s_log[i] = T.glog[i];
   const int nw = (int)((nwords - w0) < 64 ? (nwords - w0) : 64);
@@ -389,17 +389,23 @@ __global__ __launch_bounds__(64) void deint_rs_kernel(const uint8_t *__restrict_
     if (standalone) { for (int p = 0; p < 204; p++) cw[p] = in[w * 204 + p]; }
     else            { for (int p = 0; p < 204; p++) cw[p] = s_src[(tid + p % 12) * 204 + p]; }
     if (deint_tap) for (int p = 0; p < 204; p++) deint_tap[w * 204 + p] = cw[p];
-    uint8_t syn[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) syn[i] = 0;
-    for (int p = 0; p < 204; p++) {                               // :281-288 (the 51 leading zeros leave syn at 0)
-      uint8_t dd = cw[p];
-#pragma unroll
-      for (int i = 0; i < 16; i++) syn[i] = dd ^ s_mul[i * 256 + syn[i]];
+    // remainder of the received word modulo g(x): R <- R*x + c (mod g), one 16-byte table row per byte.  All 16
+    // syndromes S_i = C(alpha^i) = R(alpha^i) vanish iff R == 0 (reed_solomon.cc:281-305), so clean words stop here.
+    unsigned R0 = 0, R1 = 0, R2 = 0, R3 = 0;                       // R0 byte 0 = coefficient of x^0 ... R3 byte 3 = x^15
+    for (int p = 0; p < 204; p++) {
+      const uint4 t = *reinterpret_cast<const uint4 *>(s_div + (R3 >> 24) * 16);
+      R3 = ((R3 << 8) | (R2 >> 24)) ^ t.w; R2 = ((R2 << 8) | (R1 >> 24)) ^ t.z;
+      R1 = ((R1 << 8) | (R0 >> 24)) ^ t.y; R0 = ((R0 << 8) | cw[p]) ^ t.x;
     }
-    int any = 0;
-#pragma unroll
-    for (int i = 0; i < 16; i++) { any |= syn[i]; s_syn[tid * 16 + i] = syn[i]; }
+    const int any = (R0 | R1 | R2 | R3) != 0;
+    if (any) {                                                    // syndromes from the remainder: S_i = sum_k R_k alpha^(i k)
+      const unsigned Rw[4] = {R0, R1, R2, R3};
+      for (int i = 0; i < 16; i++) {
+        int sv = 0;
+        for (int k = 15; k >= 0; k--) { int c = (Rw[k >> 2] >> (8 * (k & 3))) & 0xff; sv = (sv ? s_exp[(s_log[sv] + i) % 255] : 0) ^ c; }
+        s_syn[tid * 16 + i] = (uint8_t)sv;
+      }
+    }
     bad = any != 0;
   }
   // words with a non-zero syndrome (reed_solomon.cc:299-305 returns early otherwise) are decoded one at a time
