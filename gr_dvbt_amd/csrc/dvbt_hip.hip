@@ -12,6 +12,7 @@
 #include "k_frontend.hpp"
 #include "k_backend.hpp"
 #include "k_viterbi2.hpp"
+#include "k_viterbi3.hpp"
 
 using namespace dvbt;
 
@@ -146,12 +147,12 @@ struct Tables {          // device lookup tables for one configuration
   }
 };
 
-// A7 kernel generation: 2 = DPP butterflies, 4 chunks per wavefront (default); 1 = one chunk per
+// A7 kernel generation: 3 = DPP butterflies on packed 16-bit cells (default); 2 = DPP butterflies, 32-bit cells; 1 = one chunk per
 // wavefront on ds_bpermute (kept for A/B runs: DVBT_VITERBI_KERNEL=1)
 static int viterbi_kernel_version()
 {
   const char *e = getenv("DVBT_VITERBI_KERNEL");
-  return (e && e[0] == '1') ? 1 : 2;
+  return (e && e[0] == '1') ? 1 : (e && e[0] == '2') ? 2 : 3;
 }
 static void launch_viterbi(hipStream_t s, const uint8_t *in, uint8_t *out, const RxState *st, long long steps_fixed, const VitParams &vp,
                            long long in_base, long long out_lo, long long max_out_bytes)
@@ -160,6 +161,8 @@ static void launch_viterbi(hipStream_t s, const uint8_t *in, uint8_t *out, const
   if (chunks < 1) chunks = 1;
   if (viterbi_kernel_version() == 1)
     hipLaunchKernelGGL(viterbi_kernel, dim3((unsigned)((chunks + 3) / 4)), dim3(256), 0, s, in, out, st, steps_fixed, vp, in_base, out_lo);
+  else if (viterbi_kernel_version() == 3)
+    hipLaunchKernelGGL(viterbi3_kernel, dim3((unsigned)((chunks + 3) / 4)), dim3(64), 0, s, in, out, st, steps_fixed, vp, in_base, out_lo);
   else {
     const long long per_wg = 4 * V2_WAVES;
     hipLaunchKernelGGL(viterbi2_kernel, dim3((unsigned)((chunks + per_wg - 1) / per_wg)), dim3(64 * V2_WAVES), 0, s, in, out, st, steps_fixed, vp, in_base, out_lo);
@@ -177,6 +180,8 @@ static VitParams make_vit_params(const Dims &d, int bsize, int chunk_bytes)
   v.punct_mask = 0; v.prefix_nib = 0;
   for (int i = 0; i < d.plen; i++) { v.punct_mask |= (unsigned)d.punct[i] << i; v.prefix_nib |= (unsigned long long)d.prefix[i] << (4 * i); }
   v.magic_plen = ~0ull / (unsigned)d.plen + 1; v.magic_m = ~0ull / (unsigned)d.m + 1;
+  for (int i = 0; i < 64; i++) v.punct_rep |= (unsigned long long)d.punct[i % d.plen] << i;
+  v.magic16_plen = (65536u + (unsigned)d.plen - 1) / (unsigned)d.plen;
   return v;
 }
 static FrontParams make_front_params(const Dims &d, float snr_db)
@@ -344,7 +349,7 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s)
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_VIT], s));
   long long max_vit = (long long)C * d.payload * d.m * d.k / (8 * d.n) + 1;
   VitParams vp = h->vp;
-  if (h->prm.viterbi_chunk_bytes <= 0 && viterbi_kernel_version() == 2) {
+  if (h->prm.viterbi_chunk_bytes <= 0 && viterbi_kernel_version() >= 2) {
     // chunk size chosen per segment so that the wavefront count is a whole number of "rounds" of the resident
     // wavefront slots (4 chunks per wavefront, V2 kernel: 8 one-wave workgroups per CU by LDS): equal-length
     // chunks then finish together instead of leaving a partial last round, and longer chunks amortise the

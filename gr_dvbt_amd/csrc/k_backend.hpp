@@ -118,6 +118,8 @@ struct VitParams {
   unsigned punct_mask;            // bit p = puncture vector entry p
   unsigned long long prefix_nib;  // nibble p = kept bits before phase p
   unsigned long long magic_plen, magic_m;   // ceil(2^64/d): x/d == umul64hi(x, magic) for x < 2^56
+  unsigned long long punct_rep;             // the puncture vector repeated over 64 bits
+  unsigned magic16_plen;                    // ceil(2^16/plen): x/plen == (x*magic)>>16 for x < 1024
   uint8_t punct[16], prefix[16];
 };
 

@@ -1,0 +1,305 @@
+// k_viterbi3.hpp -- A7, third-generation kernel: the DPP in-place trellis of k_viterbi2.hpp with TWO cells per
+// VGPR on packed 16-bit arithmetic (v_pk_add_i16 / v_pk_sub_i16 / v_pk_max_i16).
+//
+// Mapping (as v2): one wavefront decodes FOUR chunks, a chunk owns one DPP row (16 lanes); every lane holds 4 of
+// the 64 path metrics -- here as the four 16-bit halves of two VGPRs.  Cell index
+//     c = r(VGPR 0/1) : h(half 0/1) : a3 a2 a1 a0,   physical lane-in-row = (a0 + 2*a1) ^ (7*a2) ^ (8*a3)
+// and cell c holds state rotl6(c, u mod 6) at relative step u (in-place butterflies, see k_viterbi2.hpp).  The six
+// exchanges are: VGPR swap (free), half swap (one v_alignbit), and four DPP controls.
+//
+// A 16-bit cell = (2M + bias) << 8 | path byte.
+//  * metric field (8 bits, signed): M in units of half an agreement, bias = 1 when the cell holds an upper state
+//    (i+32): compares are strict and reproduce the reference's tie rule (d_viterbi.c:508-521).  For a K=7 code
+//    the spread of the 64 metrics is bounded by 6 steps x the per-step range: 2M+bias spans <= 49; it drifts by at
+//    most +-4 per step, and the minimum is subtracted every second window (the reference does it at every output
+//    only to keep ITS 8-bit metrics from wrapping, :728-732), so the field stays within [-64, 113].
+//  * path byte (8 bits): exactly the reference's path byte of the survivor: (state at the window start -- kept as
+//    that state's cell storage index) << 2 | inputs of the window's steps 7,8 (= top two bits of the state after
+//    step 6, stamped there).  It rides along with the metric through v_pk_max (metric fields never tie).
+// Per step and VGPR (two cells): v_perm (both branch-metric deltas from ONE word of four class deltas), pk_add,
+// pk_sub, exchange, pk_max, v_and_or (re-arm bias) -- 3 instructions per cell instead of 5.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <limits.h>
+#include "k_backend.hpp"
+#include "k_viterbi2.hpp"
+
+namespace dvbt {
+
+constexpr int V3_WARM = 72;        // warm-up windows before a chunk's first byte
+constexpr int V3_BLK = 24;         // windows per forward block (multiple of 6: phase cycle x renormalisation cadence)
+constexpr int V3_RINGW = 48;       // windows kept in the LDS ring (>= V3_BLK + max ntraceback - 1)
+constexpr int V3_CBW = 52;         // words of compacted received bits per decoder and block (256 bytes x 6 bits + slack)
+
+typedef short v3pk __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v3pk pk(int x) { return __builtin_bit_cast(v3pk, x); }
+__device__ __forceinline__ int ipk(v3pk x) { return __builtin_bit_cast(int, x); }
+__device__ __forceinline__ int pk_add(int a, int b) { return ipk(pk(a) + pk(b)); }
+__device__ __forceinline__ int pk_sub(int a, int b) { return ipk(pk(a) - pk(b)); }
+__device__ __forceinline__ int pk_max(int a, int b) { return ipk(__builtin_elementwise_max(pk(a), pk(b))); }
+__device__ __forceinline__ int pk_min(int a, int b) { return ipk(__builtin_elementwise_min(pk(a), pk(b))); }
+// DPP read with bound_ctrl: every control used here reads a valid lane, and with full row/bank masks the compiler
+// then needs no "old" value (no extra v_mov before the v_mov_dpp)
+template <int CTRL> __device__ __forceinline__ int dppb(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+// a constant the compiler must keep in a VGPR (v_and_or_b32 takes one literal at most)
+__device__ __forceinline__ int vconst(int c) { int x; asm("v_mov_b32 %0, %1" : "=v"(x) : "s"(c)); return x; }
+__device__ __forceinline__ int swap16(int x) { return (int)__builtin_amdgcn_alignbit((unsigned)x, (unsigned)x, 16); }
+
+struct V3Lane {
+  unsigned sel[6][2];   // v_perm selectors: [0, d(class of lo cell), 0, d(class of hi cell)] out of the step word
+  int abit[4];          // logical lane bits a0..a3 at the bias position of both halves
+  int kc[3][2];         // 63 - state of the two cells at window ends (phase 0,2,4)
+  int org[2];           // (storage index << 2) of the two cells, at the path-byte position
+  int b2[3][2];         // top two bits of the cells' states at phases 0,2,4
+  int hi_bias;          // 0x01000000: bias of the upper half
+};
+
+// storage index of a cell in the path-byte table: z = physical lane * 4 + 2r + h (a lane's four bytes are one word)
+__device__ __forceinline__ int v3_phys(int a) { const int a2 = (a >> 2) & 1; return (a & 8) | (a2 << 2) | ((a & 3) ^ (a2 ? 3 : 0)); }
+__device__ __forceinline__ int v3_log(int p) { const int q = p & 7, a2 = (q >> 2) & 1; return (p & 8) | (a2 << 2) | ((q ^ (a2 ? 7 : 0)) & 3); }
+__device__ __forceinline__ int v3_cell_of_z(int z) { return ((z & 2) << 4) | ((z & 1) << 4) | v3_log(z >> 2); }
+__device__ __forceinline__ int v3_z_of_cell(int c) { return v3_phys(c & 15) * 4 + ((c >> 5) & 1) * 2 + ((c >> 4) & 1); }
+
+__device__ inline void v3_init_lane(int pl, V3Lane &L)
+{
+  const int a = v3_log(pl);
+  for (int k = 0; k < 4; k++) L.abit[k] = ((a >> k) & 1) * 0x01000100;
+  L.hi_bias = vconst(0x01000000);
+  for (int r = 0; r < 2; r++) {
+    for (int P = 0; P < 6; P++) {
+      unsigned idx[2];
+      for (int h = 0; h < 2; h++) {
+        const int c = (r << 5) | (h << 4) | a, i = rotl6(c, P) & 31;
+        const int c0 = ((i >> 2) ^ (i >> 1) ^ i) & 1;                 // parity(2i & 0x4f)
+        const int c1 = ((i >> 4) ^ (i >> 2) ^ (i >> 1)) & 1;          // parity(2i & 0x6d)
+        idx[h] = (unsigned)(c0 | (c1 << 1));                          // byte of the step word = label class
+      }
+      L.sel[P][r] = 0x0c | (idx[0] << 8) | (0x0cu << 16) | (idx[1] << 24);
+    }
+    for (int e = 0; e < 3; e++) {
+      const int s0 = rotl6((r << 5) | a, 2 * e), s1 = rotl6((r << 5) | 16 | a, 2 * e);
+      L.kc[e][r] = (63 - s0) | ((63 - s1) << 16);
+      L.b2[e][r] = (s0 >> 4) | ((s1 >> 4) << 16);
+    }
+    L.org[r] = ((pl * 4 + 2 * r) << 2) | (((pl * 4 + 2 * r + 1) << 2) << 16);
+  }
+}
+
+template <int P> __device__ __forceinline__ void v3_step(int (&v)[2], unsigned W, const V3Lane &L)
+{
+  int X[2], Y[2], Yp[2];
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    const int D = (int)__builtin_amdgcn_perm(0u, W, L.sel[P][r]);
+    X[r] = pk_add(v[r], D); Y[r] = pk_sub(v[r], D);
+  }
+  if (P == 0) { Yp[0] = Y[1]; Yp[1] = Y[0]; }
+  else if (P == 1) { Yp[0] = swap16(Y[0]); Yp[1] = swap16(Y[1]); }
+  else {
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+      Yp[r] = P == 2 ? dppb<DPP_ROR8>(Y[r]) : P == 3 ? dppb<DPP_HALF_MIRROR>(Y[r]) : P == 4 ? dppb<DPP_XOR2>(Y[r]) : dppb<DPP_XOR1>(Y[r]);
+  }
+  constexpr int PN = (P + 1) % 6;
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    const int mx = pk_max(X[r], Yp[r]);
+    if (PN == 0) v[r] = r ? (mx | 0x01000100) : (mx & (int)0xfefffeff);      // VGPR 1 holds the upper states
+    else {
+      const int nb = PN == 1 ? L.hi_bias : PN == 2 ? L.abit[3] : PN == 3 ? L.abit[2] : PN == 4 ? L.abit[1] : L.abit[0];
+      v[r] = (mx & (int)0xfefffeff) | nb;
+    }
+  }
+}
+
+template <int P0> __device__ __forceinline__ void v3_window(int (&v)[2], const unsigned (&W)[8], const V3Lane &L)
+{
+#pragma unroll
+  for (int r = 0; r < 2; r++) v[r] = (v[r] & (int)0xff00ff00) | L.org[r];
+  v3_step<(P0 + 0) % 6>(v, W[0], L); v3_step<(P0 + 1) % 6>(v, W[1], L); v3_step<(P0 + 2) % 6>(v, W[2], L);
+  v3_step<(P0 + 3) % 6>(v, W[3], L); v3_step<(P0 + 4) % 6>(v, W[4], L); v3_step<(P0 + 5) % 6>(v, W[5], L);
+#pragma unroll
+  for (int r = 0; r < 2; r++) v[r] = (v[r] & (int)0xfffcfffc) | L.b2[P0 / 2][r];
+  v3_step<(P0 + 6) % 6>(v, W[6], L); v3_step<(P0 + 7) % 6>(v, W[7], L);
+}
+
+template <int CTRL> __device__ __forceinline__ int pk_max_dpp(int v) { return pk_max(v, dppb<CTRL>(v)); }
+template <int CTRL> __device__ __forceinline__ int pk_min_dpp(int v) { return pk_min(v, dppb<CTRL>(v)); }
+
+// end of a window: best state = first index of the maximum metric (d_viterbi.c:699-711) and, when asked, the
+// min-renormalisation.  PE = phase after the window.  Returns the best STATE in every lane of the row.
+template <int PE> __device__ __forceinline__ int v3_window_end(int (&v)[2], const V3Lane &L, bool renorm)
+{
+  const v3pk sixty4 = {64, 64};
+  int key = pk_max(ipk((pk(v[0]) >> 9) * sixty4 + pk(L.kc[PE / 2][0])), ipk((pk(v[1]) >> 9) * sixty4 + pk(L.kc[PE / 2][1])));
+  key = pk_max_dpp<DPP_XOR1>(key); key = pk_max_dpp<DPP_XOR2>(key); key = pk_max_dpp<DPP_HALF_MIRROR>(key); key = pk_max_dpp<DPP_MIRROR>(key);
+  const int k = max((key << 16) >> 16, key >> 16);
+  if (renorm) {
+    int mn = pk_min(v[0], v[1]);
+    mn = pk_min_dpp<DPP_XOR1>(mn); mn = pk_min_dpp<DPP_XOR2>(mn); mn = pk_min_dpp<DPP_HALF_MIRROR>(mn); mn = pk_min_dpp<DPP_MIRROR>(mn);
+    mn = pk_min(mn, swap16(mn)) & (int)0xfe00fe00;               // metric without bias, path byte cleared
+    v[0] = pk_sub(v[0], mn); v[1] = pk_sub(v[1], mn);
+  }
+  return 63 - (k & 63);
+}
+
+__global__ __launch_bounds__(64) void viterbi3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const RxState *st,
+                                                      long long steps_fixed, VitParams vp, long long in_base, long long out_lo)
+{
+  __shared__ __attribute__((aligned(16))) unsigned char tab[V3_RINGW * 4 * 64];   // path bytes: [window][decoder][cell z]  (the ppresult ring)
+  __shared__ __attribute__((aligned(16))) unsigned wbuf[4 * V3_BLK * 8];          // step words: [decoder][step in block]
+  __shared__ unsigned char bests[4 * V3_RINGW];                                    // best state per window
+  __shared__ unsigned cbits[4 * V3_CBW];                                           // compacted received bits per decoder (MSB first)
+  __shared__ unsigned lut[16];                                                     // (keep flags, next two received bits) -> the step word
+  const int lane = threadIdx.x & 63, dd = lane >> 4, pl = lane & 15;
+
+  const long long total_steps = st ? st->n_vit_steps : steps_fixed;
+  const long long total_out = total_steps / 8 - vp.ntb;
+  const int B = vp.chunk_bytes, ntb = vp.ntb;
+  const long long chunk0 = (long long)blockIdx.x * 4;
+  if (out_lo + chunk0 * B >= total_out) return;                   // whole wavefront idle
+  const long long b0 = out_lo + (chunk0 + dd) * B;                // this lane's decoder
+  const bool dec_active = b0 < total_out;
+  const long long b1 = (b0 + B < total_out) ? b0 + B : total_out;
+  const long long w0 = b0 + 2 - V3_WARM;                           // absolute window of relative window 0
+  const int J = ((V3_WARM + B + ntb - 1 + V3_BLK - 1) / V3_BLK) * V3_BLK;
+  const long long n_in_bytes = (total_steps * 2 / vp.plen * vp.n + vp.m - 1) / vp.m;   // input bytes that exist
+
+  if (lane < 16) {
+    // deltas of the four label classes, doubled (a step with one punctured symbol keeps the bias bit free):
+    // class 0: u0+u1 | class 1 (c0=1): -u0+u1 | class 2 (c1=1): u0-u1 | class 3: -u0-u1, u = +1/-1 for a received 0/1, 0 if erased
+    const int k0 = (lane >> 2) & 1, k1 = (lane >> 3) & 1, t1 = (lane >> 1) & 1, t0 = lane & 1;
+    const int u0 = k0 ? 1 - 2 * t1 : 0, u1 = k1 ? 1 - 2 * (k0 ? t0 : t1) : 0;
+    const unsigned d0 = (unsigned)(2 * (u0 + u1)) & 0xff, d1 = (unsigned)(2 * (-u0 + u1)) & 0xff;
+    const unsigned d2 = (unsigned)(2 * (u0 - u1)) & 0xff, d3 = (unsigned)(2 * (-u0 - u1)) & 0xff;
+    lut[lane] = d0 | (d1 << 8) | (d2 << 16) | (d3 << 24);
+  }
+  V3Lane L; v3_init_lane(pl, L);
+  int v[2] = {0, 0x01000100};                                      // phase 0: VGPR 1 holds the upper states
+
+  for (int jb = 0; jb < J; jb += V3_BLK) {
+    // ---- depuncture (viterbi_decoder_impl.cc:241-256) + delta packing for 192 steps x 4 decoders.
+    // (1) the row loads 256 input bytes of its decoder (one 16-byte load per lane) and compacts the m valid bits
+    //     of every byte into a bit stream in LDS; (2) every lane owns 12 consecutive steps: it places itself in
+    //     the puncture period with small-integer arithmetic relative to the row's base (one 64-bit locate per
+    //     row), takes the period's keep-mask for its 24 symbol positions and a 32-bit window of the bit stream,
+    //     and emits one word of four class deltas per step through a 16-entry table.
+    {
+      auto locate = [&](long long t, int &ph, long long &byte, int &bo) {
+        const unsigned long long pbit = 2ull * (unsigned long long)t;
+        const unsigned long long q = __umul64hi(pbit, vp.magic_plen);
+        ph = (int)(pbit - q * (unsigned)vp.plen);
+        const unsigned long long rb = q * (unsigned)vp.n + ((vp.prefix_nib >> (4 * ph)) & 15ull);
+        const unsigned long long by = __umul64hi(rb, vp.magic_m);
+        byte = (long long)by; bo = (int)(rb - by * (unsigned)vp.m);
+      };
+      const long long tb = 8 * (w0 - 1) + (long long)jb * 8 - 2;   // real step index of block step 0 (may be < 0)
+      const long long tbr = tb > 0 ? tb : 0;
+      int ph0, bo0; long long byte0;
+      locate(tbr, ph0, byte0, bo0);                                // same value in the 16 lanes of the row
+      const int m = vp.m;
+      const int off = (int)(((unsigned long long)(uintptr_t)in + (unsigned long long)(byte0 - in_base)) & 3ull);
+      {
+        const long long src = byte0 - off + pl * 16;               // 4-byte aligned address
+        uint4 q;
+        if (dec_active && src >= in_base && src + 16 <= n_in_bytes) q = *reinterpret_cast<const uint4 *>(in + (src - in_base));
+        else {
+          unsigned w[4] = {0, 0, 0, 0};
+          for (int i = 0; i < 16; i++) {
+            const long long bb = src + i;
+            const unsigned bv = (dec_active && bb >= in_base && bb < n_in_bytes) ? in[bb - in_base] : 0;
+            w[i >> 2] |= bv << (8 * (i & 3));
+          }
+          q = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        const unsigned mk = (1u << m) - 1;
+        auto grp = [&](unsigned d) { return ((d & mk) << (3 * m)) | (((d >> 8) & mk) << (2 * m)) | (((d >> 16) & mk) << m) | ((d >> 24) & mk); };
+        const unsigned g0 = grp(q.x), g1 = grp(q.y), g2 = grp(q.z), g3 = grp(q.w);
+        unsigned *cb = cbits + dd * V3_CBW;
+        if (m == 2) cb[pl] = (g0 << 24) | (g1 << 16) | (g2 << 8) | g3;
+        else if (m == 4) { cb[2 * pl] = (g0 << 16) | g1; cb[2 * pl + 1] = (g2 << 16) | g3; }
+        else { cb[3 * pl] = (g0 << 8) | (g1 >> 16); cb[3 * pl + 1] = (g1 << 16) | (g2 >> 8); cb[3 * pl + 2] = (g2 << 24) | g3; }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      constexpr int SPL = V3_BLK * 8 / 16;                         // steps per lane
+      const int ub0 = pl * SPL;
+      const long long t = tb + ub0;
+      int lo = 0;                                                  // leading steps before the stream start
+      if (t < 0) lo = (-t < SPL) ? (int)(-t) : SPL;
+      const long long rem = total_steps - t;
+      int hi = !dec_active ? 0 : rem <= 0 ? 0 : rem < SPL ? (int)rem : SPL;
+      if (hi < lo) hi = lo;
+      int x = ph0 + 2 * (int)((t + lo) - tbr);                      // depunctured-bit offset of the first real step from the row base
+      if (x < 0) x = 0;
+      const int dq = (int)(((unsigned)x * vp.magic16_plen) >> 16);
+      const int ph = x - dq * vp.plen;
+      const int pos = off * m + bo0 + dq * vp.n + (int)((vp.prefix_nib >> (4 * ph)) & 15ull) - (int)((vp.prefix_nib >> (4 * ph0)) & 15ull);
+      const unsigned kmask = ((unsigned)(vp.punct_rep >> ph) << (2 * lo)) & (((1u << (2 * hi)) - 1u) & ~((1u << (2 * lo)) - 1u));
+      const unsigned *cb = cbits + dd * V3_CBW;
+      const unsigned cw0 = cb[pos >> 5], cw1 = cb[(pos >> 5) + 1];
+      unsigned win = (unsigned)(((((unsigned long long)cw0) << 32) | cw1) >> (32 - (pos & 31)));
+#pragma unroll
+      for (int i = 0; i < SPL; i++) {
+        const unsigned k2 = (kmask >> (2 * i)) & 3u;                // keep flags of the step's two symbols
+        const unsigned idx = (k2 << 2) | (win >> 30);
+        win <<= (k2 - (k2 >> 1));                                  // consume one received bit per kept symbol
+        wbuf[dd * (V3_BLK * 8) + ub0 + i] = lut[idx];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    // ---- forward: three phase variants per iteration
+    for (int wi = 0; wi < V3_BLK && !(vp.dbg & 2); wi += 3) {
+#pragma unroll
+      for (int v3 = 0; v3 < 3; v3++) {
+        const int j = jb + wi + v3;                                // relative window
+        const int jr = j % V3_RINGW;
+        unsigned W[8];
+        {
+          const uint4 *wp = reinterpret_cast<const uint4 *>(wbuf + dd * (V3_BLK * 8) + (wi + v3) * 8);
+          const uint4 t0 = wp[0], t1 = wp[1];
+          W[0] = t0.x; W[1] = t0.y; W[2] = t0.z; W[3] = t0.w; W[4] = t1.x; W[5] = t1.y; W[6] = t1.z; W[7] = t1.w;
+        }
+        int s;
+        if (v3 == 0) { v3_window<0>(v, W, L); }
+        else if (v3 == 1) { v3_window<2>(v, W, L); }
+        else { v3_window<4>(v, W, L); }
+        // the four path bytes of this lane's cells = one word of the table (storage index z = 4*lane + 2r + h)
+        *reinterpret_cast<unsigned *>(tab + (jr * 4 + dd) * 64 + pl * 4) = __builtin_amdgcn_perm((unsigned)v[1], (unsigned)v[0], 0x06040200u);
+        if (v3 == 0) s = v3_window_end<2>(v, L, (j & 1) == 1);
+        else if (v3 == 1) s = v3_window_end<4>(v, L, (j & 1) == 1);
+        else s = v3_window_end<0>(v, L, (j & 1) == 1);
+        bests[dd * V3_RINGW + jr] = (unsigned char)s;              // all 16 lanes of the row write the same byte
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    // ---- traceback for the 24 calls x 4 decoders of this block (d_viterbi.c:714-724): lane = (decoder, call),
+    // two independent chains per lane (calls pl and 16+pl) so that their dependent LDS reads overlap
+    if (!(vp.dbg & 1)) {
+      int jj[2], z[2]; bool ok[2]; long long ob[2];
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        jj[q] = jb + q * 16 + pl;
+        ob[q] = b0 + (jj[q] - (V3_WARM + ntb - 1));
+        ok[q] = (q * 16 + pl < V3_BLK) && dec_active && jj[q] >= V3_WARM + ntb - 1 && ob[q] < b1;
+        if (!ok[q]) jj[q] = jb;                                    // any window inside the ring: result unused
+        const int sb = bests[dd * V3_RINGW + (jj[q] % V3_RINGW)];
+        z[q] = v3_z_of_cell(((sb | (sb << 6)) >> ((8 * jj[q] + 8) % 6)) & 63);   // cell = rotr6(state, phase after the window)
+      }
+      for (int hop = 0; hop < ntb - 1; hop++) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) z[q] = tab[(((jj[q] - hop + V3_RINGW) % V3_RINGW) * 4 + dd) * 64 + z[q]] >> 2;   // state = path_byte >> 2 (:717)
+      }
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const int w = jj[q] - (ntb - 1);
+        const unsigned t = tab[(((w + V3_RINGW) % V3_RINGW) * 4 + dd) * 64 + z[q]];
+        const int sstart = rotl6(v3_cell_of_z((int)(t >> 2)), (8 * ((w + 6 * V3_RINGW) % 6)) % 6);
+        if (ok[q]) out[ob[q] - out_lo] = (unsigned char)((sstart << 2) | (t & 3u));
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  }
+}
+
+}  // namespace dvbt
