@@ -89,10 +89,16 @@ __device__ inline void v3_init_lane(int pl, V3Lane &L)
 template <int P> __device__ __forceinline__ void v3_step(int (&v)[2], unsigned W, const V3Lane &L)
 {
   int X[2], Y[2], Yp[2];
-#pragma unroll
-  for (int r = 0; r < 2; r++) {
-    const int D = (int)__builtin_amdgcn_perm(0u, W, L.sel[P][r]);
-    X[r] = pk_add(v[r], D); Y[r] = pk_sub(v[r], D);
+  // The label class of a cell depends on bits 0,1,2,4 of its state (parity taps 0x4f, 0x6d without the MSB).  The
+  // VGPR index is cell bit 5 = state bit (5+P)%6: at phases 0 and 4 (state bits 5, 3) both VGPRs have the same
+  // deltas, at phases 2 and 3 (state bits 1, 2: both parities flip) VGPR 1 has the negated ones.
+  const int D0 = (int)__builtin_amdgcn_perm(0u, W, L.sel[P][0]);
+  X[0] = pk_add(v[0], D0); Y[0] = pk_sub(v[0], D0);
+  if (P == 0 || P == 4) { X[1] = pk_add(v[1], D0); Y[1] = pk_sub(v[1], D0); }
+  else if (P == 2 || P == 3) { X[1] = pk_sub(v[1], D0); Y[1] = pk_add(v[1], D0); }
+  else {
+    const int D1 = (int)__builtin_amdgcn_perm(0u, W, L.sel[P][1]);
+    X[1] = pk_add(v[1], D1); Y[1] = pk_sub(v[1], D1);
   }
   if (P == 0) { Yp[0] = Y[1]; Yp[1] = Y[0]; }
   else if (P == 1) { Yp[0] = swap16(Y[0]); Yp[1] = swap16(Y[1]); }
@@ -124,24 +130,49 @@ template <int P0> __device__ __forceinline__ void v3_window(int (&v)[2], const u
   v3_step<(P0 + 6) % 6>(v, W[6], L); v3_step<(P0 + 7) % 6>(v, W[7], L);
 }
 
-template <int CTRL> __device__ __forceinline__ int pk_max_dpp(int v) { return pk_max(v, dppb<CTRL>(v)); }
-template <int CTRL> __device__ __forceinline__ int pk_min_dpp(int v) { return pk_min(v, dppb<CTRL>(v)); }
+// halves of a packed register as sign-extended 32-bit values
+__device__ __forceinline__ int lo16(int x) { return (x << 16) >> 16; }
+__device__ __forceinline__ int hi16(int x) { return x >> 16; }
+template <int CTRL> __device__ __forceinline__ int max_dpp(int v) { return max(v, dppb<CTRL>(v)); }   // folds into v_max_i32_dpp
+template <int CTRL> __device__ __forceinline__ int min_dpp(int v) { return min(v, dppb<CTRL>(v)); }
 
 // end of a window: best state = first index of the maximum metric (d_viterbi.c:699-711) and, when asked, the
 // min-renormalisation.  PE = phase after the window.  Returns the best STATE in every lane of the row.
-template <int PE> __device__ __forceinline__ int v3_window_end(int (&v)[2], const V3Lane &L, bool renorm)
+template <int PE, bool RENORM> __device__ __forceinline__ int v3_window_end(int (&v)[2], const V3Lane &L)
 {
   const v3pk sixty4 = {64, 64};
-  int key = pk_max(ipk((pk(v[0]) >> 9) * sixty4 + pk(L.kc[PE / 2][0])), ipk((pk(v[1]) >> 9) * sixty4 + pk(L.kc[PE / 2][1])));
-  key = pk_max_dpp<DPP_XOR1>(key); key = pk_max_dpp<DPP_XOR2>(key); key = pk_max_dpp<DPP_HALF_MIRROR>(key); key = pk_max_dpp<DPP_MIRROR>(key);
-  const int k = max((key << 16) >> 16, key >> 16);
-  if (renorm) {
-    int mn = pk_min(v[0], v[1]);
-    mn = pk_min_dpp<DPP_XOR1>(mn); mn = pk_min_dpp<DPP_XOR2>(mn); mn = pk_min_dpp<DPP_HALF_MIRROR>(mn); mn = pk_min_dpp<DPP_MIRROR>(mn);
-    mn = pk_min(mn, swap16(mn)) & (int)0xfe00fe00;               // metric without bias, path byte cleared
+  const int kp = pk_max(ipk((pk(v[0]) >> 9) * sixty4 + pk(L.kc[PE / 2][0])), ipk((pk(v[1]) >> 9) * sixty4 + pk(L.kc[PE / 2][1])));
+  int k = max(lo16(kp), hi16(kp));
+  k = max_dpp<DPP_XOR1>(k); k = max_dpp<DPP_XOR2>(k); k = max_dpp<DPP_HALF_MIRROR>(k); k = max_dpp<DPP_MIRROR>(k);
+  if (RENORM) {
+    const int mp = pk_min(v[0], v[1]);
+    int mn = min(lo16(mp), hi16(mp));                              // ordering is decided by the metric field
+    mn = min_dpp<DPP_XOR1>(mn); mn = min_dpp<DPP_XOR2>(mn); mn = min_dpp<DPP_HALF_MIRROR>(mn); mn = min_dpp<DPP_MIRROR>(mn);
+    mn &= 0xfe00;                                                  // metric without bias, path byte cleared
+    mn |= mn << 16;
     v[0] = pk_sub(v[0], mn); v[1] = pk_sub(v[1], mn);
   }
   return 63 - (k & 63);
+}
+
+// window j0 + V6 of a decoder (j0 % 6 == 0): it starts at phase (8 V6) % 6 = 0,2,4,0,2,4; the minimum is subtracted
+// after every second window
+template <int V6> __device__ __forceinline__ void v3_fwd_window(int (&v)[2], const V3Lane &L, const unsigned *wrow, unsigned char *tab,
+                                                               unsigned char *bests, int j0, int dd, int pl)
+{
+  const int jr = (j0 + V6) % V3_RINGW;
+  unsigned W[8];
+  {
+    const uint4 *wp = reinterpret_cast<const uint4 *>(wrow + V6 * 8);
+    const uint4 t0 = wp[0], t1 = wp[1];
+    W[0] = t0.x; W[1] = t0.y; W[2] = t0.z; W[3] = t0.w; W[4] = t1.x; W[5] = t1.y; W[6] = t1.z; W[7] = t1.w;
+  }
+  constexpr int P0 = (8 * V6) % 6;
+  v3_window<P0>(v, W, L);
+  // the four path bytes of this lane's cells = one word of the table (storage index z = 4*lane + 2r + h)
+  *reinterpret_cast<unsigned *>(tab + (jr * 4 + dd) * 64 + pl * 4) = __builtin_amdgcn_perm((unsigned)v[1], (unsigned)v[0], 0x06040200u);
+  const int s = v3_window_end<(P0 + 2) % 6, (V6 & 1) == 1>(v, L);
+  bests[dd * V3_RINGW + jr] = (unsigned char)s;                    // all 16 lanes of the row write the same byte
 }
 
 __global__ __launch_bounds__(64) void viterbi3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const RxState *st,
@@ -249,28 +280,11 @@ __global__ __launch_bounds__(64) void viterbi3_kernel(const uint8_t *__restrict_
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     // ---- forward: three phase variants per iteration
-    for (int wi = 0; wi < V3_BLK && !(vp.dbg & 2); wi += 3) {
-#pragma unroll
-      for (int v3 = 0; v3 < 3; v3++) {
-        const int j = jb + wi + v3;                                // relative window
-        const int jr = j % V3_RINGW;
-        unsigned W[8];
-        {
-          const uint4 *wp = reinterpret_cast<const uint4 *>(wbuf + dd * (V3_BLK * 8) + (wi + v3) * 8);
-          const uint4 t0 = wp[0], t1 = wp[1];
-          W[0] = t0.x; W[1] = t0.y; W[2] = t0.z; W[3] = t0.w; W[4] = t1.x; W[5] = t1.y; W[6] = t1.z; W[7] = t1.w;
-        }
-        int s;
-        if (v3 == 0) { v3_window<0>(v, W, L); }
-        else if (v3 == 1) { v3_window<2>(v, W, L); }
-        else { v3_window<4>(v, W, L); }
-        // the four path bytes of this lane's cells = one word of the table (storage index z = 4*lane + 2r + h)
-        *reinterpret_cast<unsigned *>(tab + (jr * 4 + dd) * 64 + pl * 4) = __builtin_amdgcn_perm((unsigned)v[1], (unsigned)v[0], 0x06040200u);
-        if (v3 == 0) s = v3_window_end<2>(v, L, (j & 1) == 1);
-        else if (v3 == 1) s = v3_window_end<4>(v, L, (j & 1) == 1);
-        else s = v3_window_end<0>(v, L, (j & 1) == 1);
-        bests[dd * V3_RINGW + jr] = (unsigned char)s;              // all 16 lanes of the row write the same byte
-      }
+    for (int wi = 0; wi < V3_BLK && !(vp.dbg & 2); wi += 6) {
+      const unsigned *wrow = wbuf + dd * (V3_BLK * 8) + wi * 8;
+      v3_fwd_window<0>(v, L, wrow, tab, bests, jb + wi, dd, pl); v3_fwd_window<1>(v, L, wrow, tab, bests, jb + wi, dd, pl);
+      v3_fwd_window<2>(v, L, wrow, tab, bests, jb + wi, dd, pl); v3_fwd_window<3>(v, L, wrow, tab, bests, jb + wi, dd, pl);
+      v3_fwd_window<4>(v, L, wrow, tab, bests, jb + wi, dd, pl); v3_fwd_window<5>(v, L, wrow, tab, bests, jb + wi, dd, pl);
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     // ---- traceback for the 24 calls x 4 decoders of this block (d_viterbi.c:714-724): lane = (decoder, call),
