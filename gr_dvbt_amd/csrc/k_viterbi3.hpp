@@ -29,8 +29,9 @@ namespace dvbt {
 
 constexpr int V3_WARM = 72;        // warm-up windows before a chunk's first byte
 constexpr int V3_BLK = 24;         // windows per forward block (multiple of 6: phase cycle x renormalisation cadence)
-constexpr int V3_RINGW = 48;       // windows kept in the LDS ring (>= V3_BLK + max ntraceback - 1)
-constexpr int V3_CBW = 52;         // words of compacted received bits per decoder and block (256 bytes x 6 bits + slack)
+constexpr int V3_RINGW = 64;       // windows kept in the LDS ring (power of two, >= 2*V3_BLK - 12 + max ntraceback - 1: the traceback of a
+                                   // block runs during the first 12 windows of the next one)
+constexpr int V3_CBW = 17;         // words of compacted received bits per decoder and block (192 steps need <= 384 + 23 bits)
 
 typedef short v3pk __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v3pk pk(int x) { return __builtin_bit_cast(v3pk, x); }
@@ -155,12 +156,43 @@ template <int PE, bool RENORM> __device__ __forceinline__ int v3_window_end(int 
   return 63 - (k & 63);
 }
 
-// window j0 + V6 of a decoder (j0 % 6 == 0): it starts at phase (8 V6) % 6 = 0,2,4,0,2,4; the minimum is subtracted
-// after every second window
-template <int V6> __device__ __forceinline__ void v3_fwd_window(int (&v)[2], const V3Lane &L, const unsigned *wrow, unsigned char *tab,
-                                                               unsigned char *bests, int j0, int dd, int pl)
+// Two traceback chains per lane: the calls (windows) pl and 16+pl of one block of a decoder.
+struct V3Trace {
+  int z[2];             // current cell (storage index)
+  int wsh[2];           // (window whose table is read next) << 8
+  bool ok[2];
+  long long ob[2];      // output byte of the call
+};
+// one hop of both chains: state = path_byte >> 2 (d_viterbi.c:717); `live` is wave-uniform
+__device__ __forceinline__ void v3_hop(V3Trace &T, const unsigned char *tab, int rowc, bool live)
 {
-  const int jr = (j0 + V6) % V3_RINGW;
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const unsigned t = tab[(T.wsh[q] & 0x3f00) | rowc | T.z[q]];
+    T.z[q] = live ? (int)(t >> 2) : T.z[q];
+    T.wsh[q] -= live ? 256 : 0;
+  }
+}
+// the decoded byte of a call: (state at the start of the last window of the chain) << 2 | its two oldest inputs
+__device__ __forceinline__ void v3_trace_out(const V3Trace &T, const unsigned char *tab, int rowc, uint8_t *out, long long out_lo)
+{
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const unsigned t = tab[(T.wsh[q] & 0x3f00) | rowc | T.z[q]];
+    const int w = T.wsh[q] >> 8;
+    const int sstart = rotl6(v3_cell_of_z((int)(t >> 2)), 2 * (((w % 3) + 3) % 3));    // phase of window w = (8w) % 6
+    if (T.ok[q]) out[T.ob[q] - out_lo] = (unsigned char)((sstart << 2) | (t & 3u));
+  }
+}
+
+// window j0 + V6 of a decoder (j0 % 6 == 0): it starts at phase (8 V6) % 6 = 0,2,4,0,2,4; the minimum is subtracted
+// after every second window.  HOPS: two traceback hops of the previous block's calls ride along (their LDS latency
+// hides under the add-compare-select work).
+template <int V6, bool HOPS> __device__ __forceinline__ void v3_fwd_window(int (&v)[2], const V3Lane &L, const unsigned *wrow, unsigned char *tab,
+                                                                          unsigned char *bests, int j0, int dd, int pl, V3Trace &T, int hop0, int nhops)
+{
+  if (HOPS) { v3_hop(T, tab, dd * 64, hop0 + 2 * V6 < nhops); v3_hop(T, tab, dd * 64, hop0 + 2 * V6 + 1 < nhops); }
+  const int jr = (j0 + V6) & (V3_RINGW - 1);
   unsigned W[8];
   {
     const uint4 *wp = reinterpret_cast<const uint4 *>(wrow + V6 * 8);
@@ -175,6 +207,17 @@ template <int V6> __device__ __forceinline__ void v3_fwd_window(int (&v)[2], con
   bests[dd * V3_RINGW + jr] = (unsigned char)s;                    // all 16 lanes of the row write the same byte
 }
 
+// A chunk = vp.chunk_bytes decoded bytes; it is decoded by an independent decoder that starts V3_WARM windows early
+// from all-zero metrics and runs ntraceback-1 windows past its end.  Per block of 24 windows:
+//   staging   depuncture (viterbi_decoder_impl.cc:241-256) + delta packing for 192 steps x 4 decoders.  The row
+//             loads the input bytes of its decoder (one 16-byte load per lane, issued one block ahead) and compacts
+//             the m valid bits of every byte into a bit stream in LDS; every lane then owns 12 consecutive steps:
+//             it places itself in the puncture period with small-integer arithmetic relative to the row's base (one
+//             64-bit locate per row), takes the period's keep-mask for its 24 symbol positions and a 32-bit window
+//             of the bit stream, and emits one word of four class deltas per step through a 16-entry table;
+//   forward   24 windows of add-compare-select (v3_fwd_window), path bytes into the LDS ring;
+//   traceback of the PREVIOUS block's 24 calls x 4 decoders (d_viterbi.c:714-724), lane = (decoder, call): its
+//             dependent LDS reads are interleaved into the first 12 windows of the forward pass.
 __global__ __launch_bounds__(64) void viterbi3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const RxState *st,
                                                       long long steps_fixed, VitParams vp, long long in_base, long long out_lo)
 {
@@ -187,7 +230,7 @@ __global__ __launch_bounds__(64) void viterbi3_kernel(const uint8_t *__restrict_
 
   const long long total_steps = st ? st->n_vit_steps : steps_fixed;
   const long long total_out = total_steps / 8 - vp.ntb;
-  const int B = vp.chunk_bytes, ntb = vp.ntb;
+  const int B = vp.chunk_bytes, ntb = vp.ntb, m = vp.m;
   const long long chunk0 = (long long)blockIdx.x * 4;
   if (out_lo + chunk0 * B >= total_out) return;                   // whole wavefront idle
   const long long b0 = out_lo + (chunk0 + dd) * B;                // this lane's decoder
@@ -196,6 +239,7 @@ __global__ __launch_bounds__(64) void viterbi3_kernel(const uint8_t *__restrict_
   const long long w0 = b0 + 2 - V3_WARM;                           // absolute window of relative window 0
   const int J = ((V3_WARM + B + ntb - 1 + V3_BLK - 1) / V3_BLK) * V3_BLK;
   const long long n_in_bytes = (total_steps * 2 / vp.plen * vp.n + vp.m - 1) / vp.m;   // input bytes that exist
+  const int nload = ((384 + 2 * m - 2) / m + 3 + 15) / 16;         // lanes whose 16 bytes a block can need (13, 7, 5)
 
   if (lane < 16) {
     // deltas of the four label classes, doubled (a step with one punctured symbol keeps the bias bit free):
@@ -209,110 +253,116 @@ __global__ __launch_bounds__(64) void viterbi3_kernel(const uint8_t *__restrict_
   V3Lane L; v3_init_lane(pl, L);
   int v[2] = {0, 0x01000100};                                      // phase 0: VGPR 1 holds the upper states
 
-  for (int jb = 0; jb < J; jb += V3_BLK) {
-    // ---- depuncture (viterbi_decoder_impl.cc:241-256) + delta packing for 192 steps x 4 decoders.
-    // (1) the row loads 256 input bytes of its decoder (one 16-byte load per lane) and compacts the m valid bits
-    //     of every byte into a bit stream in LDS; (2) every lane owns 12 consecutive steps: it places itself in
-    //     the puncture period with small-integer arithmetic relative to the row's base (one 64-bit locate per
-    //     row), takes the period's keep-mask for its 24 symbol positions and a 32-bit window of the bit stream,
-    //     and emits one word of four class deltas per step through a 16-entry table.
-    {
-      auto locate = [&](long long t, int &ph, long long &byte, int &bo) {
-        const unsigned long long pbit = 2ull * (unsigned long long)t;
-        const unsigned long long q = __umul64hi(pbit, vp.magic_plen);
-        ph = (int)(pbit - q * (unsigned)vp.plen);
-        const unsigned long long rb = q * (unsigned)vp.n + ((vp.prefix_nib >> (4 * ph)) & 15ull);
-        const unsigned long long by = __umul64hi(rb, vp.magic_m);
-        byte = (long long)by; bo = (int)(rb - by * (unsigned)vp.m);
-      };
-      const long long tb = 8 * (w0 - 1) + (long long)jb * 8 - 2;   // real step index of block step 0 (may be < 0)
-      const long long tbr = tb > 0 ? tb : 0;
-      int ph0, bo0; long long byte0;
-      locate(tbr, ph0, byte0, bo0);                                // same value in the 16 lanes of the row
-      const int m = vp.m;
-      const int off = (int)(((unsigned long long)(uintptr_t)in + (unsigned long long)(byte0 - in_base)) & 3ull);
-      {
-        const long long src = byte0 - off + pl * 16;               // 4-byte aligned address
-        uint4 q;
-        if (dec_active && src >= in_base && src + 16 <= n_in_bytes) q = *reinterpret_cast<const uint4 *>(in + (src - in_base));
-        else {
-          unsigned w[4] = {0, 0, 0, 0};
-          for (int i = 0; i < 16; i++) {
-            const long long bb = src + i;
-            const unsigned bv = (dec_active && bb >= in_base && bb < n_in_bytes) ? in[bb - in_base] : 0;
-            w[i >> 2] |= bv << (8 * (i & 3));
-          }
-          q = make_uint4(w[0], w[1], w[2], w[3]);
+  // ---- staging, first half: where block jb starts in the input (row-uniform) and the load of its bytes
+  int ph0 = 0, bo0 = 0, off = 0; uint4 q = make_uint4(0, 0, 0, 0);
+  auto stage_load = [&](int jb) {
+    const long long tb = 8 * (w0 - 1) + (long long)jb * 8 - 2;     // real step index of block step 0 (may be < 0)
+    const unsigned long long pbit = 2ull * (unsigned long long)(tb > 0 ? tb : 0);
+    const unsigned long long pq = __umul64hi(pbit, vp.magic_plen);
+    ph0 = (int)(pbit - pq * (unsigned)vp.plen);
+    const unsigned long long rb = pq * (unsigned)vp.n + ((vp.prefix_nib >> (4 * ph0)) & 15ull);
+    const unsigned long long by = __umul64hi(rb, vp.magic_m);
+    const long long byte0 = (long long)by; bo0 = (int)(rb - by * (unsigned)m);
+    off = (int)(((unsigned long long)(uintptr_t)in + (unsigned long long)(byte0 - in_base)) & 3ull);
+    const long long src = byte0 - off + pl * 16;                   // 4-byte aligned address
+    q = make_uint4(0, 0, 0, 0);
+    if (dec_active && pl < nload) {
+      if (src >= in_base && src + 16 <= n_in_bytes) q = *reinterpret_cast<const uint4 *>(in + (src - in_base));
+      else {
+        unsigned w[4] = {0, 0, 0, 0};
+        for (int i = 0; i < 16; i++) {
+          const long long bb = src + i;
+          const unsigned bv = (bb >= in_base && bb < n_in_bytes) ? in[bb - in_base] : 0;
+          w[i >> 2] |= bv << (8 * (i & 3));
         }
-        const unsigned mk = (1u << m) - 1;
-        auto grp = [&](unsigned d) { return ((d & mk) << (3 * m)) | (((d >> 8) & mk) << (2 * m)) | (((d >> 16) & mk) << m) | ((d >> 24) & mk); };
-        const unsigned g0 = grp(q.x), g1 = grp(q.y), g2 = grp(q.z), g3 = grp(q.w);
-        unsigned *cb = cbits + dd * V3_CBW;
+        q = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+    }
+  };
+  // ---- staging, second half: bit compaction and the step words of block jb
+  auto stage_words = [&](int jb) {
+    {
+      const unsigned mk = (1u << m) - 1;
+      auto grp = [&](unsigned d) { return ((d & mk) << (3 * m)) | (((d >> 8) & mk) << (2 * m)) | (((d >> 16) & mk) << m) | ((d >> 24) & mk); };
+      const unsigned g0 = grp(q.x), g1 = grp(q.y), g2 = grp(q.z), g3 = grp(q.w);
+      unsigned *cb = cbits + dd * V3_CBW;
+      if (pl < nload) {
         if (m == 2) cb[pl] = (g0 << 24) | (g1 << 16) | (g2 << 8) | g3;
         else if (m == 4) { cb[2 * pl] = (g0 << 16) | g1; cb[2 * pl + 1] = (g2 << 16) | g3; }
         else { cb[3 * pl] = (g0 << 8) | (g1 >> 16); cb[3 * pl + 1] = (g1 << 16) | (g2 >> 8); cb[3 * pl + 2] = (g2 << 24) | g3; }
       }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      constexpr int SPL = V3_BLK * 8 / 16;                         // steps per lane
-      const int ub0 = pl * SPL;
-      const long long t = tb + ub0;
-      int lo = 0;                                                  // leading steps before the stream start
-      if (t < 0) lo = (-t < SPL) ? (int)(-t) : SPL;
-      const long long rem = total_steps - t;
-      int hi = !dec_active ? 0 : rem <= 0 ? 0 : rem < SPL ? (int)rem : SPL;
-      if (hi < lo) hi = lo;
-      int x = ph0 + 2 * (int)((t + lo) - tbr);                      // depunctured-bit offset of the first real step from the row base
-      if (x < 0) x = 0;
-      const int dq = (int)(((unsigned)x * vp.magic16_plen) >> 16);
-      const int ph = x - dq * vp.plen;
-      const int pos = off * m + bo0 + dq * vp.n + (int)((vp.prefix_nib >> (4 * ph)) & 15ull) - (int)((vp.prefix_nib >> (4 * ph0)) & 15ull);
-      const unsigned kmask = ((unsigned)(vp.punct_rep >> ph) << (2 * lo)) & (((1u << (2 * hi)) - 1u) & ~((1u << (2 * lo)) - 1u));
-      const unsigned *cb = cbits + dd * V3_CBW;
-      const unsigned cw0 = cb[pos >> 5], cw1 = cb[(pos >> 5) + 1];
-      unsigned win = (unsigned)(((((unsigned long long)cw0) << 32) | cw1) >> (32 - (pos & 31)));
-#pragma unroll
-      for (int i = 0; i < SPL; i++) {
-        const unsigned k2 = (kmask >> (2 * i)) & 3u;                // keep flags of the step's two symbols
-        const unsigned idx = (k2 << 2) | (win >> 30);
-        win <<= (k2 - (k2 >> 1));                                  // consume one received bit per kept symbol
-        wbuf[dd * (V3_BLK * 8) + ub0 + i] = lut[idx];
-      }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    // ---- forward: three phase variants per iteration
+    constexpr int SPL = V3_BLK * 8 / 16;                           // steps per lane
+    const long long tb = 8 * (w0 - 1) + (long long)jb * 8 - 2;
+    const long long tbr = tb > 0 ? tb : 0;
+    const int ub0 = pl * SPL;
+    const long long t = tb + ub0;
+    int lo = 0;                                                    // leading steps before the stream start
+    if (t < 0) lo = (-t < SPL) ? (int)(-t) : SPL;
+    const long long rem = total_steps - t;
+    int hi = !dec_active ? 0 : rem <= 0 ? 0 : rem < SPL ? (int)rem : SPL;
+    if (hi < lo) hi = lo;
+    int x = ph0 + 2 * (int)((t + lo) - tbr);                        // depunctured-bit offset of the first real step from the row base
+    if (x < 0) x = 0;
+    const int dq = (int)(((unsigned)x * vp.magic16_plen) >> 16);
+    const int ph = x - dq * vp.plen;
+    const int pos = off * m + bo0 + dq * vp.n + (int)((vp.prefix_nib >> (4 * ph)) & 15ull) - (int)((vp.prefix_nib >> (4 * ph0)) & 15ull);
+    const unsigned kmask = ((unsigned)(vp.punct_rep >> ph) << (2 * lo)) & (((1u << (2 * hi)) - 1u) & ~((1u << (2 * lo)) - 1u));
+    const unsigned *cb = cbits + dd * V3_CBW;
+    const unsigned cw0 = cb[pos >> 5], cw1 = cb[(pos >> 5) + 1];
+    unsigned win = (unsigned)(((((unsigned long long)cw0) << 32) | cw1) >> (32 - (pos & 31)));
+#pragma unroll
+    for (int i = 0; i < SPL; i++) {
+      const unsigned k2 = (kmask >> (2 * i)) & 3u;                  // keep flags of the step's two symbols
+      const unsigned idx = (k2 << 2) | (win >> 30);
+      win <<= (k2 - (k2 >> 1));                                    // consume one received bit per kept symbol
+      wbuf[dd * (V3_BLK * 8) + ub0 + i] = lut[idx];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  };
+  // ---- traceback chains of the block that starts at window jp
+  V3Trace T;
+  auto trace_init = [&](int jp) {
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      int jj = jp + c * 16 + pl;
+      T.ob[c] = b0 + (jj - (V3_WARM + ntb - 1));
+      T.ok[c] = (c * 16 + pl < V3_BLK) && dec_active && jj >= V3_WARM + ntb - 1 && T.ob[c] < b1;
+      if (!T.ok[c]) jj = jp;                                       // any window inside the ring: result unused
+      const int sb = bests[dd * V3_RINGW + (jj & (V3_RINGW - 1))];
+      T.z[c] = v3_z_of_cell(((sb | (sb << 6)) >> ((8 * jj + 8) % 6)) & 63);   // cell = rotr6(state, phase after the window)
+      T.wsh[c] = jj << 8;
+    }
+  };
+
+  stage_load(0);
+  for (int jb = 0; jb < J; jb += V3_BLK) {
+    stage_words(jb);
+    if (jb + V3_BLK < J) stage_load(jb + V3_BLK);                  // the bytes of the next block travel during this block's forward pass
+    const bool tr = jb > 0 && !(vp.dbg & 1);
+    if (tr) trace_init(jb - V3_BLK);
     for (int wi = 0; wi < V3_BLK && !(vp.dbg & 2); wi += 6) {
       const unsigned *wrow = wbuf + dd * (V3_BLK * 8) + wi * 8;
-      v3_fwd_window<0>(v, L, wrow, tab, bests, jb + wi, dd, pl); v3_fwd_window<1>(v, L, wrow, tab, bests, jb + wi, dd, pl);
-      v3_fwd_window<2>(v, L, wrow, tab, bests, jb + wi, dd, pl); v3_fwd_window<3>(v, L, wrow, tab, bests, jb + wi, dd, pl);
-      v3_fwd_window<4>(v, L, wrow, tab, bests, jb + wi, dd, pl); v3_fwd_window<5>(v, L, wrow, tab, bests, jb + wi, dd, pl);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    // ---- traceback for the 24 calls x 4 decoders of this block (d_viterbi.c:714-724): lane = (decoder, call),
-    // two independent chains per lane (calls pl and 16+pl) so that their dependent LDS reads overlap
-    if (!(vp.dbg & 1)) {
-      int jj[2], z[2]; bool ok[2]; long long ob[2];
-#pragma unroll
-      for (int q = 0; q < 2; q++) {
-        jj[q] = jb + q * 16 + pl;
-        ob[q] = b0 + (jj[q] - (V3_WARM + ntb - 1));
-        ok[q] = (q * 16 + pl < V3_BLK) && dec_active && jj[q] >= V3_WARM + ntb - 1 && ob[q] < b1;
-        if (!ok[q]) jj[q] = jb;                                    // any window inside the ring: result unused
-        const int sb = bests[dd * V3_RINGW + (jj[q] % V3_RINGW)];
-        z[q] = v3_z_of_cell(((sb | (sb << 6)) >> ((8 * jj[q] + 8) % 6)) & 63);   // cell = rotr6(state, phase after the window)
-      }
-      for (int hop = 0; hop < ntb - 1; hop++) {
-#pragma unroll
-        for (int q = 0; q < 2; q++) z[q] = tab[(((jj[q] - hop + V3_RINGW) % V3_RINGW) * 4 + dd) * 64 + z[q]] >> 2;   // state = path_byte >> 2 (:717)
-      }
-#pragma unroll
-      for (int q = 0; q < 2; q++) {
-        const int w = jj[q] - (ntb - 1);
-        const unsigned t = tab[(((w + V3_RINGW) % V3_RINGW) * 4 + dd) * 64 + z[q]];
-        const int sstart = rotl6(v3_cell_of_z((int)(t >> 2)), (8 * ((w + 6 * V3_RINGW) % 6)) % 6);
-        if (ok[q]) out[ob[q] - out_lo] = (unsigned char)((sstart << 2) | (t & 3u));
+      if (tr && wi < 12) {
+        v3_fwd_window<0, true>(v, L, wrow, tab, bests, jb + wi, dd, pl, T, 2 * wi, ntb - 1); v3_fwd_window<1, true>(v, L, wrow, tab, bests, jb + wi, dd, pl, T, 2 * wi, ntb - 1);
+        v3_fwd_window<2, true>(v, L, wrow, tab, bests, jb + wi, dd, pl, T, 2 * wi, ntb - 1); v3_fwd_window<3, true>(v, L, wrow, tab, bests, jb + wi, dd, pl, T, 2 * wi, ntb - 1);
+        v3_fwd_window<4, true>(v, L, wrow, tab, bests, jb + wi, dd, pl, T, 2 * wi, ntb - 1); v3_fwd_window<5, true>(v, L, wrow, tab, bests, jb + wi, dd, pl, T, 2 * wi, ntb - 1);
+        if (wi == 6) v3_trace_out(T, tab, dd * 64, out, out_lo);
+      } else {
+        v3_fwd_window<0, false>(v, L, wrow, tab, bests, jb + wi, dd, pl, T, 0, 0); v3_fwd_window<1, false>(v, L, wrow, tab, bests, jb + wi, dd, pl, T, 0, 0);
+        v3_fwd_window<2, false>(v, L, wrow, tab, bests, jb + wi, dd, pl, T, 0, 0); v3_fwd_window<3, false>(v, L, wrow, tab, bests, jb + wi, dd, pl, T, 0, 0);
+        v3_fwd_window<4, false>(v, L, wrow, tab, bests, jb + wi, dd, pl, T, 0, 0); v3_fwd_window<5, false>(v, L, wrow, tab, bests, jb + wi, dd, pl, T, 0, 0);
       }
     }
+    if (tr && (vp.dbg & 2)) { for (int h = 0; h < ntb - 1; h++) v3_hop(T, tab, dd * 64, true); v3_trace_out(T, tab, dd * 64, out, out_lo); }
+  }
+  // the last block's calls
+  if (!(vp.dbg & 1)) {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    trace_init(J - V3_BLK);
+    for (int h = 0; h < ntb - 1; h++) v3_hop(T, tab, dd * 64, true);
+    v3_trace_out(T, tab, dd * 64, out, out_lo);
   }
 }
 
