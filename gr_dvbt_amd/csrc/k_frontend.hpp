@@ -166,27 +166,41 @@ __global__ __launch_bounds__(256) void acq_init_fsm_kernel(FrontParams p, RxStat
       else s_avg = avg;
     }
     __syncthreads();
-    if (tid == 0) {
-      int state = 0, peak_index = 0, npk = 0, best_pos = 0;
+    if (tid < 64) {
+      // the first wavefront walks the state machine 64 samples at a time.  State 0: skip to the next sample with
+      // the rise flag.  State 1: the running maximum of the open peak is a prefix maximum over the chunk (carried in
+      // from the previous chunk); the peak is complete at the first sample that neither raises the maximum nor
+      // passes the keep test; that sample is then re-examined in state 0, exactly as peak_step does.
+      int state = 0, peak_index = 0, npk = 0, best_pos = 0, pos = 0;
       float peak_val = -INFINITY, best_val = 0.f;
-      for (int i0 = 0; i0 < N; i0 += 8) {
-        float x[8]; unsigned char f[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) { x[k] = lam[i0 + k]; f[k] = flg[i0 + k]; }
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-          const float v = x[k];
-          if (state == 1) {
-            if (v > peak_val) { peak_val = v; peak_index = i0 + k; }
-            else if (!(f[k] & 2)) {
-              if (npk == 0 || peak_val > best_val) { best_val = peak_val; best_pos = peak_index; }
-              npk++; state = 0; peak_val = -INFINITY;
-            }
+      while (pos < N) {
+        const int i = pos + tid;
+        const bool in = i < N;
+        const float v = in ? lam[i] : -INFINITY;
+        const unsigned f = in ? flg[i] : 2u;
+        if (state == 0) {
+          const unsigned long long m = __ballot(in && (f & 1u));
+          if (m) { const int l = __ffsll((long long)m) - 1; state = 1; peak_index = pos + l; peak_val = lam[peak_index]; pos = peak_index + 1; }
+          else pos += 64;
+        } else {
+          float pm = v;                                            // inclusive prefix maximum over the lanes
+          for (int o = 1; o < 64; o <<= 1) { const float u = __shfl_up(pm, o); if (tid >= o) pm = fmaxf(pm, u); }
+          float ex = __shfl_up(pm, 1); if (tid == 0) ex = -INFINITY;
+          ex = fmaxf(ex, peak_val);                                // maximum of the open peak before this lane's sample
+          const unsigned long long done = __ballot(in && !(v > ex) && !(f & 2u));
+          const int l = done ? __ffsll((long long)done) - 1 : 64;  // lanes < l extend the peak
+          const float mx = __shfl(l < 64 ? ex : fmaxf(pm, peak_val), l < 64 ? l : 63);
+          if (mx > peak_val) {                                     // a new maximum inside the chunk: its first occurrence
+            const unsigned long long at = __ballot(tid < l && v == mx);
+            peak_index = pos + __ffsll((long long)at) - 1; peak_val = mx;
           }
-          if (state == 0 && (f[k] & 1)) { state = 1; peak_val = v; peak_index = i0 + k; }
+          if (l < 64) {
+            if (npk == 0 || peak_val > best_val) { best_val = peak_val; best_pos = peak_index; }
+            npk++; state = 0; peak_val = -INFINITY; pos += l;
+          } else pos += 64;
         }
       }
-      if (npk) {
+      if (tid == 0 && npk) {
         float2 g = gamma[(size_t)t * N + best_pos];
         st->status = 0; st->call0 = t; st->cp_start0 = best_pos + N + p.cp - 1;
         st->eps_init = atan2f(g.y, g.x); s_done = 1;
@@ -784,8 +798,40 @@ constexpr int TPS_SEG = 128;          // symbols per lane
 constexpr int TPS_WARM = 204;         // three frames
 struct TpsEdge { TpsState start, end; };
 
+// verify_bch_code (:385-425) as a linear map: the LFSR register after the 53 data bits (fifo bits 1..53; the 60
+// leading zero clocks leave it at zero) is the XOR of one 14-bit response per set bit, looked up bytewise in a
+// table the kernel builds in LDS (tps_bch_table); the word is valid when it equals fifo bits 54..67.
+__device__ __forceinline__ int bch_check_tab(const unsigned short *T, unsigned long long lo, unsigned hi)
+{
+  const unsigned long long data = (lo >> 1) & ((1ull << 53) - 1);
+  unsigned reg = 0;
+#pragma unroll
+  for (int b = 0; b < 7; b++) reg ^= T[b * 256 + (int)((data >> (8 * b)) & 255ull)];
+  const unsigned parity = (unsigned)((lo >> 54) | ((unsigned long long)hi << 10)) & 0x3fffu;
+  return reg == parity ? 0 : -1;
+}
+__device__ inline void tps_bch_table(unsigned short *T, unsigned short *R, int tid, int nthreads)
+{
+  for (int i = tid; i < 56; i += nthreads) {
+    unsigned reg = 0;
+    for (int it = 0; it < 53; it++) {                             // response to a single 1 at data bit i
+      const unsigned d = it == i ? 1u : 0u, fb = 1u & (d ^ reg);
+      reg >>= 1; reg |= fb << 13;
+      reg ^= (fb << 12) ^ (fb << 11) ^ (fb << 9) ^ (fb << 8) ^ (fb << 7) ^ (fb << 5) ^ (fb << 4);
+    }
+    R[i] = (unsigned short)(i < 53 ? reg : 0);
+  }
+  __syncthreads();
+  for (int e = tid; e < 7 * 256; e += nthreads) {
+    unsigned r = 0;
+    for (int j = 0; j < 8; j++) if ((e >> j) & 1) r ^= R[(e >> 8) * 8 + j];
+    T[e] = (unsigned short)r;
+  }
+  __syncthreads();
+}
+
 __device__ __forceinline__ void tps_advance(TpsState &t, int mod, int majv, int fi_start, unsigned mask_even, unsigned mask_odd,
-                                            int &si_out, int &cand)
+                                            int &si_out, int &cand, const unsigned short *T)
 {
   int diff = (mod - t.prev_mod + 4) & 3;
   t.prev_mod = mod;
@@ -799,7 +845,7 @@ __device__ __forceinline__ void tps_advance(TpsState &t, int mod, int majv, int 
   }
   const unsigned low16 = (unsigned)(t.fifo_lo & 0xFFFEull);
   if (low16 == mask_even || low16 == mask_odd) {
-    if (bch_check(t.fifo_lo, t.fifo_hi) == 0) {
+    if (bch_check_tab(T, t.fifo_lo, t.fifo_hi) == 0) {
       t.frame_index = (int)(((t.fifo_lo >> 23) & 1ull) << 1 | ((t.fifo_lo >> 24) & 1ull));
       t.symbol_index_known = 1; t.symbol_index = 67;
     } else t.symbol_index_known = 0;
@@ -812,16 +858,21 @@ __device__ __forceinline__ void tps_advance(TpsState &t, int mod, int majv, int 
 __global__ __launch_bounds__(64) void tps_fsm_par_kernel(FrontParams p, const RxState *st, const SymInfo *__restrict__ info, const int *__restrict__ maj,
                                                         int *__restrict__ sym_index, TpsEdge *__restrict__ edges, int *first_cand)
 {
-  __shared__ signed char s_mod[64 * TPS_SEG + TPS_WARM];
-  __shared__ short s_maj[64 * TPS_SEG + TPS_WARM];
+  // symbol streams in LDS; 4 bytes of padding per 128 entries keep the lanes (128 symbols apart) on distinct banks
+  constexpr int NS = 64 * TPS_SEG + TPS_WARM;
+  __shared__ signed char s_mod[NS + (NS >> 7) * 4 + 4];
+  __shared__ short s_maj[NS + (NS >> 7) * 2 + 2];
+  __shared__ unsigned short s_T[7 * 256], s_R[56];
+  auto pm = [](int i) { return i + (i >> 7) * 4; };
+  auto pj = [](int i) { return i + (i >> 7) * 2; };
   const int tid = threadIdx.x;
   const int nsym = st->n_symbols, ntot = nsym > 0 ? nsym - 1 : 0;
   const int blk0 = blockIdx.x * 64 * TPS_SEG;
   if (blk0 >= ntot) return;
   const int lo = blk0 - TPS_WARM < 0 ? 0 : blk0 - TPS_WARM;
   const int hi = blk0 + 64 * TPS_SEG < ntot ? blk0 + 64 * TPS_SEG : ntot;
-  for (int i = lo + tid; i < hi; i += 64) { s_mod[i - lo] = (signed char)info[i].mod_index; s_maj[i - lo] = (short)maj[i]; }
-  __syncthreads();
+  for (int i = lo + tid; i < hi; i += 64) { s_mod[pm(i - lo)] = (signed char)info[i].mod_index; s_maj[pj(i - lo)] = (short)maj[i]; }
+  tps_bch_table(s_T, s_R, tid, 64);
   unsigned mask_even = 0, mask_odd = 0;
   {
     const unsigned char se[15] = {0, 0, 1, 1, 0, 1, 0, 1, 1, 1, 1, 0, 1, 1, 1};
@@ -833,12 +884,12 @@ __global__ __launch_bounds__(64) void tps_fsm_par_kernel(FrontParams p, const Rx
   int sw = s0 - TPS_WARM; if (sw < 0) sw = 0;
   TpsState t; t.fifo_lo = 0; t.fifo_hi = 0; t.symbol_index = 0; t.symbol_index_known = 0; t.frame_index = 0; t.prev_mod = 0; t.d_init = 0;
   int si, cand;
-  for (int s = sw; s < s0; s++) tps_advance(t, s_mod[s - lo], s_maj[s - lo], p.fi_start, mask_even, mask_odd, si, cand);
+  for (int s = sw; s < s0; s++) tps_advance(t, s_mod[pm(s - lo)], s_maj[pj(s - lo)], p.fi_start, mask_even, mask_odd, si, cand, s_T);
   const int seg = s0 / TPS_SEG;
   edges[seg].start = t;
   int first = 0x7fffffff;
   for (int s = s0; s < s1; s++) {
-    tps_advance(t, s_mod[s - lo], s_maj[s - lo], p.fi_start, mask_even, mask_odd, si, cand);
+    tps_advance(t, s_mod[pm(s - lo)], s_maj[pj(s - lo)], p.fi_start, mask_even, mask_odd, si, cand, s_T);
     sym_index[s] = si;
     if (cand && first == 0x7fffffff) first = s;
   }
