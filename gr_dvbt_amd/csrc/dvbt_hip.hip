@@ -270,7 +270,7 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   for (int i = 0; i < ST_COUNT; i++) RXHIP(hipEventCreate(&h->ev[i]));
   h->ev_ready = true;
   RXCHK(set_lds((const void *)derot_fft_kernel, (size_t)(N + N / 32 + N / 128 + 128) * 8));
-  RXCHK(set_lds((const void *)inner_kernel, ((P + 15) & ~(size_t)15) + 64 * 8 + 64));
+  RXCHK(set_lds((const void *)inner_kernel, inner_lds_bytes(P)));
   *out = h;
   return DVBT_OK;
 }
@@ -343,7 +343,7 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s)
   hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(64), 0, s, h->st, h->vp, h->prm.descramble);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_INNER], s));
   InnerParams ip = h->T.inner_params(d.payload);
-  hipLaunchKernelGGL(inner_kernel, dim3(C), dim3(256), ((d.payload + 15) & ~15) + 64 * 8 + 64, s, (const float2 *)h->eq, (const uint8_t *)nullptr, ip,
+  hipLaunchKernelGGL(inner_kernel, dim3(C), dim3(256), inner_lds_bytes((size_t)d.payload), s, (const float2 *)h->eq, (const uint8_t *)nullptr, ip,
                      (const RxState *)h->st, 0, 7, (const int *)h->sym_index, (const float2 *)h->T.points, (const unsigned char *)h->T.label_tab,
                      (const uint16_t *)h->T.H, (const uint16_t *)h->T.Hinv, h->demap_tap, h->symdeint_tap, h->bitdeint);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_VIT], s));

@@ -29,31 +29,40 @@ __device__ __forceinline__ int demap_all(float2 v, const float2 *pts, int csize)
   return idx;
 }
 
-// Same result from 9 candidates: the float sum dr*dr + di*di is monotone in each addend, so its
-// minimum over the table is attained on the per-axis nearest levels; a tie with any point outside the
-// 3x3 neighbourhood would need two distances that differ by >= one level spacing squared to round
-// equal, impossible below the guard magnitude.  "First strict minimum" = smallest label among equals.
+// Same result from 4 candidates.  d(i,q) = fl(fl(dx_i^2) + fl(dy_q^2)) is monotone in each addend, so the minimum
+// over the table is attained on the per-axis nearest level; the only points that can TIE with it in float are the
+// ones whose axis distance is nearly equal, i.e. the second-nearest level on the side of the sample (any other level
+// is at least one spacing farther: its square differs by >= 0.75 spacing^2, which rounding cannot absorb below the
+// guard magnitude).  So the first strict minimum of the 64-point search (dvbt_demap_impl.cc:167-203) = the smallest
+// label among the minima of {nearest, second nearest} x {nearest, second nearest}, all four computed exactly as the
+// reference computes them.
 __device__ __forceinline__ int demap_one(float2 v, const float2 *pts, const unsigned char *label_of, const InnerParams &p)
 {
   if (p.nlev == 0 || !(fabsf(v.x) < p.guard) || !(fabsf(v.y) < p.guard)) return demap_all(v, pts, p.csize);
   const int n = p.nlev;
   int ji = (int)floorf(v.x * p.inv_step + 0.5f * (float)n), jq = (int)floorf(v.y * p.inv_step + 0.5f * (float)n);
   ji = ji < 0 ? 0 : ji > n - 1 ? n - 1 : ji; jq = jq < 0 ? 0 : jq > n - 1 ? n - 1 : jq;
-  float best = 3.0e38f; int idx = 255;
-#pragma unroll
-  for (int a = -1; a <= 1; a++) {
-    int i1 = ji + a; if (i1 < 0 || i1 >= n) continue;
-#pragma unroll
-    for (int b = -1; b <= 1; b++) {
-      int q1 = jq + b; if (q1 < 0 || q1 >= n) continue;
-      const int lab = label_of[i1 * 8 + q1];
-      const float dr = v.x - pts[lab].x, di = v.y - pts[lab].y;
-      const float d = dr * dr + di * di;
-      if (d < best || (d == best && lab < idx)) { best = d; idx = lab; }
-    }
-  }
+  const int L00 = label_of[ji * 8 + jq];
+  const float px0 = pts[L00].x, py0 = pts[L00].y;
+  int ji2 = ji + (v.x > px0 ? 1 : -1), jq2 = jq + (v.y > py0 ? 1 : -1);
+  ji2 = (ji2 < 0 || ji2 > n - 1) ? ji : ji2; jq2 = (jq2 < 0 || jq2 > n - 1) ? jq : jq2;
+  const int L10 = label_of[ji2 * 8 + jq], L01 = label_of[ji * 8 + jq2], L11 = label_of[ji2 * 8 + jq2];
+  const float px1 = pts[L10].x, py1 = pts[L01].y;
+  const float dx0 = v.x - px0, dx1 = v.x - px1, dy0 = v.y - py0, dy1 = v.y - py1;
+  const float ax0 = dx0 * dx0, ax1 = dx1 * dx1, ay0 = dy0 * dy0, ay1 = dy1 * dy1;
+  const float d00 = ax0 + ay0, d01 = ax0 + ay1, d10 = ax1 + ay0, d11 = ax1 + ay1;
+  const float best = fminf(fminf(d00, d01), fminf(d10, d11));
+  int idx = 255;
+  idx = d00 == best ? min(idx, L00) : idx; idx = d01 == best ? min(idx, L01) : idx;
+  idx = d10 == best ? min(idx, L10) : idx; idx = d11 == best ? min(idx, L11) : idx;
   return idx;
 }
+
+// LDS image of a symbol's labels: blocks of 126 bytes (the bit interleaver's block) at a stride of 132, each followed
+// by a copy of its first 6 bytes, so that 4 consecutive bytes of a cyclically rotated block are one unaligned word
+constexpr int IB = 126, IBS = 132;
+__host__ __device__ inline size_t inner_lds_bytes(size_t payload) { return ((((payload + IB - 1) / IB) * IBS + 15) & ~(size_t)15) + 64 * 8 + 64; }
+__device__ __forceinline__ int ipos(int d) { const int b = d / IB; return d + b * (IBS - IB); }
 
 // mode bits: 1 = demap, 2 = symbol de-interleave, 4 = bit de-interleave (7 = fused chain path).
 // Reads are in carrier order (coalesced); the symbol permutation is applied on the LDS store:
@@ -66,8 +75,8 @@ __global__ __launch_bounds__(256) void inner_kernel(const float2 *__restrict__ e
                                                    uint8_t *__restrict__ out)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  uint8_t *v = smem_raw;                                       // payload bytes
-  float2 *pts = reinterpret_cast<float2 *>(smem_raw + ((p.payload + 15) & ~15));
+  uint8_t *v = smem_raw;                                       // labels, padded block layout
+  float2 *pts = reinterpret_cast<float2 *>(smem_raw + ((((p.payload + IB - 1) / IB) * IBS + 15) & ~15));
   unsigned char *label_of = reinterpret_cast<unsigned char *>(pts + 64);
   const int u = blockIdx.x, tid = threadIdx.x;
   int first = 0, nout = nitems_fixed;
@@ -85,25 +94,36 @@ __global__ __launch_bounds__(256) void inner_kernel(const float2 *__restrict__ e
   for (int q = tid; q < p.payload; q += 256) {
     int dst = q;
     if (mode & 2) dst = odd ? H[q] : Hinv[q];
-    int lab = (mode & 1) ? demap_one(e[q], pts, label_of, p) : ib[q];
-    v[dst] = (uint8_t)lab;
+    const int lab = (mode & 1) ? demap_one(e[q], pts, label_of, p) : ib[q];
+    const int blk = dst / IB, r = dst - blk * IB, at = blk * IBS + r;
+    v[at] = (uint8_t)lab;
+    if (r < IBS - IB) v[at + IB] = (uint8_t)lab;               // the block's wrap-around tail
     if (tap_demap && (mode & 1)) tap_demap[(size_t)u * p.payload + q] = (uint8_t)lab;
   }
   __syncthreads();
   uint8_t *o = out + (size_t)u * p.payload;
-  if (tap_symdeint) for (int q = tid; q < p.payload; q += 256) tap_symdeint[(size_t)u * p.payload + q] = v[q];
-  if (!(mode & 4)) { for (int q = tid; q < p.payload; q += 256) o[q] = v[q]; return; }
+  if (tap_symdeint) for (int q = tid; q < p.payload; q += 256) tap_symdeint[(size_t)u * p.payload + q] = v[ipos(q)];
+  if (!(mode & 4)) { for (int q = tid; q < p.payload; q += 256) o[q] = v[ipos(q)]; return; }
+  // A6: output byte i of a block, bit k (MSB first) = bit (m-1-e) of input byte (i - off_e) mod 126, e = perm(k).
+  // One item = 4 consecutive output bytes: per bit plane one (unaligned) word of the rotated block, masked and
+  // shifted into place.
   const int vb = p.m, hv = vb >> 1;
-  const int off[6] = {0, 63, 105, 42, 21, 84};
-  for (int q = tid; q < p.payload; q += 256) {
-    int blk = q / 126, i = q - blk * 126;
-    int val = 0;
+  const int nitems = (p.payload / IB) * 32;                    // 32 words cover the 126 bytes of a block
+  for (int it = tid; it < nitems; it += 256) {
+    const int blk = it >> 5, j = it & 31;
+    const unsigned *bw = reinterpret_cast<const unsigned *>(v + blk * IBS);
+    unsigned val = 0;
     for (int k = 0; k < vb; k++) {
-      int eidx = k / hv + 2 * (k % hv);                         // d_perm, non-hierarchical (:91-99)
-      int w = i - off[eidx]; if (w < 0) w += 126;
-      val = (val << 1) | ((v[blk * 126 + w] >> (vb - 1 - eidx)) & 1);
+      const int eidx = k / hv + 2 * (k % hv);                   // d_perm, non-hierarchical (:91-99)
+      const int off = eidx == 0 ? 0 : eidx == 1 ? 63 : eidx == 2 ? 105 : eidx == 3 ? 42 : eidx == 4 ? 21 : 84;
+      int w = 4 * j - off; if (w < 0) w += IB;
+      const unsigned lo = bw[w >> 2], hi = bw[(w >> 2) + 1];
+      const unsigned word = __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(w & 3));
+      val |= ((word >> (vb - 1 - eidx)) & 0x01010101u) << (vb - 1 - k);
     }
-    o[q] = (uint8_t)val;
+    uint8_t *dst = o + blk * IB + 4 * j;                        // even address
+    *reinterpret_cast<uint16_t *>(dst) = (uint16_t)val;
+    if (j < 31) *reinterpret_cast<uint16_t *>(dst + 2) = (uint16_t)(val >> 16);
   }
 }
 

@@ -416,7 +416,7 @@ __device__ __forceinline__ void bfly4(float2 a0, float2 a1, float2 a2, float2 a3
 // out; the host-built permutation undoes the reversal).  Radix-16 passes with the 16-point transform held in
 // registers (two radix-4 levels), then a radix-4 and/or radix-2 tail: 8192 = 16.16.16.2, 2048 = 16.16.4.2
 // (dvbt_tables.hpp::fft_radices lists the same sequence).  One __syncthreads per pass.
-__device__ inline void fft_dif_lds(float2 *x, int N, const float2 *tw_c, const float2 *tw_f, int tid)
+__device__ __forceinline__ void fft_dif_lds(float2 *x, int N, const float2 *tw_c, const float2 *tw_f, int tid)
 {
   // W16^m = exp(-2 pi i m / 16), m = 0..9 (products r'*k1 with r',k1 <= 3)
   const float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, h = 0.70710678118654752f;
