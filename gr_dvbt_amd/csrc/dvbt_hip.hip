@@ -63,6 +63,7 @@ struct Tables {          // device lookup tables for one configuration
   float2 *tw = nullptr; uint16_t *perm = nullptr;
   int16_t *cpilot = nullptr, *tps = nullptr; float *known = nullptr, *pref = nullptr;
   uint16_t *pay_c = nullptr, *pay_L = nullptr, *pay_R = nullptr, *tps_L = nullptr, *tps_R = nullptr;
+  uint16_t *pil_k = nullptr, *pay_Li = nullptr, *pay_Ri = nullptr, *tps_Li = nullptr, *tps_Ri = nullptr; uint8_t *pay_d = nullptr, *tps_d = nullptr; int np[4] = {0, 0, 0, 0};
   uint16_t *H = nullptr, *Hinv = nullptr; float2 *points = nullptr; uint8_t *label_tab = nullptr; int nlev = 0; float inv_step = 0.f, guard = 0.f;
   uint8_t *mul_alpha = nullptr, *gexp = nullptr, *glog = nullptr, *prbs = nullptr;
   bool front = false, inner = false, rs = false;
@@ -83,15 +84,25 @@ struct Tables {          // device lookup tables for one configuration
     for (int i = 0; i + 1 < d.n_cp; i++) { float df = pr[c[i + 1]] - pr[c[i]]; kn[i] = df * df; }
     int r;
     if ((r = upload(c16, &cpilot)) || (r = upload(t16, &tps)) || (r = upload(pr, &pref)) || (r = upload(kn, &known))) return r;
-    std::vector<uint16_t> pc, pl, prr, tl, trr;
+    std::vector<uint16_t> pc, pl, prr, tl, trr, pk((size_t)4 * DEMOD_NP, 0), pli, pri, tli, tri;
+    std::vector<uint8_t> pd, td;
     for (int s = 0; s < 4; s++) {
       PatternTables pt = pattern_tables(d, s);
       if ((int)pt.pay_c.size() != d.payload) return fail(DVBT_ERR_INVALID, "payload carrier table size mismatch");
+      if ((int)pt.pil_k.size() > DEMOD_NP) return fail(DVBT_ERR_INVALID, "estimation carrier table overflow");
+      np[s] = (int)pt.pil_k.size();
+      std::copy(pt.pil_k.begin(), pt.pil_k.end(), pk.begin() + (size_t)s * DEMOD_NP);
+      pli.insert(pli.end(), pt.pay_Li.begin(), pt.pay_Li.end()); pri.insert(pri.end(), pt.pay_Ri.begin(), pt.pay_Ri.end());
+      pd.insert(pd.end(), pt.pay_d.begin(), pt.pay_d.end());
+      tli.insert(tli.end(), pt.tps_Li.begin(), pt.tps_Li.end()); tri.insert(tri.end(), pt.tps_Ri.begin(), pt.tps_Ri.end());
+      td.insert(td.end(), pt.tps_d.begin(), pt.tps_d.end());
       pc.insert(pc.end(), pt.pay_c.begin(), pt.pay_c.end()); pl.insert(pl.end(), pt.pay_L.begin(), pt.pay_L.end());
       prr.insert(prr.end(), pt.pay_R.begin(), pt.pay_R.end()); tl.insert(tl.end(), pt.tps_L.begin(), pt.tps_L.end());
       trr.insert(trr.end(), pt.tps_R.begin(), pt.tps_R.end());
     }
     if ((r = upload(pc, &pay_c)) || (r = upload(pl, &pay_L)) || (r = upload(prr, &pay_R)) || (r = upload(tl, &tps_L)) || (r = upload(trr, &tps_R))) return r;
+    if ((r = upload(pk, &pil_k)) || (r = upload(pli, &pay_Li)) || (r = upload(pri, &pay_Ri)) || (r = upload(pd, &pay_d)) || (r = upload(tli, &tps_Li)) ||
+        (r = upload(tri, &tps_Ri)) || (r = upload(td, &tps_d))) return r;
     front = true;
     return DVBT_OK;
   }
@@ -138,11 +149,13 @@ struct Tables {          // device lookup tables for one configuration
     return DVBT_OK;
   }
   DemodTables demod_tables() const { DemodTables T; T.cpilot = cpilot; T.known_diff = known; T.tps = tps; T.pilot_ref = pref;
-    T.pay_c = pay_c; T.pay_L = pay_L; T.pay_R = pay_R; T.tps_L = tps_L; T.tps_R = tps_R; return T; }
+    T.pay_c = pay_c; T.pay_L = pay_L; T.pay_R = pay_R; T.tps_L = tps_L; T.tps_R = tps_R;
+    T.pil_k = pil_k; for (int i = 0; i < 4; i++) T.np[i] = np[i];
+    T.pay_Li = pay_Li; T.pay_Ri = pay_Ri; T.pay_d = pay_d; T.tps_Li = tps_Li; T.tps_Ri = tps_Ri; T.tps_d = tps_d; return T; }
   RsTables rs_tables() const { RsTables T; T.div_tab = mul_alpha; T.gexp = gexp; T.glog = glog; return T; }
   ~Tables()
   {
-    void *all[] = {tw, perm, cpilot, tps, known, pref, pay_c, pay_L, pay_R, tps_L, tps_R, H, Hinv, points, label_tab, mul_alpha, gexp, glog, prbs};
+    void *all[] = {tw, perm, cpilot, tps, known, pref, pay_c, pay_L, pay_R, tps_L, tps_R, pil_k, pay_Li, pay_Ri, pay_d, tps_Li, tps_Ri, tps_d, H, Hinv, points, label_tab, mul_alpha, gexp, glog, prbs};
     for (void *q : all) if (q) (void)hipFree(q);
   }
 };
@@ -260,7 +273,7 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   RXHIP(hipMalloc((void **)&h->trk_eps, sizeof(float) * C)); RXHIP(hipMalloc((void **)&h->trk_flags, sizeof(int) * 16));
   RXHIP(hipMalloc((void **)&h->tps_edges, sizeof(TpsEdge) * (C / TPS_SEG + 2))); RXHIP(hipMalloc((void **)&h->st, sizeof(RxState)));
   RXHIP(hipHostMalloc((void **)&h->st_host, sizeof(RxState))); RXHIP(hipMalloc((void **)&h->tps_state, sizeof(TpsState)));
-  RXHIP(hipMalloc((void **)&h->fft_out, sizeof(float2) * C * N)); RXHIP(hipMalloc((void **)&h->eq, sizeof(float2) * C * P));
+  RXHIP(hipMalloc((void **)&h->eq, sizeof(float2) * C * P));   // the FFT items stay in LDS (fused kernel); fft_out exists only as a debug tap
   RXHIP(hipMalloc((void **)&h->tpsval, sizeof(float2) * C * d.n_tps)); RXHIP(hipMalloc((void **)&h->info, sizeof(SymInfo) * C));
   RXHIP(hipMalloc((void **)&h->maj, sizeof(int) * C)); RXHIP(hipMalloc((void **)&h->sym_index, sizeof(int) * C));
   RXHIP(hipMalloc((void **)&h->bitdeint, C * P + 64));
@@ -269,7 +282,7 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   RXHIP(hipMemset(h->st, 0, sizeof(RxState)));
   for (int i = 0; i < ST_COUNT; i++) RXHIP(hipEventCreate(&h->ev[i]));
   h->ev_ready = true;
-  RXCHK(set_lds((const void *)derot_fft_kernel, (size_t)(N + N / 32 + N / 128 + 128) * 8));
+  RXCHK(set_lds((const void *)derot_fft_demod_kernel, fused_lds_bytes_host((int)N)));
   RXCHK(set_lds((const void *)inner_kernel, inner_lds_bytes(P)));
   *out = h;
   return DVBT_OK;
@@ -282,6 +295,7 @@ static int ensure_taps(dvbt_rx *h)
 {
   const size_t C = (size_t)h->max_calls, N = h->d.N, P = h->d.payload;
   if (!h->acq_tap) HIPCHK(hipMalloc((void **)&h->acq_tap, sizeof(float2) * C * N));
+  if (!h->fft_out) HIPCHK(hipMalloc((void **)&h->fft_out, sizeof(float2) * C * N));
   if (!h->demap_tap) HIPCHK(hipMalloc((void **)&h->demap_tap, C * P + 64));
   if (!h->symdeint_tap) HIPCHK(hipMalloc((void **)&h->symdeint_tap, C * P + 64));
   if (!h->deint_tap) HIPCHK(hipMalloc((void **)&h->deint_tap, h->vit_cap));
@@ -291,7 +305,7 @@ extern "C" int dvbt_rx_enable_taps(dvbt_rx *h, int enable)
 {
   if (!h) return DVBT_ERR_INVALID;
   if (enable) return ensure_taps(h);
-  void **all[] = {(void **)&h->acq_tap, (void **)&h->demap_tap, (void **)&h->symdeint_tap, (void **)&h->deint_tap};
+  void **all[] = {(void **)&h->acq_tap, (void **)&h->fft_out, (void **)&h->demap_tap, (void **)&h->symdeint_tap, (void **)&h->deint_tap};
   for (void **q : all) if (*q) { (void)hipFree(*q); *q = nullptr; }
   return DVBT_OK;
 }
@@ -324,11 +338,10 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s)
   hipLaunchKernelGGL(acq_track_kernel, dim3(1), dim3(64), 0, s, fp, h->st, (const float2 *)h->g_trk, (const float *)h->l_trk, h->meta,
                      (const int *)(h->trk_flags + kIters), (AcqState *)nullptr);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_FFT], s));
-  hipLaunchKernelGGL(derot_fft_kernel, dim3(C), dim3(FFT_THREADS), (size_t)(N + N / 32 + N / 128 + 128) * 8, s, iq, fp, (const RxState *)h->st, (const SymMeta *)h->meta,
-                     (const float2 *)h->T.tw, (const uint16_t *)h->T.perm, h->acq_tap, h->fft_out);
+  // A1 tail + A2 + A3 in one kernel: the FFT item of a symbol never leaves LDS (acq/fft taps are written only when enabled)
+  hipLaunchKernelGGL(derot_fft_demod_kernel, dim3(C), dim3(FFT_THREADS), fused_lds_bytes_host(N), s, iq, fp, (const RxState *)h->st, (const SymMeta *)h->meta,
+                     (const float2 *)h->T.tw, h->acq_tap, h->fft_out, h->T.demod_tables(), h->eq, h->tpsval, h->info);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_DEMOD], s));
-  hipLaunchKernelGGL(demod_kernel, dim3(C), dim3(256), 0, s, (const float2 *)h->fft_out, fp, (const RxState *)h->st, 0, h->T.demod_tables(),
-                     h->eq, h->tpsval, h->info);
   hipLaunchKernelGGL(tps_vote_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float2 *)h->tpsval, d.n_tps, (const RxState *)h->st, 0,
                      (const float2 *)nullptr, h->maj);
   {   // flags[8] = first superframe-start candidate (min), flags[9] = need_seq for the TPS bookkeeping

@@ -156,7 +156,12 @@ inline std::vector<int> spilot_list(const Dims &d, int s)
 // For pattern s: the ascending payload carrier list (process_payload_data :1065-1106) and, per
 // carrier of interest, the two estimation carriers (scattered U continual) that bracket it
 // (process_spilot_data :597-642): gain(c) = g[L] + (c-L)*(g[R]-g[L])/11, L==c for a pilot.
-struct PatternTables { std::vector<uint16_t> pay_c, pay_L, pay_R, tps_L, tps_R; };
+struct PatternTables {
+  std::vector<uint16_t> pay_c, pay_L, pay_R, tps_L, tps_R;
+  // the same brackets as ranks into the sorted list of estimation carriers (pil_k), plus the distance c - L
+  std::vector<uint16_t> pil_k, pay_Li, pay_Ri, tps_Li, tps_Ri;
+  std::vector<uint8_t> pay_d, tps_d;
+};
 inline PatternTables pattern_tables(const Dims &d, int s)
 {
   std::vector<int> cpl = cpilot_table(d), tps = tps_table(d), sp = spilot_list(d, s);
@@ -173,6 +178,14 @@ inline PatternTables pattern_tables(const Dims &d, int s)
   for (int k = 0; k < d.K; k++)
     if (!is_est[k] && !is_tps[k]) { t.pay_c.push_back((uint16_t)k); t.pay_L.push_back((uint16_t)L[k]); t.pay_R.push_back((uint16_t)R[k]); }
   for (int k : tps) { t.tps_L.push_back((uint16_t)L[k]); t.tps_R.push_back((uint16_t)R[k]); }
+  std::vector<int> rank(d.K, 0);
+  for (int k = 0; k < d.K; k++) if (is_est[k]) { rank[k] = (int)t.pil_k.size(); t.pil_k.push_back((uint16_t)k); }
+  for (size_t i = 0; i < t.pay_c.size(); i++) {
+    t.pay_Li.push_back((uint16_t)rank[t.pay_L[i]]); t.pay_Ri.push_back((uint16_t)rank[t.pay_R[i]]); t.pay_d.push_back((uint8_t)(t.pay_c[i] - t.pay_L[i]));
+  }
+  for (size_t i = 0; i < tps.size(); i++) {
+    t.tps_Li.push_back((uint16_t)rank[t.tps_L[i]]); t.tps_Ri.push_back((uint16_t)rank[t.tps_R[i]]); t.tps_d.push_back((uint8_t)(tps[i] - t.tps_L[i]));
+  }
   return t;
 }
 
