@@ -5,7 +5,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-_SO = os.path.join(_HERE, "lib", "libdvbt_hip.so")
+_SO = os.environ.get("DVBT_HIP_LIB") or os.path.join(_HERE, "lib", "libdvbt_hip.so")   # DVBT_HIP_LIB: A/B builds of the same ABI
 _SRC = os.path.join(_HERE, "csrc", "dvbt_hip.hip")
 
 QPSK, QAM16, QAM64 = 0, 1, 2

@@ -385,7 +385,10 @@ __global__ __launch_bounds__(1024) void acq_finalize_kernel(FrontParams p, RxSta
 
 // LDS image of a symbol: one float2 of padding after every 32 keeps the stride-4/16/64 accesses of the
 // late radix-4 stages conflict-free (bank = float2 index mod 32 for ds_read_b64)
-constexpr int FFT_THREADS = 256;
+#ifndef DVBT_FFT_THREADS
+#define DVBT_FFT_THREADS 512
+#endif
+constexpr int FFT_THREADS = DVBT_FFT_THREADS;   // workgroup size of the FFT kernels (a build-time experiment knob)
 __device__ __forceinline__ int fpad(int a) { return a + (a >> 5); }
 // twiddle W_N^t from a two-level table held in LDS: coarse[t >> 7] * fine[t & 127] (one complex multiply instead of
 // an L2 round trip per twiddle; relative error ~1.2e-7)
@@ -705,14 +708,31 @@ __global__ __launch_bounds__(FFT_THREADS) void derot_fft_demod_kernel(const floa
   const SymMeta m = meta[s];
   const long long low = (long long)(st->call0 + s) * (N + cp) + m.cp_start - N + 1;
   const bool rot = (m.incA != 0.0) || (m.incB != 0.0) || (m.ph_base != 0.f);
-  for (int n = tid; n < N; n += FFT_THREADS) {
+  // derot[n] = expj(phase after n+1 increments) (:285-309,:527-534).  The phase is piecewise linear in n (increment
+  // incA up to the switch position sw, incB after it), so expj(phase(tid + T*i)) = P(tid) * S(i) with one sincos per
+  // thread and piece (P) and a wave-uniform table of the T-sample steps (S) instead of one sincos per sample.
+  const bool has_sw = m.sw >= 0 && m.sw < N + cp;
+  float2 PA = make_float2(1.f, 0.f), PB = PA;
+  float2 *stab = gtab;                                            // [2][N / FFT_THREADS], free until the pilot engine runs
+  const int nstep = N / FFT_THREADS;
+  if (rot) {
+    const double thA = (double)m.ph_base + m.incA, thB = (double)m.ph_base + (double)m.sw * (m.incA - m.incB) + m.incB;
+    if (tid < 2 * nstep) {
+      const int i = tid % nstep;
+      const float ph = wrap_pi((double)FFT_THREADS * i * (tid < nstep ? m.incA : m.incB));
+      float sn, cs; sincosf(ph, &sn, &cs); stab[tid] = make_float2(cs, sn);
+    }
+    float sn, cs;
+    sincosf(wrap_pi(thA + tid * m.incA), &sn, &cs); PA = make_float2(cs, sn);
+    sincosf(wrap_pi(thB + tid * m.incB), &sn, &cs); PB = make_float2(cs, sn);
+    __syncthreads();
+  }
+  for (int i = 0; i < nstep; i++) {
+    const int n = tid + i * FFT_THREADS;
     float2 v = iq[low + n];
-    if (rot) {                                   // derot[n] = expj(phase after n+1 increments)  (:285-309,:527-534)
-      int a = n + 1, b = 0;
-      if (m.sw >= 0 && m.sw < N + cp && a > m.sw) { b = a - m.sw; a = m.sw; }
-      float ph = wrap_pi((double)m.ph_base + a * m.incA + b * m.incB);
-      float sn, cs; sincosf(ph, &sn, &cs);
-      v = cmul(make_float2(cs, sn), v);
+    if (rot) {
+      const bool pieceB = has_sw && n + 1 > m.sw;
+      v = cmul(cmul(pieceB ? PB : PA, stab[(pieceB ? nstep : 0) + i]), v);
     }
     x[fpad(n)] = v;
     if (acq_tap) acq_tap[(size_t)s * N + n] = v;
@@ -733,15 +753,15 @@ __global__ __launch_bounds__(FFT_THREADS) void derot_fft_demod_kernel(const floa
 
   // integer CFO: process_cpilot_data :715-744 -- 16 candidate shifts x (n_cp-1) pilot pairs
   {
-    const int cand = tid >> 4, sub = tid & 15, i = zl - 8 + cand;
+    const int cand = (tid >> 4) & 15, sub = tid & 15, i = zl - 8 + cand;
     float sum = 0.f;
-    for (int j = sub; j < p.n_cp - 1; j += 16) {
+    for (int j = sub; j < p.n_cp - 1 && tid < 256; j += 16) {
       const float2 a = X(i + T.cpilot[j + 1]), b = X(i + T.cpilot[j]);
       const float dx = a.x - b.x, dy = a.y - b.y;
       sum += T.known_diff[j] * (dx * dx + dy * dy);
     }
     for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    if (sub == 0) s_sum[cand] = sum;
+    if (sub == 0 && tid < 256) s_sum[cand] = sum;
   }
   __syncthreads();
   if (tid == 0) {
