@@ -54,6 +54,8 @@ struct V3Lane {
   int org[2];           // (storage index << 2) of the two cells, at the path-byte position
   int b2[3][2];         // top two bits of the cells' states at phases 0,2,4
   int hi_bias;          // 0x01000000: bias of the upper half
+  int nb2[3][2];        // bias of phase 0,2,4 | b2 of that phase   (6th step of a window)
+  int nbo[3][2];        // bias of phase 0,2,4 | org                (last step of a window)
 };
 
 // storage index of a cell in the path-byte table: z = physical lane * 4 + 2r + h (a lane's four bytes are one word)
@@ -84,10 +86,17 @@ __device__ inline void v3_init_lane(int pl, V3Lane &L)
       L.b2[e][r] = (s0 >> 4) | ((s1 >> 4) << 16);
     }
     L.org[r] = ((pl * 4 + 2 * r) << 2) | (((pl * 4 + 2 * r + 1) << 2) << 16);
+    for (int e = 0; e < 3; e++) {
+      const int nb = e == 0 ? (r ? 0x01000100 : 0) : e == 1 ? L.abit[3] : L.abit[1];   // bias when the phase is 0, 2, 4
+      L.nb2[e][r] = nb | L.b2[e][r]; L.nbo[e][r] = nb | L.org[r];
+    }
   }
 }
 
-template <int P> __device__ __forceinline__ void v3_step(int (&v)[2], unsigned W, const V3Lane &L)
+// ST: 0 plain step; 1 = the window's 6th step (the two oldest inputs are stamped into the path byte together with
+// the bias); 2 = the window's last step (raw[] keeps the survivors' path bytes for the table, v gets bias AND the
+// origin stamp of the next window in the same v_and_or)
+template <int P, int ST> __device__ __forceinline__ void v3_step(int (&v)[2], unsigned W, const V3Lane &L, int (&raw)[2])
 {
   int X[2], Y[2], Yp[2];
   // The label class of a cell depends on bits 0,1,2,4 of its state (parity taps 0x4f, 0x6d without the MSB).  The
@@ -112,7 +121,9 @@ template <int P> __device__ __forceinline__ void v3_step(int (&v)[2], unsigned W
 #pragma unroll
   for (int r = 0; r < 2; r++) {
     const int mx = pk_max(X[r], Yp[r]);
-    if (PN == 0) v[r] = r ? (mx | 0x01000100) : (mx & (int)0xfefffeff);      // VGPR 1 holds the upper states
+    if (ST == 1) v[r] = (mx & (int)0xfefcfefc) | L.nb2[PN / 2][r];
+    else if (ST == 2) { raw[r] = mx; v[r] = (mx & (int)0xfe00fe00) | L.nbo[PN / 2][r]; }
+    else if (PN == 0) v[r] = r ? (mx | 0x01000100) : (mx & (int)0xfefffeff);      // VGPR 1 holds the upper states
     else {
       const int nb = PN == 1 ? L.hi_bias : PN == 2 ? L.abit[3] : PN == 3 ? L.abit[2] : PN == 4 ? L.abit[1] : L.abit[0];
       v[r] = (mx & (int)0xfefffeff) | nb;
@@ -120,15 +131,12 @@ template <int P> __device__ __forceinline__ void v3_step(int (&v)[2], unsigned W
   }
 }
 
-template <int P0> __device__ __forceinline__ void v3_window(int (&v)[2], const unsigned (&W)[8], const V3Lane &L)
+// the 8 steps of a window that starts at phase P0 (0, 2, 4); v arrives with the origin stamp in its path bytes
+template <int P0> __device__ __forceinline__ void v3_window(int (&v)[2], const unsigned (&W)[8], const V3Lane &L, int (&raw)[2])
 {
-#pragma unroll
-  for (int r = 0; r < 2; r++) v[r] = (v[r] & (int)0xff00ff00) | L.org[r];
-  v3_step<(P0 + 0) % 6>(v, W[0], L); v3_step<(P0 + 1) % 6>(v, W[1], L); v3_step<(P0 + 2) % 6>(v, W[2], L);
-  v3_step<(P0 + 3) % 6>(v, W[3], L); v3_step<(P0 + 4) % 6>(v, W[4], L); v3_step<(P0 + 5) % 6>(v, W[5], L);
-#pragma unroll
-  for (int r = 0; r < 2; r++) v[r] = (v[r] & (int)0xfffcfffc) | L.b2[P0 / 2][r];
-  v3_step<(P0 + 6) % 6>(v, W[6], L); v3_step<(P0 + 7) % 6>(v, W[7], L);
+  v3_step<(P0 + 0) % 6, 0>(v, W[0], L, raw); v3_step<(P0 + 1) % 6, 0>(v, W[1], L, raw); v3_step<(P0 + 2) % 6, 0>(v, W[2], L, raw);
+  v3_step<(P0 + 3) % 6, 0>(v, W[3], L, raw); v3_step<(P0 + 4) % 6, 0>(v, W[4], L, raw); v3_step<(P0 + 5) % 6, 1>(v, W[5], L, raw);
+  v3_step<(P0 + 6) % 6, 0>(v, W[6], L, raw); v3_step<(P0 + 7) % 6, 2>(v, W[7], L, raw);
 }
 
 // halves of a packed register as sign-extended 32-bit values
@@ -200,9 +208,10 @@ template <int V6, bool HOPS> __device__ __forceinline__ void v3_fwd_window(int (
     W[0] = t0.x; W[1] = t0.y; W[2] = t0.z; W[3] = t0.w; W[4] = t1.x; W[5] = t1.y; W[6] = t1.z; W[7] = t1.w;
   }
   constexpr int P0 = (8 * V6) % 6;
-  v3_window<P0>(v, W, L);
+  int raw[2];
+  v3_window<P0>(v, W, L, raw);
   // the four path bytes of this lane's cells = one word of the table (storage index z = 4*lane + 2r + h)
-  *reinterpret_cast<unsigned *>(tab + (jr * 4 + dd) * 64 + pl * 4) = __builtin_amdgcn_perm((unsigned)v[1], (unsigned)v[0], 0x06040200u);
+  *reinterpret_cast<unsigned *>(tab + (jr * 4 + dd) * 64 + pl * 4) = __builtin_amdgcn_perm((unsigned)raw[1], (unsigned)raw[0], 0x06040200u);
   const int s = v3_window_end<(P0 + 2) % 6, (V6 & 1) == 1>(v, L);
   bests[dd * V3_RINGW + jr] = (unsigned char)s;                    // all 16 lanes of the row write the same byte
 }
@@ -251,7 +260,7 @@ __global__ __launch_bounds__(64) void viterbi3_kernel(const uint8_t *__restrict_
     lut[lane] = d0 | (d1 << 8) | (d2 << 16) | (d3 << 24);
   }
   V3Lane L; v3_init_lane(pl, L);
-  int v[2] = {0, 0x01000100};                                      // phase 0: VGPR 1 holds the upper states
+  int v[2] = {L.org[0], 0x01000100 | L.org[1]};                    // phase 0: VGPR 1 holds the upper states; origin stamp of window 0
 
   // ---- staging, first half: where block jb starts in the input (row-uniform) and the load of its bytes
   int ph0 = 0, bo0 = 0, off = 0; uint4 q = make_uint4(0, 0, 0, 0);
