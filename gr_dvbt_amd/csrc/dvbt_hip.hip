@@ -323,10 +323,15 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s)
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_ACQ], s));
   HIPCHK(hipMemsetAsync(h->tps_state, 0, sizeof(TpsState), s));
   int tries = C < ACQ_INIT_TRIES ? C : ACQ_INIT_TRIES;
-  hipLaunchKernelGGL(acq_metric_kernel, dim3((N + 255) / 256, tries), dim3(256), 0, s, iq, fp, (const RxState *)h->st, 0, h->g_init, h->l_init);
-  hipLaunchKernelGGL(acq_init_fsm_kernel, dim3(1), dim3(256), (size_t)N * 5, s, fp, h->st, (const float2 *)h->g_init, (const float *)h->l_init, (const AcqState *)nullptr);
+  // initial search: the first window normally holds a peak; windows 1..3 are computed and examined only if it did not
+  hipLaunchKernelGGL(acq_metric_kernel, dim3((N + 255) / 256, 1), dim3(256), 0, s, iq, fp, (const RxState *)h->st, 0, h->g_init, h->l_init, 0);
+  hipLaunchKernelGGL(acq_init_fsm_kernel, dim3(1), dim3(256), (size_t)N * 5, s, fp, h->st, (const float2 *)h->g_init, (const float *)h->l_init, (const AcqState *)nullptr, 0, 1);
+  if (tries > 1) {
+    hipLaunchKernelGGL(acq_metric_kernel, dim3((N + 255) / 256, tries - 1), dim3(256), 0, s, iq, fp, (const RxState *)h->st, 0, h->g_init, h->l_init, 1);
+    hipLaunchKernelGGL(acq_init_fsm_kernel, dim3(1), dim3(256), (size_t)N * 5, s, fp, h->st, (const float2 *)h->g_init, (const float *)h->l_init, (const AcqState *)nullptr, 1, tries);
+  }
   HIPCHK(hipMemsetAsync(h->trk_flags, 0, sizeof(int) * 16, s));
-  hipLaunchKernelGGL(acq_metric_kernel, dim3((C * 2 * ACQ_R + 255) / 256), dim3(256), 0, s, iq, fp, (const RxState *)h->st, 1, h->g_trk, h->l_trk);
+  hipLaunchKernelGGL(acq_track_metric_kernel, dim3((C + ACQ_TM_CALLS - 1) / ACQ_TM_CALLS), dim3(256), 0, s, iq, fp, (const RxState *)h->st, h->g_trk, h->l_trk);
   constexpr int kIters = 4;                     // Jacobi iterations of the window placement; flags[kIters] = need_seq
   for (int it = 0; it < kIters; it++) {
     int *cin = (it & 1) ? h->trk_cp_a : h->trk_cp_b, *cout = (it & 1) ? h->trk_cp_b : h->trk_cp_a;

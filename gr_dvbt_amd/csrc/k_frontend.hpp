@@ -51,13 +51,14 @@ __device__ __forceinline__ float2 cdiv(float2 a, float2 b)
 // One thread per lag.  mode 0: initial search, lags N+cp-1 .. 2N+cp-2 of window `try`;
 // mode 1: tracking, lags cp_start0-R .. cp_start0+R-1 of every window.
 __global__ __launch_bounds__(256) void acq_metric_kernel(const float2 *__restrict__ iq, FrontParams p, const RxState *st,
-                                                        int mode, float2 *__restrict__ gamma, float *__restrict__ lambda)
+                                                        int mode, float2 *__restrict__ gamma, float *__restrict__ lambda, int t_begin)
 {
   const int N = p.N, cp = p.cp;
   long long wbase; int lag, oidx;
   if (mode == 0) {
-    int t = blockIdx.y;
+    int t = blockIdx.y + t_begin;
     if (t >= p.ncalls) return;
+    if (t_begin > 0 && !(st->status & 1)) return;                 // later windows are searched only if the first one had no peak
     int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= N) return;
     wbase = (long long)t * (N + cp); lag = N + cp - 1 + q; oidx = t * N + q;
@@ -76,6 +77,49 @@ __global__ __launch_bounds__(256) void acq_metric_kernel(const float2 *__restric
     gr += a.x * b.x + a.y * b.y; gi += a.y * b.x - a.x * b.y;
     phi += (a.x * a.x + a.y * a.y) + (b.x * b.x + b.y * b.y);
   }
+  gamma[oidx] = make_float2(gr, gi);
+  lambda[oidx] = sqrtf(gr * gr + gi * gi) - phi * p.half_rho;
+}
+
+// tracking metric (mode 1 of acq_metric_kernel) with the samples staged through LDS: a workgroup owns 8 calls x 32
+// lags; per tile of 256 correlation taps it loads the 287 samples (and their partners N earlier) each call needs,
+// once and coalesced, instead of every thread walking its own 256 samples through L1.  The sums run over j in the
+// same order with the same expressions, so gamma/lambda are bit-identical to acq_metric_kernel.
+constexpr int ACQ_TM_CALLS = 8, ACQ_TM_SPAN = 256 + 2 * ACQ_R - 1;
+__global__ __launch_bounds__(256) void acq_track_metric_kernel(const float2 *__restrict__ iq, FrontParams p, const RxState *st,
+                                                              float2 *__restrict__ gamma, float *__restrict__ lambda)
+{
+  __shared__ float2 sA[ACQ_TM_CALLS][ACQ_TM_SPAN], sB[ACQ_TM_CALLS][ACQ_TM_SPAN];
+  if (st->status & 1) return;
+  const int N = p.N, cp = p.cp, tid = threadIdx.x, c = tid >> 5, q = tid & 31;
+  const int call0 = blockIdx.x * ACQ_TM_CALLS, call = call0 + c;
+  const int lag0 = st->cp_start0 - p.R;
+  if (call0 + ACQ_TM_CALLS <= st->call0 || call0 >= p.ncalls) return;
+  const bool active = call < p.ncalls && call >= st->call0;
+  float gr = 0.f, gi = 0.f, phi = 0.f;
+  for (int j0 = 0; j0 < cp; j0 += 256) {
+    const int jn = cp - j0 < 256 ? cp - j0 : 256;
+    __syncthreads();
+    for (int e = tid; e < ACQ_TM_CALLS * ACQ_TM_SPAN; e += 256) {
+      const int cc = e / ACQ_TM_SPAN, i = e - cc * ACQ_TM_SPAN, cl = call0 + cc;
+      float2 a = make_float2(0.f, 0.f), b = a;
+      if (cl < p.ncalls && cl >= st->call0) {
+        const long long idx = (long long)cl * (N + cp) + lag0 - j0 - 255 + i;      // sample x[lag0 + q - j] for q - (j - j0) = i - 255
+        if (idx >= 0) a = iq[idx];
+        if (idx - N >= 0) b = iq[idx - N];
+      }
+      sA[cc][i] = a; sB[cc][i] = b;
+    }
+    __syncthreads();
+    for (int jj = 0; jj < jn; jj++) {
+      const float2 a = sA[c][q + 255 - jj], b = sB[c][q + 255 - jj];
+      gr += a.x * b.x + a.y * b.y; gi += a.y * b.x - a.x * b.y;
+      phi += (a.x * a.x + a.y * a.y) + (b.x * b.x + b.y * b.y);
+    }
+  }
+  if (!active) return;
+  const int oidx = call * 2 * p.R + q;
+  if (lag0 + q - cp + 1 - N < 0) { gamma[oidx] = make_float2(0.f, 0.f); lambda[oidx] = -3.0e38f; return; }
   gamma[oidx] = make_float2(gr, gi);
   lambda[oidx] = sqrtf(gr * gr + gi * gi) - phi * p.half_rho;
 }
@@ -133,7 +177,8 @@ __device__ __forceinline__ float wrap_pi(double ph)
 //      are exact by construction).  From it the two threshold tests of sample i (rise: > 0.8 avg, keep: > 0.9 avg).
 //  (2) one lane walks the state machine on the precomputed flags; its only remaining recurrence is the running
 //      maximum of the open peak, so a step costs a few cycles instead of a dependent float chain.
-__global__ __launch_bounds__(256) void acq_init_fsm_kernel(FrontParams p, RxState *st, const float2 *gamma, const float *lambda, const AcqState *as)
+__global__ __launch_bounds__(256) void acq_init_fsm_kernel(FrontParams p, RxState *st, const float2 *gamma, const float *lambda, const AcqState *as,
+                                                          int t_begin, int t_end)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float *lam = reinterpret_cast<float *>(smem_raw);
@@ -141,8 +186,9 @@ __global__ __launch_bounds__(256) void acq_init_fsm_kernel(FrontParams p, RxStat
   __shared__ int s_done;
   __shared__ float s_avg;
   const int tid = threadIdx.x, N = p.N;
-  int tries = p.ncalls < ACQ_INIT_TRIES ? p.ncalls : ACQ_INIT_TRIES;
-  if (tid == 0) {
+  int tries = p.ncalls < t_end ? p.ncalls : t_end;
+  if (tid == 0 && t_begin > 0) { s_done = (st->status & 1) ? 0 : 2; s_avg = st->avg; }   // continuation: only if the earlier windows had no peak
+  if (tid == 0 && t_begin == 0) {
     st->status = 1; st->call0 = 0; st->cp_start0 = 0; st->n_symbols = 0; st->first_out = -1; st->n_out_symbols = 0;
     st->n_vit_in = st->n_vit_steps = st->n_vit_bytes = st->n_rs_items = st->n_ts_bytes = 0; st->rs_fail = st->rs_corr = 0;
     s_done = 0; s_avg = as ? as->avg : 0.f;
@@ -154,7 +200,7 @@ __global__ __launch_bounds__(256) void acq_init_fsm_kernel(FrontParams p, RxStat
   if (s_done == 2) { if (tid == 0) st->avg = s_avg; return; }
   const float rise = 0.8f, fall = 0.9f, alpha = 0.9f;
   constexpr int HIST = 48;
-  for (int t = 0; t < tries; t++) {
+  for (int t = t_begin; t < tries; t++) {
     for (int i = tid; i < N; i += 256) lam[i] = lambda[(size_t)t * N + i];
     __syncthreads();
     const float avg0 = s_avg;
