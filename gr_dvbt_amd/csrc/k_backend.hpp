@@ -379,12 +379,14 @@ __global__ __launch_bounds__(64) void deint_rs_kernel(const uint8_t *__restrict_
                                                      long long hist_words /* words of real history before word 0 (block API) */,
                                                      RsTables T, int compat, int *fail_cnt, int *corr_cnt)
 {
-  __shared__ __attribute__((aligned(16))) uint8_t s_src[75 * 204 + 12];
-  __shared__ __attribute__((aligned(16))) uint8_t s_cw[64 * 204];
+  // codewords of the workgroup, one row of 204 bytes each; 11 spare rows on either side absorb the bytes of the 75
+  // source words that belong to codewords of the neighbouring workgroups, so the scatter below needs no bounds test
+  __shared__ __attribute__((aligned(16))) uint8_t s_rows[(64 + 22) * 204];
   __shared__ __attribute__((aligned(16))) uint8_t s_div[256 * 16];
   __shared__ uint8_t s_exp[512], s_log[256];
   __shared__ uint8_t s_scr[64];
   __shared__ uint8_t s_syn[64 * 16];
+  uint8_t *s_cw = s_rows + 11 * 204;
   const int tid = threadIdx.x;
   const long long nwords = st ? st->n_rs_items * 8 : words_fixed;
   const long long w0 = (long long)blockIdx.x * 64;
@@ -394,30 +396,38 @@ __global__ __launch_bounds__(64) void deint_rs_kernel(const uint8_t *__restrict_
   for (int i = tid; i < 256; i += 64) s_log[i] = T.glog[i];
   const int nw = (int)((nwords - w0) < 64 ? (nwords - w0) : 64);
   if (!standalone) {
-    // source words w0-11 .. w0+63 ; dword copies (204 = 51 dwords; base is 4-byte aligned: word index*204)
+    // A8 (convolutional_deinterleaver_impl.cc:133-138 in closed form): byte p of codeword w is byte p of source word
+    // w - 11 + p % 12.  The 75 source words w0-11 .. w0+63 are read as dwords (204 = 51 dwords, 4-byte aligned) and
+    // every byte goes straight to its codeword's row: byte p of source row r belongs to row r - 11 - ... = r - p % 12
+    // (rows counted from w0 - 11), i.e. the four bytes of a dword land 203 bytes apart.
     const long long first = w0 - 11;
     for (int i = tid; i < 75 * 51; i += 64) {
-      long long word = first + i / 51;
+      const int r = i / 51, p4 = i - r * 51;
+      const long long word = first + r;
       unsigned v = 0;
-      if (word >= -hist_words && word < nwords + 0 && (word - first) < (nw + 11)) v = reinterpret_cast<const unsigned *>(in + word * 204)[i % 51];
-      reinterpret_cast<unsigned *>(s_src)[i] = v;
+      if (word >= -hist_words && word < nwords && r < nw + 11) v = reinterpret_cast<const unsigned *>(in + word * 204)[p4];
+      uint8_t *d = s_rows + (r + 11 - (p4 % 3) * 4) * 204 + 4 * p4;           // row of byte 0 of this dword (s_rows row = codeword - w0 + 11)
+      d[0] = (uint8_t)v; d[1 - 204] = (uint8_t)(v >> 8); d[2 - 408] = (uint8_t)(v >> 16); d[3 - 612] = (uint8_t)(v >> 24);
     }
+  } else {
+    for (int i = tid; i < nw * 51; i += 64) reinterpret_cast<unsigned *>(s_cw)[i] = reinterpret_cast<const unsigned *>(in + w0 * 204)[i];
   }
   __syncthreads();
-  uint8_t *cw = s_cw + tid * 204;
-  const long long w = w0 + tid;
+  if (deint_tap) for (int i = tid; i < nw * 51; i += 64) reinterpret_cast<unsigned *>(deint_tap + w0 * 204)[i] = reinterpret_cast<const unsigned *>(s_cw)[i];
+  const uint8_t *cw = s_cw + tid * 204;
   bool bad = false;
   if (tid < nw) {
-    if (standalone) { for (int p = 0; p < 204; p++) cw[p] = in[w * 204 + p]; }
-    else            { for (int p = 0; p < 204; p++) cw[p] = s_src[(tid + p % 12) * 204 + p]; }
-    if (deint_tap) for (int p = 0; p < 204; p++) deint_tap[w * 204 + p] = cw[p];
     // remainder of the received word modulo g(x): R <- R*x + c (mod g), one 16-byte table row per byte.  All 16
     // syndromes S_i = C(alpha^i) = R(alpha^i) vanish iff R == 0 (reed_solomon.cc:281-305), so clean words stop here.
     unsigned R0 = 0, R1 = 0, R2 = 0, R3 = 0;                       // R0 byte 0 = coefficient of x^0 ... R3 byte 3 = x^15
-    for (int p = 0; p < 204; p++) {
-      const uint4 t = *reinterpret_cast<const uint4 *>(s_div + (R3 >> 24) * 16);
-      R3 = ((R3 << 8) | (R2 >> 24)) ^ t.w; R2 = ((R2 << 8) | (R1 >> 24)) ^ t.z;
-      R1 = ((R1 << 8) | (R0 >> 24)) ^ t.y; R0 = ((R0 << 8) | cw[p]) ^ t.x;
+    for (int p4 = 0; p4 < 51; p4++) {
+      const unsigned d = reinterpret_cast<const unsigned *>(cw)[p4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint4 t = *reinterpret_cast<const uint4 *>(s_div + (R3 >> 24) * 16);
+        R3 = ((R3 << 8) | (R2 >> 24)) ^ t.w; R2 = ((R2 << 8) | (R1 >> 24)) ^ t.z;
+        R1 = ((R1 << 8) | (R0 >> 24)) ^ t.y; R0 = ((R0 << 8) | ((d >> (8 * k)) & 0xffu)) ^ t.x;
+      }
     }
     const int any = (R0 | R1 | R2 | R3) != 0;
     if (any) {                                                    // syndromes from the remainder: S_i = sum_k R_k alpha^(i k)
@@ -444,8 +454,9 @@ __global__ __launch_bounds__(64) void deint_rs_kernel(const uint8_t *__restrict_
     if (tid == 0) { if (nf) atomicAdd(fail_cnt, nf); if (nc) atomicAdd(corr_cnt, nc); }
   }
   __syncthreads();
-  // coalesced store of 64 x 188 payload bytes (reed_solomon_dec_impl.cc:102: output regardless of success)
-  for (int i = tid; i < nw * 188; i += 64) { int ww = i / 188, p = i - ww * 188; out[(w0 + ww) * 188 + p] = s_cw[ww * 204 + p]; }
+  // coalesced store of 64 x 188 payload bytes as dwords (reed_solomon_dec_impl.cc:102: output regardless of success)
+  unsigned *o4 = reinterpret_cast<unsigned *>(out + w0 * 188);
+  for (int i = tid; i < nw * 47; i += 64) { const int ww = i / 47, q = i - ww * 47; o4[i] = reinterpret_cast<const unsigned *>(s_cw + ww * 204)[q]; }
 }
 
 // A8 alone (block API): buf holds `hist` bytes of history followed by the call's n input bytes;
@@ -475,15 +486,20 @@ __global__ void descramble_find_kernel(const uint8_t *__restrict__ in, RxState *
   }
 }
 
+// dword-wise: one workgroup pass per 8-packet group (1504 bytes = 376 dwords; the start offset is a multiple of 188)
 __global__ __launch_bounds__(256) void descramble_apply_kernel(const uint8_t *__restrict__ in, const uint8_t *__restrict__ seq,
                                                               const RxState *st, uint8_t *__restrict__ out)
 {
-  long long n = st->n_ts_bytes;
-  const uint8_t *p = in + (long long)st->descr_base * 1504 + st->descr_index;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    int k = (int)(i % 1504);
-    out[i] = (k % 188 == 0) ? 0x47 : (p[i] ^ seq[k]);
-  }
+  const long long ngroups = st->n_ts_bytes / 1504;
+  const unsigned *p = reinterpret_cast<const unsigned *>(in + (long long)st->descr_base * 1504 + st->descr_index);
+  const unsigned *sq = reinterpret_cast<const unsigned *>(seq);
+  unsigned *o = reinterpret_cast<unsigned *>(out);
+  for (long long g = blockIdx.x; g < ngroups; g += gridDim.x)
+    for (int t = threadIdx.x; t < 376; t += 256) {
+      unsigned v = p[g * 376 + t] ^ sq[t];
+      if (t % 47 == 0) v = (v & 0xffffff00u) | 0x47u;              // sync byte restored (:151)
+      o[g * 376 + t] = v;
+    }
 }
 
 }  // namespace dvbt

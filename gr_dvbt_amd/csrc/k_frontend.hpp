@@ -397,13 +397,28 @@ __global__ __launch_bounds__(1024) void acq_finalize_kernel(FrontParams p, RxSta
   auto epsm = [&](int s) -> double { return s < 0 ? (s == -1 ? (double)st->eps_init : 0.0) : (double)eps[s]; };
   auto cpm = [&](int s) -> int { return s < 0 ? c0 : cp[s]; };
   const int per = (nsym + 1023) / 1024;
+  const int sbeg = tid * per, cnt = sbeg >= nsym ? 0 : (nsym - sbeg < per ? nsym - sbeg : per);
+  // a thread owns `per` consecutive calls; their cp/eps values are fetched 8 calls at a time with independent loads
+  // (the dependent one-by-one walk cost ~70 us of pure memory latency), then consumed in the original order
+  auto chunk = [&](int i0, int (&cv)[9], double (&ev)[10]) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) { const int s = sbeg + i0 + k - 1; cv[k] = (i0 + k - 1 < cnt) ? cpm(s) : 0; }     // cp[s-1] .. cp[s+7]
+#pragma unroll
+    for (int k = 0; k < 10; k++) { const int s = sbeg + i0 + k - 2; ev[k] = (i0 + k - 2 < cnt) ? epsm(s) : 0.0; }  // eps[s-2] .. eps[s+7]
+  };
   double local = 0.0;
-  for (int i = 0; i < per; i++) {
-    int s = tid * per + i;
-    if (s >= nsym) break;
-    int sw = cpm(s - 1) - (N + cpl);
-    double A = s == 0 ? 0.0 : (-1.0 / N) * epsm(s - 2), B = (-1.0 / N) * epsm(s - 1);
-    local += (sw >= 0 && sw < N + cpl) ? sw * A + (N + cpl - sw) * B : (double)(N + cpl) * A;
+  for (int i0 = 0; i0 < cnt; i0 += 8) {
+    int cv[9]; double ev[10];
+    chunk(i0, cv, ev);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int s = sbeg + i0 + k;
+      if (i0 + k < cnt) {
+        const int sw = cv[k] - (N + cpl);
+        const double A = s == 0 ? 0.0 : (-1.0 / N) * ev[k], B = (-1.0 / N) * ev[k + 1];
+        local += (sw >= 0 && sw < N + cpl) ? sw * A + (N + cpl - sw) * B : (double)(N + cpl) * A;
+      }
+    }
   }
   s_tot[tid] = local;
   __syncthreads();
@@ -414,14 +429,20 @@ __global__ __launch_bounds__(1024) void acq_finalize_kernel(FrontParams p, RxSta
     __syncthreads();
   }
   double base = tid == 0 ? 0.0 : s_tot[tid - 1];
-  for (int i = 0; i < per; i++) {
-    int s = tid * per + i;
-    if (s >= nsym) break;
-    int sw = cpm(s - 1) - (N + cpl);
-    double A = s == 0 ? 0.0 : (-1.0 / N) * epsm(s - 2), B = (-1.0 / N) * epsm(s - 1);
-    SymMeta m; m.cp_start = cp[s]; m.eps = eps[s]; m.sw = sw; m.incA = A; m.incB = B; m.ph_base = wrap_pi(base);
-    meta[s] = m;
-    base += (sw >= 0 && sw < N + cpl) ? sw * A + (N + cpl - sw) * B : (double)(N + cpl) * A;
+  for (int i0 = 0; i0 < cnt; i0 += 8) {
+    int cv[9]; double ev[10];
+    chunk(i0, cv, ev);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int s = sbeg + i0 + k;
+      if (i0 + k < cnt) {
+        const int sw = cv[k] - (N + cpl);
+        const double A = s == 0 ? 0.0 : (-1.0 / N) * ev[k], B = (-1.0 / N) * ev[k + 1];
+        SymMeta m; m.cp_start = cv[k + 1]; m.eps = (float)ev[k + 2]; m.sw = sw; m.incA = A; m.incB = B; m.ph_base = wrap_pi(base);
+        meta[s] = m;
+        base += (sw >= 0 && sw < N + cpl) ? sw * A + (N + cpl - sw) * B : (double)(N + cpl) * A;
+      }
+    }
   }
   if (tid == 0) {
     st->n_symbols = nsym;
