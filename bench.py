@@ -144,7 +144,7 @@ def main():
 
     if rank == 0:
         msps = world * nsamp * a.steps / dt / 1e6
-        # dominant kernel = viterbi2_kernel: per launch, algorithmic bytes = bytes in (one per m coded bits) + decoded
+        # dominant kernel = viterbi3_kernel: per launch, algorithmic bytes = bytes in (one per m coded bits) + decoded
         # bytes out (6048 + 3969 B per 8k QAM64 7/8 OFDM symbol); launch duration from HIP events
         # recorded on the segment's own stream; averages over the segments' launches
         d = rx.dims
@@ -159,7 +159,7 @@ def main():
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary_8k_qam64_7_8_65sf.json")))
             if a.workload == "8k_qam64_7_8":
-                traffic = int(pm["kernels"]["viterbi2_kernel"]["hbm_bytes_corrected"] / pm["viterbi_algorithmic_bytes"] * alg_bytes)
+                traffic = int(pm["kernels"]["viterbi3_kernel"]["hbm_bytes_corrected"] / pm["viterbi_algorithmic_bytes"] * alg_bytes)
         except Exception:
             traffic = None
         out = {
@@ -170,7 +170,7 @@ def main():
             "config": {"workload": f"{a.workload} GI 1/32 RX chain, clean TX->RX loopback", "superframes_per_gpu": a.superframes + nseg, "segments_per_gpu": nseg,
                        "samples_per_gpu_per_step": nsamp, "parallelism": f"segments x{world}" + (" + RCCL gather of TS" if world > 1 else ""),
                        "ts_bytes_per_step": n_ts, "status": [int(r.status) for r in reps], "rs_fail_words": [int(r.rs_fail_words) for r in reps]},
-            "roofline": {"bound": "hbm", "kernel": "viterbi2_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "viterbi3_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(vit_ms, 4),
                          "chain_frac": round(msps / world * 1e6 * (8 + n_ts / nsamp) / 1e9 / HBM_PEAK_GBS, 6)},

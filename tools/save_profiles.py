@@ -26,7 +26,7 @@ for k, c in out.items():
         e["hbm_bytes_corrected"] = 2 * c["FETCH_SIZE"] * 1024 + c["WRITE_SIZE"] * 1024
     summary["kernels"][k] = e
 json.dump(summary, open(os.path.join(root, "profiles", f"{tag}_pmc_summary_8k_qam64_7_8_65sf.json"), "w"), indent=1)
-v = summary["kernels"]["viterbi2_kernel"]
-print("viterbi2: hbm", v["hbm_bytes_corrected"] / 1e6, "MB; algorithmic", summary["viterbi_algorithmic_bytes"] / 1e6, "MB")
+v = summary["kernels"]["viterbi3_kernel"]
+print("viterbi3: hbm", v["hbm_bytes_corrected"] / 1e6, "MB; algorithmic", summary["viterbi_algorithmic_bytes"] / 1e6, "MB")
 for r in list(csv.DictReader(open(prof)))[:14]:
     print(r["Name"].split("(")[0][6:36].ljust(30), r["Calls"].rjust(4), f"{float(r['AverageNs'])/1e3:10.1f} us", r["Percentage"])
