@@ -11,6 +11,7 @@
 #include "dvbt_tables.hpp"
 #include "k_frontend.hpp"
 #include "k_backend.hpp"
+#include "k_symbol.hpp"
 #include "k_viterbi2.hpp"
 #include "k_viterbi3.hpp"
 
@@ -226,7 +227,7 @@ struct dvbt_rx {
   SymMeta *meta = nullptr; RxState *st = nullptr, *st_host = nullptr; TpsState *tps_state = nullptr;
   int *trk_cp_a = nullptr, *trk_cp_b = nullptr, *trk_flags = nullptr; float *trk_eps = nullptr; TpsEdge *tps_edges = nullptr;
   float2 *acq_tap = nullptr, *fft_out = nullptr, *eq = nullptr, *tpsval = nullptr; SymInfo *info = nullptr; int *maj = nullptr, *sym_index = nullptr;
-  uint8_t *demap_tap = nullptr, *symdeint_tap = nullptr, *bitdeint = nullptr, *vit = nullptr, *deint_tap = nullptr, *rs_out = nullptr, *ts_out = nullptr;
+  uint8_t *labels = nullptr, *symdeint_tap = nullptr, *bitdeint = nullptr, *vit = nullptr, *deint_tap = nullptr, *rs_out = nullptr, *ts_out = nullptr;
   size_t vit_cap = 0;
   bool timing = false, pending = false;
   hipEvent_t ev[ST_COUNT]; double acc_ms[ST_COUNT] = {0}; long n_timed = 0; bool ev_ready = false, ev_recorded = false;
@@ -236,7 +237,7 @@ struct dvbt_rx {
 static void rx_free(dvbt_rx *h)
 {
   void *all[] = {h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags, h->trk_eps, h->d_iq, h->g_init, h->l_init, h->g_trk, h->l_trk, h->meta, h->st, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
-                 h->info, h->maj, h->sym_index, h->demap_tap, h->symdeint_tap, h->bitdeint, h->vit, h->deint_tap, h->rs_out, h->ts_out};
+                 h->info, h->maj, h->sym_index, h->labels, h->symdeint_tap, h->bitdeint, h->vit, h->deint_tap, h->rs_out, h->ts_out};
   for (void *q : all) if (q) (void)hipFree(q);
   if (h->st_host) (void)hipHostFree(h->st_host);
   if (h->ev_ready) for (int i = 0; i < ST_COUNT; i++) (void)hipEventDestroy(h->ev[i]);
@@ -273,7 +274,7 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   RXHIP(hipMalloc((void **)&h->trk_eps, sizeof(float) * C)); RXHIP(hipMalloc((void **)&h->trk_flags, sizeof(int) * 16));
   RXHIP(hipMalloc((void **)&h->tps_edges, sizeof(TpsEdge) * (C / TPS_SEG + 2))); RXHIP(hipMalloc((void **)&h->st, sizeof(RxState)));
   RXHIP(hipHostMalloc((void **)&h->st_host, sizeof(RxState))); RXHIP(hipMalloc((void **)&h->tps_state, sizeof(TpsState)));
-  RXHIP(hipMalloc((void **)&h->eq, sizeof(float2) * C * P));   // the FFT items stay in LDS (fused kernel); fft_out exists only as a debug tap
+  RXHIP(hipMalloc((void **)&h->labels, C * P + 64));   // A1..A4 are one kernel: a symbol reaches HBM as label bytes; fft_out and eq exist only as debug taps
   RXHIP(hipMalloc((void **)&h->tpsval, sizeof(float2) * C * d.n_tps)); RXHIP(hipMalloc((void **)&h->info, sizeof(SymInfo) * C));
   RXHIP(hipMalloc((void **)&h->maj, sizeof(int) * C)); RXHIP(hipMalloc((void **)&h->sym_index, sizeof(int) * C));
   RXHIP(hipMalloc((void **)&h->bitdeint, C * P + 64));
@@ -296,7 +297,7 @@ static int ensure_taps(dvbt_rx *h)
   const size_t C = (size_t)h->max_calls, N = h->d.N, P = h->d.payload;
   if (!h->acq_tap) HIPCHK(hipMalloc((void **)&h->acq_tap, sizeof(float2) * C * N));
   if (!h->fft_out) HIPCHK(hipMalloc((void **)&h->fft_out, sizeof(float2) * C * N));
-  if (!h->demap_tap) HIPCHK(hipMalloc((void **)&h->demap_tap, C * P + 64));
+  if (!h->eq) HIPCHK(hipMalloc((void **)&h->eq, sizeof(float2) * C * P));
   if (!h->symdeint_tap) HIPCHK(hipMalloc((void **)&h->symdeint_tap, C * P + 64));
   if (!h->deint_tap) HIPCHK(hipMalloc((void **)&h->deint_tap, h->vit_cap));
   return DVBT_OK;
@@ -305,7 +306,7 @@ extern "C" int dvbt_rx_enable_taps(dvbt_rx *h, int enable)
 {
   if (!h) return DVBT_ERR_INVALID;
   if (enable) return ensure_taps(h);
-  void **all[] = {(void **)&h->acq_tap, (void **)&h->fft_out, (void **)&h->demap_tap, (void **)&h->symdeint_tap, (void **)&h->deint_tap};
+  void **all[] = {(void **)&h->acq_tap, (void **)&h->fft_out, (void **)&h->eq, (void **)&h->symdeint_tap, (void **)&h->deint_tap};
   for (void **q : all) if (*q) { (void)hipFree(*q); *q = nullptr; }
   return DVBT_OK;
 }
@@ -345,7 +346,8 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s)
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_FFT], s));
   // A1 tail + A2 + A3 in one kernel: the FFT item of a symbol never leaves LDS (acq/fft taps are written only when enabled)
   hipLaunchKernelGGL(derot_fft_demod_kernel, dim3(C), dim3(FFT_THREADS), fused_lds_bytes_host(N), s, iq, fp, (const RxState *)h->st, (const SymMeta *)h->meta,
-                     (const float2 *)h->T.tw, h->acq_tap, h->fft_out, h->T.demod_tables(), h->eq, h->tpsval, h->info);
+                     (const float2 *)h->T.tw, (const uint16_t *)h->T.perm, h->acq_tap, h->fft_out, h->T.demod_tables(), h->eq, h->tpsval, h->info,
+                     h->T.inner_params(d.payload), (const float2 *)h->T.points, (const unsigned char *)h->T.label_tab, h->labels);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_DEMOD], s));
   hipLaunchKernelGGL(tps_vote_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float2 *)h->tpsval, d.n_tps, (const RxState *)h->st, 0,
                      (const float2 *)nullptr, h->maj);
@@ -361,9 +363,10 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s)
   hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(64), 0, s, h->st, h->vp, h->prm.descramble);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_INNER], s));
   InnerParams ip = h->T.inner_params(d.payload);
-  hipLaunchKernelGGL(inner_kernel, dim3(C), dim3(256), inner_lds_bytes((size_t)d.payload), s, (const float2 *)h->eq, (const uint8_t *)nullptr, ip,
-                     (const RxState *)h->st, 0, 7, (const int *)h->sym_index, (const float2 *)h->T.points, (const unsigned char *)h->T.label_tab,
-                     (const uint16_t *)h->T.H, (const uint16_t *)h->T.Hinv, h->demap_tap, h->symdeint_tap, h->bitdeint);
+  // A5 + A6 on the label bytes of the symbols from first_out on (A4 ran inside the symbol kernel)
+  hipLaunchKernelGGL(inner_kernel, dim3(C), dim3(256), inner_lds_bytes((size_t)d.payload), s, (const float2 *)nullptr, (const uint8_t *)h->labels, ip,
+                     (const RxState *)h->st, 0, 6, (const int *)h->sym_index, (const float2 *)nullptr, (const unsigned char *)nullptr,
+                     (const uint16_t *)h->T.H, (const uint16_t *)h->T.Hinv, (uint8_t *)nullptr, h->symdeint_tap, h->bitdeint);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_VIT], s));
   long long max_vit = (long long)C * d.payload * d.m * d.k / (8 * d.n) + 1;
   VitParams vp = h->vp;
@@ -446,7 +449,7 @@ static int tap_info(dvbt_rx *h, int tap, void **ptr, size_t *bytes)
     case DVBT_TAP_ACQ: *ptr = h->acq_tap; *bytes = ns * d.N * 8; break;
     case DVBT_TAP_FFT: *ptr = h->fft_out; *bytes = ns * d.N * 8; break;
     case DVBT_TAP_EQ: *ptr = h->eq ? (void *)(h->eq + fo * d.payload) : nullptr; *bytes = no * d.payload * 8; break;
-    case DVBT_TAP_DEMAP: *ptr = h->demap_tap; *bytes = no * d.payload; break;
+    case DVBT_TAP_DEMAP: *ptr = h->labels ? (void *)(h->labels + fo * d.payload) : nullptr; *bytes = no * d.payload; break;
     case DVBT_TAP_SYMDEINT: *ptr = h->symdeint_tap; *bytes = no * d.payload; break;
     case DVBT_TAP_BITDEINT: *ptr = h->bitdeint; *bytes = no * d.payload; break;
     case DVBT_TAP_VITERBI: *ptr = h->vit; *bytes = (size_t)r.n_viterbi_bytes; break;

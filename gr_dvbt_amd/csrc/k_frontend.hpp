@@ -514,14 +514,15 @@ __device__ __forceinline__ void fft_dif_lds(float2 *x, int N, const float2 *tw_c
         bfly4(t[k1 * 4], t[k1 * 4 + 1], t[k1 * 4 + 2], t[k1 * 4 + 3], y0, y1, y2, y3);
         a[k1] = y0; a[k1 + 4] = y1; a[k1 + 8] = y2; a[k1 + 12] = y3;
       }
+      // inter-pass twiddles W^(r k tstep), k = 1..15, as powers of w1 = W^(r tstep) (at most 4 multiplications deep)
+      float2 w[16];
+      w[1] = twid(tw_c, tw_f, r * tstep);
+      w[2] = cmul(w[1], w[1]); w[3] = cmul(w[2], w[1]); w[4] = cmul(w[2], w[2]); w[5] = cmul(w[4], w[1]); w[6] = cmul(w[3], w[3]);
+      w[7] = cmul(w[4], w[3]); w[8] = cmul(w[4], w[4]); w[9] = cmul(w[8], w[1]); w[10] = cmul(w[5], w[5]); w[11] = cmul(w[8], w[3]);
+      w[12] = cmul(w[6], w[6]); w[13] = cmul(w[8], w[5]); w[14] = cmul(w[7], w[7]); w[15] = cmul(w[8], w[7]);
       x[fpad(base)] = a[0];
-      if (r == 0) {
 #pragma unroll
-        for (int k = 1; k < 16; k++) x[fpad(base + k * Q)] = a[k];
-      } else {
-#pragma unroll
-        for (int k = 1; k < 16; k++) x[fpad(base + k * Q)] = cmul(a[k], twid(tw_c, tw_f, r * k * tstep));
-      }
+      for (int k = 1; k < 16; k++) x[fpad(base + k * Q)] = cmul(a[k], w[k]);
     }
     __syncthreads();
     L = Q;
@@ -742,147 +743,6 @@ __global__ __launch_bounds__(256) void demod_kernel(const float2 *__restrict__ f
     int c = T.tps[tid];
     float2 g = gain_at(c, T.tps_L[mod * p.n_tps + tid], T.tps_R[mod * p.n_tps + tid]);
     tpsval[(size_t)s * p.n_tps + tid] = cmul(cmul(cph, xin[c]), g);
-  }
-}
-
-// ---------------------------------------------------------------- A1 tail + A2 + A3 fused (segment path)
-// One workgroup per OFDM symbol: derotate + strip CP + FFT as derot_fft_kernel, then the pilot engine of
-// demod_kernel on the spectrum while it is still in LDS -- the 64 KB item never travels to HBM and back.
-// Differences to demod_kernel, both inside the float tolerance of the equalised-carrier tap:
-//  * the common phasor of frequency_correction (:793-819) is not applied: it multiplies the pilots and the payload
-//    alike, so it cancels in  x[c] * ref / x[pilot]  (and with it the only use of the NEXT symbol disappears);
-//  * the LS gain of an estimation carrier is computed once (rank table) instead of once per carrier that uses it.
-inline size_t fused_lds_bytes_host(int N) { return (size_t)(N + N / 32 + N / 128 + 128 + DEMOD_NP) * 8 + 128; }
-
-__global__ __launch_bounds__(FFT_THREADS) void derot_fft_demod_kernel(const float2 *__restrict__ iq, FrontParams p, const RxState *st,
-                                                             const SymMeta *__restrict__ meta, const float2 *__restrict__ tw,
-                                                             float2 *__restrict__ acq_tap, float2 *__restrict__ fft_tap, DemodTables T,
-                                                             float2 *__restrict__ eq, float2 *__restrict__ tpsval, SymInfo *__restrict__ info)
-{
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float2 *x = reinterpret_cast<float2 *>(smem_raw);
-  const int s = blockIdx.x;
-  const int nsym = st->n_symbols;
-  if (s >= nsym) return;
-  const bool last = s + 1 >= nsym;                               // no output for the last item (the reference's demod consumes n+1 items)
-  if (last && !fft_tap && !acq_tap) return;
-  const int N = p.N, cp = p.cp, tid = threadIdx.x, zl = p.zl;
-  float2 *tw_c = x + (N + N / 32), *tw_f = tw_c + N / 128, *gtab = tw_f + 128;
-  float *s_sum = reinterpret_cast<float *>(gtab + DEMOD_NP);
-  int *s_i = reinterpret_cast<int *>(s_sum + 16);
-  for (int i = tid; i < N / 128; i += FFT_THREADS) tw_c[i] = tw[i * 128];
-  if (tid < 128) tw_f[tid] = tw[tid];
-  const SymMeta m = meta[s];
-  const long long low = (long long)(st->call0 + s) * (N + cp) + m.cp_start - N + 1;
-  const bool rot = (m.incA != 0.0) || (m.incB != 0.0) || (m.ph_base != 0.f);
-  // derot[n] = expj(phase after n+1 increments) (:285-309,:527-534).  The phase is piecewise linear in n (increment
-  // incA up to the switch position sw, incB after it), so expj(phase(tid + T*i)) = P(tid) * S(i) with one sincos per
-  // thread and piece (P) and a wave-uniform table of the T-sample steps (S) instead of one sincos per sample.
-  const bool has_sw = m.sw >= 0 && m.sw < N + cp;
-  float2 PA = make_float2(1.f, 0.f), PB = PA;
-  float2 *stab = gtab;                                            // [2][N / FFT_THREADS], free until the pilot engine runs
-  const int nstep = N / FFT_THREADS;
-  if (rot) {
-    const double thA = (double)m.ph_base + m.incA, thB = (double)m.ph_base + (double)m.sw * (m.incA - m.incB) + m.incB;
-    if (tid < 2 * nstep) {
-      const int i = tid % nstep;
-      const float ph = wrap_pi((double)FFT_THREADS * i * (tid < nstep ? m.incA : m.incB));
-      float sn, cs; sincosf(ph, &sn, &cs); stab[tid] = make_float2(cs, sn);
-    }
-    float sn, cs;
-    sincosf(wrap_pi(thA + tid * m.incA), &sn, &cs); PA = make_float2(cs, sn);
-    sincosf(wrap_pi(thB + tid * m.incB), &sn, &cs); PB = make_float2(cs, sn);
-    __syncthreads();
-  }
-  for (int i = 0; i < nstep; i++) {
-    const int n = tid + i * FFT_THREADS;
-    float2 v = iq[low + n];
-    if (rot) {
-      const bool pieceB = has_sw && n + 1 > m.sw;
-      v = cmul(cmul(pieceB ? PB : PA, stab[(pieceB ? nstep : 0) + i]), v);
-    }
-    x[fpad(n)] = v;
-    if (acq_tap) acq_tap[(size_t)s * N + n] = v;
-  }
-  __syncthreads();
-  fft_dif_lds(x, N, tw_c, tw_f, tid);
-  {   // digit-reversed -> natural, fft-shifted order, in place through registers: x[b] = X[(b - N/2) mod N]
-    float2 r[32];
-#pragma unroll
-    for (int i = 0; i < 32; i++) { const int b = tid + i * FFT_THREADS; if (b < N) r[i] = x[fpad(fft_pos_of_bin((b + (N >> 1)) & (N - 1), N))]; }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 32; i++) { const int b = tid + i * FFT_THREADS; if (b < N) { x[fpad(b)] = r[i]; if (fft_tap) fft_tap[(size_t)s * N + b] = r[i]; } }
-    __syncthreads();
-  }
-  if (last) return;
-  auto X = [&](int b) -> float2 { return x[fpad(b)]; };
-
-  // integer CFO: process_cpilot_data :715-744 -- 16 candidate shifts x (n_cp-1) pilot pairs
-  {
-    const int cand = (tid >> 4) & 15, sub = tid & 15, i = zl - 8 + cand;
-    float sum = 0.f;
-    for (int j = sub; j < p.n_cp - 1 && tid < 256; j += 16) {
-      const float2 a = X(i + T.cpilot[j + 1]), b = X(i + T.cpilot[j]);
-      const float dx = a.x - b.x, dy = a.y - b.y;
-      sum += T.known_diff[j] * (dx * dx + dy * dy);
-    }
-    for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    if (sub == 0 && tid < 256) s_sum[cand] = sum;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    float mx = 0.f; int start = 0;
-    for (int c = 0; c < 16; c++) if (s_sum[c] > mx) { mx = s_sum[c]; start = zl - 8 + c; }
-    s_i[0] = start - zl;
-  }
-  __syncthreads();
-  const int fo = s_i[0], xb = zl + fo;
-  // symbol index mod 4: process_spilot_data :549-582 -- first 10 scattered pilots of each pattern
-  if (tid < 64) {
-    const int pat = tid >> 4, j = tid & 15;
-    float cr = 0.f, ci = 0.f;
-    if (j < 10) {
-      const int k = 3 * pat + 12 * j;
-      const float2 v = X(xb + k);
-      const float r = T.pilot_ref[k];
-      cr = r * v.x; ci = -r * v.y;                // ref * conj(v)
-    }
-    for (int o = 8; o > 0; o >>= 1) { cr += __shfl_xor(cr, o); ci += __shfl_xor(ci, o); }
-    if (j == 0) s_sum[pat] = cr * cr + ci * ci;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    float mx = 0.f; int mod = 0;
-    for (int c = 0; c < 4; c++) if (s_sum[c] > mx) { mx = s_sum[c]; mod = c; }
-    s_i[1] = mod;
-    SymInfo si; si.freq_offset = fo; si.mod_index = mod; si.cfc = 0.f; si.pad = 0;
-    info[s] = si;
-  }
-  __syncthreads();
-  const int mod = s_i[1];
-  // LS gains at the estimation carriers (set_channel_gain :486-490)
-  {
-    const uint16_t *pk = T.pil_k + (size_t)mod * DEMOD_NP;
-    const int np = T.np[mod];
-    for (int r = tid; r < np; r += FFT_THREADS) { const int k = pk[r]; gtab[r] = cdiv(make_float2(T.pilot_ref[k], 0.f), X(xb + k)); }
-  }
-  __syncthreads();
-  // interpolation (:617-642, the constant 11 of :625) + equalise (:1111-1114)
-  auto gain = [&](int Li, int Ri, int dj) -> float2 {
-    const float2 gl = gtab[Li], gr = gtab[Ri];
-    const float tx = (gr.x - gl.x) / 11.0f, ty = (gr.y - gl.y) / 11.0f, j = (float)dj;
-    return make_float2(gl.x + tx * j, gl.y + ty * j);
-  };
-  {
-    const size_t tb = (size_t)mod * p.payload;
-    const uint16_t *pc = T.pay_c + tb, *pLi = T.pay_Li + tb, *pRi = T.pay_Ri + tb; const uint8_t *pd = T.pay_d + tb;
-    float2 *o = eq + (size_t)s * p.payload;
-    for (int i = tid; i < p.payload; i += FFT_THREADS) o[i] = cmul(X(xb + pc[i]), gain(pLi[i], pRi[i], pd[i]));
-  }
-  if (tid < p.n_tps) {   // equalised TPS carriers (process_tps_data :929-931)
-    const int c = T.tps[tid], q = mod * p.n_tps + tid;
-    tpsval[(size_t)s * p.n_tps + tid] = cmul(X(xb + c), gain(T.tps_Li[q], T.tps_Ri[q], T.tps_d[q]));
   }
 }
 

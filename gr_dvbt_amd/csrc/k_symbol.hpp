@@ -1,0 +1,164 @@
+// k_symbol.hpp -- the per-OFDM-symbol kernel of the segment path: A1 tail (derotate, strip CP) + A2 (FFT, shift) +
+// A3 (pilot engine, equaliser) + A4 (demapper) in one workgroup, the symbol resident in LDS from the first load of its
+// baseband samples to the store of its 6048 one-byte labels.
+#pragma once
+#include "k_frontend.hpp"
+#include "k_backend.hpp"
+
+namespace dvbt {
+
+// One workgroup per OFDM symbol: derotate + strip CP + FFT as derot_fft_kernel, then the pilot engine of
+// demod_kernel on the spectrum while it is still in LDS -- the 64 KB item never travels to HBM and back.
+// Differences to demod_kernel, both inside the float tolerance of the equalised-carrier tap:
+//  * the common phasor of frequency_correction (:793-819) is not applied: it multiplies the pilots and the payload
+//    alike, so it cancels in  x[c] * ref / x[pilot]  (and with it the only use of the NEXT symbol disappears);
+//  * the LS gain of an estimation carrier is computed once (rank table) instead of once per carrier that uses it,
+//    and the interpolation step (g[R]-g[L])/11 (:625) is a multiplication by 1/11.
+// A4 rides along: every equalised carrier is demapped at once (demap_one: the reference's first strict minimum), so a
+// symbol leaves the kernel as `payload` label bytes in carrier order; the equalised carriers themselves are written
+// only when the EQ tap is enabled.
+inline size_t fused_lds_bytes_host(int N) { return (size_t)(N + N / 32 + N / 128 + 128 + DEMOD_NP) * 8 + 128 + 64 * 8 + 64; }
+
+__global__ __launch_bounds__(FFT_THREADS) void derot_fft_demod_kernel(const float2 *__restrict__ iq, FrontParams p, const RxState *st,
+                                                             const SymMeta *__restrict__ meta, const float2 *__restrict__ tw,
+                                                             const uint16_t *__restrict__ perm, float2 *__restrict__ acq_tap,
+                                                             float2 *__restrict__ fft_tap, DemodTables T, float2 *__restrict__ eq_tap,
+                                                             float2 *__restrict__ tpsval, SymInfo *__restrict__ info, InnerParams ip,
+                                                             const float2 *__restrict__ points, const unsigned char *__restrict__ label_tab,
+                                                             uint8_t *__restrict__ labels)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float2 *x = reinterpret_cast<float2 *>(smem_raw);
+  const int s = blockIdx.x;
+  const int nsym = st->n_symbols;
+  if (s >= nsym) return;
+  const bool last = s + 1 >= nsym;                               // no output for the last item (the reference's demod consumes n+1 items)
+  if (last && !fft_tap && !acq_tap) return;
+  const int N = p.N, cp = p.cp, tid = threadIdx.x, zl = p.zl;
+  float2 *tw_c = x + (N + N / 32), *tw_f = tw_c + N / 128, *gtab = tw_f + 128;
+  float *s_sum = reinterpret_cast<float *>(gtab + DEMOD_NP);
+  int *s_i = reinterpret_cast<int *>(s_sum + 16);
+  float2 *pts = reinterpret_cast<float2 *>(s_i + 16);
+  unsigned char *label_of = reinterpret_cast<unsigned char *>(pts + 64);
+  if (tid < 64) { pts[tid] = points[tid]; label_of[tid] = label_tab[tid]; }
+  for (int i = tid; i < N / 128; i += FFT_THREADS) tw_c[i] = tw[i * 128];
+  if (tid < 128) tw_f[tid] = tw[tid];
+  const SymMeta m = meta[s];
+  const long long low = (long long)(st->call0 + s) * (N + cp) + m.cp_start - N + 1;
+  const bool rot = (m.incA != 0.0) || (m.incB != 0.0) || (m.ph_base != 0.f);
+  // derot[n] = expj(phase after n+1 increments) (:285-309,:527-534).  The phase is piecewise linear in n (increment
+  // incA up to the switch position sw, incB after it), so expj(phase(tid + T*i)) = P(tid) * S(i) with one sincos per
+  // thread and piece (P) and a wave-uniform table of the T-sample steps (S) instead of one sincos per sample.
+  const bool has_sw = m.sw >= 0 && m.sw < N + cp;
+  float2 PA = make_float2(1.f, 0.f), PB = PA;
+  float2 *stab = gtab;                                            // [2][N / FFT_THREADS], free until the pilot engine runs
+  const int nstep = N / FFT_THREADS;
+  if (rot) {
+    const double thA = (double)m.ph_base + m.incA, thB = (double)m.ph_base + (double)m.sw * (m.incA - m.incB) + m.incB;
+    if (tid < 2 * nstep) {
+      const int i = tid % nstep;
+      const float ph = wrap_pi((double)FFT_THREADS * i * (tid < nstep ? m.incA : m.incB));
+      float sn, cs; sincosf(ph, &sn, &cs); stab[tid] = make_float2(cs, sn);
+    }
+    float sn, cs;
+    sincosf(wrap_pi(thA + tid * m.incA), &sn, &cs); PA = make_float2(cs, sn);
+    sincosf(wrap_pi(thB + tid * m.incB), &sn, &cs); PB = make_float2(cs, sn);
+    __syncthreads();
+  }
+  for (int i = 0; i < nstep; i++) {
+    const int n = tid + i * FFT_THREADS;
+    float2 v = iq[low + n];
+    if (rot) {
+      const bool pieceB = has_sw && n + 1 > m.sw;
+      v = cmul(cmul(pieceB ? PB : PA, stab[(pieceB ? nstep : 0) + i]), v);
+    }
+    x[fpad(n)] = v;
+    if (acq_tap) acq_tap[(size_t)s * N + n] = v;
+  }
+  __syncthreads();
+  fft_dif_lds(x, N, tw_c, tw_f, tid);
+  {   // digit-reversed -> natural, fft-shifted order, in place through registers: x[b] = X[(b - N/2) mod N]
+    float2 r[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) { const int b = tid + i * FFT_THREADS; if (b < N) r[i] = x[fpad(perm[b])]; }     // perm: dvbt_tables.hpp::fft_out_perm
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 32; i++) { const int b = tid + i * FFT_THREADS; if (b < N) { x[fpad(b)] = r[i]; if (fft_tap) fft_tap[(size_t)s * N + b] = r[i]; } }
+    __syncthreads();
+  }
+  if (last) return;
+  auto X = [&](int b) -> float2 { return x[fpad(b)]; };
+
+  // integer CFO: process_cpilot_data :715-744 -- 16 candidate shifts x (n_cp-1) pilot pairs
+  {
+    const int cand = (tid >> 4) & 15, sub = tid & 15, i = zl - 8 + cand;
+    float sum = 0.f;
+    for (int j = sub; j < p.n_cp - 1 && tid < 256; j += 16) {
+      const float2 a = X(i + T.cpilot[j + 1]), b = X(i + T.cpilot[j]);
+      const float dx = a.x - b.x, dy = a.y - b.y;
+      sum += T.known_diff[j] * (dx * dx + dy * dy);
+    }
+    for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (sub == 0 && tid < 256) s_sum[cand] = sum;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float mx = 0.f; int start = 0;
+    for (int c = 0; c < 16; c++) if (s_sum[c] > mx) { mx = s_sum[c]; start = zl - 8 + c; }
+    s_i[0] = start - zl;
+  }
+  __syncthreads();
+  const int fo = s_i[0], xb = zl + fo;
+  // symbol index mod 4: process_spilot_data :549-582 -- first 10 scattered pilots of each pattern
+  if (tid < 64) {
+    const int pat = tid >> 4, j = tid & 15;
+    float cr = 0.f, ci = 0.f;
+    if (j < 10) {
+      const int k = 3 * pat + 12 * j;
+      const float2 v = X(xb + k);
+      const float r = T.pilot_ref[k];
+      cr = r * v.x; ci = -r * v.y;                // ref * conj(v)
+    }
+    for (int o = 8; o > 0; o >>= 1) { cr += __shfl_xor(cr, o); ci += __shfl_xor(ci, o); }
+    if (j == 0) s_sum[pat] = cr * cr + ci * ci;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float mx = 0.f; int mod = 0;
+    for (int c = 0; c < 4; c++) if (s_sum[c] > mx) { mx = s_sum[c]; mod = c; }
+    s_i[1] = mod;
+    SymInfo si; si.freq_offset = fo; si.mod_index = mod; si.cfc = 0.f; si.pad = 0;
+    info[s] = si;
+  }
+  __syncthreads();
+  const int mod = s_i[1];
+  // LS gains at the estimation carriers (set_channel_gain :486-490)
+  {
+    const uint16_t *pk = T.pil_k + (size_t)mod * DEMOD_NP;
+    const int np = T.np[mod];
+    for (int r = tid; r < np; r += FFT_THREADS) { const int k = pk[r]; gtab[r] = cdiv(make_float2(T.pilot_ref[k], 0.f), X(xb + k)); }
+  }
+  __syncthreads();
+  // interpolation (:617-642, the constant 11 of :625) + equalise (:1111-1114)
+  auto gain = [&](int Li, int Ri, int dj) -> float2 {
+    const float2 gl = gtab[Li], gr = gtab[Ri];
+    const float k11 = 1.0f / 11.0f, tx = (gr.x - gl.x) * k11, ty = (gr.y - gl.y) * k11, j = (float)dj;
+    return make_float2(gl.x + tx * j, gl.y + ty * j);
+  };
+  {
+    const size_t tb = (size_t)mod * p.payload;
+    const uint16_t *pc = T.pay_c + tb, *pLi = T.pay_Li + tb, *pRi = T.pay_Ri + tb; const uint8_t *pd = T.pay_d + tb;
+    uint8_t *lab = labels + (size_t)s * p.payload;
+    for (int i = tid; i < p.payload; i += FFT_THREADS) {
+      const float2 e = cmul(X(xb + pc[i]), gain(pLi[i], pRi[i], pd[i]));
+      if (eq_tap) eq_tap[(size_t)s * p.payload + i] = e;
+      lab[i] = (uint8_t)demap_one(e, pts, label_of, ip);
+    }
+  }
+  if (tid < p.n_tps) {   // equalised TPS carriers (process_tps_data :929-931)
+    const int c = T.tps[tid], q = mod * p.n_tps + tid;
+    tpsval[(size_t)s * p.n_tps + tid] = cmul(X(xb + c), gain(T.tps_Li[q], T.tps_Ri[q], T.tps_d[q]));
+  }
+}
+
+}  // namespace dvbt

@@ -225,7 +225,7 @@ typedef struct {
 typedef enum {
   DVBT_TAP_ACQ = 0,        /* cfloat[n_symbols][N]     output of A1 */
   DVBT_TAP_FFT = 1,        /* cfloat[n_symbols][N]     output of A2 (like ACQ/DEMAP/SYMDEINT/DEINT a debug tap: dvbt_rx_enable_taps first) */
-  DVBT_TAP_EQ = 2,         /* cfloat[n_out_symbols][payload]  output of A3 (the float-tolerance tap) */
+  DVBT_TAP_EQ = 2,         /* cfloat[n_out_symbols][payload]  output of A3 (the float-tolerance tap; written only after dvbt_rx_enable_taps) */
   DVBT_TAP_DEMAP = 3,      /* u8[n_out_symbols][payload] */
   DVBT_TAP_SYMDEINT = 4,
   DVBT_TAP_BITDEINT = 5,
