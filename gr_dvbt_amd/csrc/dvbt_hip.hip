@@ -92,7 +92,7 @@ struct Tables {          // device lookup tables for one configuration
       if ((int)pt.pay_c.size() != d.payload) return fail(DVBT_ERR_INVALID, "payload carrier table size mismatch");
       if ((int)pt.pil_k.size() > DEMOD_NP) return fail(DVBT_ERR_INVALID, "estimation carrier table overflow");
       np[s] = (int)pt.pil_k.size();
-      std::copy(pt.pil_k.begin(), pt.pil_k.end(), pk.begin() + (size_t)s * DEMOD_NP);
+      for (size_t i = 0; i < pt.pil_k.size(); i++) pk[(size_t)s * DEMOD_NP + i] = (uint16_t)(pt.pil_k[i] | (pr[pt.pil_k[i]] < 0.f ? 0x8000 : 0));   // carrier | sign of its reference value
       pli.insert(pli.end(), pt.pay_Li.begin(), pt.pay_Li.end()); pri.insert(pri.end(), pt.pay_Ri.begin(), pt.pay_Ri.end());
       pd.insert(pd.end(), pt.pay_d.begin(), pt.pay_d.end());
       tli.insert(tli.end(), pt.tps_Li.begin(), pt.tps_Li.end()); tri.insert(tri.end(), pt.tps_Ri.begin(), pt.tps_Ri.end());

@@ -91,14 +91,29 @@ __global__ __launch_bounds__(256) void inner_kernel(const float2 *__restrict__ e
   const bool odd = (mode & 2) ? (sym_index[s] & 1) : false;
   const float2 *e = eq ? eq + (size_t)s * p.payload : nullptr;
   const uint8_t *ib = in_bytes ? in_bytes + (size_t)s * p.payload : nullptr;
-  for (int q = tid; q < p.payload; q += 256) {
-    int dst = q;
-    if (mode & 2) dst = odd ? H[q] : Hinv[q];
-    const int lab = (mode & 1) ? demap_one(e[q], pts, label_of, p) : ib[q];
-    const int blk = dst / IB, r = dst - blk * IB, at = blk * IBS + r;
-    v[at] = (uint8_t)lab;
-    if (r < IBS - IB) v[at + IB] = (uint8_t)lab;               // the block's wrap-around tail
-    if (tap_demap && (mode & 1)) tap_demap[(size_t)u * p.payload + q] = (uint8_t)lab;
+  // batches of 8 carriers per thread: all table/label loads of a batch are issued before the first LDS store
+  for (int q0 = tid; q0 < p.payload; q0 += 8 * 256) {
+    int dst[8], lab[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int q = q0 + k * 256;
+      dst[k] = q; lab[k] = 0;
+      if (q < p.payload) {
+        if (mode & 2) dst[k] = odd ? H[q] : Hinv[q];
+        if (!(mode & 1)) lab[k] = ib[q];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int q = q0 + k * 256;
+      if (q < p.payload) {
+        if (mode & 1) lab[k] = demap_one(e[q], pts, label_of, p);
+        const int blk = dst[k] / IB, r = dst[k] - blk * IB, at = blk * IBS + r;
+        v[at] = (uint8_t)lab[k];
+        if (r < IBS - IB) v[at + IB] = (uint8_t)lab[k];           // the block's wrap-around tail
+        if (tap_demap && (mode & 1)) tap_demap[(size_t)u * p.payload + q] = (uint8_t)lab[k];
+      }
+    }
   }
   __syncthreads();
   uint8_t *o = out + (size_t)u * p.payload;
@@ -401,13 +416,23 @@ __global__ __launch_bounds__(64) void deint_rs_kernel(const uint8_t *__restrict_
     // every byte goes straight to its codeword's row: byte p of source row r belongs to row r - 11 - ... = r - p % 12
     // (rows counted from w0 - 11), i.e. the four bytes of a dword land 203 bytes apart.
     const long long first = w0 - 11;
-    for (int i = tid; i < 75 * 51; i += 64) {
-      const int r = i / 51, p4 = i - r * 51;
-      const long long word = first + r;
-      unsigned v = 0;
-      if (word >= -hist_words && word < nwords && r < nw + 11) v = reinterpret_cast<const unsigned *>(in + word * 204)[p4];
-      uint8_t *d = s_rows + (r + 11 - (p4 % 3) * 4) * 204 + 4 * p4;           // row of byte 0 of this dword (s_rows row = codeword - w0 + 11)
-      d[0] = (uint8_t)v; d[1 - 204] = (uint8_t)(v >> 8); d[2 - 408] = (uint8_t)(v >> 16); d[3 - 612] = (uint8_t)(v >> 24);
+    for (int i0 = tid; i0 < 75 * 51; i0 += 6 * 64) {               // 6 dword loads in flight per lane (60 = 10 x 6 per lane)
+      unsigned v[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        const int i = i0 + k * 64, r = i / 51, p4 = i - r * 51;
+        const long long word = first + r;
+        v[k] = 0;
+        if (i < 75 * 51 && word >= -hist_words && word < nwords && r < nw + 11) v[k] = reinterpret_cast<const unsigned *>(in + word * 204)[p4];
+      }
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        const int i = i0 + k * 64, r = i / 51, p4 = i - r * 51;
+        if (i < 75 * 51) {
+          uint8_t *d = s_rows + (r + 11 - (p4 % 3) * 4) * 204 + 4 * p4;         // row of byte 0 of this dword (s_rows row = codeword - w0 + 11)
+          d[0] = (uint8_t)v[k]; d[1 - 204] = (uint8_t)(v[k] >> 8); d[2 - 408] = (uint8_t)(v[k] >> 16); d[3 - 612] = (uint8_t)(v[k] >> 24);
+        }
+      }
     }
   } else {
     for (int i = tid; i < nw * 51; i += 64) reinterpret_cast<unsigned *>(s_cw)[i] = reinterpret_cast<const unsigned *>(in + w0 * 204)[i];

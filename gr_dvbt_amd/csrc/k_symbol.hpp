@@ -17,7 +17,8 @@ namespace dvbt {
 // A4 rides along: every equalised carrier is demapped at once (demap_one: the reference's first strict minimum), so a
 // symbol leaves the kernel as `payload` label bytes in carrier order; the equalised carriers themselves are written
 // only when the EQ tap is enabled.
-inline size_t fused_lds_bytes_host(int N) { return (size_t)(N + N / 32 + N / 128 + 128 + DEMOD_NP) * 8 + 128 + 64 * 8 + 64; }
+constexpr int SYM_NCP_MAX = 192;           // continual pilots of a mode (177 in 8k)
+inline size_t fused_lds_bytes_host(int N) { return (size_t)(N + N / 32 + N / 128 + 128 + DEMOD_NP) * 8 + 128 + 64 * 8 + 64 + SYM_NCP_MAX * 6; }
 
 __global__ __launch_bounds__(FFT_THREADS) void derot_fft_demod_kernel(const float2 *__restrict__ iq, FrontParams p, const RxState *st,
                                                              const SymMeta *__restrict__ meta, const float2 *__restrict__ tw,
@@ -40,7 +41,10 @@ __global__ __launch_bounds__(FFT_THREADS) void derot_fft_demod_kernel(const floa
   int *s_i = reinterpret_cast<int *>(s_sum + 16);
   float2 *pts = reinterpret_cast<float2 *>(s_i + 16);
   unsigned char *label_of = reinterpret_cast<unsigned char *>(pts + 64);
+  float *s_known = reinterpret_cast<float *>(label_of + 64);
+  short *s_cpil = reinterpret_cast<short *>(s_known + SYM_NCP_MAX);
   if (tid < 64) { pts[tid] = points[tid]; label_of[tid] = label_tab[tid]; }
+  if (tid < p.n_cp) { s_cpil[tid] = T.cpilot[tid]; if (tid < p.n_cp - 1) s_known[tid] = T.known_diff[tid]; }
   for (int i = tid; i < N / 128; i += FFT_THREADS) tw_c[i] = tw[i * 128];
   if (tid < 128) tw_f[tid] = tw[tid];
   const SymMeta m = meta[s];
@@ -53,6 +57,9 @@ __global__ __launch_bounds__(FFT_THREADS) void derot_fft_demod_kernel(const floa
   float2 PA = make_float2(1.f, 0.f), PB = PA;
   float2 *stab = gtab;                                            // [2][N / FFT_THREADS], free until the pilot engine runs
   const int nstep = N / FFT_THREADS;
+  float2 vin[8192 / FFT_THREADS];
+#pragma unroll
+  for (int i = 0; i < 8192 / FFT_THREADS; i++) if (i < nstep) vin[i] = iq[low + tid + i * FFT_THREADS];
   if (rot) {
     const double thA = (double)m.ph_base + m.incA, thB = (double)m.ph_base + (double)m.sw * (m.incA - m.incB) + m.incB;
     if (tid < 2 * nstep) {
@@ -65,9 +72,11 @@ __global__ __launch_bounds__(FFT_THREADS) void derot_fft_demod_kernel(const floa
     sincosf(wrap_pi(thB + tid * m.incB), &sn, &cs); PB = make_float2(cs, sn);
     __syncthreads();
   }
-  for (int i = 0; i < nstep; i++) {
+  constexpr int NSTEP_MAX = 8192 / FFT_THREADS;                   // every load of the symbol is in flight before the first use
+#pragma unroll
+  for (int i = 0; i < NSTEP_MAX; i++) if (i < nstep) {
     const int n = tid + i * FFT_THREADS;
-    float2 v = iq[low + n];
+    float2 v = vin[i];
     if (rot) {
       const bool pieceB = has_sw && n + 1 > m.sw;
       v = cmul(cmul(pieceB ? PB : PA, stab[(pieceB ? nstep : 0) + i]), v);
@@ -94,9 +103,9 @@ __global__ __launch_bounds__(FFT_THREADS) void derot_fft_demod_kernel(const floa
     const int cand = (tid >> 4) & 15, sub = tid & 15, i = zl - 8 + cand;
     float sum = 0.f;
     for (int j = sub; j < p.n_cp - 1 && tid < 256; j += 16) {
-      const float2 a = X(i + T.cpilot[j + 1]), b = X(i + T.cpilot[j]);
+      const float2 a = X(i + s_cpil[j + 1]), b = X(i + s_cpil[j]);
       const float dx = a.x - b.x, dy = a.y - b.y;
-      sum += T.known_diff[j] * (dx * dx + dy * dy);
+      sum += s_known[j] * (dx * dx + dy * dy);
     }
     for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     if (sub == 0 && tid < 256) s_sum[cand] = sum;
@@ -132,11 +141,24 @@ __global__ __launch_bounds__(FFT_THREADS) void derot_fft_demod_kernel(const floa
   }
   __syncthreads();
   const int mod = s_i[1];
-  // LS gains at the estimation carriers (set_channel_gain :486-490)
+  // the equaliser's table rows of this thread (carrier, bracketing ranks, distance) start travelling now
+  constexpr int PAY_IT = (6048 + FFT_THREADS - 1) / FFT_THREADS;
+  const int nit = (p.payload + FFT_THREADS - 1) / FFT_THREADS;
+  unsigned short tc[PAY_IT], tl[PAY_IT], tr[PAY_IT]; unsigned char td[PAY_IT];
+  {
+    const size_t tb = (size_t)mod * p.payload;
+#pragma unroll
+    for (int it = 0; it < PAY_IT; it++) {
+      const int i = tid + it * FFT_THREADS;
+      if (it < nit && i < p.payload) { tc[it] = T.pay_c[tb + i]; tl[it] = T.pay_Li[tb + i]; tr[it] = T.pay_Ri[tb + i]; td[it] = T.pay_d[tb + i]; }
+    }
+  }
+  // LS gains at the estimation carriers (set_channel_gain :486-490); pil_k: carrier | sign of its reference << 15
   {
     const uint16_t *pk = T.pil_k + (size_t)mod * DEMOD_NP;
     const int np = T.np[mod];
-    for (int r = tid; r < np; r += FFT_THREADS) { const int k = pk[r]; gtab[r] = cdiv(make_float2(T.pilot_ref[k], 0.f), X(xb + k)); }
+    const float amp = (float)(4.0 / 3.0);
+    for (int r = tid; r < np; r += FFT_THREADS) { const int e = pk[r], k = e & 0x7fff; gtab[r] = cdiv(make_float2((e & 0x8000) ? -amp : amp, 0.f), X(xb + k)); }
   }
   __syncthreads();
   // interpolation (:617-642, the constant 11 of :625) + equalise (:1111-1114)
@@ -146,13 +168,15 @@ __global__ __launch_bounds__(FFT_THREADS) void derot_fft_demod_kernel(const floa
     return make_float2(gl.x + tx * j, gl.y + ty * j);
   };
   {
-    const size_t tb = (size_t)mod * p.payload;
-    const uint16_t *pc = T.pay_c + tb, *pLi = T.pay_Li + tb, *pRi = T.pay_Ri + tb; const uint8_t *pd = T.pay_d + tb;
     uint8_t *lab = labels + (size_t)s * p.payload;
-    for (int i = tid; i < p.payload; i += FFT_THREADS) {
-      const float2 e = cmul(X(xb + pc[i]), gain(pLi[i], pRi[i], pd[i]));
-      if (eq_tap) eq_tap[(size_t)s * p.payload + i] = e;
-      lab[i] = (uint8_t)demap_one(e, pts, label_of, ip);
+#pragma unroll
+    for (int it = 0; it < PAY_IT; it++) {
+      const int i = tid + it * FFT_THREADS;
+      if (it < nit && i < p.payload) {
+        const float2 e = cmul(X(xb + tc[it]), gain(tl[it], tr[it], td[it]));
+        if (eq_tap) eq_tap[(size_t)s * p.payload + i] = e;
+        lab[i] = (uint8_t)demap_one(e, pts, label_of, ip);
+      }
     }
   }
   if (tid < p.n_tps) {   // equalised TPS carriers (process_tps_data :929-931)
