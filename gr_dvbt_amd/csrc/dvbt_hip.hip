@@ -14,6 +14,7 @@
 #include "k_symbol.hpp"
 #include "k_viterbi2.hpp"
 #include "k_viterbi3.hpp"
+#include "k_viterbi4.hpp"
 
 using namespace dvbt;
 
@@ -161,12 +162,13 @@ struct Tables {          // device lookup tables for one configuration
   }
 };
 
-// A7 kernel generation: 3 = DPP butterflies on packed 16-bit cells (default); 2 = DPP butterflies, 32-bit cells; 1 = one chunk per
+// A7 kernel generation: 3 = packed 16-bit cells, 4 chunks per wavefront (default); 4 = the same with 8 chunks per wavefront (fewer
+// instructions per chunk but one wavefront per SIMD: measured 8 % slower, kept for A/B runs); 2 = DPP butterflies, 32-bit cells; 1 = one chunk per
 // wavefront on ds_bpermute (kept for A/B runs: DVBT_VITERBI_KERNEL=1)
 static int viterbi_kernel_version()
 {
   const char *e = getenv("DVBT_VITERBI_KERNEL");
-  return (e && e[0] == '1') ? 1 : (e && e[0] == '2') ? 2 : 3;
+  return (e && e[0] >= '1' && e[0] <= '4') ? e[0] - '0' : 3;
 }
 static void launch_viterbi(hipStream_t s, const uint8_t *in, uint8_t *out, const RxState *st, long long steps_fixed, const VitParams &vp,
                            long long in_base, long long out_lo, long long max_out_bytes)
@@ -175,6 +177,17 @@ static void launch_viterbi(hipStream_t s, const uint8_t *in, uint8_t *out, const
   if (chunks < 1) chunks = 1;
   if (viterbi_kernel_version() == 1)
     hipLaunchKernelGGL(viterbi_kernel, dim3((unsigned)((chunks + 3) / 4)), dim3(256), 0, s, in, out, st, steps_fixed, vp, in_base, out_lo);
+  else if (viterbi_kernel_version() == 4)
+  {
+    const dim3 grid((unsigned)((chunks + V4_DEC - 1) / V4_DEC)), blk(64);
+    switch (vp.ntb) {   // the traceback depth is a template parameter (hop schedule fixed at compile time)
+      case 5: hipLaunchKernelGGL(viterbi4_kernel<5>, grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
+      case 9: hipLaunchKernelGGL(viterbi4_kernel<9>, grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
+      case 10: hipLaunchKernelGGL(viterbi4_kernel<10>, grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
+      case 15: hipLaunchKernelGGL(viterbi4_kernel<15>, grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
+      default: hipLaunchKernelGGL(viterbi4_kernel<24>, grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
+    }
+  }
   else if (viterbi_kernel_version() == 3)
     hipLaunchKernelGGL(viterbi3_kernel, dim3((unsigned)((chunks + 3) / 4)), dim3(64), 0, s, in, out, st, steps_fixed, vp, in_base, out_lo);
   else {
