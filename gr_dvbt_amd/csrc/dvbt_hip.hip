@@ -189,7 +189,16 @@ static void launch_viterbi(hipStream_t s, const uint8_t *in, uint8_t *out, const
     }
   }
   else if (viterbi_kernel_version() == 3)
-    hipLaunchKernelGGL(viterbi3_kernel, dim3((unsigned)((chunks + 3) / 4)), dim3(64), 0, s, in, out, st, steps_fixed, vp, in_base, out_lo);
+  {
+    const dim3 grid((unsigned)((chunks + 3) / 4)), blk(64);
+    switch (vp.ntb) {   // the traceback depth is a template parameter (hop schedule fixed at compile time)
+      case 5: hipLaunchKernelGGL(viterbi3_kernel<5>, grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
+      case 9: hipLaunchKernelGGL(viterbi3_kernel<9>, grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
+      case 10: hipLaunchKernelGGL(viterbi3_kernel<10>, grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
+      case 15: hipLaunchKernelGGL(viterbi3_kernel<15>, grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
+      default: hipLaunchKernelGGL(viterbi3_kernel<24>, grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
+    }
+  }
   else {
     const long long per_wg = 4 * V2_WAVES;
     hipLaunchKernelGGL(viterbi2_kernel, dim3((unsigned)((chunks + per_wg - 1) / per_wg)), dim3(64 * V2_WAVES), 0, s, in, out, st, steps_fixed, vp, in_base, out_lo);

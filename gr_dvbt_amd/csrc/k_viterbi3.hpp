@@ -171,14 +171,14 @@ struct V3Trace {
   bool ok[2];
   long long ob[2];      // output byte of the call
 };
-// one hop of both chains: state = path_byte >> 2 (d_viterbi.c:717); `live` is wave-uniform
-__device__ __forceinline__ void v3_hop(V3Trace &T, const unsigned char *tab, int rowc, bool live)
+// one hop of both chains: state = path_byte >> 2 (d_viterbi.c:717)
+__device__ __forceinline__ void v3_hop(V3Trace &T, const unsigned char *tab, int rowc)
 {
 #pragma unroll
   for (int q = 0; q < 2; q++) {
     const unsigned t = tab[(T.wsh[q] & 0x3f00) | rowc | T.z[q]];
-    T.z[q] = live ? (int)(t >> 2) : T.z[q];
-    T.wsh[q] -= live ? 256 : 0;
+    T.z[q] = (int)(t >> 2);
+    T.wsh[q] -= 256;
   }
 }
 // the decoded byte of a call: (state at the start of the last window of the chain) << 2 | its two oldest inputs
@@ -196,10 +196,13 @@ __device__ __forceinline__ void v3_trace_out(const V3Trace &T, const unsigned ch
 // window j0 + V6 of a decoder (j0 % 6 == 0): it starts at phase (8 V6) % 6 = 0,2,4,0,2,4; the minimum is subtracted
 // after every second window.  HOPS: two traceback hops of the previous block's calls ride along (their LDS latency
 // hides under the add-compare-select work).
-template <int V6, bool HOPS> __device__ __forceinline__ void v3_fwd_window(int (&v)[2], const V3Lane &L, const unsigned *wrow, unsigned char *tab,
-                                                                          unsigned char *bests, int j0, int dd, int pl, V3Trace &T, int hop0, int nhops)
+// Which hops exist is a compile-time fact (HOP0 + 2 V6 (+1) < NTB - 1 with NTB = ntraceback, a template parameter of the
+// kernel): the window stays one straight-line block and the scheduler can spread the dependent LDS reads over it.
+template <int V6, bool HOPS, int HOP0, int NTB> __device__ __forceinline__ void v3_fwd_window(int (&v)[2], const V3Lane &L, const unsigned *wrow, unsigned char *tab,
+                                                                                           unsigned char *bests, int j0, int dd, int pl, V3Trace &T)
 {
-  if (HOPS) { v3_hop(T, tab, dd * 64, hop0 + 2 * V6 < nhops); v3_hop(T, tab, dd * 64, hop0 + 2 * V6 + 1 < nhops); }
+  if (HOPS && HOP0 + 2 * V6 < NTB - 1) v3_hop(T, tab, dd * 64);
+  if (HOPS && HOP0 + 2 * V6 + 1 < NTB - 1) v3_hop(T, tab, dd * 64);
   const int jr = (j0 + V6) & (V3_RINGW - 1);
   unsigned W[8];
   {
@@ -215,6 +218,13 @@ template <int V6, bool HOPS> __device__ __forceinline__ void v3_fwd_window(int (
   const int s = v3_window_end<(P0 + 2) % 6, (V6 & 1) == 1>(v, L);
   bests[dd * V3_RINGW + jr] = (unsigned char)s;                    // all 16 lanes of the row write the same byte
 }
+template <bool HOPS, int HOP0, int NTB> __device__ __forceinline__ void v3_fwd_six(int (&v)[2], const V3Lane &L, const unsigned *wrow, unsigned char *tab,
+                                                                                  unsigned char *bests, int j0, int dd, int pl, V3Trace &T)
+{
+  v3_fwd_window<0, HOPS, HOP0, NTB>(v, L, wrow, tab, bests, j0, dd, pl, T); v3_fwd_window<1, HOPS, HOP0, NTB>(v, L, wrow, tab, bests, j0, dd, pl, T);
+  v3_fwd_window<2, HOPS, HOP0, NTB>(v, L, wrow, tab, bests, j0, dd, pl, T); v3_fwd_window<3, HOPS, HOP0, NTB>(v, L, wrow, tab, bests, j0, dd, pl, T);
+  v3_fwd_window<4, HOPS, HOP0, NTB>(v, L, wrow, tab, bests, j0, dd, pl, T); v3_fwd_window<5, HOPS, HOP0, NTB>(v, L, wrow, tab, bests, j0, dd, pl, T);
+}
 
 // A chunk = vp.chunk_bytes decoded bytes; it is decoded by an independent decoder that starts V3_WARM windows early
 // from all-zero metrics and runs ntraceback-1 windows past its end.  Per block of 24 windows:
@@ -227,7 +237,7 @@ template <int V6, bool HOPS> __device__ __forceinline__ void v3_fwd_window(int (
 //   forward   24 windows of add-compare-select (v3_fwd_window), path bytes into the LDS ring;
 //   traceback of the PREVIOUS block's 24 calls x 4 decoders (d_viterbi.c:714-724), lane = (decoder, call): its
 //             dependent LDS reads are interleaved into the first 12 windows of the forward pass.
-__global__ __launch_bounds__(64) void viterbi3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const RxState *st,
+template <int NTB> __global__ __launch_bounds__(64) void viterbi3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const RxState *st,
                                                       long long steps_fixed, VitParams vp, long long in_base, long long out_lo)
 {
   __shared__ __attribute__((aligned(16))) unsigned char tab[V3_RINGW * 4 * 64];   // path bytes: [window][decoder][cell z]  (the ppresult ring)
@@ -239,7 +249,8 @@ __global__ __launch_bounds__(64) void viterbi3_kernel(const uint8_t *__restrict_
 
   const long long total_steps = st ? st->n_vit_steps : steps_fixed;
   const long long total_out = total_steps / 8 - vp.ntb;
-  const int B = vp.chunk_bytes, ntb = vp.ntb, m = vp.m;
+  const int B = vp.chunk_bytes, m = vp.m;
+  constexpr int ntb = NTB;                                         // == vp.ntb (the host picks the instantiation)
   const long long chunk0 = (long long)blockIdx.x * 4;
   if (out_lo + chunk0 * B >= total_out) return;                   // whole wavefront idle
   const long long b0 = out_lo + (chunk0 + dd) * B;                // this lane's decoder
@@ -351,26 +362,25 @@ __global__ __launch_bounds__(64) void viterbi3_kernel(const uint8_t *__restrict_
     if (jb + V3_BLK < J) stage_load(jb + V3_BLK);                  // the bytes of the next block travel during this block's forward pass
     const bool tr = jb > 0 && !(vp.dbg & 1);
     if (tr) trace_init(jb - V3_BLK);
-    for (int wi = 0; wi < V3_BLK && !(vp.dbg & 2); wi += 6) {
-      const unsigned *wrow = wbuf + dd * (V3_BLK * 8) + wi * 8;
-      if (tr && wi < 12) {
-        v3_fwd_window<0, true>(v, L, wrow, tab, bests, jb + wi, dd, pl, T, 2 * wi, ntb - 1); v3_fwd_window<1, true>(v, L, wrow, tab, bests, jb + wi, dd, pl, T, 2 * wi, ntb - 1);
-        v3_fwd_window<2, true>(v, L, wrow, tab, bests, jb + wi, dd, pl, T, 2 * wi, ntb - 1); v3_fwd_window<3, true>(v, L, wrow, tab, bests, jb + wi, dd, pl, T, 2 * wi, ntb - 1);
-        v3_fwd_window<4, true>(v, L, wrow, tab, bests, jb + wi, dd, pl, T, 2 * wi, ntb - 1); v3_fwd_window<5, true>(v, L, wrow, tab, bests, jb + wi, dd, pl, T, 2 * wi, ntb - 1);
-        if (wi == 6) v3_trace_out(T, tab, dd * 64, out, out_lo);
+    if (!(vp.dbg & 2)) {
+      const unsigned *wrow = wbuf + dd * (V3_BLK * 8);
+      if (tr) {
+        v3_fwd_six<true, 0, NTB>(v, L, wrow, tab, bests, jb, dd, pl, T);
+        v3_fwd_six<true, 12, NTB>(v, L, wrow + 48, tab, bests, jb + 6, dd, pl, T);
+        v3_trace_out(T, tab, dd * 64, out, out_lo);
       } else {
-        v3_fwd_window<0, false>(v, L, wrow, tab, bests, jb + wi, dd, pl, T, 0, 0); v3_fwd_window<1, false>(v, L, wrow, tab, bests, jb + wi, dd, pl, T, 0, 0);
-        v3_fwd_window<2, false>(v, L, wrow, tab, bests, jb + wi, dd, pl, T, 0, 0); v3_fwd_window<3, false>(v, L, wrow, tab, bests, jb + wi, dd, pl, T, 0, 0);
-        v3_fwd_window<4, false>(v, L, wrow, tab, bests, jb + wi, dd, pl, T, 0, 0); v3_fwd_window<5, false>(v, L, wrow, tab, bests, jb + wi, dd, pl, T, 0, 0);
+        v3_fwd_six<false, 0, NTB>(v, L, wrow, tab, bests, jb, dd, pl, T);
+        v3_fwd_six<false, 0, NTB>(v, L, wrow + 48, tab, bests, jb + 6, dd, pl, T);
       }
+      for (int wi = 12; wi < V3_BLK; wi += 6) v3_fwd_six<false, 0, NTB>(v, L, wrow + wi * 8, tab, bests, jb + wi, dd, pl, T);
     }
-    if (tr && (vp.dbg & 2)) { for (int h = 0; h < ntb - 1; h++) v3_hop(T, tab, dd * 64, true); v3_trace_out(T, tab, dd * 64, out, out_lo); }
+    if (tr && (vp.dbg & 2)) { for (int h = 0; h < ntb - 1; h++) v3_hop(T, tab, dd * 64); v3_trace_out(T, tab, dd * 64, out, out_lo); }
   }
   // the last block's calls
   if (!(vp.dbg & 1)) {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     trace_init(J - V3_BLK);
-    for (int h = 0; h < ntb - 1; h++) v3_hop(T, tab, dd * 64, true);
+    for (int h = 0; h < ntb - 1; h++) v3_hop(T, tab, dd * 64);
     v3_trace_out(T, tab, dd * 64, out, out_lo);
   }
 }
