@@ -46,7 +46,8 @@ class RxParams(C.Structure):
                 ("guard_interval", C.c_int), ("transmission_mode", C.c_int), ("include_cell_id", C.c_int),
                 ("cell_id", C.c_int), ("snr_db", C.c_float), ("viterbi_bsize", C.c_int),
                 ("rs_oracle_compat", C.c_int), ("descramble", C.c_int), ("max_samples", C.c_size_t),
-                ("device", C.c_int), ("viterbi_chunk_bytes", C.c_int)]
+                ("device", C.c_int), ("viterbi_chunk_bytes", C.c_int), ("resample_interp", C.c_int), ("resample_decim", C.c_int),
+                ("front_scale", C.c_float)]
 
 
 class RxReport(C.Structure):
@@ -119,10 +120,11 @@ class Rx:
                   TAP_SYMBOL_INDEX: np.int32}
 
     def __init__(self, constellation, code_rate, mode, max_samples, guard=G1_32, hierarchy=NH, snr_db=30.0,
-                 viterbi_bsize=768, rs_oracle_compat=0, descramble=1, device=0, viterbi_chunk_bytes=0, taps=False):
+                 viterbi_bsize=768, rs_oracle_compat=0, descramble=1, device=0, viterbi_chunk_bytes=0, taps=False,
+                 resample=(0, 0), front_scale=0.0):
         self.L = lib()
         self.p = RxParams(constellation, hierarchy, code_rate, guard, mode, 0, 0, snr_db, viterbi_bsize,
-                          rs_oracle_compat, descramble, max_samples, device, viterbi_chunk_bytes)
+                          rs_oracle_compat, descramble, max_samples, device, viterbi_chunk_bytes, resample[0], resample[1], front_scale)
         self.h = C.c_void_p()
         _chk(self.L.dvbt_rx_create(C.byref(self.p), C.byref(self.h)))
         self.dims = get_dims(constellation, code_rate, mode, guard, hierarchy)
@@ -218,6 +220,7 @@ BLOCK_PARAMS = {
     "convolutional_deinterleaver": _params([("blocks", _I), ("I", _I), ("M", _I)]),
     "reed_solomon_dec": _params([(n, _I) for n in ("p", "m", "gfpoly", "n", "k", "t", "s", "blocks", "oracle_compat")]),
     "energy_descramble": _params([("nblocks", _I)]),
+    "resampler": _params([("interpolation", _I), ("decimation", _I), ("scale", C.c_float)]),
 }
 
 

@@ -12,6 +12,7 @@
 #include "k_frontend.hpp"
 #include "k_backend.hpp"
 #include "k_symbol.hpp"
+#include "k_resample.hpp"
 #include "k_viterbi2.hpp"
 #include "k_viterbi3.hpp"
 #include "k_viterbi4.hpp"
@@ -240,11 +241,28 @@ static int set_lds(const void *fn, size_t bytes)
 enum { ST_ACQ = 0, ST_FFT, ST_DEMOD, ST_INNER, ST_VIT, ST_RS, ST_END, ST_COUNT };
 static const char *kStageNames[] = {"acq", "fft", "demod", "inner", "viterbi", "rs"};
 
+// taps and polyphase branches of the stock rational_resampler (dvbt_tables.hpp::resampler_taps) on the device
+struct ResamplerDesign {
+  int ri = 0, rd = 0, nt = 0; std::vector<float> taps; float *br = nullptr;
+  int build(int interp, int decim)
+  {
+    if (interp <= 0 || decim <= 0) return fail(DVBT_ERR_INVALID, "bad resampler ratio");
+    taps = resampler_taps(interp, decim, ri, rd);
+    std::vector<float> b = resampler_branches(taps, ri, nt);
+    if ((long long)ri * nt > RS_MAX_BRANCH_FLOATS || 256ll * rd / ri + nt + 2 > RS_TILE_IN) return fail(DVBT_ERR_INVALID, "resampler ratio outside the supported range");
+    HIPCHK(hipMalloc((void **)&br, b.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(br, b.data(), b.size() * sizeof(float), hipMemcpyHostToDevice));
+    return DVBT_OK;
+  }
+  ~ResamplerDesign() { if (br) (void)hipFree(br); }
+};
+
 struct dvbt_rx {
   dvbt_rx_params prm; Dims d; Tables T; FrontParams fp; VitParams vp;
   hipStream_t own_stream = nullptr, cur_stream = nullptr;
   size_t max_samples = 0; int max_calls = 0;
   float2 *d_iq = nullptr;              // only when input comes from the host
+  ResamplerDesign rsd; float2 *rs_iq = nullptr; size_t chain_max = 0;   // front-of-chain resample + scale (next row 2): its output buffer
   float2 *g_init = nullptr; float *l_init = nullptr; float2 *g_trk = nullptr; float *l_trk = nullptr;
   SymMeta *meta = nullptr; RxState *st = nullptr, *st_host = nullptr; TpsState *tps_state = nullptr;
   int *trk_cp_a = nullptr, *trk_cp_b = nullptr, *trk_flags = nullptr; float *trk_eps = nullptr; TpsEdge *tps_edges = nullptr;
@@ -258,7 +276,7 @@ struct dvbt_rx {
 
 static void rx_free(dvbt_rx *h)
 {
-  void *all[] = {h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags, h->trk_eps, h->d_iq, h->g_init, h->l_init, h->g_trk, h->l_trk, h->meta, h->st, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
+  void *all[] = {h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags, h->trk_eps, h->d_iq, h->rs_iq, h->g_init, h->l_init, h->g_trk, h->l_trk, h->meta, h->st, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
                  h->info, h->maj, h->sym_index, h->labels, h->symdeint_tap, h->bitdeint, h->vit, h->deint_tap, h->rs_out, h->ts_out};
   for (void *q : all) if (q) (void)hipFree(q);
   if (h->st_host) (void)hipHostFree(h->st_host);
@@ -275,19 +293,27 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   if (!d.valid) return fail(DVBT_ERR_INVALID, "bad DVB-T parameters");
   if (p->viterbi_bsize <= 0 || (2 * d.k * p->viterbi_bsize) % 16 != 0 || (p->viterbi_bsize * d.n) % d.m != 0)
     return fail(DVBT_ERR_INVALID, "viterbi_bsize must make bsize*n/m integral and 2*k*bsize a multiple of 16");
-  if (p->max_samples < (size_t)(2 * d.N + d.cp + 16)) return fail(DVBT_ERR_INVALID, "max_samples smaller than one acquisition window");
   HIPCHK(hipSetDevice(p->device));
   dvbt_rx *h = new dvbt_rx();
   h->prm = *p; h->d = d; h->T.d = d;
+  // capacity of the chain proper, in samples at the OFDM elementary rate
+  size_t chain_max = p->max_samples;
+  if (p->resample_interp > 0 || p->resample_decim > 0) {
+    int r2 = h->rsd.build(p->resample_interp, p->resample_decim); if (r2) { delete h; return r2; }
+    chain_max = (size_t)(((unsigned long long)p->max_samples * h->rsd.ri + h->rsd.rd - 1) / h->rsd.rd);
+  }
+  if (chain_max < (size_t)(2 * d.N + d.cp + 16)) { delete h; return fail(DVBT_ERR_INVALID, "max_samples smaller than one acquisition window"); }
+  h->chain_max = chain_max;
   h->fp = make_front_params(d, p->snr_db);
   int cb = p->viterbi_chunk_bytes > 0 ? p->viterbi_chunk_bytes : 768;
   h->vp = make_vit_params(d, p->viterbi_bsize, cb);
   h->max_samples = p->max_samples;
-  h->max_calls = (int)((p->max_samples - (2 * d.N + d.cp + 16)) / (d.N + d.cp) + 1);
+  h->max_calls = (int)((chain_max - (2 * d.N + d.cp + 16)) / (d.N + d.cp) + 1);
 #define RXCHK(x) do { int r_ = (x); if (r_) { rx_free(h); return r_; } } while (0)
 #define RXHIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_err = std::string(#x) + ": " + hipGetErrorString(e_); rx_free(h); return DVBT_ERR_HIP; } } while (0)
   RXCHK(h->T.build_fft(d.N)); RXCHK(h->T.build_front()); RXCHK(h->T.build_inner(1.0f)); RXCHK(h->T.build_rs());
   RXHIP(hipStreamCreate(&h->own_stream));
+  if (h->rsd.ri) RXHIP(hipMalloc((void **)&h->rs_iq, sizeof(float2) * (chain_max + 16)));
   const size_t C = (size_t)h->max_calls, N = d.N, P = d.payload;
   RXHIP(hipMalloc((void **)&h->g_init, sizeof(float2) * ACQ_INIT_TRIES * N)); RXHIP(hipMalloc((void **)&h->l_init, sizeof(float) * ACQ_INIT_TRIES * N));
   RXHIP(hipMalloc((void **)&h->g_trk, sizeof(float2) * C * 2 * ACQ_R)); RXHIP(hipMalloc((void **)&h->l_trk, sizeof(float) * C * 2 * ACQ_R));
@@ -337,6 +363,12 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s)
 {
   const Dims &d = h->d;
   if (nsamples > h->max_samples) return fail(DVBT_ERR_CAPACITY, "segment longer than max_samples");
+  if (h->rsd.ri) {   // next row 2: the segment arrives at the file rate; resample + scale into the chain's input buffer first
+    const long long cnt = (long long)(((unsigned long long)nsamples * h->rsd.ri + h->rsd.rd - 1) / h->rsd.rd);
+    hipLaunchKernelGGL(resample_scale_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, iq, 0ll, (long long)nsamples, 0ll, cnt, h->rsd.ri, h->rsd.rd,
+                       h->rsd.nt, (const float *)h->rsd.br, h->prm.front_scale == 0.f ? 1.0f : h->prm.front_scale, h->rs_iq);
+    iq = h->rs_iq; nsamples = (size_t)cnt;
+  }
   if (nsamples < (size_t)(2 * d.N + d.cp + 16)) return fail(DVBT_ERR_INVALID, "segment shorter than one acquisition window");
   FrontParams fp = h->fp;
   fp.ncalls = (int)((nsamples - (2 * d.N + d.cp + 16)) / (d.N + d.cp) + 1);

@@ -233,6 +233,45 @@ inline std::vector<uint8_t> energy_prbs()
   return seq;
 }
 
+// ---- front of the flowgraph: stock gr::filter rational_resampler_ccc(64, 70, taps=None, fbw=None).
+// Third-party (gr-filter / gr-fft of the GNU Radio 3.7 series, absent from the reference tree, version unpinned): the
+// published algorithm is restated -- rational_resampler.py (gcd reduction, fractional_bw 0.4, design_filter),
+// firdes.cc (compute_ntaps, low_pass), window.cc (kaiser, Izero).  Returns the prototype low-pass; ri/rd = reduced
+// interpolation/decimation.
+inline std::vector<float> resampler_taps(int interp, int decim, int &ri, int &rd)
+{
+  auto gcd = [](int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; };
+  auto izero = [](double x) { double sum = 1, u = 1, halfx = x / 2.0; int n = 1; do { double t = halfx / (double)n; n += 1; t *= t; u *= t; sum += u; } while (u >= 1e-21 * sum); return sum; };
+  const int d = gcd(interp, decim);
+  ri = interp / d; rd = decim / d;
+  const double fractional_bw = 0.4, beta = 7.0, halfband = 0.5, rate = (double)ri / (double)rd;
+  double width, mid;
+  if (rate >= 1.0) { width = halfband - fractional_bw; mid = halfband - width / 2.0; }
+  else { width = rate * (halfband - fractional_bw); mid = rate * halfband - width / 2.0; }
+  double gain = ri; const double fs = ri, atten = beta / 0.1102 + 8.7;
+  int ntaps = (int)(atten * fs / (22.0 * width));
+  if ((ntaps & 1) == 0) ntaps++;
+  std::vector<float> w(ntaps), taps(ntaps);
+  const double ibeta = 1.0 / izero(beta), inm1 = 1.0 / (double)(ntaps - 1);
+  for (int i = 0; i < ntaps; i++) { const double t = 2 * i * inm1 - 1; w[i] = (float)(izero(beta * std::sqrt(1.0 - t * t)) * ibeta); }
+  const int M = (ntaps - 1) / 2;
+  const double fwT0 = 2 * M_PI * mid / fs;
+  for (int n = -M; n <= M; n++) taps[n + M] = n == 0 ? (float)(fwT0 / M_PI * w[n + M]) : (float)(std::sin(n * fwT0) / (n * M_PI) * w[n + M]);
+  double fmax = taps[M];
+  for (int n = 1; n <= M; n++) fmax += 2 * taps[n + M];
+  gain /= fmax;
+  for (int i = 0; i < ntaps; i++) taps[i] = (float)(taps[i] * gain);
+  return taps;
+}
+// polyphase branches as rational_resampler_base installs them: branch[i % ri][i / ri] = taps[i], zero padded; nt taps per branch
+inline std::vector<float> resampler_branches(const std::vector<float> &taps, int ri, int &nt)
+{
+  nt = ((int)taps.size() + ri - 1) / ri;
+  std::vector<float> br((size_t)ri * nt, 0.f);
+  for (size_t i = 0; i < taps.size(); i++) br[(i % ri) * nt + i / ri] = taps[i];
+  return br;
+}
+
 // GF(256) exp/log, poly 0x11d (reed_solomon.cc:48-89)
 inline void gf_tables(uint8_t *exp512, uint8_t *log256)
 {

@@ -107,6 +107,9 @@ DVBT_AMD_BLOCK(reed_solomon_dec, dvbt_reed_solomon_dec_params, (int p, int m, in
                (dvbt_reed_solomon_dec_params{p, m, gfpoly, n, k, t, s, blocks, 0}))
 // include/dvbt/energy_descramble.h
 DVBT_AMD_BLOCK(energy_descramble, dvbt_energy_descramble_params, (int nblocks), (dvbt_energy_descramble_params{nblocks}))
+// stock gr::filter::rational_resampler_ccc(interpolation, decimation, taps=None) followed by blocks::multiply_const_cc(scale)
+// (rational_resampler_xxx_0 + blocks_multiply_const_vxx_0 of apps/dvbt_rx_demo*.grc), one block here
+DVBT_AMD_BLOCK(resampler, dvbt_resampler_params, (int interpolation, int decimation, float scale), (dvbt_resampler_params{interpolation, decimation, scale}))
 
 #undef DVBT_AMD_BLOCK
 }}  // namespace gr::dvbt_amd

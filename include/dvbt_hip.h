@@ -190,6 +190,24 @@ int  dvbt_energy_descramble_work(dvbt_energy_descramble *h, int noutput_items, i
                                  const void *in, void *out, dvbt_sideband *sb);
 void dvbt_energy_descramble_destroy(dvbt_energy_descramble *h);
 
+/* ------------------------------------------------------------------ next row 2: front-of-chain resample + scale
+ * replaces the stock blocks in front of the path in apps/dvbt_rx_demo*.grc:
+ *   rational_resampler_xxx_0 (gr::filter rational_resampler_ccc, interp 64, decim 70, taps none, fbw none)
+ *   blocks_multiply_const_vxx_0 (complex const 0.0022097087 @2k, 0.00055242272 @8k)
+ * cfloat stream at the file rate (10 Msps) -> cfloat stream at the OFDM elementary rate (64/7 Msps), scaled.
+ * GNU Radio (gr-filter, gr-fft) is a third-party dependency that is absent from the reference tree and not version
+ * pinned: the taps are designed as the 3.7 series does for taps=None (interp/decim reduced by their gcd, fractional_bw
+ * 0.4, Kaiser beta 7 windowed sinc: 1149 taps, 32 branches of 36 for 64/70); parity unpinned, float-tolerance tap.
+ * scale = 1.0f for the resampler alone.  forecast/work follow rational_resampler_base (noutput*decim/interp + history). */
+typedef struct { int interpolation, decimation; float scale; } dvbt_resampler_params;
+typedef struct dvbt_resampler dvbt_resampler;
+int  dvbt_resampler_create(const dvbt_resampler_params *p, dvbt_resampler **out);
+int  dvbt_resampler_forecast(const dvbt_resampler *h, int noutput_items, int *ninput_required);
+int  dvbt_resampler_work(dvbt_resampler *h, int noutput_items, int ninput_items,
+                         const void *in, void *out, dvbt_sideband *sb);
+int  dvbt_resampler_get_taps(const dvbt_resampler *h, float *taps, int cap, int *interpolation, int *decimation);  /* returns the tap count */
+void dvbt_resampler_destroy(dvbt_resampler *h);
+
 /* ------------------------------------------------------------------ segment API: the whole chain, device resident
  * One segment = a contiguous run of baseband samples (complex64 at the OFDM elementary rate,
  * i.e. the input of ofdm_sym_acquisition in apps/dvbt_rx_demo*.grc).  The segment is processed
@@ -205,6 +223,9 @@ typedef struct {
   size_t max_samples;      /* capacity: device buffers are sized for this many input samples */
   int device;              /* HIP device ordinal */
   int viterbi_chunk_bytes; /* 0 = default; decoded bytes per wavefront-chunk */
+  int resample_interp, resample_decim;   /* 0,0: the segment is already at the OFDM elementary rate (the north-star tap).
+                                            64,70: the segment is the 10 Msps file format; resample + scale run first on the device */
+  float front_scale;       /* multiply_const of the flowgraph (used only with resampling; 0 = 1.0) */
 } dvbt_rx_params;
 
 typedef struct {

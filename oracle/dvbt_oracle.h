@@ -108,6 +108,12 @@ void o_energy_dispersal(const unsigned char *ts, unsigned char *out, size_t npac
  * returns bytes written */
 size_t o_energy_descramble(const unsigned char *in, size_t nitems1504, unsigned char *out);
 
+/* ---- front of the flowgraph: stock rational_resampler_ccc(64,70) + multiply_const; o_resample.c.
+ * Third-party (gr-filter, gr-fft; absent, unpinned): PARITY UNPINNED, restated from the GNU Radio 3.7 sources. ---- */
+int o_resampler_design(int interp, int decim, int *ri, int *rd, float *taps, int cap);
+size_t o_resampler_nout(int interp, int decim, size_t nin);
+size_t o_resample_scale(int interp, int decim, float scale, const ocf *in, size_t nin, ocf *out, size_t cap);
+
 /* ---- FFT as used between A1 and A3 (gr::fft::fft_vcc forward, shift=True) ---- */
 void o_fft_forward_shift(int N, const ocf *in, ocf *out);
 void o_ifft_shift(int N, const ocf *in, ocf *out); /* TX: reverse, shift=True, unnormalised */

@@ -88,6 +88,10 @@ def lib():
                                C.POINTER(Taps)]
         L.o_rs_decode.restype = C.c_int
         L.o_vit_get_output.restype = C.c_ubyte
+        L.o_resample_scale.restype = C.c_size_t
+        L.o_resample_scale.argtypes = [C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.o_resampler_nout.restype = C.c_size_t
+        L.o_resampler_nout.argtypes = [C.c_int, C.c_int, C.c_size_t]
         L.o_acq_new.restype = C.c_void_p
         L.o_demod_new.restype = C.c_void_p
     return _lib
@@ -190,3 +194,23 @@ def rx(c, iq, snr_db=30.0, bsize=768, rs_compat=0, want=("rs",), max_sym_taps=No
     for k in ("cp_start", "epsilon", "sym_index"):
         out[k] = bufs[k][:t.n_acquired]
     return out
+
+
+def resampler_taps(interp, decim):
+    """(taps, reduced interp, reduced decim) of rational_resampler_ccc(interp, decim, taps=None, fbw=None)"""
+    L = lib()
+    ri, rd = C.c_int(), C.c_int()
+    n = L.o_resampler_design(interp, decim, C.byref(ri), C.byref(rd), None, 0)
+    t = np.zeros(n, np.float32)
+    L.o_resampler_design(interp, decim, C.byref(ri), C.byref(rd), _p(t), n)
+    return t, ri.value, rd.value
+
+
+def resample(x, interp, decim, scale=1.0):
+    """rational_resampler_ccc(interp, decim) + multiply_const(scale) over a whole stream (oracle/o_resample.c)"""
+    L = lib()
+    x = np.ascontiguousarray(x, dtype=np.complex64)
+    no = L.o_resampler_nout(interp, decim, len(x))
+    y = np.zeros(no, np.complex64)
+    m = L.o_resample_scale(interp, decim, C.c_float(scale), _p(x), len(x), _p(y), no)
+    return y[:m]

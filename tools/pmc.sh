@@ -12,7 +12,7 @@ tot = collections.defaultdict(dict)
 for f in sorted(glob.glob('gpurun_out/pmc/*/*counter_collection.csv')):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
-        k = r['Kernel_Name'].split('(')[0].replace('dvbt::', '')
+        k = r['Kernel_Name'].split('(')[0].replace('void ', '').replace('dvbt::', '').split('<')[0]
         acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
     for k in acc:
         for c, v in acc[k].items():

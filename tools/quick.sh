@@ -5,5 +5,5 @@ python - <<'PY'
 import csv, glob
 f = glob.glob('gpurun_out/prof_q/*kernel_stats.csv')[0]
 for r in list(csv.DictReader(open(f)))[:22]:
-    print(r["Name"].split("(")[0][6:36].ljust(30), r["Calls"].rjust(4), f"{float(r['AverageNs'])/1e3:10.1f} us", r["Percentage"])
+    print(r["Name"].split("(")[0].replace("void ","").replace("dvbt::","")[:30].ljust(30), r["Calls"].rjust(4), f"{float(r['AverageNs'])/1e3:10.1f} us", r["Percentage"])
 PY

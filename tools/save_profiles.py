@@ -10,7 +10,7 @@ out = {}
 for f in sorted(glob.glob(os.path.join(root, "gpurun_out", "pmc", "*", "*counter_collection.csv"))):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0].replace("dvbt::", "")
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("dvbt::", "").split("<")[0]
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k in acc:
         for c, v in acc[k].items():
@@ -29,4 +29,4 @@ json.dump(summary, open(os.path.join(root, "profiles", f"{tag}_pmc_summary_8k_qa
 v = summary["kernels"]["viterbi3_kernel"]
 print("viterbi3: hbm", v["hbm_bytes_corrected"] / 1e6, "MB; algorithmic", summary["viterbi_algorithmic_bytes"] / 1e6, "MB")
 for r in list(csv.DictReader(open(prof)))[:14]:
-    print(r["Name"].split("(")[0][6:36].ljust(30), r["Calls"].rjust(4), f"{float(r['AverageNs'])/1e3:10.1f} us", r["Percentage"])
+    print(r["Name"].split("(")[0].replace("void ","").replace("dvbt::","")[:30].ljust(30), r["Calls"].rjust(4), f"{float(r['AverageNs'])/1e3:10.1f} us", r["Percentage"])
