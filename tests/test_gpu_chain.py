@@ -180,3 +180,25 @@ def test_concurrent_segments_on_separate_streams(po, g):
             assert tso.size == it["ref"].size > 0 and (tso == it["ref"]).all()
     for it in items:
         it["rx"].close()
+
+
+@pytest.mark.parametrize("const,cr,mode,guard", [
+    (1, 1, 0, 3),       # 2k QAM16 2/3, GI 1/4  (cp = 512)
+    (0, 0, 1, 2),       # 8k QPSK 1/2, GI 1/8   (cp = 1024: the tracking metric runs in four 256-tap tiles)
+    (2, 3, 0, 1),       # 2k QAM64 5/6, GI 1/16
+])
+def test_other_guard_intervals_and_rates(po, g, const, cr, mode, guard):
+    """Guard intervals and code rates the demo flowgraphs do not use (the blocks accept them: dvbt_config.cc:194-211)."""
+    c = po.cfg(const, cr, mode, guard=guard)
+    ibits = c.payload * c.m * c.k // c.n
+    ts = po.make_ts((272 * ibits * 3) // (204 * 8), 5)
+    iq = po.tx(c, ts, lead_in=777, tail=3 * c.N)
+    o = po.rx(c, iq, want=("bitdeint", "vit", "rs", "ts"))
+    rx = g.Rx(const, cr, mode, max_samples=len(iq), guard=guard, taps=True)
+    rep = rx.run(iq)
+    assert rep.n_symbols == o["n_acquired"] and rep.first_out_symbol == o["first_out_symbol"] >= 0
+    assert (rx.tap(g.TAP_CP_START) == o["cp_start"]).all()
+    for name, tap in (("bitdeint", g.TAP_BITDEINT), ("vit", g.TAP_VITERBI), ("rs", g.TAP_RS), ("ts", g.TAP_TS)):
+        a, b = rx.tap(tap).reshape(-1), o[name].reshape(-1)
+        assert a.size == b.size > 0 and (a == b).all(), name
+    rx.close()
