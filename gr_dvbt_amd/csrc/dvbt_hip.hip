@@ -426,12 +426,15 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s)
   VitParams vp = h->vp;
   if (h->prm.viterbi_chunk_bytes <= 0 && viterbi_kernel_version() >= 2) {
     // chunk size chosen per segment so that the wavefront count is a whole number of "rounds" of the resident
-    // wavefront slots (4 chunks per wavefront, V2 kernel: 8 one-wave workgroups per CU by LDS): equal-length
-    // chunks then finish together instead of leaving a partial last round, and longer chunks amortise the
-    // warm-up + traceback overlap (V2_WARM + ntraceback - 1 windows per chunk)
+    // wavefront slots (4 chunks per wavefront, 8 one-wave workgroups per CU by LDS): equal-length chunks then
+    // finish together instead of leaving a partial last round, and longer chunks amortise the warm-up +
+    // traceback overlap (V3_WARM + ntraceback - 1 windows per chunk).  Measured on 65 superframes: 3 rounds of
+    // ~2900-byte chunks beat 5 rounds of ~1700 (less overlap) and 1 round of ~8600 (the hardware's static
+    // placement of a single round leaves some SIMDs with one wavefront)
     int ncu = 256; (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->prm.device);
     const long long slots = (long long)ncu * 8 * 4;             // chunks resident at once
-    long long rounds = (max_vit + slots * 1792 - 1) / (slots * 1792);
+    static const long long kMaxChunk = [] { const char *e = getenv("DVBT_VITERBI_MAXCHUNK"); return e ? atoll(e) : 3000ll; }();
+    long long rounds = (max_vit + slots * kMaxChunk - 1) / (slots * kMaxChunk);
     if (rounds < 1) rounds = 1;
     long long B = (max_vit + slots * rounds - 1) / (slots * rounds);
     if (B < 256) B = 256;

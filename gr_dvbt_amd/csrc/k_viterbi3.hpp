@@ -256,8 +256,9 @@ template <int NTB> __global__ __launch_bounds__(64) void viterbi3_kernel(const u
   const long long b0 = out_lo + (chunk0 + dd) * B;                // this lane's decoder
   const bool dec_active = b0 < total_out;
   const long long b1 = (b0 + B < total_out) ? b0 + B : total_out;
-  const long long w0 = b0 + 2 - V3_WARM;                           // absolute window of relative window 0
-  const int J = ((V3_WARM + B + ntb - 1 + V3_BLK - 1) / V3_BLK) * V3_BLK;
+  constexpr int warm = V3_WARM;
+  const long long w0 = b0 + 2 - warm;                              // absolute window of relative window 0
+  const int J = ((warm + B + ntb - 1 + V3_BLK - 1) / V3_BLK) * V3_BLK;
   const long long n_in_bytes = (total_steps * 2 / vp.plen * vp.n + vp.m - 1) / vp.m;   // input bytes that exist
   const int nload = ((384 + 2 * m - 2) / m + 3 + 15) / 16;         // lanes whose 16 bytes a block can need (13, 7, 5)
 
@@ -347,8 +348,8 @@ template <int NTB> __global__ __launch_bounds__(64) void viterbi3_kernel(const u
 #pragma unroll
     for (int c = 0; c < 2; c++) {
       int jj = jp + c * 16 + pl;
-      T.ob[c] = b0 + (jj - (V3_WARM + ntb - 1));
-      T.ok[c] = (c * 16 + pl < V3_BLK) && dec_active && jj >= V3_WARM + ntb - 1 && T.ob[c] < b1;
+      T.ob[c] = b0 + (jj - (warm + ntb - 1));
+      T.ok[c] = (c * 16 + pl < V3_BLK) && dec_active && jj >= warm + ntb - 1 && T.ob[c] < b1;
       if (!T.ok[c]) jj = jp;                                       // any window inside the ring: result unused
       const int sb = bests[dd * V3_RINGW + (jj & (V3_RINGW - 1))];
       T.z[c] = v3_z_of_cell(((sb | (sb << 6)) >> ((8 * jj + 8) % 6)) & 63);   // cell = rotr6(state, phase after the window)
