@@ -332,7 +332,7 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   for (int i = 0; i < ST_COUNT; i++) RXHIP(hipEventCreate(&h->ev[i]));
   h->ev_ready = true;
   RXCHK(set_lds((const void *)derot_fft_demod_kernel, fused_lds_bytes_host((int)N)));
-  RXCHK(set_lds((const void *)inner_kernel, inner_lds_bytes(P)));
+  RXCHK(set_lds((const void *)inner_kernel<6>, inner_lds_bytes(P)));
   *out = h;
   return DVBT_OK;
 }
@@ -418,8 +418,8 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s)
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_INNER], s));
   InnerParams ip = h->T.inner_params(d.payload);
   // A5 + A6 on the label bytes of the symbols from first_out on (A4 ran inside the symbol kernel)
-  hipLaunchKernelGGL(inner_kernel, dim3(C), dim3(256), inner_lds_bytes((size_t)d.payload), s, (const float2 *)nullptr, (const uint8_t *)h->labels, ip,
-                     (const RxState *)h->st, 0, 6, (const int *)h->sym_index, (const float2 *)nullptr, (const unsigned char *)nullptr,
+  hipLaunchKernelGGL(inner_kernel<6>, dim3(C), dim3(INNER_THREADS), inner_lds_bytes((size_t)d.payload), s, (const float2 *)nullptr, (const uint8_t *)h->labels, ip,
+                     (const RxState *)h->st, 0, getenv("DVBT_INNER_DBG") ? atoi(getenv("DVBT_INNER_DBG")) : 0, (const int *)h->sym_index, (const float2 *)nullptr, (const unsigned char *)nullptr,
                      (const uint16_t *)h->T.H, (const uint16_t *)h->T.Hinv, (uint8_t *)nullptr, h->symdeint_tap, h->bitdeint);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_VIT], s));
   long long max_vit = (long long)C * d.payload * d.m * d.k / (8 * d.n) + 1;

@@ -67,8 +67,41 @@ __device__ __forceinline__ int ipos(int d) { const int b = d / IB; return d + b 
 // mode bits: 1 = demap, 2 = symbol de-interleave, 4 = bit de-interleave (7 = fused chain path).
 // Reads are in carrier order (coalesced); the symbol permutation is applied on the LDS store:
 // even symbol out[q] = in[H(q)]  <=>  label of source p lands at Hinv[p];  odd: at H[p].
-__global__ __launch_bounds__(256) void inner_kernel(const float2 *__restrict__ eq, const uint8_t *__restrict__ in_bytes, InnerParams p,
-                                                   const RxState *st, int nitems_fixed, int mode, const int *__restrict__ sym_index,
+#ifndef DVBT_INNER_THREADS
+#define DVBT_INNER_THREADS 256
+#endif
+// A6 on the padded LDS image: output byte i of a block, bit k (MSB first) = bit (m-1-e) of input byte (i - off_e) mod 126,
+// e = perm(k) (bit_inner_deinterleaver_impl.cc:91-99,138-157).  One item = 4 consecutive output bytes: per bit plane one
+// (unaligned) word of the rotated block, masked and shifted into place.  VB = bits per carrier (compile time: the plane
+// permutation and the rotations are constants).
+template <int VB> __device__ __forceinline__ void bit_deint_words(const uint8_t *v, uint8_t *o, int payload, int tid, int dbg)
+{
+  constexpr int hv = VB / 2;
+  const int nitems = (payload / 126) * 32;                       // 32 words cover the 126 bytes of a block
+  for (int it = tid; it < nitems; it += DVBT_INNER_THREADS) {
+    const int blk = it >> 5, j = it & 31;
+    const unsigned *bw = reinterpret_cast<const unsigned *>(v + blk * 132);
+    unsigned val = 0;
+#pragma unroll
+    for (int k = 0; k < VB; k++) {
+      constexpr int offs[6] = {0, 63, 105, 42, 21, 84};
+      const int eidx = k / hv + 2 * (k % hv);                     // d_perm, non-hierarchical
+      int w = 4 * j - offs[eidx]; if (w < 0) w += 126;
+      const unsigned lo = bw[w >> 2], hi = bw[(w >> 2) + 1];
+      const unsigned word = __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(w & 3));
+      val |= ((word >> (VB - 1 - eidx)) & 0x01010101u) << (VB - 1 - k);
+    }
+    uint8_t *dst = o + blk * 126 + 4 * j;                         // even address
+    if (dbg & 4) continue;
+    *reinterpret_cast<uint16_t *>(dst) = (uint16_t)val;
+    if (j < 31) *reinterpret_cast<uint16_t *>(dst + 2) = (uint16_t)(val >> 16);
+  }
+}
+
+constexpr int INNER_NB = 12;                         // carriers per thread and batch
+constexpr int INNER_THREADS = DVBT_INNER_THREADS;   // workgroup size of inner_kernel: a symbol's 6048 carriers are few serial steps per thread
+template <int MODE> __global__ __launch_bounds__(INNER_THREADS) void inner_kernel(const float2 *__restrict__ eq, const uint8_t *__restrict__ in_bytes, InnerParams p,
+                                                   const RxState *st, int nitems_fixed, int dbg, const int *__restrict__ sym_index,
                                                    const float2 *__restrict__ points, const unsigned char *__restrict__ label_tab,
                                                    const uint16_t *__restrict__ H, const uint16_t *__restrict__ Hinv,
                                                    uint8_t *__restrict__ tap_demap, uint8_t *__restrict__ tap_symdeint,
@@ -79,67 +112,55 @@ __global__ __launch_bounds__(256) void inner_kernel(const float2 *__restrict__ e
   float2 *pts = reinterpret_cast<float2 *>(smem_raw + ((((p.payload + IB - 1) / IB) * IBS + 15) & ~15));
   unsigned char *label_of = reinterpret_cast<unsigned char *>(pts + 64);
   const int u = blockIdx.x, tid = threadIdx.x;
+  constexpr int mode = MODE;                                    // compile time: no branches around the loads below
+  if (dbg & 1) return;                                          // dbg: experiment switches (DVBT_INNER_DBG)
   int first = 0, nout = nitems_fixed;
   if (st) { first = st->first_out; nout = st->n_out_symbols; if (first < 0) return; }
   if (u >= nout) return;
   const int s = first + u;
   if (mode & 1) {
-    for (int j = tid; j < p.csize; j += 256) pts[j] = points[j];
+    for (int j = tid; j < p.csize; j += INNER_THREADS) pts[j] = points[j];
     if (tid < 64) label_of[tid] = label_tab[tid];
   }
   __syncthreads();
   const bool odd = (mode & 2) ? (sym_index[s] & 1) : false;
   const float2 *e = eq ? eq + (size_t)s * p.payload : nullptr;
   const uint8_t *ib = in_bytes ? in_bytes + (size_t)s * p.payload : nullptr;
-  // batches of 8 carriers per thread: all table/label loads of a batch are issued before the first LDS store
-  for (int q0 = tid; q0 < p.payload; q0 += 8 * 256) {
-    int dst[8], lab[8];
+  // batches of INNER_NB carriers per thread (a whole 8k symbol is one batch): every table/label load of a batch is
+  // issued before the first LDS store, so a workgroup pays the memory latency once
+  const uint16_t *ptab = odd ? H : Hinv;
+  for (int q0 = tid; q0 < p.payload; q0 += INNER_NB * INNER_THREADS) {
+    unsigned pk[INNER_NB];                                       // destination | label << 16
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const int q = q0 + k * 256;
-      dst[k] = q; lab[k] = 0;
-      if (q < p.payload) {
-        if (mode & 2) dst[k] = odd ? H[q] : Hinv[q];
-        if (!(mode & 1)) lab[k] = ib[q];
-      }
+    for (int k = 0; k < INNER_NB; k++) {
+      const int q = q0 + k * INNER_THREADS, qc = q < p.payload ? q : p.payload - 1;    // clamped: unconditional loads
+      pk[k] = (mode & 2) ? (unsigned)ptab[qc] : (unsigned)qc;
+      if (!(mode & 1)) pk[k] |= (unsigned)ib[qc] << 16;
     }
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const int q = q0 + k * 256;
+    for (int k = 0; k < INNER_NB; k++) {
+      const int q = q0 + k * INNER_THREADS;
       if (q < p.payload) {
-        if (mode & 1) lab[k] = demap_one(e[q], pts, label_of, p);
-        const int blk = dst[k] / IB, r = dst[k] - blk * IB, at = blk * IBS + r;
-        v[at] = (uint8_t)lab[k];
-        if (r < IBS - IB) v[at + IB] = (uint8_t)lab[k];           // the block's wrap-around tail
-        if (tap_demap && (mode & 1)) tap_demap[(size_t)u * p.payload + q] = (uint8_t)lab[k];
+        const int lab = (mode & 1) ? demap_one(e[q], pts, label_of, p) : (int)(pk[k] >> 16);
+        const int dst = (int)(pk[k] & 0xffffu);
+        const int blk = dst / IB, r = dst - blk * IB, at = blk * IBS + r;
+        v[at] = (uint8_t)lab;
+        if (r < IBS - IB) v[at + IB] = (uint8_t)lab;             // the block's wrap-around tail
+        if (tap_demap && (mode & 1)) tap_demap[(size_t)u * p.payload + q] = (uint8_t)lab;
       }
     }
   }
   __syncthreads();
+  if (dbg & 2) return;
   uint8_t *o = out + (size_t)u * p.payload;
-  if (tap_symdeint) for (int q = tid; q < p.payload; q += 256) tap_symdeint[(size_t)u * p.payload + q] = v[ipos(q)];
-  if (!(mode & 4)) { for (int q = tid; q < p.payload; q += 256) o[q] = v[ipos(q)]; return; }
+  if (tap_symdeint) for (int q = tid; q < p.payload; q += INNER_THREADS) tap_symdeint[(size_t)u * p.payload + q] = v[ipos(q)];
+  if (!(mode & 4)) { for (int q = tid; q < p.payload; q += INNER_THREADS) o[q] = v[ipos(q)]; return; }
   // A6: output byte i of a block, bit k (MSB first) = bit (m-1-e) of input byte (i - off_e) mod 126, e = perm(k).
   // One item = 4 consecutive output bytes: per bit plane one (unaligned) word of the rotated block, masked and
   // shifted into place.
-  const int vb = p.m, hv = vb >> 1;
-  const int nitems = (p.payload / IB) * 32;                    // 32 words cover the 126 bytes of a block
-  for (int it = tid; it < nitems; it += 256) {
-    const int blk = it >> 5, j = it & 31;
-    const unsigned *bw = reinterpret_cast<const unsigned *>(v + blk * IBS);
-    unsigned val = 0;
-    for (int k = 0; k < vb; k++) {
-      const int eidx = k / hv + 2 * (k % hv);                   // d_perm, non-hierarchical (:91-99)
-      const int off = eidx == 0 ? 0 : eidx == 1 ? 63 : eidx == 2 ? 105 : eidx == 3 ? 42 : eidx == 4 ? 21 : 84;
-      int w = 4 * j - off; if (w < 0) w += IB;
-      const unsigned lo = bw[w >> 2], hi = bw[(w >> 2) + 1];
-      const unsigned word = __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(w & 3));
-      val |= ((word >> (vb - 1 - eidx)) & 0x01010101u) << (vb - 1 - k);
-    }
-    uint8_t *dst = o + blk * IB + 4 * j;                        // even address
-    *reinterpret_cast<uint16_t *>(dst) = (uint16_t)val;
-    if (j < 31) *reinterpret_cast<uint16_t *>(dst + 2) = (uint16_t)(val >> 16);
-  }
+  if (p.m == 2) bit_deint_words<2>(v, o, p.payload, tid, dbg);
+  else if (p.m == 4) bit_deint_words<4>(v, o, p.payload, tid, dbg);
+  else bit_deint_words<6>(v, o, p.payload, tid, dbg);
 }
 
 // ---------------------------------------------------------------- sizes derived on the device (no host sync)
