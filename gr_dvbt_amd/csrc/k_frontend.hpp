@@ -493,12 +493,16 @@ __device__ __forceinline__ void fft_dif_lds(float2 *x, int N, const float2 *tw_c
   const float2 w16[10] = {{1.f, 0.f}, {c1, -s1}, {h, -h}, {s1, -c1}, {0.f, -1.f}, {-s1, -c1}, {-h, -h}, {-c1, -s1}, {-1.f, 0.f}, {-c1, s1}};
   int L = N;
   while (L >= 16) {
-    const int Q = L >> 4, tstep = N / L;
+    const int Q = L >> 4, tstep = N / L, nblk = (N >> 4) / Q;
     for (int bf = tid; bf < (N >> 4); bf += FFT_THREADS) {
-      const int r = bf % Q, base = (bf / Q) * L + r;
+      // butterfly bf = (block, r): consecutive lanes take consecutive r (conflict-free LDS columns); when only two r exist
+      // (last radix-16 pass of 8k) consecutive lanes take consecutive blocks instead (stride 33 in the padded image).
+      const int r = Q <= 2 ? bf / nblk : bf % Q, base = (Q <= 2 ? bf % nblk : bf / Q) * L + r;
+      // padded address of element base + j Q: fpad is affine in j here (base % 32 = r < Q for Q < 32, and j Q % 32 = 0 otherwise)
+      const int pb = fpad(base);
       float2 a[16], t[16];
 #pragma unroll
-      for (int j = 0; j < 16; j++) a[j] = x[fpad(base + j * Q)];
+      for (int j = 0; j < 16; j++) a[j] = x[pb + j * Q + ((j * Q) >> 5)];
 #pragma unroll
       for (int rp = 0; rp < 4; rp++) {                          // level 1: span 16
         float2 y0, y1, y2, y3;
@@ -514,15 +518,18 @@ __device__ __forceinline__ void fft_dif_lds(float2 *x, int N, const float2 *tw_c
         bfly4(t[k1 * 4], t[k1 * 4 + 1], t[k1 * 4 + 2], t[k1 * 4 + 3], y0, y1, y2, y3);
         a[k1] = y0; a[k1 + 4] = y1; a[k1 + 8] = y2; a[k1 + 12] = y3;
       }
-      // inter-pass twiddles W^(r k tstep), k = 1..15, as powers of w1 = W^(r tstep) (at most 4 multiplications deep)
-      float2 w[16];
-      w[1] = twid(tw_c, tw_f, r * tstep);
-      w[2] = cmul(w[1], w[1]); w[3] = cmul(w[2], w[1]); w[4] = cmul(w[2], w[2]); w[5] = cmul(w[4], w[1]); w[6] = cmul(w[3], w[3]);
-      w[7] = cmul(w[4], w[3]); w[8] = cmul(w[4], w[4]); w[9] = cmul(w[8], w[1]); w[10] = cmul(w[5], w[5]); w[11] = cmul(w[8], w[3]);
-      w[12] = cmul(w[6], w[6]); w[13] = cmul(w[8], w[5]); w[14] = cmul(w[7], w[7]); w[15] = cmul(w[8], w[7]);
-      x[fpad(base)] = a[0];
+      {
+        // inter-pass twiddles W^(r k tstep), k = 1..15, as powers of w1 = W^(r tstep) (at most 4 multiplications deep)
+        float2 w[16];
+        w[1] = twid(tw_c, tw_f, r * tstep);
+        w[2] = cmul(w[1], w[1]); w[3] = cmul(w[2], w[1]); w[4] = cmul(w[2], w[2]); w[5] = cmul(w[4], w[1]); w[6] = cmul(w[3], w[3]);
+        w[7] = cmul(w[4], w[3]); w[8] = cmul(w[4], w[4]); w[9] = cmul(w[8], w[1]); w[10] = cmul(w[5], w[5]); w[11] = cmul(w[8], w[3]);
+        w[12] = cmul(w[6], w[6]); w[13] = cmul(w[8], w[5]); w[14] = cmul(w[7], w[7]); w[15] = cmul(w[8], w[7]);
 #pragma unroll
-      for (int k = 1; k < 16; k++) x[fpad(base + k * Q)] = cmul(a[k], w[k]);
+        for (int k = 1; k < 16; k++) a[k] = cmul(a[k], w[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < 16; k++) x[pb + k * Q + ((k * Q) >> 5)] = a[k];
     }
     __syncthreads();
     L = Q;
