@@ -36,9 +36,10 @@ __device__ __forceinline__ int demap_all(float2 v, const float2 *pts, int csize)
 // guard magnitude).  So the first strict minimum of the 64-point search (dvbt_demap_impl.cc:167-203) = the smallest
 // label among the minima of {nearest, second nearest} x {nearest, second nearest}, all four computed exactly as the
 // reference computes them.
-__device__ __forceinline__ int demap_one(float2 v, const float2 *pts, const unsigned char *label_of, const InnerParams &p)
+// returns -1 when the sample is outside the range where the 4-candidate argument holds (caller falls back to demap_all)
+__device__ __forceinline__ int demap_fast(float2 v, const float2 *pts, const unsigned char *label_of, const InnerParams &p)
 {
-  if (p.nlev == 0 || !(fabsf(v.x) < p.guard) || !(fabsf(v.y) < p.guard)) return demap_all(v, pts, p.csize);
+  const bool in_range = p.nlev != 0 && fabsf(v.x) < p.guard && fabsf(v.y) < p.guard;
   const int n = p.nlev;
   int ji = (int)floorf(v.x * p.inv_step + 0.5f * (float)n), jq = (int)floorf(v.y * p.inv_step + 0.5f * (float)n);
   ji = ji < 0 ? 0 : ji > n - 1 ? n - 1 : ji; jq = jq < 0 ? 0 : jq > n - 1 ? n - 1 : jq;
@@ -55,7 +56,12 @@ __device__ __forceinline__ int demap_one(float2 v, const float2 *pts, const unsi
   int idx = 255;
   idx = d00 == best ? min(idx, L00) : idx; idx = d01 == best ? min(idx, L01) : idx;
   idx = d10 == best ? min(idx, L10) : idx; idx = d11 == best ? min(idx, L11) : idx;
-  return idx;
+  return in_range ? idx : -1;
+}
+__device__ __forceinline__ int demap_one(float2 v, const float2 *pts, const unsigned char *label_of, const InnerParams &p)
+{
+  const int f = demap_fast(v, pts, label_of, p);
+  return f >= 0 ? f : demap_all(v, pts, p.csize);
 }
 
 // LDS image of a symbol's labels: blocks of 126 bytes (the bit interleaver's block) at a stride of 132, each followed

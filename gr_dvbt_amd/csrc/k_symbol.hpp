@@ -177,13 +177,26 @@ __global__ __launch_bounds__(FFT_THREADS, 4) void derot_fft_demod_kernel(const f
   };
   {
     uint8_t *lab = labels + (size_t)s * p.payload;
+    bool slow = false;
 #pragma unroll
     for (int it = 0; it < PAY_IT; it++) {
       const int i = tid + it * FFT_THREADS;
       if (it < nit && i < p.payload) {
         const float2 e = cmul(X(xb + tc[it]), gain(tl[it], tr[it], td[it]));
         if (eq_tap) eq_tap[(size_t)s * p.payload + i] = e;
-        lab[i] = (uint8_t)demap_one(e, pts, label_of, ip);
+        const int f = demap_fast(e, pts, label_of, ip);
+        slow |= f < 0;
+        lab[i] = (uint8_t)f;
+      }
+    }
+    // samples outside the range of the 4-candidate search (never on a locked signal): the exhaustive search, kept out of
+    // the unrolled loop above; the carrier is simply equalised again
+    if (__any(slow)) {
+      const size_t tb = (size_t)mod * p.payload;
+#pragma unroll 1
+      for (int i = tid; i < p.payload; i += FFT_THREADS) {
+        const float2 e = cmul(X(xb + T.pay_c[tb + i]), gain(T.pay_Li[tb + i], T.pay_Ri[tb + i], T.pay_d[tb + i]));
+        if (demap_fast(e, pts, label_of, ip) < 0) lab[i] = (uint8_t)demap_all(e, pts, ip.csize);
       }
     }
   }

@@ -202,3 +202,35 @@ def test_other_guard_intervals_and_rates(po, g, const, cr, mode, guard):
         a, b = rx.tap(tap).reshape(-1), o[name].reshape(-1)
         assert a.size == b.size > 0 and (a == b).all(), name
     rx.close()
+
+
+def test_out_of_range_carriers_take_the_exhaustive_demap(po, g):
+    """A notched scattered pilot makes the LS gain of its neighbourhood explode: equalised carriers land far outside the
+    range in which the symbol kernel's 4-candidate demapper is valid, so it must hand them to the exhaustive search.
+    Such values are pure rounding noise times 1e7 (the oracle's differ), hence the check is the reference RULE
+    (dvbt_demap_impl.cc:167-203, via the oracle's demapper) applied to the kernel's OWN equalised carriers: every
+    decision of every symbol must match, in and out of range."""
+    import ctypes as C
+    c, iq = _make(po, 1, 0, 0, 3, 31)                                # 2k QAM16 1/2
+    o0 = po.rx(c, iq, want=("demap",))
+    f, sym = o0["first_out_symbol"], 41
+    start = int(o0["cp_start"][f + sym]) + (f + sym) * (c.N + c.cp) - c.N + 1
+    iq = iq.copy()
+    spec = np.fft.fft(iq[start:start + c.N].astype(np.complex128))
+    kk = np.arange(c.N)
+    for carrier in (300, 301, 302, 303, 304, 305, 306, 307, 308, 309, 310, 311):   # one of them is a scattered pilot of this symbol
+        spec[(carrier + c.zeros_left - c.N // 2) % c.N] = 0
+    iq[start:start + c.N] = np.fft.ifft(spec).astype(np.complex64)
+    del kk
+    rx = g.Rx(1, 0, 0, max_samples=len(iq), taps=True)
+    rep = rx.run(iq)
+    assert rep.first_out_symbol == f
+    eq, lab = rx.tap(g.TAP_EQ), rx.tap(g.TAP_DEMAP)
+    assert np.nanmax(np.abs(eq[sym]).astype(np.float64)) > 1e4 or not np.isfinite(eq[sym]).all()   # really out of range
+    pts = np.zeros(c.csize, np.complex64)
+    po.lib().o_constellation(C.byref(c), C.c_float(1.0), pts.ctypes.data_as(C.c_void_p))
+    ref = np.zeros(lab.shape, np.uint8)
+    eqc = np.ascontiguousarray(eq)
+    po.lib().o_demap(C.byref(c), pts.ctypes.data_as(C.c_void_p), eqc.ctypes.data_as(C.c_void_p), ref.ctypes.data_as(C.c_void_p), C.c_size_t(eqc.size))
+    assert (lab == ref).all()
+    rx.close()
