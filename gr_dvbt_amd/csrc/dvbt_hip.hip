@@ -403,12 +403,12 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s)
                      (const float2 *)h->T.tw, (const uint16_t *)h->T.perm, h->acq_tap, h->fft_out, h->T.demod_tables(), h->eq, h->tpsval, h->info,
                      h->T.inner_params(d.payload), (const float2 *)h->T.points, (const unsigned char *)h->T.label_tab, h->labels);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_DEMOD], s));
-  hipLaunchKernelGGL(tps_vote_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float2 *)h->tpsval, d.n_tps, (const RxState *)h->st, 0,
+  hipLaunchKernelGGL(tps_vote_kernel, dim3((C + 63) / 64), dim3(256), 0, s, (const float2 *)h->tpsval, d.n_tps, (const RxState *)h->st, 0,
                      (const float2 *)nullptr, h->maj);
   {   // flags[8] = first superframe-start candidate (min), flags[9] = need_seq for the TPS bookkeeping
     static const int kInit[2] = {0x7fffffff, 0};
     HIPCHK(hipMemcpyAsync(h->trk_flags + 8, kInit, sizeof kInit, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(tps_fsm_par_kernel, dim3((C + 64 * TPS_SEG - 1) / (64 * TPS_SEG)), dim3(64), 0, s, fp, (const RxState *)h->st, (const SymInfo *)h->info,
+    hipLaunchKernelGGL(tps_fsm_par_kernel, dim3((C + TPS_THREADS * TPS_SEG - 1) / (TPS_THREADS * TPS_SEG)), dim3(TPS_THREADS), 0, s, fp, (const RxState *)h->st, (const SymInfo *)h->info,
                        (const int *)h->maj, h->sym_index, h->tps_edges, h->trk_flags + 8);
     hipLaunchKernelGGL(tps_finalize_kernel, dim3(1), dim3(256), 0, s, h->st, (const TpsEdge *)h->tps_edges, (const int *)(h->trk_flags + 8), h->trk_flags + 9);
     hipLaunchKernelGGL(tps_fsm_kernel, dim3(1), dim3(256), 0, s, fp, h->st, 0, (const SymInfo *)h->info, (const int *)h->maj, h->tps_state,

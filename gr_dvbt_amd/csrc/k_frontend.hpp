@@ -172,8 +172,8 @@ __device__ __forceinline__ float wrap_pi(double ph)
 
 // initial acquisition FSM (general_work :498-510).  Two phases per try:
 //  (1) all lanes: the IIR average seen by every sample.  Every sample updates d_avg with the same expression in
-//      every FSM state, so avg_i is a plain recursion over lambda; restarted 48 samples back its older history
-//      weighs 1e-48, i.e. it reproduces the float value (the first 48 samples start from the carried average and
+//      every FSM state, so avg_i is a plain recursion over lambda; restarted 32 samples back its older history
+//      weighs 1e-32, i.e. it reproduces the float value (the first 32 samples start from the carried average and
 //      are exact by construction).  From it the two threshold tests of sample i (rise: > 0.8 avg, keep: > 0.9 avg).
 //  (2) one lane walks the state machine on the precomputed flags; its only remaining recurrence is the running
 //      maximum of the open peak, so a step costs a few cycles instead of a dependent float chain.
@@ -199,15 +199,24 @@ __global__ __launch_bounds__(256) void acq_init_fsm_kernel(FrontParams p, RxStat
   __syncthreads();
   if (s_done == 2) { if (tid == 0) st->avg = s_avg; return; }
   const float rise = 0.8f, fall = 0.9f, alpha = 0.9f;
-  constexpr int HIST = 48;
+  constexpr int HIST = 32;
   for (int t = t_begin; t < tries; t++) {
     for (int i = tid; i < N; i += 256) lam[i] = lambda[(size_t)t * N + i];
     __syncthreads();
     const float avg0 = s_avg;
     for (int i = tid; i <= N; i += 256) {                          // avg before sample i (i == N: the carried value)
-      int j0 = i > HIST ? i - HIST : 0;
-      float avg = i > HIST ? 0.f : avg0;
-      for (int j = j0; j < i; j++) avg = alpha * lam[j] + (1 - alpha) * avg;
+      float avg;
+      if (i > HIST) {                                              // fixed-length history: its LDS reads are issued together
+        float hbuf[HIST];
+#pragma unroll
+        for (int k = 0; k < HIST; k++) hbuf[k] = lam[i - HIST + k];
+        avg = 0.f;
+#pragma unroll
+        for (int k = 0; k < HIST; k++) avg = alpha * hbuf[k] + (1 - alpha) * avg;
+      } else {
+        avg = avg0;
+        for (int j = 0; j < i; j++) avg = alpha * lam[j] + (1 - alpha) * avg;
+      }
       if (i < N) { const float v = lam[i]; flg[i] = (unsigned char)((v > avg * rise ? 1 : 0) | (v > avg * fall ? 2 : 0)); }
       else s_avg = avg;
     }
@@ -757,17 +766,21 @@ __global__ __launch_bounds__(256) void demod_kernel(const float2 *__restrict__ f
 __global__ __launch_bounds__(256) void tps_vote_kernel(const float2 *__restrict__ tpsval, int n_tps, const RxState *st, int nitems_fixed,
                                                       const float2 *__restrict__ prev0, int *__restrict__ maj)
 {
-  int s = blockIdx.x * 256 + threadIdx.x;
-  int nsym = st ? st->n_symbols : nitems_fixed;
-  if (s + 1 >= nsym) return;
+  // four lanes per symbol, each a quarter of the TPS carriers
+  const int s = blockIdx.x * 64 + (threadIdx.x >> 2), part = threadIdx.x & 3;
+  const int nsym = st ? st->n_symbols : nitems_fixed;
+  const bool act = s + 1 < nsym;
+  const int per = (n_tps + 3) / 4, k0 = part * per, k1 = k0 + per < n_tps ? k0 + per : n_tps;
   int m = 0;
-  for (int k = 0; k < n_tps; k++) {
-    float2 v = tpsval[(size_t)s * n_tps + k];
-    float2 pv = s > 0 ? tpsval[(size_t)(s - 1) * n_tps + k] : (prev0 ? prev0[k] : make_float2(0.f, 0.f));
-    float re = v.x * pv.x + v.y * pv.y;
-    m += (re >= 0.0f) ? 1 : -1;
-  }
-  maj[s] = m;
+  if (act)
+    for (int k = k0; k < k1; k++) {
+      const float2 v = tpsval[(size_t)s * n_tps + k];
+      const float2 pv = s > 0 ? tpsval[(size_t)(s - 1) * n_tps + k] : (prev0 ? prev0[k] : make_float2(0.f, 0.f));
+      const float re = v.x * pv.x + v.y * pv.y;
+      m += (re >= 0.0f) ? 1 : -1;
+    }
+  m += __shfl_xor(m, 1); m += __shfl_xor(m, 2);
+  if (act && part == 0) maj[s] = m;
 }
 
 // persistent TPS / frame-sync state (pilot_gen members + demod block members)
@@ -878,7 +891,8 @@ __global__ __launch_bounds__(256) void tps_fsm_kernel(FrontParams p, RxState *st
 // a frame end with an intact TPS word lies in the warm-up.  Every lane records its state at the
 // start and at the end of its segment; tps_finalize_kernel checks that neighbours agree and
 // otherwise requests the sequential kernel (need_seq), so the result is always the sequential one.
-constexpr int TPS_SEG = 128;          // symbols per lane
+constexpr int TPS_SEG = 32;           // symbols per lane
+constexpr int TPS_THREADS = 256;      // lanes per workgroup (a workgroup covers TPS_THREADS * TPS_SEG symbols)
 constexpr int TPS_WARM = 204;         // three frames
 struct TpsEdge { TpsState start, end; };
 
@@ -939,24 +953,30 @@ __device__ __forceinline__ void tps_advance(TpsState &t, int mod, int majv, int 
   cand = (si == 0) && ((fi & 3) == fi_start);
 }
 
-__global__ __launch_bounds__(64) void tps_fsm_par_kernel(FrontParams p, const RxState *st, const SymInfo *__restrict__ info, const int *__restrict__ maj,
-                                                        int *__restrict__ sym_index, TpsEdge *__restrict__ edges, int *first_cand)
+__global__ __launch_bounds__(TPS_THREADS) void tps_fsm_par_kernel(FrontParams p, const RxState *st, const SymInfo *__restrict__ info, const int *__restrict__ maj,
+                                                                 int *__restrict__ sym_index, TpsEdge *__restrict__ edges, int *first_cand)
 {
-  // symbol streams in LDS; 4 bytes of padding per 128 entries keep the lanes (128 symbols apart) on distinct banks
-  constexpr int NS = 64 * TPS_SEG + TPS_WARM;
-  __shared__ signed char s_mod[NS + (NS >> 7) * 4 + 4];
-  __shared__ short s_maj[NS + (NS >> 7) * 2 + 2];
+  // symbol streams in LDS; padding per TPS_SEG entries keeps the lanes (TPS_SEG symbols apart) on distinct banks
+  constexpr int NS = TPS_THREADS * TPS_SEG + TPS_WARM;
+  __shared__ signed char s_mod[NS + (NS / TPS_SEG) * 4 + 4];
+  __shared__ short s_maj[NS + (NS / TPS_SEG) * 2 + 2];
   __shared__ unsigned short s_T[7 * 256], s_R[56];
-  auto pm = [](int i) { return i + (i >> 7) * 4; };
-  auto pj = [](int i) { return i + (i >> 7) * 2; };
+  auto pm = [](int i) { return i + (i / TPS_SEG) * 4; };
+  auto pj = [](int i) { return i + (i / TPS_SEG) * 2; };
   const int tid = threadIdx.x;
   const int nsym = st->n_symbols, ntot = nsym > 0 ? nsym - 1 : 0;
-  const int blk0 = blockIdx.x * 64 * TPS_SEG;
+  const int blk0 = blockIdx.x * TPS_THREADS * TPS_SEG;
   if (blk0 >= ntot) return;
   const int lo = blk0 - TPS_WARM < 0 ? 0 : blk0 - TPS_WARM;
-  const int hi = blk0 + 64 * TPS_SEG < ntot ? blk0 + 64 * TPS_SEG : ntot;
-  for (int i = lo + tid; i < hi; i += 64) { s_mod[pm(i - lo)] = (signed char)info[i].mod_index; s_maj[pj(i - lo)] = (short)maj[i]; }
-  tps_bch_table(s_T, s_R, tid, 64);
+  const int hi = blk0 + TPS_THREADS * TPS_SEG < ntot ? blk0 + TPS_THREADS * TPS_SEG : ntot;
+  for (int i0 = lo + tid; i0 < hi; i0 += 8 * TPS_THREADS) {       // 8 symbols per lane in flight (clamped, unconditional loads)
+    int mv[8], jv[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const int i = i0 + k * TPS_THREADS, ic = i < hi ? i : hi - 1; mv[k] = info[ic].mod_index; jv[k] = maj[ic]; }
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const int i = i0 + k * TPS_THREADS; if (i < hi) { s_mod[pm(i - lo)] = (signed char)mv[k]; s_maj[pj(i - lo)] = (short)jv[k]; } }
+  }
+  tps_bch_table(s_T, s_R, tid, TPS_THREADS);
   unsigned mask_even = 0, mask_odd = 0;
   {
     const unsigned char se[15] = {0, 0, 1, 1, 0, 1, 0, 1, 1, 1, 1, 0, 1, 1, 1};
