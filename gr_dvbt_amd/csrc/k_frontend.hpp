@@ -393,11 +393,24 @@ __global__ __launch_bounds__(1024) void acq_finalize_kernel(FrontParams p, RxSta
   if (tid == 0) { *need_seq = 0; s_first_bad = p.ncalls - st->call0; s_viol = 0; }
   __syncthreads();
   const int ntot = p.ncalls - st->call0, N = p.N, cpl = p.cp, c0 = st->cp_start0;
-  for (int s = tid; s < ntot; s += 1024) if (cp[s] < 0) atomicMin(&s_first_bad, s);
+  // first call without a peak; 8 clamped loads per lane in flight
+  for (int s0 = tid; s0 < ntot; s0 += 8 * 1024) {
+    int cv[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const int s = s0 + k * 1024; cv[k] = cp[s < ntot ? s : ntot - 1]; }
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const int s = s0 + k * 1024; if (s < ntot && cv[k] < 0) atomicMin(&s_first_bad, s); }
+  }
   __syncthreads();
   const int nsym = s_first_bad;
   // the closed form below needs every phase-increment switch to fall inside its call
-  for (int s = tid; s < nsym; s += 1024) { int sw = (s == 0 ? c0 : cp[s - 1]) - (N + cpl); if (sw < 0 || sw >= N + cpl) s_viol = 1; }
+  for (int s0 = tid; s0 < nsym; s0 += 8 * 1024) {
+    int cv[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const int s = s0 + k * 1024; cv[k] = (s == 0 || s >= nsym) ? c0 : cp[s - 1]; }
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const int s = s0 + k * 1024; const int sw = cv[k] - (N + cpl); if (s < nsym && (sw < 0 || sw >= N + cpl)) s_viol = 1; }
+  }
   __syncthreads();
   if (s_viol) { if (tid == 0) *need_seq = 1; return; }
   // per-call quantities: entering call s: nextpos = cp[s-1]-(N+cp), incB = -eps[s-1]/N, incA = -eps[s-2]/N
@@ -937,9 +950,10 @@ __device__ __forceinline__ void tps_advance(TpsState &t, int mod, int majv, int 
   const int si = t.symbol_index, fi = t.frame_index;
   const int use = (!t.symbol_index_known || t.symbol_index != 0);
   const unsigned bitv = use ? (majv >= 0 ? 0u : 1u) : 0u;
-  for (int k = 0; k < diff; k++) {
-    t.fifo_lo = (t.fifo_lo >> 1) | ((unsigned long long)(t.fifo_hi & 1u) << 63);
-    t.fifo_hi = (t.fifo_hi >> 1) | (bitv << 3);
+  // `diff` shifts of the 68-bit FIFO, each inserting bitv at the top (process_tps_data :952-960), in closed form
+  if (diff) {
+    t.fifo_lo = (t.fifo_lo >> diff) | ((unsigned long long)t.fifo_hi << (64 - diff));
+    t.fifo_hi = (t.fifo_hi >> diff) | (bitv ? (((1u << diff) - 1u) << (4 - diff)) : 0u);
   }
   const unsigned low16 = (unsigned)(t.fifo_lo & 0xFFFEull);
   if (low16 == mask_even || low16 == mask_odd) {
@@ -988,6 +1002,7 @@ __global__ __launch_bounds__(TPS_THREADS) void tps_fsm_par_kernel(FrontParams p,
   int sw = s0 - TPS_WARM; if (sw < 0) sw = 0;
   TpsState t; t.fifo_lo = 0; t.fifo_hi = 0; t.symbol_index = 0; t.symbol_index_known = 0; t.frame_index = 0; t.prev_mod = 0; t.d_init = 0;
   int si, cand;
+#pragma unroll 4
   for (int s = sw; s < s0; s++) tps_advance(t, s_mod[pm(s - lo)], s_maj[pj(s - lo)], p.fi_start, mask_even, mask_odd, si, cand, s_T);
   const int seg = s0 / TPS_SEG;
   edges[seg].start = t;
