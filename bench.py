@@ -107,6 +107,12 @@ def main():
     ap.add_argument("--cpu-superframes", type=int, default=3)
     a = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON of rank 0): libraries that print banners to the C-level stdout (RCCL does at the
+    # first collective) are sent to stderr by swapping file descriptor 1; the JSON goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import gr_dvbt_amd as g
 
@@ -137,24 +143,43 @@ def main():
     rx = segs[0]["rx"]
     ts_cap = int(nsamp * 0.45) + 4096
     ts_views = [torch.as_tensor(_DevView(sg["rx"].tap_device_ptr(g.TAP_TS), int(sg["n"] * 0.45) + 4096), device=f"cuda:{local}") for sg in segs]
-    ts_send = torch.zeros(ts_cap, dtype=torch.uint8, device=f"cuda:{local}") if dist else None
-    gathered = [torch.empty(ts_cap, dtype=torch.uint8, device=f"cuda:{local}") for _ in range(world)] if (dist and rank == 0) else None
+    # the single exchange step: TS packets -> rank 0 over xGMI.  Double buffered and asynchronous: the gather of
+    # step k travels while step k+1 decodes; every gather is complete before the closing barrier of the timed region.
+    ts_send = [torch.zeros(ts_cap, dtype=torch.uint8, device=f"cuda:{local}") for _ in range(2)] if dist else None
+    gathered = [[torch.empty(ts_cap, dtype=torch.uint8, device=f"cuda:{local}") for _ in range(world)] for _ in range(2)] if (dist and rank == 0) else [None, None]
+    pending = [None, None]
+    nstep = [0]
 
     def step():
         for sg in segs:
             sg["rx"].enqueue_device(sg["iq"].data_ptr(), sg["n"], sg["stream"].cuda_stream)
         reps = [sg["rx"].finish() for sg in segs]
-        if dist:                                   # the single exchange step: TS packets -> rank 0 over xGMI
+        if dist:
+            b = nstep[0] & 1
+            if pending[b] is not None:
+                pending[b].wait()                  # the buffer pair of two steps ago is free again
             off = 0
             for v, r in zip(ts_views, reps):
                 n = int(r.n_ts_bytes)
-                ts_send[off:off + n].copy_(v[:n])
+                ts_send[b][off:off + n].copy_(v[:n])
                 off += n
-            dist.gather(ts_send, gathered, dst=0)
+            ev = torch.cuda.Event(); ev.record()   # the next decode may overwrite the TS buffers only after these copies
+            for sg in segs:
+                sg["stream"].wait_event(ev)
+            pending[b] = dist.gather(ts_send[b], gathered[b], dst=0, async_op=True)
+            nstep[0] += 1
         return reps
+
+    def drain():
+        if dist:
+            for b in range(2):
+                if pending[b] is not None:
+                    pending[b].wait(); pending[b] = None
+            torch.cuda.synchronize()
 
     for _ in range(a.warmup):
         reps = step()
+    drain()
     for sg in segs:
         sg["rx"].enable_timing(True)
     torch.cuda.synchronize()
@@ -164,6 +189,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         reps = step()
+    drain()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -211,7 +237,7 @@ def main():
         }
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_superframes)
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     for sg in segs:
         sg["rx"].close()
     if dist:
