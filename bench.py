@@ -103,6 +103,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--segments", type=int, default=1,
                     help="independent baseband segments per GPU per step, each on its own HIP stream (each gets its own lead-in superframe)")
+    ap.add_argument("--from-file-rate", action="store_true",
+                    help="feed the 10 Msps file format: rational_resampler 64/70 + multiply_const run on the device in front of the chain "
+                         "(SURVEY 8f row 2; samples are then counted at the 10 Msps input)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-superframes", type=int, default=3)
     a = ap.parse_args()
@@ -135,8 +138,14 @@ def main():
     segs = []
     for i, nsf in enumerate(per):
         (const, cr, mode), c, iq = make_input(a.workload, nsf, 20240607 + 100 * rank + i)
+        rs_kw = {}
+        if a.from_file_rate:
+            from oracle import pyoracle as po
+            rx_const = 0.0022097087 if mode == po.T2k else 0.00055242272       # blocks_multiply_const_vxx_0 of the RX flowgraph
+            iq = po.resample(iq / np.float32(rx_const), 70, 64, 1.0)            # what dvbt_tx_demo writes: the 10 Msps stream
+            rs_kw = {"resample": (64, 70), "front_scale": rx_const}
         d_iq = torch.from_numpy(iq.view(np.float32)).cuda()
-        rxi = g.Rx(const, cr, mode, max_samples=len(iq), device=local, viterbi_chunk_bytes=a.chunk)
+        rxi = g.Rx(const, cr, mode, max_samples=len(iq), device=local, viterbi_chunk_bytes=a.chunk, **rs_kw)
         segs.append({"iq": d_iq, "n": len(iq), "rx": rxi, "stream": torch.cuda.Stream()})
     nsamp = sum(sg["n"] for sg in segs)
     torch.cuda.synchronize()                       # uploads done before any segment stream reads them
@@ -225,7 +234,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 (Viterbi/RS) + f32 (front end)",
             "data": "synthetic", "x_realtime": round(msps / REALTIME_MSPS / world, 1),
-            "config": {"workload": f"{a.workload} GI 1/32 RX chain, clean TX->RX loopback", "superframes_per_gpu": a.superframes + nseg, "segments_per_gpu": nseg,
+            "config": {"workload": f"{a.workload} GI 1/32 RX chain, clean TX->RX loopback" + (", input at the 10 Msps file rate (resampler 64/70 + scale on the device)" if a.from_file_rate else ""), "superframes_per_gpu": a.superframes + nseg, "segments_per_gpu": nseg,
                        "samples_per_gpu_per_step": nsamp, "parallelism": f"segments x{world}" + (" + RCCL gather of TS" if world > 1 else ""),
                        "ts_bytes_per_step": n_ts, "status": [int(r.status) for r in reps], "rs_fail_words": [int(r.rs_fail_words) for r in reps]},
             "roofline": {"bound": "hbm", "kernel": "viterbi3_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
