@@ -51,7 +51,7 @@ struct V3Lane {
   unsigned sel[6][2];   // v_perm selectors: [0, d(class of lo cell), 0, d(class of hi cell)] out of the step word
   int abit[4];          // logical lane bits a0..a3 at the bias position of both halves
   int kc[3][2];         // 63 - state of the two cells at window ends (phase 0,2,4)
-  int org[2];           // (storage index << 2) of the two cells, at the path-byte position
+  int org[2];           // storage index of the two cells, at the path-byte position (bits 5:0)
   int b2[3][2];         // top two bits of the cells' states at phases 0,2,4
   int hi_bias;          // 0x01000000: bias of the upper half
   int nb2[3][2];        // bias of phase 0,2,4 | b2 of that phase   (6th step of a window)
@@ -83,9 +83,9 @@ __device__ inline void v3_init_lane(int pl, V3Lane &L)
     for (int e = 0; e < 3; e++) {
       const int s0 = rotl6((r << 5) | a, 2 * e), s1 = rotl6((r << 5) | 16 | a, 2 * e);
       L.kc[e][r] = (63 - s0) | ((63 - s1) << 16);
-      L.b2[e][r] = (s0 >> 4) | ((s1 >> 4) << 16);
+      L.b2[e][r] = ((s0 >> 4) << 6) | (((s1 >> 4) << 6) << 16);   // at bits 7:6 of the path byte
     }
-    L.org[r] = ((pl * 4 + 2 * r) << 2) | (((pl * 4 + 2 * r + 1) << 2) << 16);
+    L.org[r] = (pl * 4 + 2 * r) | ((pl * 4 + 2 * r + 1) << 16);     // bits 5:0 of the path byte
     for (int e = 0; e < 3; e++) {
       const int nb = e == 0 ? (r ? 0x01000100 : 0) : e == 1 ? L.abit[3] : L.abit[1];   // bias when the phase is 0, 2, 4
       L.nb2[e][r] = nb | L.b2[e][r]; L.nbo[e][r] = nb | L.org[r];
@@ -121,7 +121,7 @@ template <int P, int ST> __device__ __forceinline__ void v3_step(int (&v)[2], un
 #pragma unroll
   for (int r = 0; r < 2; r++) {
     const int mx = pk_max(X[r], Yp[r]);
-    if (ST == 1) v[r] = (mx & (int)0xfefcfefc) | L.nb2[PN / 2][r];
+    if (ST == 1) v[r] = (mx & (int)0xfe3ffe3f) | L.nb2[PN / 2][r];
     else if (ST == 2) { raw[r] = mx; v[r] = (mx & (int)0xfe00fe00) | L.nbo[PN / 2][r]; }
     else if (PN == 0) v[r] = r ? (mx | 0x01000100) : (mx & (int)0xfefffeff);      // VGPR 1 holds the upper states
     else {
@@ -154,11 +154,11 @@ template <int PE, bool RENORM> __device__ __forceinline__ int v3_window_end(int 
   int k = max(lo16(kp), hi16(kp));
   k = max_dpp<DPP_XOR1>(k); k = max_dpp<DPP_XOR2>(k); k = max_dpp<DPP_HALF_MIRROR>(k); k = max_dpp<DPP_MIRROR>(k);
   if (RENORM) {
-    const int mp = pk_min(v[0], v[1]);
-    int mn = min(lo16(mp), hi16(mp));                              // ordering is decided by the metric field
-    mn = min_dpp<DPP_XOR1>(mn); mn = min_dpp<DPP_XOR2>(mn); mn = min_dpp<DPP_HALF_MIRROR>(mn); mn = min_dpp<DPP_MIRROR>(mn);
-    mn &= 0xfe00;                                                  // metric without bias, path byte cleared
-    mn |= mn << 16;
+    // any offset common to the 64 metrics will do (the reference subtracts the minimum, d_viterbi.c:728-732, only to keep
+    // its 8-bit metrics from wrapping): the maximum is already here, so the best metric is set to 2*24 -- the spread is
+    // at most 49, so the field restarts inside [-1, 49] and drifts by at most +-64 until the next renormalisation
+    const unsigned sub = (unsigned)(((k >> 6) - 24) << 9);           // 2 * (M_best - 24) at the metric position, bias and path byte untouched
+    const int mn = (int)__builtin_amdgcn_perm(sub, sub, 0x01000100u);
     v[0] = pk_sub(v[0], mn); v[1] = pk_sub(v[1], mn);
   }
   return 63 - (k & 63);
@@ -167,29 +167,32 @@ template <int PE, bool RENORM> __device__ __forceinline__ int v3_window_end(int 
 // Two traceback chains per lane: the calls (windows) pl and 16+pl of one block of a decoder.
 struct V3Trace {
   int z[2];             // current cell (storage index)
-  int wsh[2];           // (window whose table is read next) << 8
+  int wsh[2];           // ring row of the window whose table is read next (<< 8) | decoder row
+  int wlast[2];         // the window a chain ends in (relative index)
   bool ok[2];
   long long ob[2];      // output byte of the call
 };
-// one hop of both chains: state = path_byte >> 2 (d_viterbi.c:717)
+// one hop of both chains: state = path_byte >> 2 in the reference's layout (d_viterbi.c:717) = the low six bits here.
+// wa = ring row of the window to read | decoder row; the v_and_or that extracts the origin also forms the address.
 __device__ __forceinline__ void v3_hop(V3Trace &T, const unsigned char *tab, int rowc)
 {
 #pragma unroll
   for (int q = 0; q < 2; q++) {
-    const unsigned t = tab[(T.wsh[q] & 0x3f00) | rowc | T.z[q]];
-    T.z[q] = (int)(t >> 2);
-    T.wsh[q] -= 256;
+    const unsigned t = tab[T.z[q]];                                  // z holds the full LDS index
+    T.wsh[q] = ((T.wsh[q] - 256) & 0x3f00) | rowc;
+    T.z[q] = (int)((t & 63u) | (unsigned)T.wsh[q]);
   }
 }
-// the decoded byte of a call: (state at the start of the last window of the chain) << 2 | its two oldest inputs
+// the decoded byte of a call: (state at the start of the last window of the chain) << 2 | its two oldest inputs.
+// w = that window (relative index, for its phase)
 __device__ __forceinline__ void v3_trace_out(const V3Trace &T, const unsigned char *tab, int rowc, uint8_t *out, long long out_lo)
 {
 #pragma unroll
   for (int q = 0; q < 2; q++) {
-    const unsigned t = tab[(T.wsh[q] & 0x3f00) | rowc | T.z[q]];
-    const int w = T.wsh[q] >> 8;
-    const int sstart = rotl6(v3_cell_of_z((int)(t >> 2)), 2 * (((w % 3) + 3) % 3));    // phase of window w = (8w) % 6
-    if (T.ok[q]) out[T.ob[q] - out_lo] = (unsigned char)((sstart << 2) | (t & 3u));
+    const unsigned t = tab[T.z[q]];
+    const int w = T.wlast[q];
+    const int sstart = rotl6(v3_cell_of_z((int)(t & 63u)), 2 * (((w % 3) + 3) % 3));    // phase of window w = (8w) % 6
+    if (T.ok[q]) out[T.ob[q] - out_lo] = (unsigned char)((sstart << 2) | (t >> 6));
   }
 }
 
@@ -352,8 +355,9 @@ template <int NTB> __global__ __launch_bounds__(64) void viterbi3_kernel(const u
       T.ok[c] = (c * 16 + pl < V3_BLK) && dec_active && jj >= warm + ntb - 1 && T.ob[c] < b1;
       if (!T.ok[c]) jj = jp;                                       // any window inside the ring: result unused
       const int sb = bests[dd * V3_RINGW + (jj & (V3_RINGW - 1))];
-      T.z[c] = v3_z_of_cell(((sb | (sb << 6)) >> ((8 * jj + 8) % 6)) & 63);   // cell = rotr6(state, phase after the window)
-      T.wsh[c] = jj << 8;
+      T.wsh[c] = ((jj << 8) & 0x3f00) | (dd * 64);
+      T.z[c] = v3_z_of_cell(((sb | (sb << 6)) >> ((8 * jj + 8) % 6)) & 63) | T.wsh[c];   // cell = rotr6(state, phase after the window)
+      T.wlast[c] = jj - (ntb - 1);
     }
   };
 
