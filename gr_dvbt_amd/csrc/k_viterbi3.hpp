@@ -146,22 +146,23 @@ template <int CTRL> __device__ __forceinline__ int max_dpp(int v) { return max(v
 template <int CTRL> __device__ __forceinline__ int min_dpp(int v) { return min(v, dppb<CTRL>(v)); }
 
 // end of a window: best state = first index of the maximum metric (d_viterbi.c:699-711) and, when asked, the
-// min-renormalisation.  PE = phase after the window.  Returns the best STATE in every lane of the row.
+// renormalisation.  PE = phase after the window.  Key of a cell = (2M + bias ^ 1) << 8 | 63 - state: among equal M the
+// cells holding a lower state (bias 0) win over the upper ones, then the smaller state; one v_xor + v_and_or per VGPR.
+// Returns the key's low byte (63 - best state in bits 5:0) in every lane of the row.
 template <int PE, bool RENORM> __device__ __forceinline__ int v3_window_end(int (&v)[2], const V3Lane &L)
 {
-  const v3pk sixty4 = {64, 64};
-  const int kp = pk_max(ipk((pk(v[0]) >> 9) * sixty4 + pk(L.kc[PE / 2][0])), ipk((pk(v[1]) >> 9) * sixty4 + pk(L.kc[PE / 2][1])));
+  const int kp = pk_max(((v[0] ^ 0x01000100) & (int)0xff00ff00) | L.kc[PE / 2][0], ((v[1] ^ 0x01000100) & (int)0xff00ff00) | L.kc[PE / 2][1]);
   int k = max(lo16(kp), hi16(kp));
   k = max_dpp<DPP_XOR1>(k); k = max_dpp<DPP_XOR2>(k); k = max_dpp<DPP_HALF_MIRROR>(k); k = max_dpp<DPP_MIRROR>(k);
   if (RENORM) {
     // any offset common to the 64 metrics will do (the reference subtracts the minimum, d_viterbi.c:728-732, only to keep
     // its 8-bit metrics from wrapping): the maximum is already here, so the best metric is set to 2*24 -- the spread is
     // at most 49, so the field restarts inside [-1, 49] and drifts by at most +-64 until the next renormalisation
-    const unsigned sub = (unsigned)(((k >> 6) - 24) << 9);           // 2 * (M_best - 24) at the metric position, bias and path byte untouched
+    const unsigned sub = (unsigned)((k & ~0x1ff) - (48 << 8));        // (2 M_best - 48) at the metric position; bias and path byte untouched
     const int mn = (int)__builtin_amdgcn_perm(sub, sub, 0x01000100u);
     v[0] = pk_sub(v[0], mn); v[1] = pk_sub(v[1], mn);
   }
-  return 63 - (k & 63);
+  return k;
 }
 
 // Two traceback chains per lane: the calls (windows) pl and 16+pl of one block of a decoder.
@@ -219,7 +220,7 @@ template <int V6, bool HOPS, int HOP0, int NTB> __device__ __forceinline__ void 
   // the four path bytes of this lane's cells = one word of the table (storage index z = 4*lane + 2r + h)
   *reinterpret_cast<unsigned *>(tab + (jr * 4 + dd) * 64 + pl * 4) = __builtin_amdgcn_perm((unsigned)raw[1], (unsigned)raw[0], 0x06040200u);
   const int s = v3_window_end<(P0 + 2) % 6, (V6 & 1) == 1>(v, L);
-  bests[dd * V3_RINGW + jr] = (unsigned char)s;                    // all 16 lanes of the row write the same byte
+  bests[dd * V3_RINGW + jr] = (unsigned char)s;                    // low byte of the key (63 - best state in bits 5:0); all 16 lanes of the row write the same byte
 }
 template <bool HOPS, int HOP0, int NTB> __device__ __forceinline__ void v3_fwd_six(int (&v)[2], const V3Lane &L, const unsigned *wrow, unsigned char *tab,
                                                                                   unsigned char *bests, int j0, int dd, int pl, V3Trace &T)
@@ -354,7 +355,7 @@ template <int NTB> __global__ __launch_bounds__(64) void viterbi3_kernel(const u
       T.ob[c] = b0 + (jj - (warm + ntb - 1));
       T.ok[c] = (c * 16 + pl < V3_BLK) && dec_active && jj >= warm + ntb - 1 && T.ob[c] < b1;
       if (!T.ok[c]) jj = jp;                                       // any window inside the ring: result unused
-      const int sb = bests[dd * V3_RINGW + (jj & (V3_RINGW - 1))];
+      const int sb = 63 - (bests[dd * V3_RINGW + (jj & (V3_RINGW - 1))] & 63);
       T.wsh[c] = ((jj << 8) & 0x3f00) | (dd * 64);
       T.z[c] = v3_z_of_cell(((sb | (sb << 6)) >> ((8 * jj + 8) % 6)) & 63) | T.wsh[c];   // cell = rotr6(state, phase after the window)
       T.wlast[c] = jj - (ntb - 1);
