@@ -223,10 +223,15 @@ def main():
         # HBM bytes of that kernel from the committed rocprofv3 PMC passes (tools/pmc.sh; FETCH_SIZE doubled per the
         # gfx950 note in MI355X_MICROARCH.md), scaled per algorithmic byte of the profiled launch
         traffic = None
+        valu_frac = None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary_8k_qam64_7_8_65sf.json")))
             if a.workload == "8k_qam64_7_8":
-                traffic = int(pm["kernels"]["viterbi3_kernel"]["hbm_bytes_corrected"] / pm["viterbi_algorithmic_bytes"] * alg_bytes)
+                kv = pm["kernels"]["viterbi3_kernel"]
+                traffic = int(kv["hbm_bytes_corrected"] / pm["viterbi_algorithmic_bytes"] * alg_bytes)
+                # what actually bounds the kernel: VALU issue slots used = wavefront VALU instructions x 4 cycles / (1024 SIMDs x
+                # kernel cycles); GRBM_GUI_ACTIVE sums the 8 XCDs (same committed PMC passes)
+                valu_frac = round(kv["SQ_INSTS_VALU"] * 4 / 1024 / (kv["GRBM_GUI_ACTIVE"] / 8), 3)
         except Exception:
             traffic = None
         out = {
@@ -238,7 +243,7 @@ def main():
                        "samples_per_gpu_per_step": nsamp, "parallelism": f"segments x{world}" + (" + RCCL gather of TS" if world > 1 else ""),
                        "ts_bytes_per_step": n_ts, "status": [int(r.status) for r in reps], "rs_fail_words": [int(r.rs_fail_words) for r in reps]},
             "roofline": {"bound": "hbm", "kernel": "viterbi3_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "valu_issue_frac": valu_frac,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(vit_ms, 4),
                          "chain_frac": round(msps / world * 1e6 * (8 + n_ts / nsamp) / 1e9 / HBM_PEAK_GBS, 6),
                          "hbm_copy_gbs": hbm_copy_gbs(torch, f"cuda:{local}")},
