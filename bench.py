@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="8k_qam64_7_8")
-    ap.add_argument("--superframes", type=int, default=64, help="payload superframes per GPU per step")
+    ap.add_argument("--superframes", type=int, default=64, help="payload superframes per GPU per step (SURVEY 8d: >= 64 for throughput runs)")
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--segments", type=int, default=1,
                     help="independent baseband segments per GPU per step, each on its own HIP stream (each gets its own lead-in superframe)")
