@@ -313,3 +313,24 @@ def test_demod_block_streaming(po, g):
     si = [t[2] for t in all_tags if t[1] == g.TAG_SYMBOL_INDEX]
     assert si[:n] == list(o["sym_index"][fo:fo + n])
     b.close()
+
+
+def test_cpp_host_mirror_example(po, g, tmp_path):
+    """gr_dvbt_amd/host/rx_flowgraph_example: the back half of apps/dvbt_rx_demo.grc written against the C++ mirror of the
+    gr::dvbt block classes (same make() calls and general_work contract), fed with the oracle's bit-de-interleaver output."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gr_dvbt_amd", "host", "rx_flowgraph_example")
+    if not os.path.exists(exe):
+        subprocess.check_call(["bash", os.path.join(os.path.dirname(exe), "build.sh")], stdout=subprocess.DEVNULL)
+    c = po.cfg(po.QAM16, po.C1_2, po.T2k)
+    ts = po.make_ts(504 * 3, 9)
+    iq = po.tx(c, ts, lead_in=500, tail=3 * c.N)
+    o = po.rx(c, iq, want=("bitdeint", "ts"))
+    fin, fout = tmp_path / "bitdeint.bin", tmp_path / "out.ts"
+    o["bitdeint"].tofile(fin)
+    subprocess.check_call([exe, str(fin), str(fout)], stdout=subprocess.DEVNULL)
+    got = np.fromfile(fout, np.uint8)
+    n = min(len(got), len(o["ts"]))
+    assert n > 100000 and abs(len(got) - len(o["ts"])) <= 4 * 1504
+    assert (got[:n] == o["ts"][:n]).all()
