@@ -81,47 +81,70 @@ __global__ __launch_bounds__(256) void acq_metric_kernel(const float2 *__restric
   lambda[oidx] = sqrtf(gr * gr + gi * gi) - phi * p.half_rho;
 }
 
-// tracking metric (mode 1 of acq_metric_kernel) with the samples staged through LDS: a workgroup owns 8 calls x 32
-// lags; per tile of 256 correlation taps it loads the 287 samples (and their partners N earlier) each call needs,
-// once and coalesced, instead of every thread walking its own 256 samples through L1.  The sums run over j in the
-// same order with the same expressions, so gamma/lambda are bit-identical to acq_metric_kernel.
-constexpr int ACQ_TM_CALLS = 8, ACQ_TM_SPAN = 256 + 2 * ACQ_R - 1;
+// tracking metric (mode 1 of acq_metric_kernel) with the samples staged through LDS and register blocking: a workgroup
+// owns 32 calls x 32 lags; a thread owns 4 consecutive lags of a call.  Per tile of 64 correlation taps the workgroup
+// loads the 95 samples (and their partners N earlier) each call needs, once and coalesced; a thread then walks the tile's
+// samples downwards: sample i is tap (q + 63 - i) of lag q, so every sample is read once per thread and feeds up to 4
+// lags, each lag still seeing its taps in ascending order.  The sums use the same expressions in the same order as
+// acq_metric_kernel, so gamma/lambda are bit-identical.
+constexpr int ACQ_TM_CALLS = 32, ACQ_TM_TILE = 64, ACQ_TM_SPAN = ACQ_TM_TILE + 2 * ACQ_R - 1;
 __global__ __launch_bounds__(256) void acq_track_metric_kernel(const float2 *__restrict__ iq, FrontParams p, const RxState *st,
                                                               float2 *__restrict__ gamma, float *__restrict__ lambda)
 {
   __shared__ float2 sA[ACQ_TM_CALLS][ACQ_TM_SPAN], sB[ACQ_TM_CALLS][ACQ_TM_SPAN];
   if (st->status & 1) return;
-  const int N = p.N, cp = p.cp, tid = threadIdx.x, c = tid >> 5, q = tid & 31;
+  const int N = p.N, cp = p.cp, tid = threadIdx.x, c = tid >> 3, g4 = (tid & 7) * 4;
   const int call0 = blockIdx.x * ACQ_TM_CALLS, call = call0 + c;
   const int lag0 = st->cp_start0 - p.R;
   if (call0 + ACQ_TM_CALLS <= st->call0 || call0 >= p.ncalls) return;
   const bool active = call < p.ncalls && call >= st->call0;
-  float gr = 0.f, gi = 0.f, phi = 0.f;
-  for (int j0 = 0; j0 < cp; j0 += 256) {
-    const int jn = cp - j0 < 256 ? cp - j0 : 256;
+  float gr[4] = {0.f, 0.f, 0.f, 0.f}, gi[4] = {0.f, 0.f, 0.f, 0.f}, phi[4] = {0.f, 0.f, 0.f, 0.f};
+  constexpr int T = ACQ_TM_TILE;
+  for (int j0 = 0; j0 < cp; j0 += T) {
+    const int jn = cp - j0 < T ? cp - j0 : T;
     __syncthreads();
-    for (int e = tid; e < ACQ_TM_CALLS * ACQ_TM_SPAN; e += 256) {
-      const int cc = e / ACQ_TM_SPAN, i = e - cc * ACQ_TM_SPAN, cl = call0 + cc;
-      float2 a = make_float2(0.f, 0.f), b = a;
-      if (cl < p.ncalls && cl >= st->call0) {
-        const long long idx = (long long)cl * (N + cp) + lag0 - j0 - 255 + i;      // sample x[lag0 + q - j] for q - (j - j0) = i - 255
-        if (idx >= 0) a = iq[idx];
-        if (idx - N >= 0) b = iq[idx - N];
+    for (int e0 = tid; e0 < ACQ_TM_CALLS * ACQ_TM_SPAN; e0 += 4 * 256) {       // 8 clamped loads per lane in flight
+      float2 av[4], bv[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int e = e0 + k * 256, ec = e < ACQ_TM_CALLS * ACQ_TM_SPAN ? e : 0;
+        const int cc = ec / ACQ_TM_SPAN, i = ec - cc * ACQ_TM_SPAN, cl = call0 + cc;
+        const long long idx = (long long)cl * (N + cp) + lag0 - j0 - (T - 1) + i;    // sample x[lag0 + q - j] for q - (j - j0) = i - (T - 1)
+        const bool okc = cl < p.ncalls && cl >= st->call0;
+        av[k] = iq[okc && idx >= 0 ? idx : 0]; bv[k] = iq[okc && idx - N >= 0 ? idx - N : 0];
+        if (!(okc && idx >= 0)) av[k] = make_float2(0.f, 0.f);
+        if (!(okc && idx - N >= 0)) bv[k] = make_float2(0.f, 0.f);
       }
-      sA[cc][i] = a; sB[cc][i] = b;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int e = e0 + k * 256;
+        if (e < ACQ_TM_CALLS * ACQ_TM_SPAN) { const int cc = e / ACQ_TM_SPAN, i = e - cc * ACQ_TM_SPAN; sA[cc][i] = av[k]; sB[cc][i] = bv[k]; }
+      }
     }
     __syncthreads();
-    for (int jj = 0; jj < jn; jj++) {
-      const float2 a = sA[c][q + 255 - jj], b = sB[c][q + 255 - jj];
-      gr += a.x * b.x + a.y * b.y; gi += a.y * b.x - a.x * b.y;
-      phi += (a.x * a.x + a.y * a.y) + (b.x * b.x + b.y * b.y);
-    }
+    // step s reads sample i = g4 + 3 + (T - 1) - s, which is tap (s - 3 + u) of lag g4 + u
+    auto step = [&](int s, bool all) {
+      const int i = g4 + 3 + (T - 1) - s;
+      const float2 a = sA[c][i], b = sB[c][i];
+      const float cr = a.x * b.x + a.y * b.y, ci = a.y * b.x - a.x * b.y, en = (a.x * a.x + a.y * a.y) + (b.x * b.x + b.y * b.y);
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int jj = s - 3 + u;
+        if (all || (jj >= 0 && jj < jn)) { gr[u] += cr; gi[u] += ci; phi[u] += en; }
+      }
+    };
+    step(0, false); step(1, false); step(2, false);
+    for (int s = 3; s < jn; s++) step(s, true);
+    step(jn, false); step(jn + 1, false); step(jn + 2, false);
   }
   if (!active) return;
-  const int oidx = call * 2 * p.R + q;
-  if (lag0 + q - cp + 1 - N < 0) { gamma[oidx] = make_float2(0.f, 0.f); lambda[oidx] = -3.0e38f; return; }
-  gamma[oidx] = make_float2(gr, gi);
-  lambda[oidx] = sqrtf(gr * gr + gi * gi) - phi * p.half_rho;
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int q = g4 + u, oidx = call * 2 * p.R + q;
+    if (lag0 + q - cp + 1 - N < 0) { gamma[oidx] = make_float2(0.f, 0.f); lambda[oidx] = -3.0e38f; continue; }
+    gamma[oidx] = make_float2(gr[u], gi[u]);
+    lambda[oidx] = sqrtf(gr[u] * gr[u] + gi[u] * gi[u]) - phi[u] * p.half_rho;
+  }
 }
 
 // peak_detect_process (ofdm_sym_acquisition_impl.cc:72-146); avg persists across calls.
