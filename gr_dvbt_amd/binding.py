@@ -52,9 +52,10 @@ class RxParams(C.Structure):
 
 class RxReport(C.Structure):
     _fields_ = [("status", C.c_int32), ("n_symbols", C.c_int32), ("first_out_symbol", C.c_int32),
-                ("n_out_symbols", C.c_int32), ("cp_start0", C.c_int32), ("reserved0", C.c_int32),
+                ("n_out_symbols", C.c_int32), ("cp_start0", C.c_int32), ("first_call", C.c_int32),
                 ("n_viterbi_bytes", C.c_int64), ("n_rs_items", C.c_int64), ("n_rs_bytes", C.c_int64),
-                ("n_ts_bytes", C.c_int64), ("rs_fail_words", C.c_int32), ("rs_corrected_symbols", C.c_int32)]
+                ("n_ts_bytes", C.c_int64), ("rs_fail_words", C.c_int32), ("rs_corrected_symbols", C.c_int32),
+                ("resume_sample", C.c_int64)]
 
 
 class Dims(C.Structure):

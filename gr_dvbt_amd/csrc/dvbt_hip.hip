@@ -262,7 +262,8 @@ struct dvbt_rx {
   hipStream_t own_stream = nullptr, cur_stream = nullptr;
   size_t max_samples = 0; int max_calls = 0;
   float2 *d_iq = nullptr;              // only when input comes from the host
-  ResamplerDesign rsd; float2 *rs_iq = nullptr; size_t chain_max = 0;   // front-of-chain resample + scale (next row 2): its output buffer
+  ResamplerDesign rsd; float2 *rs_iq = nullptr; size_t chain_max = 0;
+  AcqState *acq_carry = nullptr; bool use_carry = false;     // peak-detector state carried into a restart after a lost lock   // front-of-chain resample + scale (next row 2): its output buffer
   float2 *g_init = nullptr; float *l_init = nullptr; float2 *g_trk = nullptr; float *l_trk = nullptr;
   SymMeta *meta = nullptr; RxState *st = nullptr, *st_host = nullptr; TpsState *tps_state = nullptr;
   int *trk_cp_a = nullptr, *trk_cp_b = nullptr, *trk_flags = nullptr; float *trk_eps = nullptr; TpsEdge *tps_edges = nullptr;
@@ -276,7 +277,7 @@ struct dvbt_rx {
 
 static void rx_free(dvbt_rx *h)
 {
-  void *all[] = {h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags, h->trk_eps, h->d_iq, h->rs_iq, h->g_init, h->l_init, h->g_trk, h->l_trk, h->meta, h->st, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
+  void *all[] = {h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags, h->trk_eps, h->d_iq, h->rs_iq, h->acq_carry, h->g_init, h->l_init, h->g_trk, h->l_trk, h->meta, h->st, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
                  h->info, h->maj, h->sym_index, h->labels, h->symdeint_tap, h->bitdeint, h->vit, h->deint_tap, h->rs_out, h->ts_out};
   for (void *q : all) if (q) (void)hipFree(q);
   if (h->st_host) (void)hipHostFree(h->st_host);
@@ -321,7 +322,7 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   RXHIP(hipMalloc((void **)&h->trk_cp_a, sizeof(int) * C)); RXHIP(hipMalloc((void **)&h->trk_cp_b, sizeof(int) * C));
   RXHIP(hipMalloc((void **)&h->trk_eps, sizeof(float) * C)); RXHIP(hipMalloc((void **)&h->trk_flags, sizeof(int) * 16));
   RXHIP(hipMalloc((void **)&h->tps_edges, sizeof(TpsEdge) * (C / TPS_SEG + 2))); RXHIP(hipMalloc((void **)&h->st, sizeof(RxState)));
-  RXHIP(hipHostMalloc((void **)&h->st_host, sizeof(RxState))); RXHIP(hipMalloc((void **)&h->tps_state, sizeof(TpsState)));
+  RXHIP(hipHostMalloc((void **)&h->st_host, sizeof(RxState))); RXHIP(hipMalloc((void **)&h->acq_carry, sizeof(AcqState))); RXHIP(hipMalloc((void **)&h->tps_state, sizeof(TpsState)));
   RXHIP(hipMalloc((void **)&h->labels, C * P + 64));   // A1..A4 are one kernel: a symbol reaches HBM as label bytes; fft_out and eq exist only as debug taps
   RXHIP(hipMalloc((void **)&h->tpsval, sizeof(float2) * C * d.n_tps)); RXHIP(hipMalloc((void **)&h->info, sizeof(SymInfo) * C));
   RXHIP(hipMalloc((void **)&h->maj, sizeof(int) * C)); RXHIP(hipMalloc((void **)&h->sym_index, sizeof(int) * C));
@@ -380,10 +381,10 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s)
   int tries = C < ACQ_INIT_TRIES ? C : ACQ_INIT_TRIES;
   // initial search: the first window normally holds a peak; windows 1..3 are computed and examined only if it did not
   hipLaunchKernelGGL(acq_metric_kernel, dim3((N + 255) / 256, 1), dim3(256), 0, s, iq, fp, (const RxState *)h->st, 0, h->g_init, h->l_init, 0);
-  hipLaunchKernelGGL(acq_init_fsm_kernel, dim3(1), dim3(256), (size_t)N * 5, s, fp, h->st, (const float2 *)h->g_init, (const float *)h->l_init, (const AcqState *)nullptr, 0, 1);
+  hipLaunchKernelGGL(acq_init_fsm_kernel, dim3(1), dim3(256), (size_t)N * 5, s, fp, h->st, (const float2 *)h->g_init, (const float *)h->l_init, (const AcqState *)(h->use_carry ? h->acq_carry : nullptr), 0, 1);
   if (tries > 1) {
     hipLaunchKernelGGL(acq_metric_kernel, dim3((N + 255) / 256, tries - 1), dim3(256), 0, s, iq, fp, (const RxState *)h->st, 0, h->g_init, h->l_init, 1);
-    hipLaunchKernelGGL(acq_init_fsm_kernel, dim3(1), dim3(256), (size_t)N * 5, s, fp, h->st, (const float2 *)h->g_init, (const float *)h->l_init, (const AcqState *)nullptr, 1, tries);
+    hipLaunchKernelGGL(acq_init_fsm_kernel, dim3(1), dim3(256), (size_t)N * 5, s, fp, h->st, (const float2 *)h->g_init, (const float *)h->l_init, (const AcqState *)(h->use_carry ? h->acq_carry : nullptr), 1, tries);
   }
   HIPCHK(hipMemsetAsync(h->trk_flags, 0, sizeof(int) * 16, s));
   hipLaunchKernelGGL(acq_track_metric_kernel, dim3((C + ACQ_TM_CALLS - 1) / ACQ_TM_CALLS), dim3(256), 0, s, iq, fp, (const RxState *)h->st, h->g_trk, h->l_trk);
@@ -397,6 +398,7 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s)
                      (const int *)h->trk_flags, kIters - 1, h->meta, h->trk_flags + kIters);
   hipLaunchKernelGGL(acq_track_kernel, dim3(1), dim3(64), 0, s, fp, h->st, (const float2 *)h->g_trk, (const float *)h->l_trk, h->meta,
                      (const int *)(h->trk_flags + kIters), (AcqState *)nullptr);
+  hipLaunchKernelGGL(acq_lost_avg_kernel, dim3(1), dim3(64), 0, s, fp, h->st, (const int *)h->trk_cp_a, (const float *)h->l_trk);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_FFT], s));
   // A1 tail + A2 + A3 in one kernel: the FFT item of a symbol never leaves LDS (acq/fft taps are written only when enabled)
   hipLaunchKernelGGL(derot_fft_demod_kernel, dim3(C), dim3(FFT_THREADS), fused_lds_bytes_host(N), s, iq, fp, (const RxState *)h->st, (const SymMeta *)h->meta,
@@ -478,7 +480,9 @@ extern "C" int dvbt_rx_segment_finish(dvbt_rx *h, dvbt_rx_report *rep)
   const RxState &s = *h->st_host;
   dvbt_rx_report r; memset(&r, 0, sizeof r);
   r.status = s.status; r.n_symbols = s.n_symbols; r.first_out_symbol = s.first_out; r.n_out_symbols = s.n_out_symbols;
-  r.cp_start0 = s.cp_start0; r.n_viterbi_bytes = s.n_vit_bytes; r.n_rs_items = s.n_rs_items; r.n_rs_bytes = s.n_rs_items * 1504;
+  r.cp_start0 = s.cp_start0; r.first_call = s.call0;
+  r.resume_sample = ((s.status & 2) && !(s.status & 1)) ? (int64_t)(s.call0 + s.n_symbols + 1) * (h->d.N + h->d.cp) : 0;
+  r.n_viterbi_bytes = s.n_vit_bytes; r.n_rs_items = s.n_rs_items; r.n_rs_bytes = s.n_rs_items * 1504;
   r.n_ts_bytes = s.n_ts_bytes; r.rs_fail_words = s.rs_fail; r.rs_corrected_symbols = s.rs_corr;
   h->last = r; h->have_last = true;
   if (rep) *rep = r;
@@ -492,8 +496,33 @@ extern "C" int dvbt_rx_segment_run(dvbt_rx *h, const void *iq_host, size_t nsamp
   if (nsamples > h->max_samples) return fail(DVBT_ERR_CAPACITY, "segment longer than max_samples");
   if (!h->d_iq) HIPCHK(hipMalloc((void **)&h->d_iq, sizeof(float2) * h->max_samples));
   HIPCHK(hipMemcpyAsync(h->d_iq, iq_host, sizeof(float2) * nsamples, hipMemcpyHostToDevice, h->own_stream));
+  h->use_carry = false;
   int r = enqueue(h, h->d_iq, nsamples, h->own_stream); if (r) return r;
-  return dvbt_rx_segment_finish(h, rep);
+  dvbt_rx_report rp;
+  r = dvbt_rx_segment_finish(h, &rp); if (r) return r;
+  // Start-up transient: a segment that begins with more than one window of silence makes the reference lock on the
+  // leading edge of the signal, lose that lock within a few calls and re-acquire (ofdm_sym_acquisition_impl.cc:545-559).
+  // While no superframe start has been found, do the same: restart at the call after the one that lost the lock, with
+  // the peak detector's average carried over.  (The rotator phase is not carried: it is a common phasor that the
+  // equaliser removes; the ACQ/FFT debug taps of a restarted segment differ from the reference's by that constant.)
+  const float2 *chain = h->rsd.ri ? h->rs_iq : h->d_iq;
+  size_t chain_n = h->rsd.ri ? (size_t)(((unsigned long long)nsamples * h->rsd.ri + h->rsd.rd - 1) / h->rsd.rd) : nsamples;
+  size_t off = 0;
+  const int saved_ri = h->rsd.ri;
+  for (int attempt = 0; attempt < 8 && (rp.status & 2) && !(rp.status & 1) && rp.first_out_symbol < 0 && rp.resume_sample > 0; attempt++) {
+    off += (size_t)rp.resume_sample;
+    if (off + (size_t)(2 * h->d.N + h->d.cp + 16) > chain_n) break;
+    AcqState as; memset(&as, 0, sizeof as); as.avg = h->st_host->avg_lost;
+    HIPCHK(hipMemcpyAsync(h->acq_carry, &as, sizeof as, hipMemcpyHostToDevice, h->own_stream));
+    h->use_carry = true;
+    h->rsd.ri = 0;                                               // the stream is already at the chain's rate
+    r = enqueue(h, chain + off, chain_n - off, h->own_stream);
+    h->rsd.ri = saved_ri; h->use_carry = false;
+    if (r) return r;
+    r = dvbt_rx_segment_finish(h, &rp); if (r) return r;
+  }
+  if (rep) *rep = rp;
+  return DVBT_OK;
 }
 
 static int tap_info(dvbt_rx *h, int tap, void **ptr, size_t *bytes)

@@ -25,6 +25,8 @@ struct RxState {
   long long n_ts_bytes;
   int descr_base, descr_index;
   int rs_fail, rs_corr;
+  float avg_lost;        // d_avg after the call that lost the lock (what a re-acquisition starts from)
+  int pad0;
 };
 
 struct FrontParams {
@@ -493,6 +495,26 @@ __global__ __launch_bounds__(1024) void acq_finalize_kernel(FrontParams p, RxSta
     st->n_symbols = nsym;
     if (nsym < ntot) st->status |= (cp[nsym] == -2) ? 8 : 2;
   }
+}
+
+// d_avg after the call in which the tracker lost the lock: the reference re-acquires in the next call with this value
+// (ofdm_sym_acquisition_impl.cc:545-559; d_avg persists).  IIR over the last two windows (see acq_track_par_kernel).
+__global__ void acq_lost_avg_kernel(FrontParams p, RxState *st, const int *__restrict__ cp, const float *__restrict__ lambda)
+{
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  st->avg_lost = st->avg;
+  if (!(st->status & 2) || (st->status & 1)) return;
+  const int f = st->n_symbols, R = p.R, c0 = st->cp_start0;      // f: first call (relative to call0) without a peak
+  float avg; int w0;
+  if (f <= 1) { avg = st->avg; w0 = 0; } else { avg = 0.f; w0 = f - 1; }
+  for (int ws = w0; ws <= f; ws++) {
+    const int cur = ws <= 0 ? c0 : cp[ws - 1];
+    const int rel0 = (cur - 8) - (c0 - R);
+    if (cur < 0 || rel0 < 0 || rel0 + 16 > 2 * R) return;
+    const float *lam = lambda + (size_t)(st->call0 + ws) * 2 * R + rel0;
+    for (int i = 0; i < 16; i++) avg = 0.9f * lam[i] + (1 - 0.9f) * avg;
+  }
+  st->avg_lost = avg;
 }
 
 // LDS image of a symbol: one float2 of padding after every 32 keeps the stride-4/16/64 accesses of the

@@ -235,12 +235,16 @@ typedef struct {
   int32_t first_out_symbol;    /* symbol at which superframe_start fired, -1 if none */
   int32_t n_out_symbols;       /* symbols passed downstream */
   int32_t cp_start0;           /* d_cp_start after initial acquisition */
-  int32_t reserved0;
+  int32_t first_call;          /* general_work call (window of N+cp samples) in which the initial acquisition succeeded */
   int64_t n_viterbi_bytes;
   int64_t n_rs_items;          /* items of 8 codewords */
   int64_t n_rs_bytes;          /* = n_rs_items*1504 */
   int64_t n_ts_bytes;          /* after energy_descramble (0 when descramble==0) */
   int32_t rs_fail_words, rs_corrected_symbols;
+  int64_t resume_sample;       /* status bit1 (lock lost): sample of the segment (at the OFDM elementary rate) at which the reference
+                                  would start re-acquiring, i.e. the start of the call after the one that lost the lock; else 0.
+                                  dvbt_rx_segment_run restarts there by itself while no superframe start has been found yet (the
+                                  start-up transient of a segment that begins with more than one window of silence). */
 } dvbt_rx_report;
 
 typedef enum {

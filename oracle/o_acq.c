@@ -34,7 +34,9 @@ o_acq *o_acq_new(const o_cfg *c, float snr_db)
   a->gamma = calloc(a->N, sizeof(ocf)); a->lambda = calloc(a->N, sizeof(float));
   a->phi = calloc(a->N, sizeof(float)); a->peak_pos = calloc(a->N, sizeof(int));
   a->derot = calloc(a->N + a->cp, sizeof(ocf));
-  a->norm = calloc(W, sizeof(float)); a->corr = calloc(W, sizeof(ocf));
+  /* +16: in tracking the look-up window reaches cp_start + 8, and cp_start may sit at the very end of the 2N+cp samples the
+   * reference forecasts (its own d_norm/d_corr are W long: it would write past them there); o_rx_run keeps 16 more samples visible */
+  a->norm = calloc(W + 16, sizeof(float)); a->corr = calloc(W + 16, sizeof(ocf));
   return a;
 }
 

@@ -234,3 +234,29 @@ def test_out_of_range_carriers_take_the_exhaustive_demap(po, g):
     po.lib().o_demap(C.byref(c), pts.ctypes.data_as(C.c_void_p), eqc.ctypes.data_as(C.c_void_p), ref.ctypes.data_as(C.c_void_p), C.c_size_t(eqc.size))
     assert (lab == ref).all()
     rx.close()
+
+
+@pytest.mark.parametrize("const,cr,mode,guard,lead", [
+    (2, 1, 0, 1, 4623),     # 2k GI 1/16: lead-in longer than two windows
+    (1, 3, 0, 2, 3057),     # 2k GI 1/8: signal starts inside window 1
+    (1, 0, 0, 0, 2500),     # 2k GI 1/32
+    (0, 4, 1, 0, 9000),     # 8k GI 1/32
+])
+def test_long_silence_before_the_signal(po, g, const, cr, mode, guard, lead):
+    """More than one window of silence in front: the reference locks on the leading edge of the signal, loses that lock
+    within a few calls and re-acquires (ofdm_sym_acquisition_impl.cc:545-559).  dvbt_rx_segment_run follows it by
+    restarting at the call after the loss with the peak detector's average carried over; the decoded bytes must be
+    the reference's."""
+    c = po.cfg(const, cr, mode, guard=guard)
+    ibits = c.payload * c.m * c.k // c.n
+    ts = po.make_ts((272 * ibits * 3) // (204 * 8), 5)
+    iq = po.tx(c, ts, lead_in=lead, tail=3 * c.N)
+    o = po.rx(c, iq, want=("vit", "rs", "ts"))
+    assert o["ts"].size > 0
+    rx = g.Rx(const, cr, mode, max_samples=len(iq), guard=guard)
+    rep = rx.run(iq)
+    assert rep.first_out_symbol >= 0
+    for name, tap in (("vit", g.TAP_VITERBI), ("rs", g.TAP_RS), ("ts", g.TAP_TS)):
+        a, b = rx.tap(tap).reshape(-1), o[name].reshape(-1)
+        assert a.size == b.size and (a == b).all(), name
+    rx.close()
