@@ -481,7 +481,9 @@ extern "C" int dvbt_rx_segment_finish(dvbt_rx *h, dvbt_rx_report *rep)
   dvbt_rx_report r; memset(&r, 0, sizeof r);
   r.status = s.status; r.n_symbols = s.n_symbols; r.first_out_symbol = s.first_out; r.n_out_symbols = s.n_out_symbols;
   r.cp_start0 = s.cp_start0; r.first_call = s.call0;
-  r.resume_sample = ((s.status & 2) && !(s.status & 1)) ? (int64_t)(s.call0 + s.n_symbols + 1) * (h->d.N + h->d.cp) : 0;
+  // the call that loses the lock consumes half a window (to_consume / 2, ofdm_sym_acquisition_impl.cc:545-559): that half step is
+  // what moves the search windows of the re-acquisition to a different phase of the symbol grid
+  r.resume_sample = ((s.status & 2) && !(s.status & 1)) ? (int64_t)(s.call0 + s.n_symbols) * (h->d.N + h->d.cp) + (h->d.N + h->d.cp) / 2 : 0;
   r.n_viterbi_bytes = s.n_vit_bytes; r.n_rs_items = s.n_rs_items; r.n_rs_bytes = s.n_rs_items * 1504;
   r.n_ts_bytes = s.n_ts_bytes; r.rs_fail_words = s.rs_fail; r.rs_corrected_symbols = s.rs_corr;
   h->last = r; h->have_last = true;

@@ -242,7 +242,7 @@ typedef struct {
   int64_t n_ts_bytes;          /* after energy_descramble (0 when descramble==0) */
   int32_t rs_fail_words, rs_corrected_symbols;
   int64_t resume_sample;       /* status bit1 (lock lost): sample of the segment (at the OFDM elementary rate) at which the reference
-                                  would start re-acquiring, i.e. the start of the call after the one that lost the lock; else 0.
+                                  would start re-acquiring: the call that lost the lock consumes half a window (N+cp)/2; else 0.
                                   dvbt_rx_segment_run restarts there by itself while no superframe start has been found yet (the
                                   start-up transient of a segment that begins with more than one window of silence). */
 } dvbt_rx_report;
