@@ -449,8 +449,10 @@ __global__ __launch_bounds__(64) void deint_rs_kernel(const uint8_t *__restrict_
       for (int k = 0; k < 6; k++) {
         const int i = i0 + k * 64, r = i / 51, p4 = i - r * 51;
         const long long word = first + r;
-        v[k] = 0;
-        if (i < 75 * 51 && word >= -hist_words && word < nwords && r < nw + 11) v[k] = reinterpret_cast<const unsigned *>(in + word * 204)[p4];
+        const bool valid = i < 75 * 51 && word >= -hist_words && word < nwords && r < nw + 11;
+        const long long wc = valid ? word : (nwords > 0 ? 0 : -hist_words);      // unconditional load from a valid address, selected afterwards
+        const unsigned ld = reinterpret_cast<const unsigned *>(in + wc * 204)[valid ? p4 : 0];
+        v[k] = valid ? ld : 0u;
       }
 #pragma unroll
       for (int k = 0; k < 6; k++) {
