@@ -11,11 +11,13 @@
 //  * metric field (8 bits, signed): M in units of half an agreement, bias = 1 when the cell holds an upper state
 //    (i+32): compares are strict and reproduce the reference's tie rule (d_viterbi.c:508-521).  For a K=7 code
 //    the spread of the 64 metrics is bounded by 6 steps x the per-step range: 2M+bias spans <= 49; it drifts by at
-//    most +-4 per step, and the minimum is subtracted every second window (the reference does it at every output
-//    only to keep ITS 8-bit metrics from wrapping, :728-732), so the field stays within [-64, 113].
-//  * path byte (8 bits): exactly the reference's path byte of the survivor: (state at the window start -- kept as
-//    that state's cell storage index) << 2 | inputs of the window's steps 7,8 (= top two bits of the state after
-//    step 6, stamped there).  It rides along with the metric through v_pk_max (metric fields never tie).
+//    most +-4 per step, and every second window the best metric is set back to 48 (the reference subtracts the
+//    minimum at every output only to keep ITS 8-bit metrics from wrapping, :728-732; any common offset is
+//    equivalent), so the field stays within [-65, 113].
+//  * path byte (8 bits): the content of the reference's path byte of the survivor -- the state at the window start
+//    (kept as that state's cell storage index, bits 5:0) and the two oldest inputs of the window (= top two bits of
+//    the state after step 6, stamped there, bits 7:6).  It rides along with the metric through v_pk_max (metric
+//    fields never tie).  In the LDS ring a hop is one v_and_or: origin = byte & 63, merged with the next row address.
 // Per step and VGPR (two cells): v_perm (both branch-metric deltas from ONE word of four class deltas), pk_add,
 // pk_sub, exchange, pk_max, v_and_or (re-arm bias) -- 3 instructions per cell instead of 5.
 #pragma once
