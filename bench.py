@@ -4,14 +4,21 @@
 One step = one pass of the whole chain (ofdm_sym_acquisition -> FFT -> demod_reference_signals ->
 dvbt_demap -> symbol/bit de-interleave -> viterbi_decoder -> convolutional_deinterleaver ->
 reed_solomon_dec -> energy_descramble) over one batch of synthetic loopback baseband that is already
-resident in HBM.  N>1: one process per GPU (torch.distributed / RCCL), every rank decodes its own
-independent segment (weak scaling) and the decoded TS bytes are gathered on rank 0 once per step.
+resident in HBM.
+
+The batch is ONE stream (1 lead-in superframe + N x --superframes payload superframes).  It is cut at
+superframe boundaries into N x --segments pieces (gr_dvbt_amd/multi.py::plan_cuts, SURVEY 8e); every
+rank (one process per GPU, torch.distributed / RCCL) generates and decodes only ITS pieces, each on its own
+handle and HIP stream, and the decoded packets travel to rank 0 in the design's single collective per step
+(multi.gather_pieces).  After the timed loop rank 0 stitches the pieces of the last step and compares the TS
+with the packets that were transmitted: the bench fails (exit 1) when a single byte differs.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -19,12 +26,15 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# independent segments run on separate HIP streams; give the runtime enough hardware queues that two
+# independent pieces run on separate HIP streams; give the runtime enough hardware queues that two
 # streams of one process do not share one (the ROCm default maps them onto 4 queues round-robin)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md)
 REALTIME_MSPS = 64.0 / 7.0       # OFDM elementary rate at the input of ofdm_sym_acquisition
+SEED = 20240607
+
+WORKLOADS = {"8k_qam64_7_8": ("QAM64", "C7_8", "T8k"), "2k_qam16_1_2": ("QAM16", "C1_2", "T2k"), "8k_qpsk_7_8": ("QPSK", "C7_8", "T8k")}
 
 
 class _DevView:
@@ -34,28 +44,28 @@ class _DevView:
         self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
 
 
-def make_input(cfg_name, n_superframes, seed):
-    """Synthetic loopback baseband from the test-utility TX generator: seeded random TS,
-    one extra lead-in superframe so the superframe hunt locks before the payload region."""
+def workload_cfg(name):
     from oracle import pyoracle as po
-    const, cr, mode = {"8k_qam64_7_8": (po.QAM64, po.C7_8, po.T8k), "2k_qam16_1_2": (po.QAM16, po.C1_2, po.T2k),
-                       "8k_qpsk_7_8": (po.QPSK, po.C7_8, po.T8k)}[cfg_name]
-    c = po.cfg(const, cr, mode)
-    ibits = c.payload * c.m * c.k // c.n
-    npk = (272 * ibits * (n_superframes + 1)) // (204 * 8)
-    ts = po.make_ts(npk, seed)
-    iq = po.tx(c, ts, lead_in=1000, tail=3 * c.N)
-    return (const, cr, mode), c, iq
+    const, cr, mode = (getattr(po, x) for x in WORKLOADS[name])
+    return (const, cr, mode), po.cfg(const, cr, mode)
 
 
-def cpu_baseline(cfg_name, n_superframes=3):
+def add_awgn(iq, snr_db, seed, ref_power):
+    rng = np.random.RandomState(seed)
+    sig = np.sqrt(ref_power / (10 ** (snr_db / 10)) / 2)
+    n = (rng.randn(len(iq)) + 1j * rng.randn(len(iq))).astype(np.complex64)
+    return (iq + np.float32(sig) * n).astype(np.complex64)
+
+
+def cpu_baseline(cfg_name, n_superframes=3, all_cores=True):
     """The oracle port (oracle/o_chain.c, -O3 -funroll-loops -msse2) timed on a bounded sample of the same workload on this
     box's host cores: (i) one thread end to end = the reported value; (ii) what a thread-per-block scheduler
     like GNU Radio's could reach = sample / slowest stage; (iii) segment-parallel on all cores (every thread decodes its
     own copy of the sample; ctypes releases the GIL)."""
     import threading
     from oracle import pyoracle as po
-    (_, _, _), c, iq = make_input(cfg_name, n_superframes, 99)
+    _, c = workload_cfg(cfg_name)
+    iq = po.stream_slice(c, n_superframes + 1, 99)
     t0 = time.time()
     r = po.rx(c, iq, want=("ts",))
     dt = time.time() - t0
@@ -66,7 +76,7 @@ def cpu_baseline(cfg_name, n_superframes=3):
            "pipeline_parallel_bound": {"value": round(len(iq) / max(r["t_stage"]) / 1e6, 3), "cores": sum(1 for x in r["t_stage"] if x > 0.0005),
                                        "note": "sample / slowest stage (thread-per-block scheduler)"}}
     ncores = os.cpu_count() or 1
-    if ncores > 1:
+    if all_cores and ncores > 1:
         nthr = min(ncores, 16)                                  # bounded: every thread holds its own working set
         ths = [threading.Thread(target=lambda: po.rx(c, iq, want=("ts",))) for _ in range(nthr)]
         t0 = time.time()
@@ -77,6 +87,32 @@ def cpu_baseline(cfg_name, n_superframes=3):
         dta = time.time() - t0
         out["all_cores"] = {"value": round(nthr * len(iq) / dta / 1e6, 3), "cores": nthr, "note": "segment-parallel, one copy of the sample per thread"}
     return out
+
+
+def reference_sse2_viterbi():
+    """The reference's own SSE2 Viterbi kernels (oracle/_ref, built from /root/reference in the authoring container; the
+    prebuilt .so travels to the GPU box) timed beside the port on one host core: decoded Mbit/s of d_viterbi_butterfly2_sse2
+    + d_viterbi_get_output_sse2 in the block's calling pattern."""
+    import ctypes as C
+    from oracle import pyoracle as po
+    L = po.ref_lib()
+    if L is None:
+        return None
+    rng = np.random.RandomState(1)
+    nbits = 4 * 1000 * 1000                                     # depunctured symbols (2 per trellis step)
+    sym = rng.randint(0, 2, nbits).astype(np.uint8)
+    out = C.c_ubyte()
+    st = (C.c_ubyte * 64)()
+    L.d_viterbi_chunks_init_sse2(st, st)
+    t0 = time.time()
+    p = sym.ctypes.data
+    for i in range(0, nbits, 16):                               # 16 symbols = 8 steps = one output byte (viterbi_decoder_impl.cc:261-292)
+        for j in range(0, 16, 4):
+            L.d_viterbi_butterfly2_sse2(C.c_void_p(p + i + j), st, st, st, st)
+        L.d_viterbi_get_output_sse2(st, st, 24, C.byref(out))
+    dt = time.time() - t0
+    return {"value": round(nbits / 2 / dt / 1e6, 2), "unit": "Mbit/s decoded", "cores": 1, "kind": "reference",
+            "note": "lib/d_viterbi.c SSE2 kernels via ctypes (call overhead included: a lower bound of the kernel rate)"}
 
 
 def hbm_copy_gbs(torch, device):
@@ -93,22 +129,196 @@ def hbm_copy_gbs(torch, device):
     return round(best, 1)
 
 
+class Job:
+    """One stream cut into world x segments pieces; this rank's pieces resident in HBM, one handle + stream each."""
+
+    def __init__(self, a, torch, g, dist, rank, world, local, workload, superframes, snr=None, chunk=0, from_file_rate=False):
+        from oracle import pyoracle as po
+        from gr_dvbt_amd import multi
+        self.torch, self.g, self.dist, self.rank, self.world, self.local, self.multi, self.po = torch, g, dist, rank, world, local, multi, po
+        (const, cr, mode), c = workload_cfg(workload)
+        self.c, self.workload, self.snr = c, workload, snr
+        self.dims = d = g.get_dims(const, cr, mode)
+        self.nsf = 1 + world * superframes                      # lead-in superframe + the payload
+        self.seed = SEED
+        self.n_total = po.stream_len(c, self.nsf)
+        L = c.N + c.cp
+        nseg = max(1, a.segments)
+        snr_db = 30.0 if snr is None else snr                   # ofdm_sym_acquisition's snr parameter (30 in the demo flowgraphs)
+        self.ref_power = None
+        # ---- pre-scan (rank 0): where does the reference's chain start decoding?  Two numbers, broadcast once.
+        plan = torch.zeros(2, dtype=torch.int64, device=f"cuda:{local}")
+        if rank == 0:
+            head = po.stream_slice(c, self.nsf, self.seed, 0, po.STREAM_LEAD_IN + 360 * L)
+            if snr is not None:
+                self.ref_power = float(np.mean(np.abs(head[po.STREAM_LEAD_IN:po.STREAM_LEAD_IN + 100000]) ** 2))
+                head = add_awgn(head, snr, 5, self.ref_power)
+            pre = g.Rx(const, cr, mode, max_samples=len(head), device=local, snr_db=snr_db)
+            rep = pre.run(head)
+            pre.close()
+            if rep.status != 0:
+                raise SystemExit(f"pre-scan failed: status {rep.status}")
+            plan[0], plan[1] = int(rep.segment_offset), int(rep.first_call + rep.first_out_symbol)
+        if dist:
+            dist.broadcast(plan, src=0)
+            if snr is not None:
+                pw = torch.tensor([self.ref_power or 0.0], dtype=torch.float64, device=f"cuda:{local}")
+                dist.broadcast(pw, src=0)
+                self.ref_power = float(pw.item())
+        self.grid0, self.sf_call = int(plan[0]), int(plan[1])
+        cuts = multi.plan_cuts(d, self.n_total, self.grid0, self.sf_call, world * nseg)
+        if len(cuts) != world * nseg:
+            raise SystemExit(f"stream of {self.nsf} superframes cannot be cut into {world * nseg} pieces")
+        self.cuts = cuts
+        mine = cuts[rank * nseg:(rank + 1) * nseg]
+        self.pieces = []
+        for i, cu in enumerate(mine):
+            iq = po.stream_slice(c, self.nsf, self.seed, cu["begin"], cu["end"])       # only this rank's part of THE stream
+            if snr is not None:
+                iq = add_awgn(iq, snr, 1000 + rank * nseg + i, self.ref_power)
+            kw = {}
+            if from_file_rate:
+                rx_const = 0.0022097087 if mode == po.T2k else 0.00055242272           # blocks_multiply_const_vxx_0 of the RX flowgraph
+                iq = po.resample(iq / np.float32(rx_const), 70, 64, 1.0)                # what dvbt_tx_demo writes: the 10 Msps stream
+                kw = {"resample": (64, 70), "front_scale": rx_const}
+            d_iq = torch.from_numpy(iq.view(np.float32)).cuda()
+            rx = g.Rx(const, cr, mode, max_samples=len(iq), device=local, viterbi_chunk_bytes=chunk, snr_db=snr_db, **kw)
+            rx.set_cut(cu["sym_off"])
+            cap = int(len(iq) * 0.45) + 4096
+            self.pieces.append({"iq": d_iq, "n": len(iq), "rx": rx, "stream": torch.cuda.Stream(), "cut": cu, "cap": cap,
+                                "ts_view": torch.as_tensor(_DevView(rx.tap_device_ptr(g.TAP_TS), cap), device=f"cuda:{local}")})
+        # samples of the stream this rank is responsible for (overlaps between pieces are overhead, not throughput)
+        self.samples_owned = (cuts[min((rank + 1) * nseg, len(cuts)) - 1]["end"] if rank == world - 1 else cuts[(rank + 1) * nseg]["begin"]) - mine[0]["begin"]
+        self.samples_decoded = sum(p["n"] for p in self.pieces)
+        torch.cuda.synchronize()                       # uploads done before any piece's stream reads them
+        # the single exchange step (SURVEY 8e): packets + their counts -> rank 0 over xGMI, ONE gather per step.  Double
+        # buffered and asynchronous: the gather of step k travels while step k+1 decodes; every gather is complete before
+        # the closing barrier of the timed region.
+        self.slot = multi.HEADER_BYTES + max(p["cap"] for p in self.pieces)
+        if dist:
+            mx = torch.tensor([self.slot], dtype=torch.int64, device=f"cuda:{local}")
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            self.slot = int(mx.item())
+        self.send = [torch.zeros(self.slot * nseg, dtype=torch.uint8, device=f"cuda:{local}") for _ in range(2)] if dist else None
+        self.recv = [[torch.empty(self.slot * nseg, dtype=torch.uint8, device=f"cuda:{local}") for _ in range(world)] for _ in range(2)] if (dist and rank == 0) else [None, None]
+        self.pending = [None, None]
+        self.nstep = 0
+        self.reps = None
+
+    def step(self):
+        torch, multi, dist = self.torch, self.multi, self.dist
+        for p in self.pieces:
+            p["rx"].enqueue_device(p["iq"].data_ptr(), p["n"], p["stream"].cuda_stream)
+        self.reps = [p["rx"].finish() for p in self.pieces]
+        if dist:
+            b = self.nstep & 1
+            if self.pending[b] is not None:
+                self.pending[b].wait()                 # the buffer pair of two steps ago is free again
+            for i, (p, r) in enumerate(zip(self.pieces, self.reps)):
+                multi.pack_piece(self.send[b][i * self.slot:(i + 1) * self.slot], multi.piece_meta(r), p["ts_view"])
+            ev = torch.cuda.Event(); ev.record()       # the next decode may overwrite the TS buffers only after these copies
+            for p in self.pieces:
+                p["stream"].wait_event(ev)
+            self.pending[b] = multi.gather_pieces(self.send[b], self.recv[b], dst=0, async_op=True)
+            self.last_buf = b
+        self.nstep += 1
+
+    def drain(self):
+        if self.dist:
+            for b in range(2):
+                if self.pending[b] is not None:
+                    self.pending[b].wait(); self.pending[b] = None
+        self.torch.cuda.synchronize()
+
+    def collect(self):
+        """rank 0: the pieces of the last step in stream order, [(meta, uint8 device tensor)]"""
+        multi = self.multi
+        if self.dist:
+            out = []
+            for buf in self.recv[self.last_buf]:
+                for i in range(len(self.pieces)):
+                    out.append(multi.unpack_piece(buf[i * self.slot:(i + 1) * self.slot]))
+            return out
+        return [(multi.piece_meta(r), p["ts_view"][:int(r.n_ts_bytes)]) for p, r in zip(self.pieces, self.reps)]
+
+    def verify(self):
+        """rank 0: stitch the last step's pieces and compare with what was transmitted.  Returns a dict for the JSON line."""
+        po, multi, c = self.po, self.multi, self.c
+        pieces = self.collect()
+        ts = multi.stitch_ts(pieces, self.dims).cpu().numpy()
+        # the TS tap of the stream starts ts_first_packet RS words after the first superframe start; RS word w of the receiver
+        # is the packet sent 11 words earlier (the Forney interleaver pair delays by 11 x 204 bytes end to end)
+        ibits = multi.info_bits_per_symbol(self.dims)
+        first_out = self.sf_call                                  # symbols of the stream before the superframe start (lead-in is < 1 symbol: call 0 holds symbol 0)
+        p0 = first_out * ibits // 8 // 204 + pieces[0][0]["ts_first_packet"] - 11
+        npk = len(ts) // 188
+        pps = po.packets_per_superframe(c)
+        bad_bytes, bad_packets = 0, 0
+        for j in range(p0 // pps, (p0 + npk - 1) // pps + 1):    # superframe by superframe: the whole transmitted TS never sits in memory
+            sent = po.stream_ts(c, j, 1, self.seed).reshape(-1, 188)
+            a, b = max(p0, j * pps), min(p0 + npk, (j + 1) * pps)
+            got = ts[(a - p0) * 188:(b - p0) * 188].reshape(-1, 188)
+            diff = got != sent[a - j * pps:b - j * pps]
+            bad_bytes += int(diff.sum()); bad_packets += int(diff.any(axis=1).sum())
+        res = {"verified": bool(bad_bytes == 0 and npk > 0), "ts_bytes": int(len(ts)), "ts_packets": npk, "first_packet_of_stream": int(p0),
+               "packets_transmitted_after_first": int(self.nsf * 272 * ibits // 8 // 204 - p0), "wrong_bytes": bad_bytes, "wrong_packets": bad_packets}
+        if self.snr is not None:
+            res["verified"] = bool(npk > 0)                      # with noise the criterion is the error rate below, not identity
+            res["post_rs_byte_error_rate"] = bad_bytes / max(len(ts), 1)
+            res["packet_error_rate"] = bad_packets / max(npk, 1)
+        return res
+
+    def close(self):
+        for p in self.pieces:
+            p["rx"].close()
+
+
+def timed_run(job, steps, warmup):
+    torch, dist = job.torch, job.dist
+    for _ in range(warmup):
+        job.step()
+    job.drain()
+    for p in job.pieces:
+        p["rx"].enable_timing(True)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        job.step()
+    job.drain()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{job.local}")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    return dt
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="8k_qam64_7_8")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="8k_qam64_7_8", choices=sorted(WORKLOADS))
+    ap.add_argument("--snr", type=float, default=None, help="add AWGN at this SNR (dB); BASELINE config 5 = --workload 8k_qpsk_7_8 --snr 14")
     ap.add_argument("--superframes", type=int, default=64, help="payload superframes per GPU per step (SURVEY 8d: >= 64 for throughput runs)")
     ap.add_argument("--chunk", type=int, default=0)
-    ap.add_argument("--segments", type=int, default=1,
-                    help="independent baseband segments per GPU per step, each on its own HIP stream (each gets its own lead-in superframe)")
+    ap.add_argument("--segments", type=int, default=1, help="pieces per GPU: the rank's part of the stream is cut again, one handle + HIP stream per piece")
     ap.add_argument("--from-file-rate", action="store_true",
                     help="feed the 10 Msps file format: rational_resampler 64/70 + multiply_const run on the device in front of the chain "
-                         "(SURVEY 8f row 2; samples are then counted at the 10 Msps input)")
+                         "(SURVEY 8f row 2; samples are then counted at the 10 Msps input; single piece only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra workload lines (BASELINE configs 1, 2, 5) and the per-block ABI timing")
     ap.add_argument("--cpu-superframes", type=int, default=3)
     a = ap.parse_args()
+    if a.from_file_rate and (a.gpus > 1 or a.segments > 1):
+        raise SystemExit("--from-file-rate runs one piece on one GPU")
 
     # stdout carries exactly ONE line (the JSON of rank 0): libraries that print banners to the C-level stdout (RCCL does at the
     # first collective) are sent to stderr by swapping file descriptor 1; the JSON goes to the saved descriptor
@@ -131,131 +341,55 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
-    # the per-GPU batch is cut into `segments` independent segments (whole superframes + one lead-in each); they are
-    # enqueued on separate streams so that the short sequential kernels of one overlap the Viterbi kernel of another
-    nseg = max(1, a.segments)
-    per = [a.superframes // nseg + (1 if i < a.superframes % nseg else 0) for i in range(nseg)]
-    segs = []
-    for i, nsf in enumerate(per):
-        (const, cr, mode), c, iq = make_input(a.workload, nsf, 20240607 + 100 * rank + i)
-        rs_kw = {}
-        if a.from_file_rate:
-            from oracle import pyoracle as po
-            rx_const = 0.0022097087 if mode == po.T2k else 0.00055242272       # blocks_multiply_const_vxx_0 of the RX flowgraph
-            iq = po.resample(iq / np.float32(rx_const), 70, 64, 1.0)            # what dvbt_tx_demo writes: the 10 Msps stream
-            rs_kw = {"resample": (64, 70), "front_scale": rx_const}
-        d_iq = torch.from_numpy(iq.view(np.float32)).cuda()
-        rxi = g.Rx(const, cr, mode, max_samples=len(iq), device=local, viterbi_chunk_bytes=a.chunk, **rs_kw)
-        segs.append({"iq": d_iq, "n": len(iq), "rx": rxi, "stream": torch.cuda.Stream()})
-    nsamp = sum(sg["n"] for sg in segs)
-    torch.cuda.synchronize()                       # uploads done before any segment stream reads them
-    rx = segs[0]["rx"]
-    ts_cap = int(nsamp * 0.45) + 4096
-    ts_views = [torch.as_tensor(_DevView(sg["rx"].tap_device_ptr(g.TAP_TS), int(sg["n"] * 0.45) + 4096), device=f"cuda:{local}") for sg in segs]
-    # the single exchange step: TS packets -> rank 0 over xGMI.  Double buffered and asynchronous: the gather of
-    # step k travels while step k+1 decodes; every gather is complete before the closing barrier of the timed region.
-    ts_send = [torch.zeros(ts_cap, dtype=torch.uint8, device=f"cuda:{local}") for _ in range(2)] if dist else None
-    gathered = [[torch.empty(ts_cap, dtype=torch.uint8, device=f"cuda:{local}") for _ in range(world)] for _ in range(2)] if (dist and rank == 0) else [None, None]
-    pending = [None, None]
-    nstep = [0]
-
-    def step():
-        for sg in segs:
-            sg["rx"].enqueue_device(sg["iq"].data_ptr(), sg["n"], sg["stream"].cuda_stream)
-        reps = [sg["rx"].finish() for sg in segs]
-        if dist:
-            b = nstep[0] & 1
-            if pending[b] is not None:
-                pending[b].wait()                  # the buffer pair of two steps ago is free again
-            off = 0
-            for v, r in zip(ts_views, reps):
-                n = int(r.n_ts_bytes)
-                ts_send[b][off:off + n].copy_(v[:n])
-                off += n
-            ev = torch.cuda.Event(); ev.record()   # the next decode may overwrite the TS buffers only after these copies
-            for sg in segs:
-                sg["stream"].wait_event(ev)
-            pending[b] = dist.gather(ts_send[b], gathered[b], dst=0, async_op=True)
-            nstep[0] += 1
-        return reps
-
-    def drain():
-        if dist:
-            for b in range(2):
-                if pending[b] is not None:
-                    pending[b].wait(); pending[b] = None
-            torch.cuda.synchronize()
-
-    for _ in range(a.warmup):
-        reps = step()
-    drain()
-    for sg in segs:
-        sg["rx"].enable_timing(True)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        reps = step()
-    drain()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-
+    job = Job(a, torch, g, dist, rank, world, local, a.workload, a.superframes, snr=a.snr, chunk=a.chunk, from_file_rate=a.from_file_rate)
+    dt = timed_run(job, a.steps, a.warmup)
+    nseg = len(job.pieces)
+    ok = True
     if rank == 0:
-        msps = world * nsamp * a.steps / dt / 1e6
+        n_stream = job.n_total if not a.from_file_rate else sum(p["n"] for p in job.pieces)
+        msps = n_stream * a.steps / dt / 1e6
+        check = job.verify() if not a.from_file_rate else {"verified": None}
+        ok = check["verified"] is not False
+        reps = job.reps
         # dominant kernel = viterbi3_kernel: per launch, algorithmic bytes = bytes in (one per m coded bits) + decoded
         # bytes out (6048 + 3969 B per 8k QAM64 7/8 OFDM symbol); launch duration from HIP events
-        # recorded on the segment's own stream; averages over the segments' launches
-        d = rx.dims
-        vit_ms = sum(sg["rx"].stage_ms("viterbi") for sg in segs) / nseg
+        # recorded on the piece's own stream; averages over this rank's pieces
+        d = job.dims
+        vit_ms = sum(p["rx"].stage_ms("viterbi") for p in job.pieces) / nseg
         alg_bytes = sum(r.n_out_symbols * d.payload_length + r.n_viterbi_bytes for r in reps) / nseg
-        rep = reps[0]
-        n_ts = sum(int(r.n_ts_bytes) for r in reps)
         achieved = alg_bytes / (vit_ms * 1e-3) / 1e9 if vit_ms > 0 else 0.0
-        # HBM bytes of that kernel from the committed rocprofv3 PMC passes (tools/pmc.sh; FETCH_SIZE doubled per the
-        # gfx950 note in MI355X_MICROARCH.md), scaled per algorithmic byte of the profiled launch
-        traffic = None
-        valu_frac = None
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary_8k_qam64_7_8_65sf.json")))
-            if a.workload == "8k_qam64_7_8":
-                kv = pm["kernels"]["viterbi3_kernel"]
-                traffic = int(kv["hbm_bytes_corrected"] / pm["viterbi_algorithmic_bytes"] * alg_bytes)
-                # what actually bounds the kernel: VALU issue slots used = wavefront VALU instructions x 4 cycles / (1024 SIMDs x
-                # kernel cycles); GRBM_GUI_ACTIVE sums the 8 XCDs (same committed PMC passes)
-                valu_frac = round(kv["SQ_INSTS_VALU"] * 4 / 1024 / (kv["GRBM_GUI_ACTIVE"] / 8), 3)
-        except Exception:
-            traffic = None
+        n_ts = check.get("ts_bytes") or sum(int(r.n_ts_bytes) for r in reps)
         out = {
             "metric": "RX Msamples/s (baseband in -> TS out)", "value": round(msps, 2), "unit": "Msamples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 (Viterbi/RS) + f32 (front end)",
-            "data": "synthetic", "x_realtime": round(msps / REALTIME_MSPS / world, 1),
-            "config": {"workload": f"{a.workload} GI 1/32 RX chain, clean TX->RX loopback" + (", input at the 10 Msps file rate (resampler 64/70 + scale on the device)" if a.from_file_rate else ""), "superframes_per_gpu": a.superframes + nseg, "segments_per_gpu": nseg,
-                       "samples_per_gpu_per_step": nsamp, "parallelism": f"segments x{world}" + (" + RCCL gather of TS" if world > 1 else ""),
-                       "ts_bytes_per_step": n_ts, "status": [int(r.status) for r in reps], "rs_fail_words": [int(r.rs_fail_words) for r in reps]},
-            "roofline": {"bound": "hbm", "kernel": "viterbi3_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "valu_issue_frac": valu_frac,
+            "data": "synthetic", "x_realtime": round(msps / REALTIME_MSPS / world, 1), "timed_region_s": round(dt, 3),
+            "config": {"workload": f"{a.workload} GI 1/32 RX chain, " + (f"AWGN {a.snr} dB" if a.snr is not None else "clean TX->RX loopback")
+                                   + (", input at the 10 Msps file rate (resampler 64/70 + scale on the device)" if a.from_file_rate else ""),
+                       "stream_superframes": job.nsf, "superframes_per_gpu": a.superframes, "pieces_per_gpu": nseg,
+                       "stream_samples": n_stream, "samples_decoded_per_gpu_per_step": job.samples_decoded,
+                       "parallelism": f"one stream cut into {world * nseg} pieces at superframe boundaries, {nseg} per GPU" + (" + one RCCL gather of TS per step" if world > 1 else ""),
+                       "ts_bytes_per_step": n_ts, "status": [int(r.status) for r in reps], "rs_fail_words": [int(r.rs_fail_words) for r in reps],
+                       **check},
+            "roofline": {"bound": "valu", "kernel": "viterbi3_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(vit_ms, 4),
-                         "chain_frac": round(msps / world * 1e6 * (8 + n_ts / nsamp) / 1e9 / HBM_PEAK_GBS, 6),
+                         "chain_frac": round(msps / world * 1e6 * (8 + n_ts / n_stream) / 1e9 / HBM_PEAK_GBS, 6),
                          "hbm_copy_gbs": hbm_copy_gbs(torch, f"cuda:{local}")},
-            "stage_ms_per_segment": {k: round(sum(sg["rx"].stage_ms(k) for sg in segs) / nseg, 4) for k in ("acq", "fft", "demod", "inner", "viterbi", "rs", "total")},
+            "stage_ms_per_piece": {k: round(sum(p["rx"].stage_ms(k) for p in job.pieces) / nseg, 4) for k in ("acq", "fft", "demod", "inner", "viterbi", "rs", "total")},
         }
+    job.close()
+    if rank == 0:
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_superframes)
+            ref = reference_sse2_viterbi()
+            if ref:
+                out["cpu_baseline"]["reference_sse2_viterbi"] = ref
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    for sg in segs:
-        sg["rx"].close()
     if dist:
         dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(1)
 
 
 if __name__ == "__main__":

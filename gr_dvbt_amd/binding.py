@@ -55,7 +55,12 @@ class RxReport(C.Structure):
                 ("n_out_symbols", C.c_int32), ("cp_start0", C.c_int32), ("first_call", C.c_int32),
                 ("n_viterbi_bytes", C.c_int64), ("n_rs_items", C.c_int64), ("n_rs_bytes", C.c_int64),
                 ("n_ts_bytes", C.c_int64), ("rs_fail_words", C.c_int32), ("rs_corrected_symbols", C.c_int32),
-                ("resume_sample", C.c_int64)]
+                ("resume_sample", C.c_int64), ("segment_offset", C.c_int64), ("stream_symbol_offset", C.c_int64),
+                ("ts_first_packet", C.c_int64), ("stream_rs_items", C.c_int64)]
+
+
+class RxCut(C.Structure):
+    _fields_ = [("stream_symbol_offset", C.c_int64)]
 
 
 class Dims(C.Structure):
@@ -92,6 +97,7 @@ def lib():
         L.dvbt_rx_stage_ms.argtypes = [C.c_void_p, C.c_char_p]
         L.dvbt_rx_enable_timing.argtypes = [C.c_void_p, C.c_int]
         L.dvbt_rx_enable_taps.argtypes = [C.c_void_p, C.c_int]
+        L.dvbt_rx_set_cut.argtypes = [C.c_void_p, C.POINTER(RxCut)]
         L.dvbt_rx_destroy.argtypes = [C.c_void_p]
         L.dvbt_get_dims.argtypes = [C.c_int] * 5 + [C.POINTER(Dims)]
         _lib = L
@@ -140,6 +146,11 @@ class Rx:
         self.report = rep
         return rep
 
+    def set_cut(self, stream_symbol_offset):
+        """Declare the following segments as the continuation of a cut stream (include/dvbt_hip.h: dvbt_rx_set_cut)."""
+        cut = RxCut(int(stream_symbol_offset))
+        _chk(self.L.dvbt_rx_set_cut(self.h, C.byref(cut)))
+
     def enqueue_device(self, dptr, nsamples, stream=None):
         _chk(self.L.dvbt_rx_segment_enqueue_device(self.h, C.c_void_p(dptr), nsamples,
                                                    C.c_void_p(stream) if stream else None))
@@ -156,7 +167,7 @@ class Rx:
         sizes = {TAP_ACQ: r.n_symbols * d.fft_length * 8, TAP_FFT: r.n_symbols * d.fft_length * 8,
                  TAP_EQ: r.n_out_symbols * d.payload_length * 8, TAP_DEMAP: r.n_out_symbols * d.payload_length,
                  TAP_SYMDEINT: r.n_out_symbols * d.payload_length, TAP_BITDEINT: r.n_out_symbols * d.payload_length,
-                 TAP_VITERBI: r.n_viterbi_bytes, TAP_DEINT: r.n_rs_items * 1632, TAP_RS: r.n_rs_bytes,
+                 TAP_VITERBI: r.n_viterbi_bytes, TAP_DEINT: r.n_rs_bytes // 188 * 204, TAP_RS: r.n_rs_bytes,
                  TAP_TS: r.n_ts_bytes, TAP_CP_START: r.n_symbols * 4, TAP_SYMBOL_INDEX: max(r.n_symbols - 1, 0) * 4}
         nbytes = max(int(sizes[tap]), 0)
         buf = np.zeros(nbytes, np.uint8)

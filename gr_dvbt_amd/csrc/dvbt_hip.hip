@@ -13,9 +13,7 @@
 #include "k_backend.hpp"
 #include "k_symbol.hpp"
 #include "k_resample.hpp"
-#include "k_viterbi2.hpp"
 #include "k_viterbi3.hpp"
-#include "k_viterbi4.hpp"
 
 using namespace dvbt;
 
@@ -25,7 +23,7 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #define HIPCHKV(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_err = std::string(#x) + ": " + hipGetErrorString(e_); } } while (0)
 
 extern "C" const char *dvbt_last_error(void) { return g_err.c_str(); }
-extern "C" const char *dvbt_version(void) { return "dvbt_hip 0.1 (gfx950)"; }
+extern "C" const char *dvbt_version(void) { return "dvbt_hip 0.2 (gfx950)"; }
 extern "C" int dvbt_device_count(void)
 {
   int n = 0;
@@ -163,64 +161,22 @@ struct Tables {          // device lookup tables for one configuration
   }
 };
 
-// A7 kernel generation: 3 = packed 16-bit cells, 4 chunks per wavefront (default); 4 = the same with 8 chunks per wavefront (fewer
-// instructions per chunk but one wavefront per SIMD: measured 8 % slower, kept for A/B runs); 2 = DPP butterflies, 32-bit cells; 1 = one chunk per
-// wavefront on ds_bpermute (kept for A/B runs: DVBT_VITERBI_KERNEL=1)
-static int viterbi_kernel_version()
-{
-  const char *e = getenv("DVBT_VITERBI_KERNEL");
-  return (e && e[0] >= '1' && e[0] <= '4') ? e[0] - '0' : 3;
-}
+// A7: 4 chunks per wavefront, one-wave workgroups (k_viterbi3.hpp)
 static void launch_viterbi(hipStream_t s, const uint8_t *in, uint8_t *out, const RxState *st, long long steps_fixed, const VitParams &vp,
                            long long in_base, long long out_lo, long long max_out_bytes)
 {
   long long chunks = (max_out_bytes + vp.chunk_bytes - 1) / vp.chunk_bytes;
   if (chunks < 1) chunks = 1;
-  if (viterbi_kernel_version() == 1)
-    hipLaunchKernelGGL(viterbi_kernel, dim3((unsigned)((chunks + 3) / 4)), dim3(256), 0, s, in, out, st, steps_fixed, vp, in_base, out_lo);
-  else if (viterbi_kernel_version() == 4)
-  {
-    const dim3 grid((unsigned)((chunks + V4_DEC - 1) / V4_DEC)), blk(64);
-    switch (vp.ntb) {   // the traceback depth is a template parameter (hop schedule fixed at compile time)
-      case 5: hipLaunchKernelGGL(viterbi4_kernel<5>, grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
-      case 9: hipLaunchKernelGGL(viterbi4_kernel<9>, grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
-      case 10: hipLaunchKernelGGL(viterbi4_kernel<10>, grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
-      case 15: hipLaunchKernelGGL(viterbi4_kernel<15>, grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
-      default: hipLaunchKernelGGL(viterbi4_kernel<24>, grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
-    }
-  }
-  else if (viterbi_kernel_version() == 3)
-  {
-    const dim3 grid((unsigned)((chunks + 3) / 4)), blk(64);
-    switch (vp.ntb) {   // the traceback depth is a template parameter (hop schedule fixed at compile time)
-      case 5: hipLaunchKernelGGL(viterbi3_kernel<5>, grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
-      case 9: hipLaunchKernelGGL(viterbi3_kernel<9>, grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
-      case 10: hipLaunchKernelGGL(viterbi3_kernel<10>, grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
-      case 15: hipLaunchKernelGGL(viterbi3_kernel<15>, grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
-      default: hipLaunchKernelGGL(viterbi3_kernel<24>, grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
-    }
-  }
-  else {
-    const long long per_wg = 4 * V2_WAVES;
-    hipLaunchKernelGGL(viterbi2_kernel, dim3((unsigned)((chunks + per_wg - 1) / per_wg)), dim3(64 * V2_WAVES), 0, s, in, out, st, steps_fixed, vp, in_base, out_lo);
+  const dim3 grid((unsigned)((chunks + 4 * V3_WGW - 1) / (4 * V3_WGW))), blk(64 * V3_WGW);
+  switch (vp.ntb) {   // the traceback depth is a template parameter (hop schedule fixed at compile time)
+    case 5: hipLaunchKernelGGL(viterbi3_kernel<5>, grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
+    case 9: hipLaunchKernelGGL(viterbi3_kernel<9>, grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
+    case 10: hipLaunchKernelGGL(viterbi3_kernel<10>, grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
+    case 15: hipLaunchKernelGGL(viterbi3_kernel<15>, grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
+    default: hipLaunchKernelGGL(viterbi3_kernel<24>, grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
   }
 }
 
-static VitParams make_vit_params(const Dims &d, int bsize, int chunk_bytes)
-{
-  VitParams v; memset(&v, 0, sizeof v);
-  v.m = d.m; v.k = d.k; v.n = d.n; v.plen = d.plen; v.ntb = d.ntb; v.bsize = bsize;
-  v.d_nsymbols = bsize * d.n / d.m; v.d_nbits = 2 * d.k * bsize;
-  v.chunk_bytes = chunk_bytes > 0 ? chunk_bytes : 768; v.payload = d.payload;
-  memcpy(v.punct, d.punct, 16); memcpy(v.prefix, d.prefix, 16);
-  { const char *e = getenv("DVBT_VITERBI_DBG"); v.dbg = e ? atoi(e) : 0; }
-  v.punct_mask = 0; v.prefix_nib = 0;
-  for (int i = 0; i < d.plen; i++) { v.punct_mask |= (unsigned)d.punct[i] << i; v.prefix_nib |= (unsigned long long)d.prefix[i] << (4 * i); }
-  v.magic_plen = ~0ull / (unsigned)d.plen + 1; v.magic_m = ~0ull / (unsigned)d.m + 1;
-  for (int i = 0; i < 64; i++) v.punct_rep |= (unsigned long long)d.punct[i % d.plen] << i;
-  v.magic16_plen = (65536u + (unsigned)d.plen - 1) / (unsigned)d.plen;
-  return v;
-}
 static FrontParams make_front_params(const Dims &d, float snr_db)
 {
   FrontParams p; memset(&p, 0, sizeof p);
@@ -273,6 +229,7 @@ struct dvbt_rx {
   bool timing = false, pending = false;
   hipEvent_t ev[ST_COUNT]; double acc_ms[ST_COUNT] = {0}; long n_timed = 0; bool ev_ready = false, ev_recorded = false;
   dvbt_rx_report last; bool have_last = false;
+  dvbt_rx_cut cut = {0};
 };
 
 static void rx_free(dvbt_rx *h)
@@ -338,6 +295,14 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   return DVBT_OK;
 }
 
+extern "C" int dvbt_rx_set_cut(dvbt_rx *h, const dvbt_rx_cut *cut)
+{
+  if (!h || !cut) return fail(DVBT_ERR_INVALID, "null argument");
+  if (cut->stream_symbol_offset < 0 || cut->stream_symbol_offset % 272) return fail(DVBT_ERR_INVALID, "stream_symbol_offset must be a non-negative multiple of 272 (whole superframes)");
+  h->cut = *cut;
+  return DVBT_OK;
+}
+
 extern "C" int dvbt_rx_enable_timing(dvbt_rx *h, int enable) { if (!h) return DVBT_ERR_INVALID; h->timing = enable != 0; return DVBT_OK; }
 
 // debug taps that are not pipeline buffers are allocated on first request
@@ -360,11 +325,12 @@ extern "C" int dvbt_rx_enable_taps(dvbt_rx *h, int enable)
   return DVBT_OK;
 }
 
-static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s)
+// chain_rate: the samples are already at the OFDM elementary rate (a restart inside a resampled segment)
+static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s, bool chain_rate = false)
 {
   const Dims &d = h->d;
-  if (nsamples > h->max_samples) return fail(DVBT_ERR_CAPACITY, "segment longer than max_samples");
-  if (h->rsd.ri) {   // next row 2: the segment arrives at the file rate; resample + scale into the chain's input buffer first
+  if (nsamples > (chain_rate ? h->chain_max : h->max_samples)) return fail(DVBT_ERR_CAPACITY, "segment longer than max_samples");
+  if (h->rsd.ri && !chain_rate) {   // next row 2: the segment arrives at the file rate; resample + scale into the chain's input buffer first
     const long long cnt = (long long)(((unsigned long long)nsamples * h->rsd.ri + h->rsd.rd - 1) / h->rsd.rd);
     hipLaunchKernelGGL(resample_scale_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, iq, 0ll, (long long)nsamples, 0ll, cnt, h->rsd.ri, h->rsd.rd,
                        h->rsd.nt, (const float *)h->rsd.br, h->prm.front_scale == 0.f ? 1.0f : h->prm.front_scale, h->rs_iq);
@@ -416,26 +382,26 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s)
     hipLaunchKernelGGL(tps_fsm_kernel, dim3(1), dim3(256), 0, s, fp, h->st, 0, (const SymInfo *)h->info, (const int *)h->maj, h->tps_state,
                        h->sym_index, (int *)nullptr, (const unsigned char *)nullptr, (const int *)(h->trk_flags + 9));
   }
-  hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(64), 0, s, h->st, h->vp, h->prm.descramble);
+  hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(64), 0, s, h->st, h->vp, h->prm.descramble, (long long)h->cut.stream_symbol_offset);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_INNER], s));
   InnerParams ip = h->T.inner_params(d.payload);
   // A5 + A6 on the label bytes of the symbols from first_out on (A4 ran inside the symbol kernel)
   hipLaunchKernelGGL(inner_kernel<6>, dim3(C), dim3(INNER_THREADS), inner_lds_bytes((size_t)d.payload), s, (const float2 *)nullptr, (const uint8_t *)h->labels, ip,
-                     (const RxState *)h->st, 0, getenv("DVBT_INNER_DBG") ? atoi(getenv("DVBT_INNER_DBG")) : 0, (const int *)h->sym_index, (const float2 *)nullptr, (const unsigned char *)nullptr,
+                     (const RxState *)h->st, 0, (const int *)h->sym_index, (const float2 *)nullptr, (const unsigned char *)nullptr,
                      (const uint16_t *)h->T.H, (const uint16_t *)h->T.Hinv, (uint8_t *)nullptr, h->symdeint_tap, h->bitdeint);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_VIT], s));
   long long max_vit = (long long)C * d.payload * d.m * d.k / (8 * d.n) + 1;
   VitParams vp = h->vp;
-  if (h->prm.viterbi_chunk_bytes <= 0 && viterbi_kernel_version() >= 2) {
+  if (h->prm.viterbi_chunk_bytes <= 0) {
     // chunk size chosen per segment so that the wavefront count is a whole number of "rounds" of the resident
-    // wavefront slots (4 chunks per wavefront, 8 one-wave workgroups per CU by LDS): equal-length chunks then
+    // wavefront slots (4 chunks per wavefront, V3_WAVES_PER_CU one-wave workgroups per CU: 3 per SIMD): equal-length chunks then
     // finish together instead of leaving a partial last round, and longer chunks amortise the warm-up +
     // traceback overlap (V3_WARM + ntraceback - 1 windows per chunk).  Measured on 65 superframes: 3 rounds of
     // ~2900-byte chunks beat 5 rounds of ~1700 (less overlap) and 1 round of ~8600 (the hardware's static
     // placement of a single round leaves some SIMDs with one wavefront)
     int ncu = 256; (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->prm.device);
-    const long long slots = (long long)ncu * 8 * 4;             // chunks resident at once
-    static const long long kMaxChunk = [] { const char *e = getenv("DVBT_VITERBI_MAXCHUNK"); return e ? atoll(e) : 3000ll; }();
+    const long long slots = (long long)ncu * V3_WAVES_PER_CU * 4;   // chunks resident at once
+    constexpr long long kMaxChunk = 3000;
     long long rounds = (max_vit + slots * kMaxChunk - 1) / (slots * kMaxChunk);
     if (rounds < 1) rounds = 1;
     long long B = (max_vit + slots * rounds - 1) / (slots * rounds);
@@ -484,8 +450,9 @@ extern "C" int dvbt_rx_segment_finish(dvbt_rx *h, dvbt_rx_report *rep)
   // the call that loses the lock consumes half a window (to_consume / 2, ofdm_sym_acquisition_impl.cc:545-559): that half step is
   // what moves the search windows of the re-acquisition to a different phase of the symbol grid
   r.resume_sample = ((s.status & 2) && !(s.status & 1)) ? (int64_t)(s.call0 + s.n_symbols) * (h->d.N + h->d.cp) + (h->d.N + h->d.cp) / 2 : 0;
-  r.n_viterbi_bytes = s.n_vit_bytes; r.n_rs_items = s.n_rs_items; r.n_rs_bytes = s.n_rs_items * 1504;
+  r.n_viterbi_bytes = s.n_vit_bytes; r.n_rs_items = s.n_rs_items; r.n_rs_bytes = s.n_rs_words * 188;
   r.n_ts_bytes = s.n_ts_bytes; r.rs_fail_words = s.rs_fail; r.rs_corrected_symbols = s.rs_corr;
+  r.stream_symbol_offset = s.sym_off; r.ts_first_packet = s.ts_first_packet; r.stream_rs_items = s.stream_rs_items;
   h->last = r; h->have_last = true;
   if (rep) *rep = r;
   return DVBT_OK;
@@ -510,19 +477,20 @@ extern "C" int dvbt_rx_segment_run(dvbt_rx *h, const void *iq_host, size_t nsamp
   const float2 *chain = h->rsd.ri ? h->rs_iq : h->d_iq;
   size_t chain_n = h->rsd.ri ? (size_t)(((unsigned long long)nsamples * h->rsd.ri + h->rsd.rd - 1) / h->rsd.rd) : nsamples;
   size_t off = 0;
-  const int saved_ri = h->rsd.ri;
   for (int attempt = 0; attempt < 8 && (rp.status & 2) && !(rp.status & 1) && rp.first_out_symbol < 0 && rp.resume_sample > 0; attempt++) {
     off += (size_t)rp.resume_sample;
     if (off + (size_t)(2 * h->d.N + h->d.cp + 16) > chain_n) break;
     AcqState as; memset(&as, 0, sizeof as); as.avg = h->st_host->avg_lost;
     HIPCHK(hipMemcpyAsync(h->acq_carry, &as, sizeof as, hipMemcpyHostToDevice, h->own_stream));
     h->use_carry = true;
-    h->rsd.ri = 0;                                               // the stream is already at the chain's rate
-    r = enqueue(h, chain + off, chain_n - off, h->own_stream);
-    h->rsd.ri = saved_ri; h->use_carry = false;
+    r = enqueue(h, chain + off, chain_n - off, h->own_stream, true);   // the stream is already at the chain's rate
+    h->use_carry = false;
     if (r) return r;
     r = dvbt_rx_segment_finish(h, &rp); if (r) return r;
   }
+  rp.segment_offset = (int64_t)off;
+  if (rp.resume_sample) rp.resume_sample += (int64_t)off;       // in the caller's sample numbering
+  h->last = rp;
   if (rep) *rep = rp;
   return DVBT_OK;
 }
@@ -541,7 +509,7 @@ static int tap_info(dvbt_rx *h, int tap, void **ptr, size_t *bytes)
     case DVBT_TAP_SYMDEINT: *ptr = h->symdeint_tap; *bytes = no * d.payload; break;
     case DVBT_TAP_BITDEINT: *ptr = h->bitdeint; *bytes = no * d.payload; break;
     case DVBT_TAP_VITERBI: *ptr = h->vit; *bytes = (size_t)r.n_viterbi_bytes; break;
-    case DVBT_TAP_DEINT: *ptr = h->deint_tap; *bytes = (size_t)r.n_rs_items * 1632; break;
+    case DVBT_TAP_DEINT: *ptr = h->deint_tap; *bytes = (size_t)(r.n_rs_bytes / 188) * 204; break;
     case DVBT_TAP_RS: *ptr = h->rs_out; *bytes = (size_t)r.n_rs_bytes; break;
     case DVBT_TAP_TS: *ptr = h->ts_out; *bytes = (size_t)r.n_ts_bytes; break;
     case DVBT_TAP_SYMBOL_INDEX: *ptr = h->sym_index; *bytes = (ns > 0 ? ns - 1 : 0) * 4; break;

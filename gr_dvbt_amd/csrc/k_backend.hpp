@@ -80,7 +80,7 @@ __device__ __forceinline__ int ipos(int d) { const int b = d / IB; return d + b 
 // e = perm(k) (bit_inner_deinterleaver_impl.cc:91-99,138-157).  One item = 4 consecutive output bytes: per bit plane one
 // (unaligned) word of the rotated block, masked and shifted into place.  VB = bits per carrier (compile time: the plane
 // permutation and the rotations are constants).
-template <int VB> __device__ __forceinline__ void bit_deint_words(const uint8_t *v, uint8_t *o, int payload, int tid, int dbg)
+template <int VB> __device__ __forceinline__ void bit_deint_words(const uint8_t *v, uint8_t *o, int payload, int tid)
 {
   constexpr int hv = VB / 2;
   const int nitems = (payload / 126) * 32;                       // 32 words cover the 126 bytes of a block
@@ -98,7 +98,6 @@ template <int VB> __device__ __forceinline__ void bit_deint_words(const uint8_t 
       val |= ((word >> (VB - 1 - eidx)) & 0x01010101u) << (VB - 1 - k);
     }
     uint8_t *dst = o + blk * 126 + 4 * j;                         // even address
-    if (dbg & 4) continue;
     *reinterpret_cast<uint16_t *>(dst) = (uint16_t)val;
     if (j < 31) *reinterpret_cast<uint16_t *>(dst + 2) = (uint16_t)(val >> 16);
   }
@@ -107,7 +106,7 @@ template <int VB> __device__ __forceinline__ void bit_deint_words(const uint8_t 
 constexpr int INNER_NB = 12;                         // carriers per thread and batch
 constexpr int INNER_THREADS = DVBT_INNER_THREADS;   // workgroup size of inner_kernel: a symbol's 6048 carriers are few serial steps per thread
 template <int MODE> __global__ __launch_bounds__(INNER_THREADS) void inner_kernel(const float2 *__restrict__ eq, const uint8_t *__restrict__ in_bytes, InnerParams p,
-                                                   const RxState *st, int nitems_fixed, int dbg, const int *__restrict__ sym_index,
+                                                   const RxState *st, int nitems_fixed, const int *__restrict__ sym_index,
                                                    const float2 *__restrict__ points, const unsigned char *__restrict__ label_tab,
                                                    const uint16_t *__restrict__ H, const uint16_t *__restrict__ Hinv,
                                                    uint8_t *__restrict__ tap_demap, uint8_t *__restrict__ tap_symdeint,
@@ -119,7 +118,6 @@ template <int MODE> __global__ __launch_bounds__(INNER_THREADS) void inner_kerne
   unsigned char *label_of = reinterpret_cast<unsigned char *>(pts + 64);
   const int u = blockIdx.x, tid = threadIdx.x;
   constexpr int mode = MODE;                                    // compile time: no branches around the loads below
-  if (dbg & 1) return;                                          // dbg: experiment switches (DVBT_INNER_DBG)
   int first = 0, nout = nitems_fixed;
   if (st) { first = st->first_out; nout = st->n_out_symbols; if (first < 0) return; }
   if (u >= nout) return;
@@ -157,16 +155,15 @@ template <int MODE> __global__ __launch_bounds__(INNER_THREADS) void inner_kerne
     }
   }
   __syncthreads();
-  if (dbg & 2) return;
   uint8_t *o = out + (size_t)u * p.payload;
   if (tap_symdeint) for (int q = tid; q < p.payload; q += INNER_THREADS) tap_symdeint[(size_t)u * p.payload + q] = v[ipos(q)];
   if (!(mode & 4)) { for (int q = tid; q < p.payload; q += INNER_THREADS) o[q] = v[ipos(q)]; return; }
   // A6: output byte i of a block, bit k (MSB first) = bit (m-1-e) of input byte (i - off_e) mod 126, e = perm(k).
   // One item = 4 consecutive output bytes: per bit plane one (unaligned) word of the rotated block, masked and
   // shifted into place.
-  if (p.m == 2) bit_deint_words<2>(v, o, p.payload, tid, dbg);
-  else if (p.m == 4) bit_deint_words<4>(v, o, p.payload, tid, dbg);
-  else bit_deint_words<6>(v, o, p.payload, tid, dbg);
+  if (p.m == 2) bit_deint_words<2>(v, o, p.payload, tid);
+  else if (p.m == 4) bit_deint_words<4>(v, o, p.payload, tid);
+  else bit_deint_words<6>(v, o, p.payload, tid);
 }
 
 // ---------------------------------------------------------------- sizes derived on the device (no host sync)
@@ -176,7 +173,6 @@ struct VitParams {
   int d_nbits;           // depunctured bits per block       (:151)
   int chunk_bytes;       // decoded bytes per wavefront chunk
   int payload;
-  int dbg;               // experiment switches (DVBT_VITERBI_DBG): 1 skip traceback, 2 skip forward, 4 skip staging
   unsigned punct_mask;            // bit p = puncture vector entry p
   unsigned long long prefix_nib;  // nibble p = kept bits before phase p
   unsigned long long magic_plen, magic_m;   // ceil(2^64/d): x/d == umul64hi(x, magic) for x < 2^56
@@ -185,145 +181,37 @@ struct VitParams {
   uint8_t punct[16], prefix[16];
 };
 
-__global__ void plan_kernel(RxState *st, VitParams vp, int descramble)
+// sym_off = 0: the segment holds the beginning of a stream, every size is the reference's for a chain that starts at the
+// segment's superframe start.  sym_off > 0 (a multiple of 272): the segment CONTINUES a cut stream whose
+// first superframe start lies sym_off OFDM symbols before this segment's; the Viterbi block count
+// (viterbi_decoder_impl.cc:198), the delay of ntraceback bytes and the even item count of the byte de-interleaver
+// (set_output_multiple(2)) are then taken in STREAM coordinates, so that the segments' outputs end exactly where
+// the outputs of one chain over the whole stream would.
+__global__ void plan_kernel(RxState *st, VitParams vp, int descramble, long long sym_off)
 {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  long long nin = (long long)st->n_out_symbols * vp.payload;
-  long long nblocks = nin / vp.d_nsymbols;
-  st->n_vit_in = nblocks * vp.d_nsymbols;
-  st->n_vit_steps = nblocks * (vp.d_nbits / 2);
-  long long nb = st->n_vit_steps / 8 - vp.ntb;
+  const long long ibits = (long long)vp.payload * vp.m * vp.k / vp.n;          // decoded bits per OFDM symbol
+  const long long nin_g = (sym_off + (long long)st->n_out_symbols) * vp.payload;
+  const long long nblocks_g = nin_g / vp.d_nsymbols;
+  long long nin = nblocks_g * vp.d_nsymbols - sym_off * vp.payload;
+  long long steps = nblocks_g * (vp.d_nbits / 2) - sym_off * ibits;
+  if (nin < 0 || steps < 0) { nin = 0; steps = 0; }
+  st->n_vit_in = nin;
+  st->n_vit_steps = steps;
+  long long nb_g = nblocks_g * (vp.d_nbits / 2) / 8 - vp.ntb;
+  if (nb_g < 0) nb_g = 0;
+  long long nb = steps / 8 - vp.ntb;
   if (nb < 0) nb = 0;
   st->n_vit_bytes = nb;
-  st->n_rs_items = (nb / 1632) & ~1ll;                          // convolutional_deinterleaver set_output_multiple(2)
-  st->n_ts_bytes = 0; st->rs_fail = 0; st->rs_corr = 0;
+  const long long items_g = (nb_g / 1632) & ~1ll;               // convolutional_deinterleaver set_output_multiple(2)
+  long long words = items_g * 8 - sym_off * ibits / (8 * 204);
+  if (words < 0) words = 0;
+  st->stream_rs_items = items_g;
+  st->n_rs_words = words;
+  st->n_rs_items = words / 8;
+  st->sym_off = sym_off;
+  st->n_ts_bytes = 0; st->rs_fail = 0; st->rs_corr = 0; st->ts_first_packet = 0;
   (void)descramble;
-}
-
-// ---------------------------------------------------------------- A7: depuncture + K=7 Viterbi, one wavefront per chunk
-// Lane s holds the metric of trellis state s (state = last 6 input bits, newest at LSB;
-// d_viterbi.c:272-277,503-524).  Per step: predecessors s>>1 and (s>>1)+32 via ds_bpermute,
-// branch metrics as "number of agreeing non-erased symbols", decision bit = (hi >= lo) exactly as
-// decision0/decision1 of the SSE2 butterfly, ballot -> one 64-bit decision word per step in LDS.
-// Every 8 steps (the reference's get_output cadence, viterbi_decoder_impl.cc:263-268): first-index
-// arg-max of the metrics, subtract the minimum.  Traceback runs with lanes = output bytes:
-// (ntraceback-1) hops of 8 decisions from the window's best state, then the 8 decisions of the
-// next-older window are the decoded byte (d_viterbi.c:699-724).
-//
-// Stream-parallel decode: chunk c produces decoded bytes [c*B, (c+1)*B).  It starts VIT_WARM
-// windows early from all-zero metrics (exactly the reference's state only at the stream start) and
-// runs ntraceback windows past its end.  The extended step index g counts two leading null steps
-// (both symbols erased) so that every window, including the reference's 6-step first one, is 8 steps.
-constexpr int VIT_WARM = 64;        // windows of warm-up before the first wanted byte
-constexpr int VIT_RING = 128;       // windows kept in LDS (>= 64 + ntraceback)
-
-__device__ __forceinline__ int parity6(int x) { return __popc(x) & 1; }
-
-// in_base: stream index of in[0]; out_lo: first decoded byte this launch has to produce (out[0] is
-// that byte).  Both 0 for a whole segment; non-zero only for the streaming block API.
-__global__ __launch_bounds__(256) void viterbi_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const RxState *st,
-                                                     long long steps_fixed, VitParams vp, long long in_base, long long out_lo)
-{
-  __shared__ unsigned long long s_dec[4][VIT_RING * 8];
-  __shared__ unsigned char s_best[4][VIT_RING];
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  unsigned long long *dec = s_dec[wv];
-  unsigned char *bestw = s_best[wv];
-  const long long total_steps = st ? st->n_vit_steps : steps_fixed;
-  const long long total_out = total_steps / 8 - vp.ntb;
-  const long long chunk = (long long)blockIdx.x * 4 + wv;
-  const long long b0 = out_lo + chunk * vp.chunk_bytes;
-  if (b0 >= total_out) return;
-  long long b1 = b0 + vp.chunk_bytes; if (b1 > total_out) b1 = total_out;
-  const int ntb = vp.ntb;
-  long long w_start = b0 + 2 - VIT_WARM; if (w_start < 1) w_start = 1;
-  const long long w_end = b1 + ntb;                   // last window needed (inclusive)
-  const long long c_first = b0 + ntb + 1;             // get_output call that emits byte b0
-
-  // lane constants: butterfly i = lane>>1, appended bit x = lane&1
-  const int bi = lane >> 1, xb = lane & 1;
-  const int e0 = parity6((2 * bi) & 0x4f) ^ xb, e1 = parity6((2 * bi) & 0x6d) ^ xb;
-  const int cls_shift = 8 * (e0 | (e1 << 1));
-  const int pred0 = bi, pred1 = bi + 32;
-  int M = 0;
-
-  for (long long wb = w_start; wb <= w_end; wb += 64) {
-    // ---- depuncture (viterbi_decoder_impl.cc:241-256) for the 64 windows of this block: lane = window
-    unsigned codes = 0;
-    {
-      long long w = wb + lane;
-      long long g0 = 8 * (w - 1);
-      for (int k = 0; k < 8; k++) {
-        long long g = g0 + k;
-        unsigned code = 2u | (2u << 2);                                     // both erased (null step)
-        if (g >= 2 && (g - 2) < total_steps && w <= w_end) {
-          unsigned long long pbit = 2ull * (unsigned long long)(g - 2);
-          unsigned long long q = pbit / (unsigned)vp.plen; int ph = (int)(pbit - q * vp.plen);
-          unsigned r[2];
-          for (int h = 0; h < 2; h++) {
-            int phh = ph + h;                                                // plen is even: no wrap inside a step
-            if (vp.punct[phh]) {
-              unsigned long long rb = q * (unsigned)vp.n + vp.prefix[phh];
-              unsigned long long byte = rb / (unsigned)vp.m; int bo = (int)(rb - byte * vp.m);
-              r[h] = (in[byte - in_base] >> (vp.m - 1 - bo)) & 1u;
-            } else r[h] = 2u;
-          }
-          code = r[0] | (r[1] << 2);
-        }
-        codes |= code << (4 * k);
-      }
-    }
-    // ---- forward ACS over up to 64 windows
-    long long nwin = w_end - wb + 1; if (nwin > 64) nwin = 64;
-    for (int wi = 0; wi < (int)nwin; wi++) {
-      const unsigned wc = __shfl(codes, wi);
-      const long long w = wb + wi;
-      const int ring = (int)(w & (VIT_RING - 1));
-#pragma unroll
-      for (int k = 0; k < 8; k++) {
-        const unsigned r0 = (wc >> (4 * k)) & 3u, r1 = (wc >> (4 * k + 2)) & 3u;
-        const unsigned w0 = r0 != 2u, w1 = r1 != 2u;
-        // disagreement count for the 4 label classes (e0,e1), one byte each
-        unsigned packed = 0;
-#pragma unroll
-        for (int c = 0; c < 4; c++) packed |= ((w0 & ((c & 1u) ^ r0)) + (w1 & ((c >> 1) ^ r1))) << (8 * c);
-        const int hi_add = (packed >> cls_shift) & 0xff;
-        const int lo_add = (int)(w0 + w1) - hi_add;
-        const int lo = __shfl(M, pred0) + lo_add;
-        const int hi = __shfl(M, pred1) + hi_add;
-        const bool bit = hi >= lo;
-        M = bit ? hi : lo;
-        const unsigned long long d = __ballot(bit);
-        if (lane == 0) dec[ring * 8 + k] = d;
-      }
-      // get_output cadence: best state (first index of the maximum) and min-renormalisation
-      int key = (M << 6) | (63 - lane), mn = M;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { key = max(key, __shfl_xor(key, o)); mn = min(mn, __shfl_xor(mn, o)); }
-      M -= mn;
-      if (lane == 0) bestw[ring] = (unsigned char)(63 - (key & 63));
-    }
-    // ---- traceback for the calls completed in this block: lane = call
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // lane 0's decision/best stores -> all lanes
-    {
-      long long c = wb + lane;
-      bool active = (lane < nwin) && c >= c_first && c <= w_end && (c - ntb - 1) < b1;
-      if (active) {
-        int s = bestw[c & (VIT_RING - 1)];
-        long long w = c;
-        for (int hop = 0; hop < ntb - 1; hop++, w--) {
-          const unsigned long long *dw = dec + (w & (VIT_RING - 1)) * 8;
-#pragma unroll
-          for (int k = 7; k >= 0; k--) { unsigned b = (unsigned)(dw[k] >> s) & 1u; s = (s >> 1) | (b << 5); }
-        }
-        const unsigned long long *dw = dec + (w & (VIT_RING - 1)) * 8;
-        unsigned byte = 0;
-#pragma unroll
-        for (int k = 7; k >= 0; k--) { unsigned b = (unsigned)(dw[k] >> s) & 1u; byte |= b << (7 - k); s = (s >> 1) | (b << 5); }
-        out[c - ntb - 1 - out_lo] = (unsigned char)byte;
-      }
-    }
-  }
 }
 
 // ---------------------------------------------------------------- A8+A9 fused: Forney de-interleave gather + RS(204,188) decode
@@ -430,7 +318,7 @@ __global__ __launch_bounds__(64) void deint_rs_kernel(const uint8_t *__restrict_
   __shared__ uint8_t s_syn[64 * 16];
   uint8_t *s_cw = s_rows + 11 * 204;
   const int tid = threadIdx.x;
-  const long long nwords = st ? st->n_rs_items * 8 : words_fixed;
+  const long long nwords = st ? st->n_rs_words : words_fixed;
   const long long w0 = (long long)blockIdx.x * 64;
   if (w0 >= nwords) return;
   for (int i = tid; i < 1024; i += 64) reinterpret_cast<unsigned *>(s_div)[i] = reinterpret_cast<const unsigned *>(T.div_tab)[i];
@@ -528,13 +416,28 @@ __global__ __launch_bounds__(256) void conv_deint_kernel(const uint8_t *__restri
 __global__ void descramble_find_kernel(const uint8_t *__restrict__ in, RxState *st)
 {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  st->n_ts_bytes = 0; st->descr_base = 0; st->descr_index = 0; st->ts_first_packet = 0;
+  if (st->sym_off > 0) {
+    // continuation of a cut stream: the descrambler of the whole-stream chain locked long ago; this segment delivers
+    // every whole 8-packet group from its first NSYNC on (the words before it mix the de-interleaver's zero fill with
+    // data, exactly like the first words of a stream; their sync positions hold zeros).  Which of them the stitched
+    // stream keeps is the host's decision (gr_dvbt_amd/multi.py::stitch_ts): the two-item hold-back of :139-141
+    // belongs to the stream's end, not to a cut.
+    const long long nw = st->n_rs_words;
+    long long q = 0;
+    while (q < nw && in[q * 188] != 0xB8) q++;
+    if (q >= nw) return;
+    st->descr_index = (int)(q * 188); st->ts_first_packet = q;
+    st->n_ts_bytes = ((nw - q) / 8) * 1504;
+    return;
+  }
   long long nitems = st->n_rs_items, base = 0; int d_index = 0;
-  st->n_ts_bytes = 0; st->descr_base = 0; st->descr_index = 0;
   while (nitems - base >= 4) {
     const uint8_t *p = in + base * 1504;
     while (d_index < 2 * 1504 && p[d_index] != 0xB8) d_index += 188;
     if (d_index >= 2 * 1504) { d_index = 0; base += 2; continue; }
     st->descr_base = (int)base; st->descr_index = d_index;
+    st->ts_first_packet = base * 8 + d_index / 188;
     st->n_ts_bytes = (nitems - base - 2) * 1504;
     return;
   }

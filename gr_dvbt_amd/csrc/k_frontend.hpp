@@ -27,6 +27,10 @@ struct RxState {
   int rs_fail, rs_corr;
   float avg_lost;        // d_avg after the call that lost the lock (what a re-acquisition starts from)
   int pad0;
+  long long sym_off;         // cut stream: OFDM symbols between the stream's first superframe start and this segment's (0: stream start)
+  long long n_rs_words;      // RS words decoded (= 8 n_rs_items unless the segment continues a cut stream)
+  long long stream_rs_items; // items the byte de-interleaver of a chain over the whole stream has produced up to this segment's end
+  long long ts_first_packet; // RS word index (of this segment) of the first packet of the TS tap
 };
 
 struct FrontParams {
@@ -216,6 +220,7 @@ __global__ __launch_bounds__(256) void acq_init_fsm_kernel(FrontParams p, RxStat
   if (tid == 0 && t_begin == 0) {
     st->status = 1; st->call0 = 0; st->cp_start0 = 0; st->n_symbols = 0; st->first_out = -1; st->n_out_symbols = 0;
     st->n_vit_in = st->n_vit_steps = st->n_vit_bytes = st->n_rs_items = st->n_ts_bytes = 0; st->rs_fail = st->rs_corr = 0;
+    st->n_rs_words = st->stream_rs_items = st->ts_first_packet = 0;
     s_done = 0; s_avg = as ? as->avg : 0.f;
     if (as && as->acquired) {          // block API: still locked from the previous work() call, nothing to search
       st->status = 0; st->cp_start0 = as->cp_start; st->eps_init = 0.f; s_done = 2;

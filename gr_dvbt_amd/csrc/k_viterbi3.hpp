@@ -1,11 +1,19 @@
-// k_viterbi3.hpp -- A7, third-generation kernel: the DPP in-place trellis of k_viterbi2.hpp with TWO cells per
-// VGPR on packed 16-bit arithmetic (v_pk_add_i16 / v_pk_sub_i16 / v_pk_max_i16).
+// k_viterbi3.hpp -- A7 (viterbi_decoder): depuncture + K=7 Viterbi + traceback, the dominant kernel of the chain.
+// Add-compare-select butterflies on DPP lane exchanges (no LDS crossbar, no ds_bpermute in the inner loop), TWO cells
+// per VGPR on packed 16-bit arithmetic (v_pk_add_i16 / v_pk_sub_i16 / v_pk_max_i16).
 //
-// Mapping (as v2): one wavefront decodes FOUR chunks, a chunk owns one DPP row (16 lanes); every lane holds 4 of
-// the 64 path metrics -- here as the four 16-bit halves of two VGPRs.  Cell index
+// Mapping: one wavefront decodes FOUR chunks, a chunk owns one DPP row (16 lanes); every lane holds 4 of the 64 path
+// metrics as the four 16-bit halves of two VGPRs.  The trellis is updated IN PLACE: the butterfly (i, i+32) -> (2i, 2i+1)
+// is computed by the two cells that hold states i and i+32, each keeping one output, so after a step the cell that held
+// state s holds state rotl6(s): cell c holds state rotl6(c, u mod 6) at relative step u.  The two cells of a butterfly
+// differ in exactly one bit of the cell index, which walks 5,4,3,2,1,0,5,... with the step.  Cell index
 //     c = r(VGPR 0/1) : h(half 0/1) : a3 a2 a1 a0,   physical lane-in-row = (a0 + 2*a1) ^ (7*a2) ^ (8*a3)
-// and cell c holds state rotl6(c, u mod 6) at relative step u (in-place butterflies, see k_viterbi2.hpp).  The six
-// exchanges are: VGPR swap (free), half swap (one v_alignbit), and four DPP controls.
+// so the six exchanges are: VGPR swap (free), half swap (one v_alignbit), and four DPP controls (row_ror:8,
+// row_half_mirror, quad_perm[2,3,0,1], quad_perm[1,0,3,2]).
+//
+// Branch metrics enter as delta = 2*(agreements - disagreements) of the butterfly's label with the received pair:
+// X = M + delta (own), Y = M - delta (offered to the partner), new = max(X, Y_partner); this is the reference's m0..m3
+// (d_viterbi.c:503-506) up to an offset common to all 64 states, which the renormalisation removes anyway.
 //
 // A 16-bit cell = (2M + bias) << 8 | path byte.
 //  * metric field (8 bits, signed): M in units of half an agreement, bias = 1 when the cell holds an upper state
@@ -19,20 +27,56 @@
 //    the state after step 6, stamped there, bits 7:6).  It rides along with the metric through v_pk_max (metric
 //    fields never tie).  In the LDS ring a hop is one v_and_or: origin = byte & 63, merged with the next row address.
 // Per step and VGPR (two cells): v_perm (both branch-metric deltas from ONE word of four class deltas), pk_add,
-// pk_sub, exchange, pk_max, v_and_or (re-arm bias) -- 3 instructions per cell instead of 5.
+// pk_sub, exchange, pk_max, v_and_or (re-arm bias) -- 3 instructions per cell.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <limits.h>
+#include <string.h>
+#include "dvbt_tables.hpp"
 #include "k_backend.hpp"
-#include "k_viterbi2.hpp"
 
 namespace dvbt {
 
+// host side: the decoder's parameters for one configuration (viterbi_decoder_impl.cc:61-65,95-124,149-153)
+inline VitParams make_vit_params(const Dims &d, int bsize, int chunk_bytes)
+{
+  VitParams v; memset(&v, 0, sizeof v);
+  v.m = d.m; v.k = d.k; v.n = d.n; v.plen = d.plen; v.ntb = d.ntb; v.bsize = bsize;
+  v.d_nsymbols = bsize * d.n / d.m; v.d_nbits = 2 * d.k * bsize;
+  v.chunk_bytes = chunk_bytes > 0 ? chunk_bytes : 768; v.payload = d.payload;
+  memcpy(v.punct, d.punct, 16); memcpy(v.prefix, d.prefix, 16);
+  v.punct_mask = 0; v.prefix_nib = 0;
+  for (int i = 0; i < d.plen; i++) { v.punct_mask |= (unsigned)d.punct[i] << i; v.prefix_nib |= (unsigned long long)d.prefix[i] << (4 * i); }
+  v.magic_plen = ~0ull / (unsigned)d.plen + 1; v.magic_m = ~0ull / (unsigned)d.m + 1;
+  for (int i = 0; i < 64; i++) v.punct_rep |= (unsigned long long)d.punct[i % d.plen] << i;
+  v.magic16_plen = (65536u + (unsigned)d.plen - 1) / (unsigned)d.plen;
+  return v;
+}
+
+#define DPP_XOR1 0xB1              /* quad_perm [1,0,3,2] */
+#define DPP_XOR2 0x4E              /* quad_perm [2,3,0,1] */
+#define DPP_HALF_MIRROR 0x141      /* lane i <-> 7-i inside each half row: logical bit a2 */
+#define DPP_ROR8 0x128             /* row_ror:8: lane i <-> i^8 */
+#define DPP_MIRROR 0x140
+
+__device__ __forceinline__ int rotl6(int c, int p) { return ((c << p) | (c >> (6 - p))) & 63; }
+
+constexpr int V3_WGW = 1;          // wavefronts per workgroup (independent: no barrier).  Four-wave workgroups were measured equal (round 2)
+#ifndef V3_EXP
+#define V3_EXP 0                   // tools/vit_kbench.hip only, never the product library (cost attribution; the output is wrong for bits 1..8, 256):
+                                   // 1 no traceback, 2 no window end, 4 no path-byte store, 8 stage once, 16 record every wavefront's SIMD and
+                                   // lifetime, 32 alternate s_setprio window by window, 64 s_nop after every step, 128 s_sleep per window,
+                                   // 256 step words from registers (no LDS read in the loop)
+#endif
 constexpr int V3_WARM = 72;        // warm-up windows before a chunk's first byte
 constexpr int V3_BLK = 24;         // windows per forward block (multiple of 6: phase cycle x renormalisation cadence)
 constexpr int V3_RINGW = 64;       // windows kept in the LDS ring (power of two, >= 2*V3_BLK - 12 + max ntraceback - 1: the traceback of a
-                                   // block runs during the first 12 windows of the next one)
+                                   // block runs during the first 12 windows of the next one).  20 KB of LDS per one-wave workgroup = 2 wavefronts
+                                   // per SIMD.  A 32-window ring with traceback groups of six windows (3 wavefronts per SIMD) was built and
+                                   // measured in round 2: +14 % instructions for -7 % cycles per instruction, 4.33 ms against 4.03 ms
+                                   // (tools/experiments/viterbi_w3_ring32.patch, profiles/r02_viterbi_attribution.json)
+constexpr int V3_WAVES_PER_CU = 4 * 2; // one-wave workgroups resident per CU (3 per SIMD; the kernel is built with amdgpu_waves_per_eu(3, 3))
 constexpr int V3_CBW = 17;         // words of compacted received bits per decoder and block (192 steps need <= 384 + 23 bits)
 
 typedef short v3pk __attribute__((ext_vector_type(2)));
@@ -134,11 +178,16 @@ template <int P, int ST> __device__ __forceinline__ void v3_step(int (&v)[2], un
 }
 
 // the 8 steps of a window that starts at phase P0 (0, 2, 4); v arrives with the origin stamp in its path bytes
+#if V3_EXP & 64
+#define V3_YIELD() asm volatile("s_nop 3" ::: "memory")
+#else
+#define V3_YIELD()
+#endif
 template <int P0> __device__ __forceinline__ void v3_window(int (&v)[2], const unsigned (&W)[8], const V3Lane &L, int (&raw)[2])
 {
-  v3_step<(P0 + 0) % 6, 0>(v, W[0], L, raw); v3_step<(P0 + 1) % 6, 0>(v, W[1], L, raw); v3_step<(P0 + 2) % 6, 0>(v, W[2], L, raw);
-  v3_step<(P0 + 3) % 6, 0>(v, W[3], L, raw); v3_step<(P0 + 4) % 6, 0>(v, W[4], L, raw); v3_step<(P0 + 5) % 6, 1>(v, W[5], L, raw);
-  v3_step<(P0 + 6) % 6, 0>(v, W[6], L, raw); v3_step<(P0 + 7) % 6, 2>(v, W[7], L, raw);
+  v3_step<(P0 + 0) % 6, 0>(v, W[0], L, raw); V3_YIELD(); v3_step<(P0 + 1) % 6, 0>(v, W[1], L, raw); V3_YIELD(); v3_step<(P0 + 2) % 6, 0>(v, W[2], L, raw); V3_YIELD();
+  v3_step<(P0 + 3) % 6, 0>(v, W[3], L, raw); V3_YIELD(); v3_step<(P0 + 4) % 6, 0>(v, W[4], L, raw); V3_YIELD(); v3_step<(P0 + 5) % 6, 1>(v, W[5], L, raw); V3_YIELD();
+  v3_step<(P0 + 6) % 6, 0>(v, W[6], L, raw); V3_YIELD(); v3_step<(P0 + 7) % 6, 2>(v, W[7], L, raw);
 }
 
 // halves of a packed register as sign-extended 32-bit values
@@ -211,16 +260,27 @@ template <int V6, bool HOPS, int HOP0, int NTB> __device__ __forceinline__ void 
   if (HOPS && HOP0 + 2 * V6 + 1 < NTB - 1) v3_hop(T, tab, dd * 64);
   const int jr = (j0 + V6) & (V3_RINGW - 1);
   unsigned W[8];
+#if V3_EXP & 256
+  for (int i = 0; i < 8; i++) { W[i] = (unsigned)(j0 * 0x01010101 + i * 0x00020406 + pl); asm volatile("" : "+v"(W[i])); }   // no LDS read in the loop
+#else
   {
     const uint4 *wp = reinterpret_cast<const uint4 *>(wrow + V6 * 8);
     const uint4 t0 = wp[0], t1 = wp[1];
     W[0] = t0.x; W[1] = t0.y; W[2] = t0.z; W[3] = t0.w; W[4] = t1.x; W[5] = t1.y; W[6] = t1.z; W[7] = t1.w;
   }
+#endif
   constexpr int P0 = (8 * V6) % 6;
   int raw[2];
+#if V3_EXP & 32
+  if (V6 & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);   // alternate the wavefront's issue priority window by window
+#endif
+#if V3_EXP & 128
+  __builtin_amdgcn_s_sleep(1);
+#endif
   v3_window<P0>(v, W, L, raw);
   // the four path bytes of this lane's cells = one word of the table (storage index z = 4*lane + 2r + h)
-  *reinterpret_cast<unsigned *>(tab + (jr * 4 + dd) * 64 + pl * 4) = __builtin_amdgcn_perm((unsigned)raw[1], (unsigned)raw[0], 0x06040200u);
+  if (!(V3_EXP & 4)) *reinterpret_cast<unsigned *>(tab + (jr * 4 + dd) * 64 + pl * 4) = __builtin_amdgcn_perm((unsigned)raw[1], (unsigned)raw[0], 0x06040200u);
+  if (V3_EXP & 2) { if (raw[0] == 0x12345) bests[jr] = 1; return; }
   const int s = v3_window_end<(P0 + 2) % 6, (V6 & 1) == 1>(v, L);
   bests[dd * V3_RINGW + jr] = (unsigned char)s;                    // low byte of the key (63 - best state in bits 5:0); all 16 lanes of the row write the same byte
 }
@@ -243,13 +303,22 @@ template <bool HOPS, int HOP0, int NTB> __device__ __forceinline__ void v3_fwd_s
 //   forward   24 windows of add-compare-select (v3_fwd_window), path bytes into the LDS ring;
 //   traceback of the PREVIOUS block's 24 calls x 4 decoders (d_viterbi.c:714-724), lane = (decoder, call): its
 //             dependent LDS reads are interleaved into the first 12 windows of the forward pass.
+#if V3_EXP & 16
+__device__ unsigned long long *v3_dbg;     // tools/vit_kbench.hip: (hw id, start, end in 100 MHz ticks) per wavefront
+#endif
 template <int NTB> __global__ __launch_bounds__(64) void viterbi3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const RxState *st,
                                                       long long steps_fixed, VitParams vp, long long in_base, long long out_lo)
 {
   __shared__ __attribute__((aligned(16))) unsigned char tab[V3_RINGW * 4 * 64];   // path bytes: [window][decoder][cell z]  (the ppresult ring)
   __shared__ __attribute__((aligned(16))) unsigned wbuf[4 * V3_BLK * 8];          // step words: [decoder][step in block]
   __shared__ unsigned char bests[4 * V3_RINGW];                                    // best state per window
-  __shared__ unsigned cbits[4 * V3_CBW];                                           // compacted received bits per decoder (MSB first)
+  // compacted received bits per decoder (MSB first): V3_CBW words at the head of the decoder's wbuf row.  stage_words reads them (every
+  // lane its two words) before the wavefront writes the block's step words over them, and the previous block's step words are dead by
+  // then; a wavefront's LDS operations execute in order.  The overlay keeps the workgroup at 19,776 B of LDS: eight workgroups per CU
+  // (two wavefronts per SIMD) with room to spare
+  unsigned *const cbits = wbuf;
+  constexpr int V3_CBS = V3_BLK * 8;                                               // stride between the decoders' bit streams
+  static_assert(V3_CBW <= V3_CBS, "bit stream does not fit the step-word row");
   __shared__ unsigned lut[16];                                                     // (keep flags, next two received bits) -> the step word
   const int lane = threadIdx.x & 63, dd = lane >> 4, pl = lane & 15;
 
@@ -257,7 +326,7 @@ template <int NTB> __global__ __launch_bounds__(64) void viterbi3_kernel(const u
   const long long total_out = total_steps / 8 - vp.ntb;
   const int B = vp.chunk_bytes, m = vp.m;
   constexpr int ntb = NTB;                                         // == vp.ntb (the host picks the instantiation)
-  const long long chunk0 = (long long)blockIdx.x * 4;
+  const long long chunk0 = (long long)blockIdx.x * 4;   // V3_WGW == 1
   if (out_lo + chunk0 * B >= total_out) return;                   // whole wavefront idle
   const long long b0 = out_lo + (chunk0 + dd) * B;                // this lane's decoder
   const bool dec_active = b0 < total_out;
@@ -277,6 +346,9 @@ template <int NTB> __global__ __launch_bounds__(64) void viterbi3_kernel(const u
     const unsigned d2 = (unsigned)(2 * (u0 - u1)) & 0xff, d3 = (unsigned)(2 * (-u0 - u1)) & 0xff;
     lut[lane] = d0 | (d1 << 8) | (d2 << 16) | (d3 << 24);
   }
+#if V3_EXP & 16
+  const unsigned long long dbg_t0 = wall_clock64();
+#endif
   V3Lane L; v3_init_lane(pl, L);
   int v[2] = {L.org[0], 0x01000100 | L.org[1]};                    // phase 0: VGPR 1 holds the upper states; origin stamp of window 0
 
@@ -312,7 +384,7 @@ template <int NTB> __global__ __launch_bounds__(64) void viterbi3_kernel(const u
       const unsigned mk = (1u << m) - 1;
       auto grp = [&](unsigned d) { return ((d & mk) << (3 * m)) | (((d >> 8) & mk) << (2 * m)) | (((d >> 16) & mk) << m) | ((d >> 24) & mk); };
       const unsigned g0 = grp(q.x), g1 = grp(q.y), g2 = grp(q.z), g3 = grp(q.w);
-      unsigned *cb = cbits + dd * V3_CBW;
+      unsigned *cb = cbits + dd * V3_CBS;
       if (pl < nload) {
         if (m == 2) cb[pl] = (g0 << 24) | (g1 << 16) | (g2 << 8) | g3;
         else if (m == 4) { cb[2 * pl] = (g0 << 16) | g1; cb[2 * pl + 1] = (g2 << 16) | g3; }
@@ -336,7 +408,7 @@ template <int NTB> __global__ __launch_bounds__(64) void viterbi3_kernel(const u
     const int ph = x - dq * vp.plen;
     const int pos = off * m + bo0 + dq * vp.n + (int)((vp.prefix_nib >> (4 * ph)) & 15ull) - (int)((vp.prefix_nib >> (4 * ph0)) & 15ull);
     const unsigned kmask = ((unsigned)(vp.punct_rep >> ph) << (2 * lo)) & (((1u << (2 * hi)) - 1u) & ~((1u << (2 * lo)) - 1u));
-    const unsigned *cb = cbits + dd * V3_CBW;
+    const unsigned *cb = cbits + dd * V3_CBS;
     const unsigned cw0 = cb[pos >> 5], cw1 = cb[(pos >> 5) + 1];
     unsigned win = (unsigned)(((((unsigned long long)cw0) << 32) | cw1) >> (32 - (pos & 31)));
 #pragma unroll
@@ -366,31 +438,35 @@ template <int NTB> __global__ __launch_bounds__(64) void viterbi3_kernel(const u
 
   stage_load(0);
   for (int jb = 0; jb < J; jb += V3_BLK) {
-    stage_words(jb);
-    if (jb + V3_BLK < J) stage_load(jb + V3_BLK);                  // the bytes of the next block travel during this block's forward pass
-    const bool tr = jb > 0 && !(vp.dbg & 1);
+    if (!(V3_EXP & 8) || jb == 0) stage_words(jb);
+    if (jb + V3_BLK < J && !(V3_EXP & 8)) stage_load(jb + V3_BLK);                  // the bytes of the next block travel during this block's forward pass
+    const bool tr = jb > 0 && !(V3_EXP & 1);
     if (tr) trace_init(jb - V3_BLK);
-    if (!(vp.dbg & 2)) {
-      const unsigned *wrow = wbuf + dd * (V3_BLK * 8);
-      if (tr) {
-        v3_fwd_six<true, 0, NTB>(v, L, wrow, tab, bests, jb, dd, pl, T);
-        v3_fwd_six<true, 12, NTB>(v, L, wrow + 48, tab, bests, jb + 6, dd, pl, T);
-        v3_trace_out(T, tab, dd * 64, out, out_lo);
-      } else {
-        v3_fwd_six<false, 0, NTB>(v, L, wrow, tab, bests, jb, dd, pl, T);
-        v3_fwd_six<false, 0, NTB>(v, L, wrow + 48, tab, bests, jb + 6, dd, pl, T);
-      }
-      for (int wi = 12; wi < V3_BLK; wi += 6) v3_fwd_six<false, 0, NTB>(v, L, wrow + wi * 8, tab, bests, jb + wi, dd, pl, T);
+    const unsigned *wrow = wbuf + dd * (V3_BLK * 8);
+    if (tr) {
+      v3_fwd_six<true, 0, NTB>(v, L, wrow, tab, bests, jb, dd, pl, T);
+      v3_fwd_six<true, 12, NTB>(v, L, wrow + 48, tab, bests, jb + 6, dd, pl, T);
+      v3_trace_out(T, tab, dd * 64, out, out_lo);
+    } else {
+      v3_fwd_six<false, 0, NTB>(v, L, wrow, tab, bests, jb, dd, pl, T);
+      v3_fwd_six<false, 0, NTB>(v, L, wrow + 48, tab, bests, jb + 6, dd, pl, T);
     }
-    if (tr && (vp.dbg & 2)) { for (int h = 0; h < ntb - 1; h++) v3_hop(T, tab, dd * 64); v3_trace_out(T, tab, dd * 64, out, out_lo); }
+    for (int wi = 12; wi < V3_BLK; wi += 6) v3_fwd_six<false, 0, NTB>(v, L, wrow + wi * 8, tab, bests, jb + wi, dd, pl, T);
   }
   // the last block's calls
-  if (!(vp.dbg & 1)) {
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    trace_init(J - V3_BLK);
-    for (int h = 0; h < ntb - 1; h++) v3_hop(T, tab, dd * 64);
-    v3_trace_out(T, tab, dd * 64, out, out_lo);
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  trace_init(J - V3_BLK);
+  for (int h = 0; h < ntb - 1; h++) v3_hop(T, tab, dd * 64);
+  v3_trace_out(T, tab, dd * 64, out, out_lo);
+#if V3_EXP & 16
+  if (lane == 0) {
+    unsigned id, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned long long *d = v3_dbg + 3 * (long long)blockIdx.x;
+    d[0] = (id & 0xffffu) | ((xcc & 0xfu) << 16); d[1] = dbg_t0; d[2] = wall_clock64();
   }
+#endif
 }
 
 }  // namespace dvbt

@@ -238,13 +238,19 @@ typedef struct {
   int32_t first_call;          /* general_work call (window of N+cp samples) in which the initial acquisition succeeded */
   int64_t n_viterbi_bytes;
   int64_t n_rs_items;          /* items of 8 codewords */
-  int64_t n_rs_bytes;          /* = n_rs_items*1504 */
+  int64_t n_rs_bytes;          /* RS words decoded x 188 (= n_rs_items*1504 unless the segment continues a cut stream) */
   int64_t n_ts_bytes;          /* after energy_descramble (0 when descramble==0) */
   int32_t rs_fail_words, rs_corrected_symbols;
-  int64_t resume_sample;       /* status bit1 (lock lost): sample of the segment (at the OFDM elementary rate) at which the reference
+  int64_t resume_sample;       /* status bit1 (lock lost): sample of the caller's segment (at the OFDM elementary rate) at which the reference
                                   would start re-acquiring: the call that lost the lock consumes half a window (N+cp)/2; else 0.
                                   dvbt_rx_segment_run restarts there by itself while no superframe start has been found yet (the
                                   start-up transient of a segment that begins with more than one window of silence). */
+  int64_t segment_offset;      /* sample of the caller's segment (OFDM elementary rate) at which the reported decode started: 0 unless
+                                  dvbt_rx_segment_run restarted; cp_start0, first_call and the CP_START tap count from here */
+  /* cut streams (dvbt_rx_set_cut) */
+  int64_t stream_symbol_offset; /* the cut's offset, echoed */
+  int64_t ts_first_packet;     /* index, among this segment's RS words, of the first packet of the TS tap */
+  int64_t stream_rs_items;     /* items of 8 RS words a chain over the whole stream has produced up to this segment's end */
 } dvbt_rx_report;
 
 typedef enum {
@@ -255,7 +261,7 @@ typedef enum {
   DVBT_TAP_SYMDEINT = 4,
   DVBT_TAP_BITDEINT = 5,
   DVBT_TAP_VITERBI = 6,    /* u8[n_viterbi_bytes] */
-  DVBT_TAP_DEINT = 7,      /* u8[n_rs_items*1632] */
+  DVBT_TAP_DEINT = 7,      /* u8[n_rs_bytes/188*204] */
   DVBT_TAP_RS = 8,         /* u8[n_rs_bytes] */
   DVBT_TAP_TS = 9,         /* u8[n_ts_bytes] */
   DVBT_TAP_CP_START = 10,  /* i32[n_symbols] */
@@ -264,6 +270,20 @@ typedef enum {
 
 typedef struct dvbt_rx dvbt_rx;
 int  dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out);
+/* Cut streams (the path shards over independent baseband segments).  A long stream is cut near superframe
+ * boundaries; every piece is decoded as a segment of its own (other handle, stream or GPU).  A piece that does not hold the
+ * beginning of the stream begins a pre-roll before the superframe start it is to deliver (long enough for CP lock and one
+ * whole TPS frame) and declares, before it is enqueued, how many OFDM symbols lie between the stream's FIRST superframe
+ * start (where the reference's chain starts decoding: demod_reference_signals_impl.cc:118-136) and its own: a multiple of
+ * 272.  The library then takes the Viterbi block count (viterbi_decoder_impl.cc:198), the ntraceback delay and the even
+ * item count of the byte de-interleaver (convolutional_deinterleaver_impl.cc:55-61) in stream coordinates, and the TS tap
+ * starts at the piece's first NSYNC and runs in whole 8-packet groups to the end of its RS words (no two-item hold-back,
+ * energy_descramble_impl.cc:139-141: that belongs to the stream's end).  The first RS words of a piece mix the
+ * de-interleaver's zero fill with data, as at a stream start: the piece before delivers those packets (post-roll).
+ * gr_dvbt_amd/multi.py (plan_cuts / stitch_ts) holds the host side: concatenating the trimmed pieces gives, byte for byte,
+ * the TS of one chain over the whole stream.  offset 0 (the default) = the piece holds the beginning of the stream. */
+typedef struct { int64_t stream_symbol_offset; } dvbt_rx_cut;
+int  dvbt_rx_set_cut(dvbt_rx *h, const dvbt_rx_cut *cut);   /* applies to the segments enqueued afterwards */
 /* iq: host pointer to nsamples complex64 (copied to the device first) */
 int  dvbt_rx_segment_run(dvbt_rx *h, const void *iq_host, size_t nsamples, dvbt_rx_report *report);
 /* iq_device: device pointer (hipMalloc'd, e.g. a torch tensor's data_ptr). stream: a hipStream_t or NULL.

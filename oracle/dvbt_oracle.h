@@ -95,6 +95,8 @@ const unsigned char *o_vit_puncture(int code_rate, int *len);
  * (= nblocks*bsize*k/8 - ntraceback). */
 size_t o_viterbi_decode(const o_cfg *c, int bsize, const unsigned char *in, size_t nsym,
                         unsigned char *out);
+/* the same over exactly nsym input bytes (the depunctured bit count must be a multiple of 16) */
+size_t o_viterbi_decode_n(const o_cfg *c, const unsigned char *in, size_t nsym, unsigned char *out);
 
 /* ---- Forney byte de-interleaver (lib/convolutional_deinterleaver_impl.cc) ---- */
 /* closed form of the 12 FIFOs starting from all-zero state; n bytes -> n bytes */
@@ -104,6 +106,8 @@ void o_conv_interleave(const unsigned char *in, unsigned char *out, size_t n);
 /* ---- energy dispersal / descramble (next-row component) ---- */
 void o_energy_prbs(unsigned char *seq1504); /* xor pattern for one 8-packet group, byte0 of each pkt=0 */
 void o_energy_dispersal(const unsigned char *ts, unsigned char *out, size_t npackets);
+void o_energy_dispersal_from(const unsigned char *ts, unsigned char *out, size_t npackets, size_t packet0);
+size_t o_energy_descramble_groups(const unsigned char *in, size_t ngroups, unsigned char *out);
 /* restates energy_descramble_impl::general_work given the whole RS output;
  * returns bytes written */
 size_t o_energy_descramble(const unsigned char *in, size_t nitems1504, unsigned char *out);
@@ -142,6 +146,8 @@ int o_demod_work(o_demod *d, const ocf *in, ocf *out, int sync_start_tag,
 size_t o_tx_symbols_for_packets(const o_cfg *c, size_t npackets);
 size_t o_tx_generate(const o_cfg *c, const unsigned char *ts, size_t npackets, float scale,
                      ocf *iq, size_t cap_samples, ocf *freq_taps /* optional nsym*N or NULL */);
+size_t o_tx_generate_from(const o_cfg *c, const unsigned char *ts, size_t npackets, size_t packet0, float scale,
+                          ocf *iq, size_t cap_samples, ocf *freq_taps);
 
 /* ---- whole RX chain, emulating the GNU Radio flowgraph in the 1-item regime ---- */
 typedef struct {
@@ -159,10 +165,15 @@ typedef struct {
   int n_acquired;
   int rs_fail, rs_corr;
   double t_stage[10];     /* seconds per stage (acq,fft,demod,demap,symd,bitd,vit,deint,rs,descr) */
+  long long ts_first_packet;  /* RS word index (of this run) of the first TS packet */
+  long long stream_rs_items;  /* byte de-interleaver items in stream coordinates (== rs_n/1504 unless the run continues a cut stream) */
 } o_rx_taps;
 
 int o_rx_run(const o_cfg *c, const ocf *iq, size_t nsamples, float snr_db, int bsize,
              int rs_compat, o_rx_taps *t);
+/* checker of the product's cut mode (include/dvbt_hip.h: dvbt_rx_set_cut); sym_off = 0 is o_rx_run */
+int o_rx_run_cut(const o_cfg *c, const ocf *iq, size_t nsamples, float snr_db, int bsize,
+                 int rs_compat, long long sym_off, o_rx_taps *t);
 
 #ifdef __cplusplus
 }

@@ -13,6 +13,15 @@ static double now(void)
 
 int o_rx_run(const o_cfg *c, const ocf *iq, size_t nsamples, float snr_db, int bsize,
              int rs_compat, o_rx_taps *t)
+{ return o_rx_run_cut(c, iq, nsamples, snr_db, bsize, rs_compat, 0, t); }
+
+/* sym_off > 0: the segment continues a cut stream (include/dvbt_hip.h: dvbt_rx_set_cut) whose first superframe start
+ * lies sym_off OFDM symbols (a multiple of 272) before this segment's.  This is NOT reference behaviour (the reference
+ * has no notion of a cut): it is the checker of the product's cut mode and of gr_dvbt_amd/multi.py -- block, delay and
+ * item roundings are taken in stream coordinates, and the TS starts at the first NSYNC and runs in whole 8-packet
+ * groups to the end of the RS words. */
+int o_rx_run_cut(const o_cfg *c, const ocf *iq, size_t nsamples, float snr_db, int bsize,
+                 int rs_compat, long long sym_off, o_rx_taps *t)
 {
   const int N = c->N, cp = c->cp, P = c->payload;
   int truncated = 0;
@@ -106,36 +115,60 @@ int o_rx_run(const o_cfg *c, const ocf *iq, size_t nsamples, float snr_db, int b
   size_t vit_cap = (size_t)P * nout * c->m * c->k / (8 * c->n) + 64;
   unsigned char *vit = malloc(vit_cap);
   t0 = now();
-  size_t nvit = o_viterbi_decode(c, bsize, b2, (size_t)P * nout, vit);
+  const long long ibits = (long long)P * c->m * c->k / c->n;            /* decoded bits per OFDM symbol */
+  const long long d_nsym = (long long)bsize * c->n / c->m;
+  const long long nblocks_g = (sym_off + (long long)nout) * P / d_nsym;   /* viterbi_decoder_impl.cc:198 in stream coordinates */
+  long long nin_l = nblocks_g * d_nsym - sym_off * P;
+  if (nin_l < 0) nin_l = 0;
+  size_t nvit = o_viterbi_decode_n(c, b2, (size_t)nin_l, vit);
+  long long nb_g = nblocks_g * (long long)c->k * bsize / 8 - o_vit_ntraceback(c->code_rate);
+  if (nb_g < 0) nb_g = 0;
   t->t_stage[6] = now() - t0;
   free(b2);
   if (t->vit_out) { size_t n = nvit < t->vit_cap ? nvit : t->vit_cap; memcpy(t->vit_out, vit, n); t->vit_n = n; }
 
   /* ---- A8 byte de-interleave: items of 12*136 bytes, output multiple of 2 (:55-61) */
-  size_t nitems = (nvit / 1632) & ~(size_t)1;
-  unsigned char *dei = malloc(nitems * 1632 + 1);
+  const long long items_g = (nb_g / 1632) & ~1ll;
+  long long nwords_l = items_g * 8 - sym_off * ibits / (8 * 204);
+  if (nwords_l < 0) nwords_l = 0;
+  if ((size_t)nwords_l * 204 > nvit) nwords_l = (long long)(nvit / 204);   /* cannot happen; keeps the reads in bounds */
+  size_t nitems = (size_t)nwords_l / 8;                  /* whole items (all of them unless the segment continues a cut stream) */
+  const size_t nwords = (size_t)nwords_l;
+  t->stream_rs_items = items_g; t->ts_first_packet = 0;
+  unsigned char *dei = malloc(nwords * 204 + 1);
   t0 = now();
-  o_conv_deinterleave(vit, dei, nitems * 1632);
+  o_conv_deinterleave(vit, dei, nwords * 204);
   t->t_stage[7] = now() - t0;
   free(vit);
-  if (t->deint_out) { size_t n = nitems * 1632 < t->deint_cap ? nitems * 1632 : t->deint_cap; memcpy(t->deint_out, dei, n); t->deint_n = n; }
+  if (t->deint_out) { size_t n = nwords * 204 < t->deint_cap ? nwords * 204 : t->deint_cap; memcpy(t->deint_out, dei, n); t->deint_n = n; }
 
   /* ---- A9 RS */
-  unsigned char *rso = malloc(nitems * 1504 + 1);
+  unsigned char *rso = malloc(nwords * 188 + 1);
   {
     o_rs rs; o_rs_init(&rs);
     t0 = now();
-    o_rs_dec_block(&rs, dei, rso, nitems * 8, rs_compat, &t->rs_fail, &t->rs_corr);
+    o_rs_dec_block(&rs, dei, rso, nwords, rs_compat, &t->rs_fail, &t->rs_corr);
     t->t_stage[8] = now() - t0;
   }
   free(dei);
-  if (t->rs_out) { size_t n = nitems * 1504 < t->rs_cap ? nitems * 1504 : t->rs_cap; memcpy(t->rs_out, rso, n); t->rs_n = n; }
+  if (t->rs_out) { size_t n = nwords * 188 < t->rs_cap ? nwords * 188 : t->rs_cap; memcpy(t->rs_out, rso, n); t->rs_n = n; }
 
   /* ---- next: energy descramble */
   if (t->ts_out) {
-    unsigned char *tso = malloc(nitems * 1504 + 1);
+    unsigned char *tso = malloc(nwords * 188 + 1);
     t0 = now();
-    size_t n = o_energy_descramble(rso, nitems, tso);
+    size_t n;
+    if (sym_off > 0) {
+      size_t q = 0;
+      while (q < nwords && rso[q * 188] != 0xB8) q++;
+      n = q < nwords ? o_energy_descramble_groups(rso + q * 188, (nwords - q) / 8, tso) : 0;
+      t->ts_first_packet = (long long)q;
+    } else {
+      size_t q = 0;                                       /* what o_energy_descramble locks on: the first NSYNC, 16 packets at a time */
+      while (q < nitems * 8 && rso[q * 188] != 0xB8) q++;
+      t->ts_first_packet = (long long)q;
+      n = o_energy_descramble(rso, nitems, tso);
+    }
     t->t_stage[9] = now() - t0;
     if (n > t->ts_cap) n = t->ts_cap;
     memcpy(t->ts_out, tso, n); t->ts_n = n;

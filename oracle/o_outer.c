@@ -46,16 +46,34 @@ void o_energy_prbs(unsigned char *seq)
   }
 }
 
-/* lib/energy_dispersal_impl.cc:106-141 for a TS that starts on a sync byte */
-void o_energy_dispersal(const unsigned char *ts, unsigned char *out, size_t npackets)
+/* lib/energy_dispersal_impl.cc:106-141 for a TS that starts on a sync byte; packet0 = index in the whole TS of
+ * ts[0] (the 8-packet groups count from the start of the whole TS) */
+void o_energy_dispersal_from(const unsigned char *ts, unsigned char *out, size_t npackets, size_t packet0)
 {
   unsigned char seq[1504];
   o_energy_prbs(seq);
   for (size_t p = 0; p < npackets; p++) {
-    size_t g = p % 8;
+    size_t g = (p + packet0) % 8;
     out[p * 188] = g == 0 ? 0xB8 : 0x47;
     for (int k = 1; k < 188; k++) out[p * 188 + k] = ts[p * 188 + k] ^ seq[g * 188 + k];
   }
+}
+
+void o_energy_dispersal(const unsigned char *ts, unsigned char *out, size_t npackets)
+{ o_energy_dispersal_from(ts, out, npackets, 0); }
+
+/* the descrambling of :143-163 alone: ngroups groups of 8 packets that start on an NSYNC packet */
+size_t o_energy_descramble_groups(const unsigned char *in, size_t ngroups, unsigned char *out)
+{
+  unsigned char seq[1504];
+  o_energy_prbs(seq);
+  size_t written = 0;
+  for (size_t i = 0; i < ngroups; i++)
+    for (int k = 0; k < 1504; k++) {
+      unsigned char b = in[i * 1504 + k];
+      out[written++] = (k % 188 == 0) ? 0x47 : (b ^ seq[k]);
+    }
+  return written;
 }
 
 /* lib/energy_descramble_impl.cc:108-174 with the whole RS output visible in one call

@@ -32,6 +32,14 @@ static void codeword(unsigned *reg, int bit, int *x, int *y)
 
 size_t o_tx_generate(const o_cfg *c, const unsigned char *ts, size_t npackets, float scale,
                      ocf *iq, size_t cap, ocf *freq_taps)
+{ return o_tx_generate_from(c, ts, npackets, 0, scale, iq, cap, freq_taps); }
+
+/* packet0: index of ts[0] in the whole TS when the generator starts at a later superframe of a long stream (a multiple
+ * of the packets per superframe): only the phase of the 8-packet energy-dispersal groups depends on it.  The byte
+ * interleaver and the convolutional encoder start from zero state, so the first 11 RS words' worth of symbols differ
+ * from the same symbols of a generator that started at packet 0; everything after is identical. */
+size_t o_tx_generate_from(const o_cfg *c, const unsigned char *ts, size_t npackets, size_t packet0, float scale,
+                          ocf *iq, size_t cap, ocf *freq_taps)
 {
   const int N = c->N, cp = c->cp, K = c->Kmax + 1, zl = c->zeros_left;
   const size_t ibits = info_bits_per_symbol(c);
@@ -43,7 +51,7 @@ size_t o_tx_generate(const o_cfg *c, const unsigned char *ts, size_t npackets, f
   o_rs rs; o_rs_init(&rs);
   size_t nbytes = npackets * 204;
   unsigned char *disp = malloc(npackets * 188), *rsout = malloc(nbytes), *il = malloc(nbytes);
-  o_energy_dispersal(ts, disp, npackets);
+  o_energy_dispersal_from(ts, disp, npackets, packet0);
   unsigned char w[255];
   for (size_t p = 0; p < npackets; p++) {
     memset(w, 0, 51); memcpy(w + 51, disp + p * 188, 188);

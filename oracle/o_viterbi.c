@@ -115,40 +115,37 @@ int o_vit_ntraceback(int cr)
                 case O_C7_8: return 24; default: return 5; }
 }
 
-/* viterbi_decoder_impl.cc:192-324 for a stream that starts with a reset (d_init = 0) */
-size_t o_viterbi_decode(const o_cfg *c, int bsize, const unsigned char *in, size_t nsym,
-                        unsigned char *out)
+/* viterbi_decoder_impl.cc:192-324 for a stream that starts with a reset (d_init = 0), over exactly nsym input bytes:
+ * the depuncturer and the butterfly/output cadence (:241-292) depend only on the running bit count modulo the puncture
+ * period and modulo 16, and a block is a whole number of both, so a run of blocks is one long block.  nsym must
+ * make the depunctured bit count a multiple of 16 (any whole number of blocks does). */
+size_t o_viterbi_decode_n(const o_cfg *c, const unsigned char *in, size_t nsym, unsigned char *out)
 {
   int plen; const unsigned char *punct = o_vit_puncture(c->code_rate, &plen);
   int nt = o_vit_ntraceback(c->code_rate);
-  int d_nsymbols = bsize * c->n / c->m;          /* :149 */
-  int d_nbits = 2 * c->k * bsize;                /* :151 */
-  size_t nblocks = nsym / (size_t)d_nsymbols;
-  unsigned char *bits = malloc((size_t)d_nbits + 32);
   o_vit_core v; v.store_pos = 0;
   o_vit_core_init(&v, nt);
-  size_t out_count = 0;
-  for (size_t nb = 0; nb < nblocks; nb++) {
-    /* depuncture :241-256 */
-    int count = 0;
-    for (int i = 0; i < d_nsymbols; i++)
-      for (int j = c->m - 1; j >= 0; j--) {
-        while (punct[count % (2 * c->k)] == 0) bits[count++] = 2;
-        bits[count++] = (in[nb * d_nsymbols + i] >> j) & 1;
-        while (punct[count % (2 * c->k)] == 0) bits[count++] = 2;
-      }
-    /* decode :261-292 */
-    for (int ic = 0; ic < d_nbits; ic++) {
-      if ((ic % 4) == 0) {
-        o_vit_butterfly2(&v, &bits[ic & ~3]);
-        if (ic > 0 && (ic % 16) == 8) {
-          unsigned char ch = o_vit_get_output(&v);
-          if (out_count >= (size_t)nt) out[out_count - nt] = ch;   /* d_init==0 for the whole first call */
-          out_count++;
-        }
-      }
+  size_t out_count = 0, count = 0, ic = 0;
+  unsigned char bits[4]; int nb = 0;
+  /* depuncture :241-256 feeding the decoder :261-292 four bits (two trellis steps) at a time */
+#define O_PUSH(b) do { bits[nb++] = (unsigned char)(b); count++; if (nb == 4) { nb = 0; \
+    o_vit_butterfly2(&v, bits); \
+    if (ic > 0 && (ic % 16) == 8) { unsigned char ch = o_vit_get_output(&v); if (out_count >= (size_t)nt) out[out_count - nt] = ch; out_count++; } \
+    ic += 4; } } while (0)
+  for (size_t i = 0; i < nsym; i++)
+    for (int j = c->m - 1; j >= 0; j--) {
+      while (punct[count % (size_t)(2 * c->k)] == 0) O_PUSH(2);
+      O_PUSH((in[i] >> j) & 1);
+      while (punct[count % (size_t)(2 * c->k)] == 0) O_PUSH(2);
     }
-  }
-  free(bits);
+#undef O_PUSH
   return out_count >= (size_t)nt ? out_count - nt : 0;
+}
+
+/* block-level entry: whole blocks of bsize*n/m input bytes only (:149,:198) */
+size_t o_viterbi_decode(const o_cfg *c, int bsize, const unsigned char *in, size_t nsym,
+                        unsigned char *out)
+{
+  int d_nsymbols = bsize * c->n / c->m;          /* :149 */
+  return o_viterbi_decode_n(c, in, (nsym / (size_t)d_nsymbols) * (size_t)d_nsymbols, out);
 }

@@ -62,7 +62,7 @@ class Taps(C.Structure):
         ("meta_cap", C.c_size_t),
         ("first_out_symbol", C.c_int), ("n_acquired", C.c_int),
         ("rs_fail", C.c_int), ("rs_corr", C.c_int),
-        ("t_stage", C.c_double * 10)]
+        ("t_stage", C.c_double * 10), ("ts_first_packet", C.c_longlong), ("stream_rs_items", C.c_longlong)]
 
 
 _lib = None
@@ -86,6 +86,12 @@ def lib():
         L.o_rx_run.restype = C.c_int
         L.o_rx_run.argtypes = [C.POINTER(Cfg), C.c_void_p, C.c_size_t, C.c_float, C.c_int, C.c_int,
                                C.POINTER(Taps)]
+        L.o_rx_run_cut.restype = C.c_int
+        L.o_rx_run_cut.argtypes = [C.POINTER(Cfg), C.c_void_p, C.c_size_t, C.c_float, C.c_int, C.c_int, C.c_longlong,
+                                   C.POINTER(Taps)]
+        L.o_tx_generate_from.restype = C.c_size_t
+        L.o_tx_generate_from.argtypes = [C.POINTER(Cfg), C.c_void_p, C.c_size_t, C.c_size_t, C.c_float, C.c_void_p,
+                                         C.c_size_t, C.c_void_p]
         L.o_rs_decode.restype = C.c_int
         L.o_vit_get_output.restype = C.c_ubyte
         L.o_resample_scale.restype = C.c_size_t
@@ -123,13 +129,62 @@ def make_ts(npackets, seed):
     return ts.reshape(-1)
 
 
+def packets_per_superframe(c):
+    return 272 * (c.payload * c.m * c.k // c.n) // (204 * 8)
+
+
+def stream_ts(c, first_sf, n_sf, seed):
+    """TS of superframes [first_sf, first_sf + n_sf) of THE synthetic stream `seed`: every superframe's packets come
+    from their own generator, so any part of a long stream can be produced without the rest (bench.py: every rank
+    generates only the piece it decodes)."""
+    pps = packets_per_superframe(c)
+    out = np.empty((n_sf * pps, 188), np.uint8)
+    for j in range(n_sf):
+        rng = np.random.RandomState((seed * 1000003 + first_sf + j) % (2 ** 31))
+        out[j * pps:(j + 1) * pps] = rng.randint(0, 256, size=(pps, 188)).astype(np.uint8)
+    out[:, 0] = 0x47
+    return out.reshape(-1)
+
+
+STREAM_LEAD_IN = 1000
+
+
+def stream_len(c, n_sf, lead_in=STREAM_LEAD_IN):
+    return lead_in + n_sf * 272 * (c.N + c.cp) + 3 * c.N
+
+
+def stream_slice(c, n_sf, seed, begin=0, end=None, lead_in=STREAM_LEAD_IN):
+    """Samples [begin, end) of the synthetic stream (lead_in zeros, n_sf superframes of stream_ts, 3N zeros).
+    A slice that starts inside superframe j > 0 is generated from the start of superframe j (or j - 1 when it begins
+    within the first 16 symbols of j): the generator's interleaver and encoder start from zero there, which changes
+    only the first 11 RS words' worth of symbols of that superframe -- ahead of the slice or, for a cut piece, deep in
+    its pre-roll's discarded output."""
+    L = c.N + c.cp
+    total = stream_len(c, n_sf, lead_in)
+    end = total if end is None else min(end, total)
+    out = np.zeros(end - begin, np.complex64)
+    sym_b = max(0, (begin - lead_in) // L)
+    j0 = sym_b // 272
+    if j0 > 0 and sym_b - 272 * j0 < 16:
+        j0 -= 1
+    j1 = min(n_sf, -(-max(end - lead_in, 0) // (272 * L)))
+    if j1 > j0:
+        body = tx(c, stream_ts(c, j0, j1 - j0, seed), packet0=j0 * packets_per_superframe(c))
+        s0 = lead_in + j0 * 272 * L                                  # stream sample of body[0]
+        a, b = max(begin, s0), min(end, s0 + len(body))
+        if b > a:
+            out[a - begin:b - begin] = body[a - s0:b - s0]
+    return out
+
+
 def tx_scale(c):
     """TX multiply_const * RX multiply_const of the demo flowgraphs (apps/dvbt_{tx,rx}_demo*.grc)."""
     return float(np.float32(0.0022097087) * np.float32(0.0022097087 if c.mode == T2k else 0.00055242272))
 
 
-def tx(c, ts, scale=None, lead_in=0, tail=0, want_freq=False):
-    """TS bytes -> complex64 baseband at the 64/7 Msps tap. lead_in/tail: zero samples added."""
+def tx(c, ts, scale=None, lead_in=0, tail=0, want_freq=False, packet0=0):
+    """TS bytes -> complex64 baseband at the 64/7 Msps tap. lead_in/tail: zero samples added.
+    packet0: index of ts[0] in the whole TS (o_tx_generate_from)."""
     L = lib()
     npk = len(ts) // 188
     nsym = L.o_tx_symbols_for_packets(C.byref(c), npk)
@@ -139,14 +194,15 @@ def tx(c, ts, scale=None, lead_in=0, tail=0, want_freq=False):
     if scale is None:
         scale = tx_scale(c)
     body = iq[lead_in:lead_in + n]
-    w = L.o_tx_generate(C.byref(c), _p(ts), npk, C.c_float(scale), _p(body), n,
-                        _p(freq) if want_freq else None)
+    w = L.o_tx_generate_from(C.byref(c), _p(ts), npk, packet0, C.c_float(scale), _p(body), n,
+                             _p(freq) if want_freq else None)
     assert w == n
     return (iq, freq) if want_freq else iq
 
 
-def rx(c, iq, snr_db=30.0, bsize=768, rs_compat=0, want=("rs",), max_sym_taps=None):
-    """Run the whole oracle chain; returns dict of requested taps + metadata."""
+def rx(c, iq, snr_db=30.0, bsize=768, rs_compat=0, want=("rs",), max_sym_taps=None, sym_off=0):
+    """Run the whole oracle chain; returns dict of requested taps + metadata.
+    sym_off > 0: the segment continues a cut stream (o_rx_run_cut)."""
     L = lib()
     iq = np.ascontiguousarray(iq, dtype=np.complex64)
     nsym = len(iq) // (c.N + c.cp) + 2
@@ -183,9 +239,10 @@ def rx(c, iq, snr_db=30.0, bsize=768, rs_compat=0, want=("rs",), max_sym_taps=No
     t.epsilon = alloc("epsilon", (nsym,), np.float32)
     t.sym_index = alloc("sym_index", (nsym,), np.int32)
     t.meta_cap = nsym
-    trunc = L.o_rx_run(C.byref(c), _p(iq), len(iq), C.c_float(snr_db), bsize, rs_compat, C.byref(t))
+    trunc = L.o_rx_run_cut(C.byref(c), _p(iq), len(iq), C.c_float(snr_db), bsize, rs_compat, sym_off, C.byref(t))
     out = {"truncated": trunc, "n_acquired": t.n_acquired, "first_out_symbol": t.first_out_symbol,
-           "rs_fail": t.rs_fail, "rs_corr": t.rs_corr, "t_stage": list(t.t_stage)}
+           "rs_fail": t.rs_fail, "rs_corr": t.rs_corr, "t_stage": list(t.t_stage),
+           "ts_first_packet": t.ts_first_packet, "stream_rs_items": t.stream_rs_items, "stream_symbol_offset": sym_off}
     for k, n in (("acq", t.acq_n), ("fft", t.fft_n), ("eq", t.eq_n), ("demap", t.sym_n),
                  ("symdeint", t.sym_n), ("bitdeint", t.sym_n), ("vit", t.vit_n), ("deint", t.deint_n),
                  ("rs", t.rs_n), ("ts", t.ts_n)):
