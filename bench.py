@@ -273,6 +273,23 @@ class Job:
             p["rx"].close()
 
 
+def extra_workloads(a, torch, g, local):
+    """Throughput lines for the other single-GPU BASELINE configs (2: 2k QAM16 1/2 clean; 5: 8k QPSK 7/8 + AWGN at 14 dB), same
+    machinery, shorter streams; each is verified like the main line (config 5: post-RS error rate against the transmitted packets)."""
+    class A:
+        segments = 1
+    res = {}
+    for name, wl, snr, nsf, steps in (("config2_2k_qam16_1_2", "2k_qam16_1_2", None, 64, 100), ("config5_8k_qpsk_7_8_awgn14", "8k_qpsk_7_8", 14.0, 16, 100)):
+        job = Job(A, torch, g, None, 0, 1, local, wl, nsf, snr=snr)
+        dt = timed_run(job, steps, 3)
+        chk = job.verify()
+        res[name] = {"value": round(job.n_total * steps / dt / 1e6, 2), "unit": "Msamples/s", "x_realtime": round(job.n_total * steps / dt / 1e6 / REALTIME_MSPS, 1),
+                     "ms_per_step": round(dt / steps * 1e3, 3), "stream_superframes": job.nsf, "stream_samples": job.n_total, "steps": steps,
+                     "rs_fail_words": [int(r.rs_fail_words) for r in job.reps], "rs_corrected_symbols": [int(r.rs_corrected_symbols) for r in job.reps], **chk}
+        job.close()
+    return res
+
+
 def timed_run(job, steps, warmup):
     torch, dist = job.torch, job.dist
     for _ in range(warmup):
@@ -303,7 +320,7 @@ def timed_run(job, steps, warmup):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="8k_qam64_7_8", choices=sorted(WORKLOADS))
     ap.add_argument("--snr", type=float, default=None, help="add AWGN at this SNR (dB); BASELINE config 5 = --workload 8k_qpsk_7_8 --snr 14")
@@ -373,18 +390,26 @@ def main():
                        **check},
             "roofline": {"bound": "valu", "kernel": "viterbi3_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "note": "the dominant kernel is bound by VALU issue, not by HBM: it is made of half-rate instructions (v_pk_*, v_perm, v_and_or, DPP: 4 cycles "
+                                 "per wave64 instruction and SIMD, profiles/r02_ubench_valu.json) and spends 4.5 cycles per instruction (DESIGN.md 5); "
+                                 "achieved/peak/frac are the HBM figures the contract asks for; traffic (PMC) is in profiles/, not measured in this run",
                          "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(vit_ms, 4),
                          "chain_frac": round(msps / world * 1e6 * (8 + n_ts / n_stream) / 1e9 / HBM_PEAK_GBS, 6),
                          "hbm_copy_gbs": hbm_copy_gbs(torch, f"cuda:{local}")},
             "stage_ms_per_piece": {k: round(sum(p["rx"].stage_ms(k) for p in job.pieces) / nseg, 4) for k in ("acq", "fft", "demod", "inner", "viterbi", "rs", "total")},
         }
     job.close()
+    if rank == 0 and world == 1 and not a.no_extras and not a.from_file_rate:
+        out["extra_workloads"] = extra_workloads(a, torch, g, local)
     if rank == 0:
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_superframes)
             ref = reference_sse2_viterbi()
             if ref:
                 out["cpu_baseline"]["reference_sse2_viterbi"] = ref
+            if not a.no_extras and a.workload != "2k_qam16_1_2":
+                # BASELINE config 1 (apps/dvbt_rx_demo.grc on CPU: 2k QAM16 1/2): the same port, one core
+                out["cpu_baseline"]["config1_2k_qam16_1_2"] = cpu_baseline("2k_qam16_1_2", 8, all_cores=False)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist:
         dist.destroy_process_group()

@@ -56,7 +56,10 @@ class RxReport(C.Structure):
                 ("n_viterbi_bytes", C.c_int64), ("n_rs_items", C.c_int64), ("n_rs_bytes", C.c_int64),
                 ("n_ts_bytes", C.c_int64), ("rs_fail_words", C.c_int32), ("rs_corrected_symbols", C.c_int32),
                 ("resume_sample", C.c_int64), ("segment_offset", C.c_int64), ("stream_symbol_offset", C.c_int64),
-                ("ts_first_packet", C.c_int64), ("stream_rs_items", C.c_int64)]
+                ("ts_first_packet", C.c_int64), ("stream_rs_items", C.c_int64), ("tps_bits", C.c_uint64), ("tps_valid", C.c_int32),
+                ("tps_length_indicator", C.c_int32), ("tps_constellation", C.c_int32), ("tps_hierarchy", C.c_int32),
+                ("tps_code_rate_hp", C.c_int32), ("tps_code_rate_lp", C.c_int32), ("tps_guard_interval", C.c_int32),
+                ("tps_transmission_mode", C.c_int32), ("tps_cell_id", C.c_int32), ("tps_mismatch", C.c_int32)]
 
 
 class RxCut(C.Structure):

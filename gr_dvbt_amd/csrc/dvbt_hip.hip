@@ -377,7 +377,7 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
     static const int kInit[2] = {0x7fffffff, 0};
     HIPCHK(hipMemcpyAsync(h->trk_flags + 8, kInit, sizeof kInit, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(tps_fsm_par_kernel, dim3((C + TPS_THREADS * TPS_SEG - 1) / (TPS_THREADS * TPS_SEG)), dim3(TPS_THREADS), 0, s, fp, (const RxState *)h->st, (const SymInfo *)h->info,
-                       (const int *)h->maj, h->sym_index, h->tps_edges, h->trk_flags + 8);
+                       (const int *)h->maj, h->sym_index, h->tps_edges, h->trk_flags + 8, &h->st->tps_bits);
     hipLaunchKernelGGL(tps_finalize_kernel, dim3(1), dim3(256), 0, s, h->st, (const TpsEdge *)h->tps_edges, (const int *)(h->trk_flags + 8), h->trk_flags + 9);
     hipLaunchKernelGGL(tps_fsm_kernel, dim3(1), dim3(256), 0, s, fp, h->st, 0, (const SymInfo *)h->info, (const int *)h->maj, h->tps_state,
                        h->sym_index, (int *)nullptr, (const unsigned char *)nullptr, (const int *)(h->trk_flags + 9));
@@ -453,6 +453,18 @@ extern "C" int dvbt_rx_segment_finish(dvbt_rx *h, dvbt_rx_report *rep)
   r.n_viterbi_bytes = s.n_vit_bytes; r.n_rs_items = s.n_rs_items; r.n_rs_bytes = s.n_rs_words * 188;
   r.n_ts_bytes = s.n_ts_bytes; r.rs_fail_words = s.rs_fail; r.rs_corrected_symbols = s.rs_corr;
   r.stream_symbol_offset = s.sym_off; r.ts_first_packet = s.ts_first_packet; r.stream_rs_items = s.stream_rs_items;
+  // TPS as received (reference_signals_impl.cc:883-916: fields are MSB first, s_i = bit i of the word)
+  r.tps_valid = (int32_t)(s.tps_bits >> 63); r.tps_bits = s.tps_bits & ~(1ull << 63);
+  if (r.tps_valid) {
+    auto fld = [&](int first, int last) { int v = 0; for (int i = first; i <= last; i++) v = (v << 1) | (int)((s.tps_bits >> i) & 1ull); return v; };
+    r.tps_length_indicator = fld(17, 22); r.tps_constellation = fld(25, 26); r.tps_hierarchy = fld(27, 29);
+    r.tps_code_rate_hp = fld(30, 32); r.tps_code_rate_lp = fld(33, 35); r.tps_guard_interval = fld(36, 37);
+    r.tps_transmission_mode = fld(38, 39); r.tps_cell_id = fld(40, 47);
+    const dvbt_rx_params &q = h->prm;
+    r.tps_mismatch = (r.tps_constellation != q.constellation ? 1 : 0) | (r.tps_hierarchy != q.hierarchy ? 2 : 0) | (r.tps_code_rate_hp != q.code_rate ? 4 : 0) |
+                     (r.tps_guard_interval != q.guard_interval ? 8 : 0) | (r.tps_transmission_mode != q.transmission_mode ? 16 : 0);
+    if (r.tps_mismatch) r.status |= 16;
+  }
   h->last = r; h->have_last = true;
   if (rep) *rep = r;
   return DVBT_OK;

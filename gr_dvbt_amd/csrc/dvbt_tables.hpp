@@ -122,24 +122,23 @@ inline std::vector<uint16_t> symbol_H(const Dims &d)
   return h;
 }
 
-// constellation table indexed by bit label y0..y(m-1) (dvbt_demap_impl.cc:117-165); returns re,im pairs
+// Constellation table indexed by the bit label y0..y(m-1) (y0 = MSB of the label): what dvbt_demap_impl.cc:117-165 builds, from
+// the closed form of ETSI EN 300 744 4.3.5 (checked there against the compiled reference): even bits belong
+// to I, odd bits to Q; the first bit of an axis is its sign (1 = negative), the others are the Gray code of the level counted
+// from the outside: |level| = alpha + 2 (L - 1 - g), L = levels per half axis, g = Gray-decoded index.  Returns re,im pairs.
 inline std::vector<float> constellation_points(const Dims &d, float gain_in)
 {
-  float gain = gain_in * d.norm;
-  int bpa = d.m / 2, spa = (1 << bpa) / 2 - 1;
+  const float scale = gain_in * d.norm;
+  const int per_axis = d.m / 2, half_levels = 1 << (per_axis - 1);
   std::vector<float> pts(2 * d.csize);
-  auto gray = [](int v) { return (v >> 1) ^ v; };
-  for (int i = 0; i < d.csize; i++) {
-    int q = (i >> (2 * (bpa - 1))) & 3;
-    int s0 = (q >> 1) ? -1 : 1, s1 = (q & 1) ? -1 : 1;
-    int x = (i >> (bpa - 1)) & ((1 << (bpa - 1)) - 1), y = i & ((1 << (bpa - 1)) - 1);
-    int xv = d.alpha + (spa - x) * 2, yv = d.alpha + (spa - y) * 2;
-    int val = (gray(x) << (bpa - 1)) + gray(y);
-    x = 0; y = 0;
-    for (int j = 0; j < bpa - 1; j++) { x += ((val >> (1 + 2 * j)) & 1) << j; y += ((val >> (2 * j)) & 1) << j; }
-    val = (q << (2 * (bpa - 1))) + (x << (bpa - 1)) + y;
-    pts[2 * val] = gain * (float)(s0 * xv); pts[2 * val + 1] = gain * (float)(s1 * yv);
-  }
+  for (int label = 0; label < d.csize; label++)
+    for (int axis = 0; axis < 2; axis++) {                        // 0: I (y0, y2, y4), 1: Q (y1, y3, y5)
+      auto y = [&](int j) { return (label >> (d.m - 1 - (2 * j + axis))) & 1; };   // j-th bit of this axis
+      int g = 0, acc = 0;
+      for (int j = 1; j < per_axis; j++) { acc ^= y(j); g = (g << 1) | acc; }      // Gray -> binary, MSB first
+      const int level = d.alpha + 2 * (half_levels - 1 - g);
+      pts[2 * label + axis] = scale * (float)(y(0) ? -level : level);
+    }
   return pts;
 }
 

@@ -31,7 +31,11 @@ struct RxState {
   long long n_rs_words;      // RS words decoded (= 8 n_rs_items unless the segment continues a cut stream)
   long long stream_rs_items; // items the byte de-interleaver of a chain over the whole stream has produced up to this segment's end
   long long ts_first_packet; // RS word index (of this segment) of the first packet of the TS tap
+  unsigned long long tps_bits; // TPS word of a BCH-valid frame, bit i = s_i, with the fields that change from frame to frame (sync word s1-s16,
+                               // frame number s23-s24, parity s54-s67) cleared: identical for every frame of a stream; 0 = none seen
 };
+// fields of a TPS word that are the same in every frame (reference_signals_impl.cc:883-916): s17-s22 length, s25-s53 parameters
+constexpr unsigned long long TPS_STATIC_MASK = ((1ull << 54) - 1) & ~((1ull << 17) - 1) & ~(3ull << 23);
 
 struct FrontParams {
   int N, cp, K, zl, payload, n_cp, n_tps, fi_start;
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(256) void acq_init_fsm_kernel(FrontParams p, RxStat
   if (tid == 0 && t_begin == 0) {
     st->status = 1; st->call0 = 0; st->cp_start0 = 0; st->n_symbols = 0; st->first_out = -1; st->n_out_symbols = 0;
     st->n_vit_in = st->n_vit_steps = st->n_vit_bytes = st->n_rs_items = st->n_ts_bytes = 0; st->rs_fail = st->rs_corr = 0;
-    st->n_rs_words = st->stream_rs_items = st->ts_first_packet = 0;
+    st->n_rs_words = st->stream_rs_items = st->ts_first_packet = 0; st->tps_bits = 0;
     s_done = 0; s_avg = as ? as->avg : 0.f;
     if (as && as->acquired) {          // block API: still locked from the previous work() call, nothing to search
       st->status = 0; st->cp_start0 = as->cp_start; st->eps_init = 0.f; s_done = 2;
@@ -918,6 +922,7 @@ __global__ __launch_bounds__(256) void tps_fsm_kernel(FrontParams p, RxState *st
           if (bch_check(t.fifo_lo, t.fifo_hi) == 0) {
             t.frame_index = (int)(((t.fifo_lo >> 23) & 1ull) << 1 | ((t.fifo_lo >> 24) & 1ull));
             t.symbol_index_known = 1; t.symbol_index = 67;
+            if (st) st->tps_bits = (t.fifo_lo & TPS_STATIC_MASK) | (1ull << 63);
           } else t.symbol_index_known = 0;
           t.fifo_lo = 0; t.fifo_hi = 0;
         }
@@ -992,7 +997,7 @@ __device__ inline void tps_bch_table(unsigned short *T, unsigned short *R, int t
 }
 
 __device__ __forceinline__ void tps_advance(TpsState &t, int mod, int majv, int fi_start, unsigned mask_even, unsigned mask_odd,
-                                            int &si_out, int &cand, const unsigned short *T)
+                                            int &si_out, int &cand, const unsigned short *T, unsigned long long *tps_bits)
 {
   int diff = (mod - t.prev_mod + 4) & 3;
   t.prev_mod = mod;
@@ -1010,6 +1015,7 @@ __device__ __forceinline__ void tps_advance(TpsState &t, int mod, int majv, int 
     if (bch_check_tab(T, t.fifo_lo, t.fifo_hi) == 0) {
       t.frame_index = (int)(((t.fifo_lo >> 23) & 1ull) << 1 | ((t.fifo_lo >> 24) & 1ull));
       t.symbol_index_known = 1; t.symbol_index = 67;
+      if (tps_bits) *tps_bits = (t.fifo_lo & TPS_STATIC_MASK) | (1ull << 63);   // every valid frame of a stream stores the same word
     } else t.symbol_index_known = 0;
     t.fifo_lo = 0; t.fifo_hi = 0;
   }
@@ -1018,7 +1024,7 @@ __device__ __forceinline__ void tps_advance(TpsState &t, int mod, int majv, int 
 }
 
 __global__ __launch_bounds__(TPS_THREADS) void tps_fsm_par_kernel(FrontParams p, const RxState *st, const SymInfo *__restrict__ info, const int *__restrict__ maj,
-                                                                 int *__restrict__ sym_index, TpsEdge *__restrict__ edges, int *first_cand)
+                                                                 int *__restrict__ sym_index, TpsEdge *__restrict__ edges, int *first_cand, unsigned long long *tps_bits)
 {
   // symbol streams in LDS; padding per TPS_SEG entries keeps the lanes (TPS_SEG symbols apart) on distinct banks
   constexpr int NS = TPS_THREADS * TPS_SEG + TPS_WARM;
@@ -1053,12 +1059,12 @@ __global__ __launch_bounds__(TPS_THREADS) void tps_fsm_par_kernel(FrontParams p,
   TpsState t; t.fifo_lo = 0; t.fifo_hi = 0; t.symbol_index = 0; t.symbol_index_known = 0; t.frame_index = 0; t.prev_mod = 0; t.d_init = 0;
   int si, cand;
 #pragma unroll 4
-  for (int s = sw; s < s0; s++) tps_advance(t, s_mod[pm(s - lo)], s_maj[pj(s - lo)], p.fi_start, mask_even, mask_odd, si, cand, s_T);
+  for (int s = sw; s < s0; s++) tps_advance(t, s_mod[pm(s - lo)], s_maj[pj(s - lo)], p.fi_start, mask_even, mask_odd, si, cand, s_T, nullptr);
   const int seg = s0 / TPS_SEG;
   edges[seg].start = t;
   int first = 0x7fffffff;
   for (int s = s0; s < s1; s++) {
-    tps_advance(t, s_mod[pm(s - lo)], s_maj[pj(s - lo)], p.fi_start, mask_even, mask_odd, si, cand, s_T);
+    tps_advance(t, s_mod[pm(s - lo)], s_maj[pj(s - lo)], p.fi_start, mask_even, mask_odd, si, cand, s_T, tps_bits);
     sym_index[s] = si;
     if (cand && first == 0x7fffffff) first = s;
   }

@@ -34,12 +34,16 @@ typedef enum {
   DVBT_ERR_STATE = -5         /* call sequence violates the block's contract */
 } dvbt_status;
 
-/* enums: include/dvbt/dvbt_config.h:34-75 (values double as TPS field encodings) */
+/* enums: include/dvbt/dvbt_config.h:34-75 (values double as TPS field encodings).  Every function takes them as int.  A
+ * translation unit that also includes gr-dvbt's dvbt/dvbt_config.h (the GNU Radio block shells, gr_dvbt_amd/host/gr) defines
+ * DVBT_HIP_NO_ENUMS first: that header puts the same type names into the global namespace (:160-167). */
+#ifndef DVBT_HIP_NO_ENUMS
 typedef enum { DVBT_QPSK = 0, DVBT_QAM16 = 1, DVBT_QAM64 = 2 } dvbt_constellation_t;
 typedef enum { DVBT_NH = 0, DVBT_ALPHA1, DVBT_ALPHA2, DVBT_ALPHA4 } dvbt_hierarchy_t;
 typedef enum { DVBT_C1_2 = 0, DVBT_C2_3, DVBT_C3_4, DVBT_C5_6, DVBT_C7_8 } dvbt_code_rate_t;
 typedef enum { DVBT_T2k = 0, DVBT_T8k = 1 } dvbt_transmission_mode_t;
 typedef enum { DVBT_G1_32 = 0, DVBT_G1_16, DVBT_G1_8, DVBT_G1_4 } dvbt_guard_interval_t;
+#endif
 
 /* sideband: replaces the stream tags of SURVEY Appendix D */
 typedef enum { DVBT_TAG_SYNC_START = 1, DVBT_TAG_SUPERFRAME_START = 2, DVBT_TAG_SYMBOL_INDEX = 3 } dvbt_tag_key;
@@ -230,7 +234,8 @@ typedef struct {
 
 typedef struct {
   int32_t status;              /* 0 ok; bit0: initial acquisition failed; bit1: CP tracking lost;
-                                  bit2: no superframe start found; bit3: tracking left the precomputed lag range */
+                                  bit2: no superframe start found; bit3: tracking left the precomputed lag range;
+                                  bit4: the stream's TPS disagrees with the configured parameters (tps_mismatch) */
   int32_t n_symbols;           /* OFDM symbols acquired */
   int32_t first_out_symbol;    /* symbol at which superframe_start fired, -1 if none */
   int32_t n_out_symbols;       /* symbols passed downstream */
@@ -251,6 +256,15 @@ typedef struct {
   int64_t stream_symbol_offset; /* the cut's offset, echoed */
   int64_t ts_first_packet;     /* index, among this segment's RS words, of the first packet of the TS tap */
   int64_t stream_rs_items;     /* items of 8 RS words a chain over the whole stream has produced up to this segment's end */
+  /* transmission parameters as signalled by the stream (TODO.txt:25-28 "TPS auto-detection"): the TPS word of a frame that passed the
+   * BCH check (reference_signals_impl.cc:385-425), decoded per the layout of format_tps_data (:883-916).  The values use the enums above
+   * (they double as the TPS encodings).  status bit 4 is raised when they disagree with the handle's parameters: the segment is still
+   * decoded as configured (the reference does not look at them either), but its bytes are then meaningless. */
+  uint64_t tps_bits;           /* bit i = s_i; s1-s16 (sync word), s23-s24 (frame number) and s54-s67 (parity) cleared */
+  int32_t tps_valid;           /* 1: a BCH-valid TPS frame was received and the fields below are set */
+  int32_t tps_length_indicator, tps_constellation, tps_hierarchy, tps_code_rate_hp, tps_code_rate_lp,
+          tps_guard_interval, tps_transmission_mode, tps_cell_id;
+  int32_t tps_mismatch;        /* bit0 constellation, bit1 hierarchy, bit2 HP code rate, bit3 guard interval, bit4 transmission mode differ */
 } dvbt_rx_report;
 
 typedef enum {
