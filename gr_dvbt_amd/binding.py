@@ -250,6 +250,10 @@ class Block:
         _chk(getattr(self.L, f"dvbt_{name}_create")(C.byref(self.params), C.byref(self.h)))
         self._work = getattr(self.L, f"dvbt_{name}_work")
         self._work.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(Sideband)]
+        self._work_device = getattr(self.L, f"dvbt_{name}_work_device", None)
+        if self._work_device is not None:
+            self._work_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(Sideband), C.c_void_p]
+        self._tout = (Tag * 4096)()
 
     def forecast(self, noutput_items):
         n = C.c_int()
@@ -262,6 +266,15 @@ class Block:
         tout = (Tag * 4096)()
         sb = Sideband(tin, len(tags), tout, 4096, 0, 0)
         r = _chk(self._work(self.h, noutput_items, ninput_items, inp.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.byref(sb)))
+        return r, sb.n_consumed, [(tout[i].rel_offset, tout[i].key, tout[i].value) for i in range(min(sb.n_out_tags, 4096))]
+
+    def work_device(self, noutput_items, ninput_items, in_ptr, out_ptr, tags=(), stream=None):
+        """dvbt_<name>_work_device: device pointers (ints) in and out, the caller's HIP stream; same return as work()"""
+        tin = (Tag * max(len(tags), 1))(*[Tag(*t) for t in tags])
+        tout = self._tout
+        sb = Sideband(tin, len(tags), tout, 4096, 0, 0)
+        r = _chk(self._work_device(self.h, noutput_items, ninput_items, C.c_void_p(in_ptr), C.c_void_p(out_ptr), C.byref(sb),
+                                   C.c_void_p(stream) if stream else None))
         return r, sb.n_consumed, [(tout[i].rel_offset, tout[i].key, tout[i].value) for i in range(min(sb.n_out_tags, 4096))]
 
     def close(self):

@@ -30,6 +30,11 @@ extern "C" int dvbt_device_count(void)
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
 }
+extern "C" void *dvbt_device_malloc(size_t bytes) { void *p = nullptr; if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { g_err = "hipMalloc failed"; return nullptr; } return p; }
+extern "C" void dvbt_device_free(void *p) { if (p) (void)hipFree(p); }
+extern "C" int dvbt_copy_to_device(void *dst, const void *src, size_t bytes) { HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return DVBT_OK; }
+extern "C" int dvbt_copy_to_host(void *dst, const void *src, size_t bytes) { HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return DVBT_OK; }
+extern "C" int dvbt_synchronize(void *stream) { if (stream) HIPCHK(hipStreamSynchronize((hipStream_t)stream)); else HIPCHK(hipDeviceSynchronize()); return DVBT_OK; }
 static int need_device()
 {
   if (dvbt_device_count() <= 0) return fail(DVBT_ERR_NO_DEVICE, "no HIP device visible: libdvbt_hip has no CPU fallback");
@@ -56,6 +61,15 @@ template <class T> static int upload(const std::vector<T> &v, T **dptr)
 struct DevBuf {          // growable device scratch
   void *p = nullptr; size_t cap = 0;
   int reserve(size_t n) { if (n <= cap) return DVBT_OK; if (p) (void)hipFree(p); p = nullptr; cap = 0; HIPCHK(hipMalloc(&p, n + 64)); cap = n; return DVBT_OK; }
+  // grow and keep the first `keep` bytes (a block's history at the front of its input buffer)
+  int reserve_keep(size_t n, size_t keep)
+  {
+    if (n <= cap) return DVBT_OK;
+    void *q = nullptr; HIPCHK(hipMalloc(&q, n + 64));
+    if (p && keep) HIPCHK(hipMemcpy(q, p, keep, hipMemcpyDeviceToDevice));
+    if (p) (void)hipFree(p);
+    p = q; cap = n; return DVBT_OK;
+  }
   ~DevBuf() { if (p) (void)hipFree(p); }
 };
 

@@ -33,8 +33,9 @@ template <class H, class P> class block_base {
   typedef int (*create_fn)(const P *, H **);
   typedef int (*forecast_fn)(const H *, int, int *);
   typedef int (*work_fn)(H *, int, int, const void *, void *, dvbt_sideband *);
+  typedef int (*work_device_fn)(H *, int, int, const void *, void *, dvbt_sideband *, void *);
   typedef void (*destroy_fn)(H *);
-  block_base(const P &p, create_fn c, forecast_fn f, work_fn w, destroy_fn d) : d_forecast(f), d_work(w), d_destroy(d)
+  block_base(const P &p, create_fn c, forecast_fn f, work_fn w, destroy_fn d, work_device_fn wd = nullptr) : d_forecast(f), d_work(w), d_destroy(d), d_work_device(wd)
   { check(c(&p, &d_h)); }
   ~block_base() { if (d_h) d_destroy(d_h); }
   block_base(const block_base &) = delete;
@@ -58,8 +59,24 @@ template <class H, class P> class block_base {
     n_consumed = sb.n_consumed;
     return r;
   }
+  // the same call on DEVICE buffers and a HIP stream (dvbt_<blk>_work_device): adjacent HIP blocks hand items over in HBM
+  int general_work_device(int noutput_items, int ninput_items, const void *in_device, void *out_device, const std::vector<tag_t> &tags_in,
+                          std::vector<tag_t> &tags_out, int &n_consumed, void *stream = nullptr)
+  {
+    if (!d_work_device) throw std::runtime_error("block has no device entry");
+    std::vector<dvbt_tag> ti(tags_in.size()), to(4096);
+    for (size_t i = 0; i < tags_in.size(); i++) { ti[i].rel_offset = tags_in[i].offset; ti[i].key = tags_in[i].key; ti[i].value = tags_in[i].value; }
+    dvbt_sideband sb; sb.in_tags = ti.data(); sb.n_in_tags = (int)ti.size(); sb.out_tags = to.data(); sb.out_cap = (int)to.size();
+    sb.n_out_tags = 0; sb.n_consumed = 0;
+    int r = d_work_device(d_h, noutput_items, ninput_items, in_device, out_device, &sb, stream);
+    check(r);
+    tags_out.clear();
+    for (int i = 0; i < sb.n_out_tags && i < sb.out_cap; i++) tags_out.push_back(tag_t{to[i].rel_offset, to[i].key, to[i].value});
+    n_consumed = sb.n_consumed;
+    return r;
+  }
  private:
-  H *d_h = nullptr; forecast_fn d_forecast; work_fn d_work; destroy_fn d_destroy;
+  H *d_h = nullptr; forecast_fn d_forecast; work_fn d_work; destroy_fn d_destroy; work_device_fn d_work_device;
 };
 
 #define DVBT_AMD_BLOCK(NAME, PARAMS, MAKE_ARGS, PARAM_INIT)                                                     \
@@ -69,7 +86,7 @@ template <class H, class P> class block_base {
     static sptr make MAKE_ARGS { PARAMS prm__ = PARAM_INIT; return sptr(new NAME(prm__)); }                             \
    private:                                                                                                     \
     explicit NAME(const PARAMS &p)                                                                              \
-        : block_base<::dvbt_##NAME, PARAMS>(p, dvbt_##NAME##_create, dvbt_##NAME##_forecast, dvbt_##NAME##_work, dvbt_##NAME##_destroy) {} \
+        : block_base<::dvbt_##NAME, PARAMS>(p, dvbt_##NAME##_create, dvbt_##NAME##_forecast, dvbt_##NAME##_work, dvbt_##NAME##_destroy, dvbt_##NAME##_work_device) {} \
   };
 
 // include/dvbt/ofdm_sym_acquisition.h:49

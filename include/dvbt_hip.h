@@ -54,7 +54,22 @@ typedef struct {
   int n_consumed;                              /* what the block would pass to consume_each() */
 } dvbt_sideband;
 
+/* Every block has two work entries.  dvbt_<blk>_work takes HOST buffers, like gr::block::general_work: it copies in, computes, copies
+ * out and synchronises.  dvbt_<blk>_work_device takes DEVICE pointers (hipMalloc'd; same item layout) and a hipStream_t (NULL: the
+ * device's default stream, on which blocks chained without an explicit stream are ordered): it only enqueues, so adjacent HIP blocks of a flowgraph hand items to each other without crossing PCIe.
+ * Tags still travel through the host-side dvbt_sideband.  Two blocks must know data-dependent counts before they return and
+ * therefore read a few bytes back and synchronise the stream once per call (ofdm_sym_acquisition: items produced / samples consumed;
+ * demod_reference_signals: which items passed the superframe hunt, and their symbol indices); energy_descramble reads the 16 sync
+ * positions of its window (NSYNC search).  The others return counts that follow from the call's sizes and tags alone.  A handle is
+ * driven through one of the two entries for its whole life (the history of the streaming blocks lives on the device either way). */
 const char *dvbt_last_error(void);
+/* device buffers for hosts that do not link the HIP runtime themselves (a GNU Radio block shell, gr_dvbt_amd/host/rx_flowgraph_example.cpp):
+ * hipMalloc / hipFree / hipMemcpy (synchronous) / hipStreamSynchronize (stream NULL: the whole device) */
+void *dvbt_device_malloc(size_t bytes);
+void  dvbt_device_free(void *p);
+int   dvbt_copy_to_device(void *dst_device, const void *src_host, size_t bytes);
+int   dvbt_copy_to_host(void *dst_host, const void *src_device, size_t bytes);
+int   dvbt_synchronize(void *stream);
 int dvbt_device_count(void);                   /* HIP devices visible; <=0 means the library cannot run */
 const char *dvbt_version(void);
 
@@ -81,6 +96,8 @@ int  dvbt_ofdm_sym_acquisition_create(const dvbt_ofdm_sym_acquisition_params *p,
 int  dvbt_ofdm_sym_acquisition_forecast(const dvbt_ofdm_sym_acquisition *h, int noutput_items, int *ninput_required);
 int  dvbt_ofdm_sym_acquisition_work(dvbt_ofdm_sym_acquisition *h, int noutput_items, int ninput_items,
                                     const void *in, void *out, dvbt_sideband *sb);
+int  dvbt_ofdm_sym_acquisition_work_device(dvbt_ofdm_sym_acquisition *h, int noutput_items, int ninput_items, const void *in_device, void *out_device,
+                                            dvbt_sideband *sb, void *stream);
 void dvbt_ofdm_sym_acquisition_destroy(dvbt_ofdm_sym_acquisition *h);
 
 /* ------------------------------------------------------------------ A2 forward FFT (stock fft_vxx in the flowgraph)
@@ -91,6 +108,8 @@ typedef struct dvbt_fft dvbt_fft;
 int  dvbt_fft_create(const dvbt_fft_params *p, dvbt_fft **out);
 int  dvbt_fft_forecast(const dvbt_fft *h, int noutput_items, int *ninput_required);
 int  dvbt_fft_work(dvbt_fft *h, int noutput_items, int ninput_items, const void *in, void *out, dvbt_sideband *sb);
+int  dvbt_fft_work_device(dvbt_fft *h, int noutput_items, int ninput_items, const void *in_device, void *out_device,
+                           dvbt_sideband *sb, void *stream);
 void dvbt_fft_destroy(dvbt_fft *h);
 
 /* ------------------------------------------------------------------ A3 demod_reference_signals
@@ -106,6 +125,8 @@ int  dvbt_demod_reference_signals_create(const dvbt_demod_reference_signals_para
 int  dvbt_demod_reference_signals_forecast(const dvbt_demod_reference_signals *h, int noutput_items, int *ninput_required);
 int  dvbt_demod_reference_signals_work(dvbt_demod_reference_signals *h, int noutput_items, int ninput_items,
                                        const void *in, void *out, dvbt_sideband *sb);
+int  dvbt_demod_reference_signals_work_device(dvbt_demod_reference_signals *h, int noutput_items, int ninput_items, const void *in_device, void *out_device,
+                                               dvbt_sideband *sb, void *stream);
 void dvbt_demod_reference_signals_destroy(dvbt_demod_reference_signals *h);
 
 /* ------------------------------------------------------------------ A4 dvbt_demap
@@ -116,6 +137,8 @@ typedef struct dvbt_demap dvbt_demap;
 int  dvbt_demap_create(const dvbt_demap_params *p, dvbt_demap **out);
 int  dvbt_demap_forecast(const dvbt_demap *h, int noutput_items, int *ninput_required);
 int  dvbt_demap_work(dvbt_demap *h, int noutput_items, int ninput_items, const void *in, void *out, dvbt_sideband *sb);
+int  dvbt_demap_work_device(dvbt_demap *h, int noutput_items, int ninput_items, const void *in_device, void *out_device,
+                             dvbt_sideband *sb, void *stream);
 void dvbt_demap_destroy(dvbt_demap *h);
 
 /* ------------------------------------------------------------------ A5 symbol_inner_interleaver
@@ -128,6 +151,8 @@ int  dvbt_symbol_inner_interleaver_create(const dvbt_symbol_inner_interleaver_pa
 int  dvbt_symbol_inner_interleaver_forecast(const dvbt_symbol_inner_interleaver *h, int noutput_items, int *ninput_required);
 int  dvbt_symbol_inner_interleaver_work(dvbt_symbol_inner_interleaver *h, int noutput_items, int ninput_items,
                                         const void *in, void *out, dvbt_sideband *sb);
+int  dvbt_symbol_inner_interleaver_work_device(dvbt_symbol_inner_interleaver *h, int noutput_items, int ninput_items, const void *in_device, void *out_device,
+                                                dvbt_sideband *sb, void *stream);
 void dvbt_symbol_inner_interleaver_destroy(dvbt_symbol_inner_interleaver *h);
 
 /* ------------------------------------------------------------------ A6 bit_inner_deinterleaver
@@ -140,6 +165,8 @@ int  dvbt_bit_inner_deinterleaver_create(const dvbt_bit_inner_deinterleaver_para
 int  dvbt_bit_inner_deinterleaver_forecast(const dvbt_bit_inner_deinterleaver *h, int noutput_items, int *ninput_required);
 int  dvbt_bit_inner_deinterleaver_work(dvbt_bit_inner_deinterleaver *h, int noutput_items, int ninput_items,
                                        const void *in, void *out, dvbt_sideband *sb);
+int  dvbt_bit_inner_deinterleaver_work_device(dvbt_bit_inner_deinterleaver *h, int noutput_items, int ninput_items, const void *in_device, void *out_device,
+                                               dvbt_sideband *sb, void *stream);
 void dvbt_bit_inner_deinterleaver_destroy(dvbt_bit_inner_deinterleaver *h);
 
 /* ------------------------------------------------------------------ A7 viterbi_decoder
@@ -155,6 +182,8 @@ int  dvbt_viterbi_decoder_create(const dvbt_viterbi_decoder_params *p, dvbt_vite
 int  dvbt_viterbi_decoder_forecast(const dvbt_viterbi_decoder *h, int noutput_items, int *ninput_required);
 int  dvbt_viterbi_decoder_work(dvbt_viterbi_decoder *h, int noutput_items, int ninput_items,
                                const void *in, void *out, dvbt_sideband *sb);
+int  dvbt_viterbi_decoder_work_device(dvbt_viterbi_decoder *h, int noutput_items, int ninput_items, const void *in_device, void *out_device,
+                                       dvbt_sideband *sb, void *stream);
 void dvbt_viterbi_decoder_destroy(dvbt_viterbi_decoder *h);
 
 /* ------------------------------------------------------------------ A8 convolutional_deinterleaver
@@ -167,6 +196,8 @@ int  dvbt_convolutional_deinterleaver_create(const dvbt_convolutional_deinterlea
 int  dvbt_convolutional_deinterleaver_forecast(const dvbt_convolutional_deinterleaver *h, int noutput_items, int *ninput_required);
 int  dvbt_convolutional_deinterleaver_work(dvbt_convolutional_deinterleaver *h, int noutput_items, int ninput_items,
                                            const void *in, void *out, dvbt_sideband *sb);
+int  dvbt_convolutional_deinterleaver_work_device(dvbt_convolutional_deinterleaver *h, int noutput_items, int ninput_items, const void *in_device, void *out_device,
+                                                   dvbt_sideband *sb, void *stream);
 void dvbt_convolutional_deinterleaver_destroy(dvbt_convolutional_deinterleaver *h);
 
 /* ------------------------------------------------------------------ A9 reed_solomon_dec
@@ -181,6 +212,8 @@ int  dvbt_reed_solomon_dec_create(const dvbt_reed_solomon_dec_params *p, dvbt_re
 int  dvbt_reed_solomon_dec_forecast(const dvbt_reed_solomon_dec *h, int noutput_items, int *ninput_required);
 int  dvbt_reed_solomon_dec_work(dvbt_reed_solomon_dec *h, int noutput_items, int ninput_items,
                                 const void *in, void *out, dvbt_sideband *sb);
+int  dvbt_reed_solomon_dec_work_device(dvbt_reed_solomon_dec *h, int noutput_items, int ninput_items, const void *in_device, void *out_device,
+                                        dvbt_sideband *sb, void *stream);
 void dvbt_reed_solomon_dec_destroy(dvbt_reed_solomon_dec *h);
 
 /* ------------------------------------------------------------------ next row: energy_descramble
@@ -192,6 +225,8 @@ int  dvbt_energy_descramble_create(const dvbt_energy_descramble_params *p, dvbt_
 int  dvbt_energy_descramble_forecast(const dvbt_energy_descramble *h, int noutput_items, int *ninput_required);
 int  dvbt_energy_descramble_work(dvbt_energy_descramble *h, int noutput_items, int ninput_items,
                                  const void *in, void *out, dvbt_sideband *sb);
+int  dvbt_energy_descramble_work_device(dvbt_energy_descramble *h, int noutput_items, int ninput_items, const void *in_device, void *out_device,
+                                         dvbt_sideband *sb, void *stream);
 void dvbt_energy_descramble_destroy(dvbt_energy_descramble *h);
 
 /* ------------------------------------------------------------------ next row 2: front-of-chain resample + scale
@@ -209,6 +244,8 @@ int  dvbt_resampler_create(const dvbt_resampler_params *p, dvbt_resampler **out)
 int  dvbt_resampler_forecast(const dvbt_resampler *h, int noutput_items, int *ninput_required);
 int  dvbt_resampler_work(dvbt_resampler *h, int noutput_items, int ninput_items,
                          const void *in, void *out, dvbt_sideband *sb);
+int  dvbt_resampler_work_device(dvbt_resampler *h, int noutput_items, int ninput_items, const void *in_device, void *out_device,
+                                dvbt_sideband *sb, void *stream);
 int  dvbt_resampler_get_taps(const dvbt_resampler *h, float *taps, int cap, int *interpolation, int *decimation);  /* returns the tap count */
 void dvbt_resampler_destroy(dvbt_resampler *h);
 

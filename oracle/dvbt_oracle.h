@@ -149,6 +149,9 @@ size_t o_tx_generate(const o_cfg *c, const unsigned char *ts, size_t npackets, f
 size_t o_tx_generate_from(const o_cfg *c, const unsigned char *ts, size_t npackets, size_t packet0, float scale,
                           ocf *iq, size_t cap_samples, ocf *freq_taps);
 
+/* ---- the reference's own SSE2 Viterbi kernels (oracle/_ref), timed natively: decoded Mbit/s, -1 when the library is missing */
+double o_ref_viterbi_mbps(const char *so_path, size_t nsym, int ntraceback);
+
 /* ---- whole RX chain, emulating the GNU Radio flowgraph in the 1-item regime ---- */
 typedef struct {
   /* capacities in items; any pointer may be NULL to skip that tap */
