@@ -237,6 +237,7 @@ struct dvbt_rx {
   float2 *g_init = nullptr; float *l_init = nullptr; float2 *g_trk = nullptr; float *l_trk = nullptr;
   SymMeta *meta = nullptr; RxState *st = nullptr, *st_host = nullptr; TpsState *tps_state = nullptr;
   int *trk_cp_a = nullptr, *trk_cp_b = nullptr, *trk_flags = nullptr; float *trk_eps = nullptr; TpsEdge *tps_edges = nullptr;
+  int *centre = nullptr, *anchor_pos = nullptr;   // predicted CP position per call / coarse estimates every ACQ_ANCHOR calls
   float2 *acq_tap = nullptr, *fft_out = nullptr, *eq = nullptr, *tpsval = nullptr; SymInfo *info = nullptr; int *maj = nullptr, *sym_index = nullptr;
   uint8_t *labels = nullptr, *symdeint_tap = nullptr, *bitdeint = nullptr, *vit = nullptr, *deint_tap = nullptr, *rs_out = nullptr, *ts_out = nullptr;
   size_t vit_cap = 0;
@@ -248,7 +249,7 @@ struct dvbt_rx {
 
 static void rx_free(dvbt_rx *h)
 {
-  void *all[] = {h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags, h->trk_eps, h->d_iq, h->rs_iq, h->acq_carry, h->g_init, h->l_init, h->g_trk, h->l_trk, h->meta, h->st, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
+  void *all[] = {h->centre, h->anchor_pos, h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags, h->trk_eps, h->d_iq, h->rs_iq, h->acq_carry, h->g_init, h->l_init, h->g_trk, h->l_trk, h->meta, h->st, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
                  h->info, h->maj, h->sym_index, h->labels, h->symdeint_tap, h->bitdeint, h->vit, h->deint_tap, h->rs_out, h->ts_out};
   for (void *q : all) if (q) (void)hipFree(q);
   if (h->st_host) (void)hipHostFree(h->st_host);
@@ -292,6 +293,7 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   RXHIP(hipMalloc((void **)&h->meta, sizeof(SymMeta) * C));
   RXHIP(hipMalloc((void **)&h->trk_cp_a, sizeof(int) * C)); RXHIP(hipMalloc((void **)&h->trk_cp_b, sizeof(int) * C));
   RXHIP(hipMalloc((void **)&h->trk_eps, sizeof(float) * C)); RXHIP(hipMalloc((void **)&h->trk_flags, sizeof(int) * 16));
+  RXHIP(hipMalloc((void **)&h->centre, sizeof(int) * (C + 1))); RXHIP(hipMalloc((void **)&h->anchor_pos, sizeof(int) * (C / ACQ_ANCHOR + 4)));
   RXHIP(hipMalloc((void **)&h->tps_edges, sizeof(TpsEdge) * (C / TPS_SEG + 2))); RXHIP(hipMalloc((void **)&h->st, sizeof(RxState)));
   RXHIP(hipHostMalloc((void **)&h->st_host, sizeof(RxState))); RXHIP(hipMalloc((void **)&h->acq_carry, sizeof(AcqState))); RXHIP(hipMalloc((void **)&h->tps_state, sizeof(TpsState)));
   RXHIP(hipMalloc((void **)&h->labels, C * P + 64));   // A1..A4 are one kernel: a symbol reaches HBM as label bytes; fft_out and eq exist only as debug taps
@@ -340,7 +342,7 @@ extern "C" int dvbt_rx_enable_taps(dvbt_rx *h, int enable)
 }
 
 // chain_rate: the samples are already at the OFDM elementary rate (a restart inside a resampled segment)
-static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s, bool chain_rate = false)
+static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s, bool chain_rate = false, long long hist = 0)
 {
   const Dims &d = h->d;
   if (nsamples > (chain_rate ? h->chain_max : h->max_samples)) return fail(DVBT_ERR_CAPACITY, "segment longer than max_samples");
@@ -353,6 +355,7 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
   if (nsamples < (size_t)(2 * d.N + d.cp + 16)) return fail(DVBT_ERR_INVALID, "segment shorter than one acquisition window");
   FrontParams fp = h->fp;
   fp.ncalls = (int)((nsamples - (2 * d.N + d.cp + 16)) / (d.N + d.cp) + 1);
+  fp.hist = hist;
   const int C = fp.ncalls, N = d.N;
   h->cur_stream = s;
   const bool tm = h->timing;
@@ -367,18 +370,24 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
     hipLaunchKernelGGL(acq_init_fsm_kernel, dim3(1), dim3(256), (size_t)N * 5, s, fp, h->st, (const float2 *)h->g_init, (const float *)h->l_init, (const AcqState *)(h->use_carry ? h->acq_carry : nullptr), 1, tries);
   }
   HIPCHK(hipMemsetAsync(h->trk_flags, 0, sizeof(int) * 16, s));
-  hipLaunchKernelGGL(acq_track_metric_kernel, dim3((C + ACQ_TM_CALLS - 1) / ACQ_TM_CALLS), dim3(256), 0, s, iq, fp, (const RxState *)h->st, h->g_trk, h->l_trk);
+  {   // where the tracking metric is computed: CP position predicted per call from coarse estimates every ACQ_ANCHOR calls (sample-clock drift)
+    const int n_anchors = (C - 1) / ACQ_ANCHOR;
+    if (n_anchors > 0) hipLaunchKernelGGL(acq_anchor_kernel, dim3(n_anchors), dim3(256), 0, s, iq, fp, (const RxState *)h->st, h->anchor_pos);
+    hipLaunchKernelGGL(acq_centre_kernel, dim3(1), dim3(1024), 0, s, fp, (const RxState *)h->st, h->anchor_pos, n_anchors, h->centre);
+  }
+  hipLaunchKernelGGL(acq_track_metric_kernel, dim3((C + ACQ_TM_CALLS - 1) / ACQ_TM_CALLS), dim3(256), 0, s, iq, fp, (const RxState *)h->st, (const int *)h->centre, h->g_trk, h->l_trk);
   constexpr int kIters = 4;                     // Jacobi iterations of the window placement; flags[kIters] = need_seq
   for (int it = 0; it < kIters; it++) {
     int *cin = (it & 1) ? h->trk_cp_a : h->trk_cp_b, *cout = (it & 1) ? h->trk_cp_b : h->trk_cp_a;
     hipLaunchKernelGGL(acq_track_par_kernel, dim3((C + 255) / 256), dim3(256), 0, s, fp, (const RxState *)h->st, (const float2 *)h->g_trk,
-                       (const float *)h->l_trk, (const int *)cin, cout, h->trk_eps, h->trk_flags, it);
+                       (const float *)h->l_trk, (const int *)cin, cout, h->trk_eps, h->trk_flags, it, (const int *)h->centre);
   }
   hipLaunchKernelGGL(acq_finalize_kernel, dim3(1), dim3(1024), 0, s, fp, h->st, (const int *)h->trk_cp_a, (const float *)h->trk_eps,
                      (const int *)h->trk_flags, kIters - 1, h->meta, h->trk_flags + kIters);
   hipLaunchKernelGGL(acq_track_kernel, dim3(1), dim3(64), 0, s, fp, h->st, (const float2 *)h->g_trk, (const float *)h->l_trk, h->meta,
-                     (const int *)(h->trk_flags + kIters), (AcqState *)nullptr);
-  hipLaunchKernelGGL(acq_lost_avg_kernel, dim3(1), dim3(64), 0, s, fp, h->st, (const int *)h->trk_cp_a, (const float *)h->l_trk);
+                     (const int *)(h->trk_flags + kIters), (AcqState *)nullptr, (const int *)h->centre, iq);
+  hipLaunchKernelGGL(acq_lost_avg_kernel, dim3(1), dim3(64), 0, s, fp, h->st, (const int *)h->trk_cp_a, (const float *)h->l_trk, (const int *)h->centre,
+                     (const int *)(h->trk_flags + kIters));
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_FFT], s));
   // A1 tail + A2 + A3 in one kernel: the FFT item of a symbol never leaves LDS (acq/fft taps are written only when enabled)
   hipLaunchKernelGGL(derot_fft_demod_kernel, dim3(C), dim3(FFT_THREADS), fused_lds_bytes_host(N), s, iq, fp, (const RxState *)h->st, (const SymMeta *)h->meta,
@@ -509,7 +518,7 @@ extern "C" int dvbt_rx_segment_run(dvbt_rx *h, const void *iq_host, size_t nsamp
     AcqState as; memset(&as, 0, sizeof as); as.avg = h->st_host->avg_lost;
     HIPCHK(hipMemcpyAsync(h->acq_carry, &as, sizeof as, hipMemcpyHostToDevice, h->own_stream));
     h->use_carry = true;
-    r = enqueue(h, chain + off, chain_n - off, h->own_stream, true);   // the stream is already at the chain's rate
+    r = enqueue(h, chain + off, chain_n - off, h->own_stream, true, (long long)off);   // the stream is already at the chain's rate; `off` samples lie before it
     h->use_carry = false;
     if (r) return r;
     r = dvbt_rx_segment_finish(h, &rp); if (r) return r;

@@ -10,7 +10,7 @@ namespace dvbt {
 
 // ---------------------------------------------------------------- device-resident run state
 struct RxState {
-  int status;            // bit0 init-acq failed, bit1 tracking lost, bit2 no superframe start, bit3 lag range exceeded
+  int status;            // bit0 init-acq failed, bit1 tracking lost, bit2 no superframe start
   int call0;             // general_work call (window index) in which initial acquisition succeeded
   int cp_start0;         // d_cp_start returned by the initial ml_sync
   int n_symbols;         // items produced by A1
@@ -40,8 +40,10 @@ constexpr unsigned long long TPS_STATIC_MASK = ((1ull << 54) - 1) & ~((1ull << 1
 struct FrontParams {
   int N, cp, K, zl, payload, n_cp, n_tps, fi_start;
   int ncalls;            // windows available: (ncalls-1)*(N+cp) + 2N+cp+16 <= nsamples
-  int R;                 // half-width of the precomputed lag range around cp_start0
+  int R;                 // half-width of the precomputed lag range around the predicted CP position of a call (centre[call])
   float half_rho;        // (float)(rho/2)
+  long long hist;        // samples of the stream that lie BEFORE the segment's first sample in memory (a restart inside a segment): a tracking
+                         // window at the left edge of its call reads them, as the reference reads the history of its input buffer
 };
 
 // persistent members of the acquisition block between work() calls (block API only)
@@ -58,28 +60,19 @@ __device__ __forceinline__ float2 cdiv(float2 a, float2 b)
 // ---------------------------------------------------------------- A1: CP correlation metric
 // ml_sync (ofdm_sym_acquisition_impl.cc:148-250): gamma(i) = sum_{j<cp} x[i-j] conj(x[i-j-N]),
 // phi(i) = sum |x[i-j]|^2 + |x[i-j-N]|^2, lambda = |gamma| - rho/2 * phi.
-// One thread per lag.  mode 0: initial search, lags N+cp-1 .. 2N+cp-2 of window `try`;
-// mode 1: tracking, lags cp_start0-R .. cp_start0+R-1 of every window.
+// One thread per lag: the initial search, lags N+cp-1 .. 2N+cp-2 of window `try`.
 __global__ __launch_bounds__(256) void acq_metric_kernel(const float2 *__restrict__ iq, FrontParams p, const RxState *st,
                                                         int mode, float2 *__restrict__ gamma, float *__restrict__ lambda, int t_begin)
 {
   const int N = p.N, cp = p.cp;
-  long long wbase; int lag, oidx;
-  if (mode == 0) {
-    int t = blockIdx.y + t_begin;
-    if (t >= p.ncalls) return;
-    if (t_begin > 0 && !(st->status & 1)) return;                 // later windows are searched only if the first one had no peak
-    int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= N) return;
-    wbase = (long long)t * (N + cp); lag = N + cp - 1 + q; oidx = t * N + q;
-  } else {
-    int idx = blockIdx.x * 256 + threadIdx.x;
-    int call = idx / (2 * p.R), q = idx % (2 * p.R);
-    if (call >= p.ncalls || call < st->call0 || (st->status & 1)) return;
-    lag = st->cp_start0 - p.R + q;
-    wbase = (long long)call * (N + cp); oidx = idx;
-    if (lag - cp + 1 - N < 0) { gamma[oidx] = make_float2(0.f, 0.f); lambda[oidx] = -3.0e38f; return; }
-  }
+  (void)mode;
+  const int t = blockIdx.y + t_begin;
+  if (t >= p.ncalls) return;
+  if (t_begin > 0 && !(st->status & 1)) return;                 // later windows are searched only if the first one had no peak
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= N) return;
+  const long long wbase = (long long)t * (N + cp);
+  const int lag = N + cp - 1 + q, oidx = t * N + q;
   const float2 *x = iq + wbase + lag;
   float gr = 0.f, gi = 0.f, phi = 0.f;
   for (int j = 0; j < cp; j++) {
@@ -91,6 +84,85 @@ __global__ __launch_bounds__(256) void acq_metric_kernel(const float2 *__restric
   lambda[oidx] = sqrtf(gr * gr + gi * gi) - phi * p.half_rho;
 }
 
+// ---- following a sample-clock offset.  The reference's tracking window is centred on the previous call's peak
+// (ofdm_sym_acquisition_impl.cc:516), so it follows a drifting CP position for as long as that stays inside the call's window.
+// Here the tracking metric of ALL calls is computed up front for 2R lags per call, so the lags must be placed before the tracker
+// has run: a coarse, FSM-free estimate of the CP position (arg max of lambda over the whole window, sliding sums) is taken at
+// every ACQ_ANCHOR-th call ("anchors"), outliers are rejected against the previous accepted anchor, and centre[call] is the linear
+// interpolation.  The tracker itself is unchanged and decides everything; the centres only say which 2R lags are available to it.
+// If it ever needs a lag outside them (prediction off by more than R-8), the sequential tracker computes that call's metric on the
+// spot (acq_track_kernel), so the result is always the reference's.
+constexpr int ACQ_ANCHOR = 256;                // calls between anchors
+constexpr int ACQ_ANCHOR_LAGS = 32;            // lags per thread in acq_anchor_kernel
+
+__global__ __launch_bounds__(256) void acq_anchor_kernel(const float2 *__restrict__ iq, FrontParams p, const RxState *st, int *__restrict__ anchor_pos)
+{
+  __shared__ float s_best[256]; __shared__ int s_arg[256];
+  const int k = blockIdx.x + 1, tid = threadIdx.x, N = p.N, cp = p.cp;          // anchor 0 is the initial acquisition itself
+  if (st->status & 1) return;
+  const int call = st->call0 + k * ACQ_ANCHOR;
+  if (call >= p.ncalls) { if (tid == 0) anchor_pos[k] = -1; return; }
+  const float2 *w = iq + (long long)call * (N + cp);
+  float best = -3.0e38f; int arg = 0;
+  for (int q0 = tid * ACQ_ANCHOR_LAGS; q0 < N; q0 += 256 * ACQ_ANCHOR_LAGS) {
+    // lag q0: direct sums over cp taps; the following lags slide the window by one sample (short runs: no drift of the float sums)
+    const float2 *x = w + (N + cp - 1 + q0);
+    float gr = 0.f, gi = 0.f, phi = 0.f;
+    for (int j = 0; j < cp; j++) {
+      const float2 a = x[-j], b = x[-j - N];
+      gr += a.x * b.x + a.y * b.y; gi += a.y * b.x - a.x * b.y; phi += (a.x * a.x + a.y * a.y) + (b.x * b.x + b.y * b.y);
+    }
+    for (int u = 0; u < ACQ_ANCHOR_LAGS && q0 + u < N; u++) {
+      const float lam = sqrtf(gr * gr + gi * gi) - phi * p.half_rho;
+      if (lam > best) { best = lam; arg = q0 + u; }
+      const float2 a = x[u + 1], b = x[u + 1 - N], c = x[u + 1 - cp], d = x[u + 1 - cp - N];     // enters / leaves
+      gr += (a.x * b.x + a.y * b.y) - (c.x * d.x + c.y * d.y); gi += (a.y * b.x - a.x * b.y) - (c.y * d.x - c.x * d.y);
+      phi += ((a.x * a.x + a.y * a.y) + (b.x * b.x + b.y * b.y)) - ((c.x * c.x + c.y * c.y) + (d.x * d.x + d.y * d.y));
+    }
+  }
+  s_best[tid] = best; s_arg[tid] = arg;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o && (s_best[tid + o] > s_best[tid] || (s_best[tid + o] == s_best[tid] && s_arg[tid + o] < s_arg[tid]))) { s_best[tid] = s_best[tid + o]; s_arg[tid] = s_arg[tid + o]; }
+    __syncthreads();
+  }
+  if (tid == 0) anchor_pos[k] = s_arg[0] + N + cp - 1;
+}
+
+// centre[call] for every call from call0 on.  n_anchors: anchors computed (slots 1..n_anchors of anchor_pos); 0 = none (block API: the
+// window of one work() call is short, every call is centred on the carried CP position)
+__global__ __launch_bounds__(1024) void acq_centre_kernel(FrontParams p, const RxState *st, int *anchor_pos, int n_anchors, int *__restrict__ centre)
+{
+  if (st->status & 1) return;
+  const int tid = threadIdx.x, c0 = st->cp_start0, call0 = st->call0;
+  if (tid == 0) {
+    anchor_pos[0] = c0;
+    int acc = c0, kacc = 0;
+    for (int k = 1; k <= n_anchors; k++) {
+      const int v = anchor_pos[k];
+      // a sample clock off by more than ~100 ppm moves the peak by more than one sample per symbol: anything faster is not drift
+      if (v >= 0 && abs(v - acc) <= (k - kacc) * ACQ_ANCHOR) { acc = v; kacc = k; } else anchor_pos[k] = -1;
+    }
+  }
+  __syncthreads();
+  for (int call = call0 + tid; call < p.ncalls; call += 1024) {
+    const int s = call - call0, k = s / ACQ_ANCHOR, f = s - k * ACQ_ANCHOR;
+    int k0 = k; while (k0 > 0 && (k0 > n_anchors || anchor_pos[k0] < 0)) k0--;          // last accepted anchor at or before the call
+    int k1 = k + 1; while (k1 <= n_anchors && anchor_pos[k1] < 0) k1++;                   // next accepted anchor after it
+    const int p0 = anchor_pos[k0];
+    int c = p0;
+    if (k1 <= n_anchors) {
+      const long long num = (long long)(anchor_pos[k1] - p0) * ((long long)(k - k0) * ACQ_ANCHOR + f), den = (long long)(k1 - k0) * ACQ_ANCHOR;
+      c = p0 + (int)((num >= 0 ? num + den / 2 : num - den / 2) / den);
+    } else if (k0 > 0) {                                                                  // beyond the last anchor: keep the last slope
+      int kp = k0 - 1; while (kp > 0 && anchor_pos[kp] < 0) kp--;
+      const long long num = (long long)(p0 - anchor_pos[kp]) * ((long long)(k - k0) * ACQ_ANCHOR + f), den = (long long)(k0 - kp) * ACQ_ANCHOR;
+      c = p0 + (int)((num >= 0 ? num + den / 2 : num - den / 2) / den);
+    }
+    centre[call] = c;
+  }
+}
+
 // tracking metric (mode 1 of acq_metric_kernel) with the samples staged through LDS and register blocking: a workgroup
 // owns 32 calls x 32 lags; a thread owns 4 consecutive lags of a call.  Per tile of 64 correlation taps the workgroup
 // loads the 95 samples (and their partners N earlier) each call needs, once and coalesced; a thread then walks the tile's
@@ -98,16 +170,16 @@ __global__ __launch_bounds__(256) void acq_metric_kernel(const float2 *__restric
 // lags, each lag still seeing its taps in ascending order.  The sums use the same expressions in the same order as
 // acq_metric_kernel, so gamma/lambda are bit-identical.
 constexpr int ACQ_TM_CALLS = 32, ACQ_TM_TILE = 64, ACQ_TM_SPAN = ACQ_TM_TILE + 2 * ACQ_R - 1;
-__global__ __launch_bounds__(256) void acq_track_metric_kernel(const float2 *__restrict__ iq, FrontParams p, const RxState *st,
+__global__ __launch_bounds__(256) void acq_track_metric_kernel(const float2 *__restrict__ iq, FrontParams p, const RxState *st, const int *__restrict__ centre,
                                                               float2 *__restrict__ gamma, float *__restrict__ lambda)
 {
   __shared__ float2 sA[ACQ_TM_CALLS][ACQ_TM_SPAN], sB[ACQ_TM_CALLS][ACQ_TM_SPAN];
   if (st->status & 1) return;
   const int N = p.N, cp = p.cp, tid = threadIdx.x, c = tid >> 3, g4 = (tid & 7) * 4;
   const int call0 = blockIdx.x * ACQ_TM_CALLS, call = call0 + c;
-  const int lag0 = st->cp_start0 - p.R;
   if (call0 + ACQ_TM_CALLS <= st->call0 || call0 >= p.ncalls) return;
   const bool active = call < p.ncalls && call >= st->call0;
+  const int lag0 = (active ? centre[call] : 0) - p.R;             // first lag of this thread's call
   float gr[4] = {0.f, 0.f, 0.f, 0.f}, gi[4] = {0.f, 0.f, 0.f, 0.f}, phi[4] = {0.f, 0.f, 0.f, 0.f};
   constexpr int T = ACQ_TM_TILE;
   for (int j0 = 0; j0 < cp; j0 += T) {
@@ -119,11 +191,12 @@ __global__ __launch_bounds__(256) void acq_track_metric_kernel(const float2 *__r
       for (int k = 0; k < 4; k++) {
         const int e = e0 + k * 256, ec = e < ACQ_TM_CALLS * ACQ_TM_SPAN ? e : 0;
         const int cc = ec / ACQ_TM_SPAN, i = ec - cc * ACQ_TM_SPAN, cl = call0 + cc;
-        const long long idx = (long long)cl * (N + cp) + lag0 - j0 - (T - 1) + i;    // sample x[lag0 + q - j] for q - (j - j0) = i - (T - 1)
         const bool okc = cl < p.ncalls && cl >= st->call0;
-        av[k] = iq[okc && idx >= 0 ? idx : 0]; bv[k] = iq[okc && idx - N >= 0 ? idx - N : 0];
-        if (!(okc && idx >= 0)) av[k] = make_float2(0.f, 0.f);
-        if (!(okc && idx - N >= 0)) bv[k] = make_float2(0.f, 0.f);
+        const int lag0c = centre[okc ? cl : st->call0] - p.R;
+        const long long idx = (long long)cl * (N + cp) + lag0c - j0 - (T - 1) + i;   // sample x[lag0 + q - j] for q - (j - j0) = i - (T - 1)
+        av[k] = iq[okc && idx >= -p.hist ? idx : 0]; bv[k] = iq[okc && idx - N >= -p.hist ? idx - N : 0];
+        if (!(okc && idx >= -p.hist)) av[k] = make_float2(0.f, 0.f);
+        if (!(okc && idx - N >= -p.hist)) bv[k] = make_float2(0.f, 0.f);
       }
 #pragma unroll
       for (int k = 0; k < 4; k++) {
@@ -151,7 +224,7 @@ __global__ __launch_bounds__(256) void acq_track_metric_kernel(const float2 *__r
 #pragma unroll
   for (int u = 0; u < 4; u++) {
     const int q = g4 + u, oidx = call * 2 * p.R + q;
-    if (lag0 + q - cp + 1 - N < 0) { gamma[oidx] = make_float2(0.f, 0.f); lambda[oidx] = -3.0e38f; continue; }
+    if ((long long)call * (N + cp) + lag0 + q - cp + 1 - N < -p.hist) { gamma[oidx] = make_float2(0.f, 0.f); lambda[oidx] = -3.0e38f; continue; }   // before the stream's first sample
     gamma[oidx] = make_float2(gr[u], gi[u]);
     lambda[oidx] = sqrtf(gr[u] * gr[u] + gi[u] * gi[u]) - phi[u] * p.half_rho;
   }
@@ -306,12 +379,13 @@ __global__ __launch_bounds__(256) void acq_init_fsm_kernel(FrontParams p, RxStat
 struct SymMeta { int cp_start; int sw; float eps; float ph_base; double incA, incB; };
 
 __global__ void acq_track_kernel(FrontParams p, RxState *st, const float2 *gamma, const float *lambda, SymMeta *meta, const int *need_seq,
-                                 AcqState *as)
+                                 AcqState *as, const int *__restrict__ centre, const float2 *__restrict__ iq)
 {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   if (st->status & 1) { if (as) { as->avg = st->avg; as->lost = 0; } return; }
   if (need_seq && *need_seq == 0) return;
   const int N = p.N, cp = p.cp, R = p.R, c0 = st->cp_start0;
+  (void)c0;
   float avg = st->avg, phase = 0.f;
   double phaseinc = 0.0, nextphaseinc = (-1.0 / (double)N) * (double)st->eps_init;
   int nextpos = c0 - (N + cp), cur = c0, s = 0;
@@ -328,13 +402,28 @@ __global__ void acq_track_kernel(FrontParams p, RxState *st, const float2 *gamma
   }
   bool lost = false;
   for (int call = st->call0; call < p.ncalls; call++, s++) {
-    int rel0 = (cur - 8) - (c0 - R);
-    if (rel0 < 0 || rel0 + 16 > 2 * R) { st->status |= 8; break; }
-    const float *lam = lambda + (size_t)call * 2 * R + rel0;
+    int rel0 = (cur - 8) - (centre[call] - R);
+    float lam_here[16]; float2 gam_here[16];
+    const bool direct = rel0 < 0 || rel0 + 16 > 2 * R;            // the window left the precomputed lags: this call's metric on the spot
+    if (direct) {
+      for (int q = 0; q < 16; q++) {
+        const int lag = cur - 8 + q;
+        float gr = 0.f, gi = 0.f, phi = 0.f;
+        if ((long long)call * (N + cp) + lag - cp + 1 - N < -p.hist) { lam_here[q] = -3.0e38f; gam_here[q] = make_float2(0.f, 0.f); continue; }
+        const float2 *x = iq + (long long)call * (N + cp) + lag;
+        for (int j = 0; j < cp; j++) {                              // the expressions and the order of acq_track_metric_kernel
+          const float2 a = x[-j], b = x[-j - N];
+          gr += a.x * b.x + a.y * b.y; gi += a.y * b.x - a.x * b.y; phi += (a.x * a.x + a.y * a.y) + (b.x * b.x + b.y * b.y);
+        }
+        gam_here[q] = make_float2(gr, gi); lam_here[q] = sqrtf(gr * gr + gi * gi) - phi * p.half_rho;
+      }
+      rel0 = 0;
+    }
+    const float *lam = direct ? lam_here : lambda + (size_t)call * 2 * R + rel0;
     int pos = 0;
     int npk = peak_detect(lam, 16, avg, pos);
     if (!npk) { st->status |= 2; lost = true; break; }   // the reference drops lock and re-acquires (:545-559)
-    float2 g = gamma[(size_t)call * 2 * R + rel0 + pos];
+    float2 g = direct ? gam_here[pos] : gamma[(size_t)call * 2 * R + rel0 + pos];
     float eps = atan2f(g.y, g.x);
     int peak = pos + cur - 8;
     SymMeta m; m.cp_start = peak; m.eps = eps; m.ph_base = phase; m.incA = phaseinc; m.incB = nextphaseinc; m.sw = nextpos;
@@ -348,6 +437,7 @@ __global__ void acq_track_kernel(FrontParams p, RxState *st, const float2 *gamma
     cur = peak;
   }
   st->n_symbols = s;
+  st->avg_lost = lost ? avg : st->avg;                            // d_avg after the call that lost the lock
   if (as) {
     if (lost) {   // the failing call still advanced the phase by N+cp steps without switching (:336-345)
       phase = wrap_pi((double)phase + (double)(N + cp) * phaseinc);
@@ -371,7 +461,8 @@ struct TrackWork { int *cp_a; int *cp_b; float *eps; int *changed; /* [iters+1] 
 
 __global__ __launch_bounds__(256) void acq_track_par_kernel(FrontParams p, const RxState *st, const float2 *__restrict__ gamma,
                                                            const float *__restrict__ lambda, const int *__restrict__ cp_in,
-                                                           int *__restrict__ cp_out, float *__restrict__ eps_out, int *changed, int iter)
+                                                           int *__restrict__ cp_out, float *__restrict__ eps_out, int *changed, int iter,
+                                                           const int *__restrict__ centre)
 {
   if (st->status & 1) return;
   if (iter > 0 && changed[iter - 1] == 0) return;               // already at the fixed point
@@ -387,15 +478,15 @@ __global__ __launch_bounds__(256) void acq_track_par_kernel(FrontParams p, const
   for (int ws = first_warm; ws < s; ws++) {                      // IIR over the earlier windows (fact 1)
     int cur = prev_cp(ws);
     if (cur < 0) { bad = true; break; }
-    int rel0 = (cur - 8) - (c0 - R);
+    int rel0 = (cur - 8) - (centre[st->call0 + ws] - R);
     if (rel0 < 0 || rel0 + 16 > 2 * R) { bad = true; break; }
     const float *lam = lambda + (size_t)(st->call0 + ws) * 2 * R + rel0;
     for (int i = 0; i < 16; i++) avg = 0.9f * lam[i] + (1 - 0.9f) * avg;
   }
-  int cur = prev_cp(s), res = -1; float eps = 0.f;
+  int cur = prev_cp(s), res = bad ? -2 : -1; float eps = 0.f;
   if (!bad && cur >= 0) {
-    int rel0 = (cur - 8) - (c0 - R);
-    if (rel0 < 0 || rel0 + 16 > 2 * R) res = -2;                // left the precomputed lag range
+    int rel0 = (cur - 8) - (centre[call] - R);
+    if (rel0 < 0 || rel0 + 16 > 2 * R) res = -2;                // left the precomputed lags: the sequential tracker takes over
     else {
       float lam[16];
       const float *lp = lambda + (size_t)call * 2 * R + rel0;
@@ -437,6 +528,7 @@ __global__ __launch_bounds__(1024) void acq_finalize_kernel(FrontParams p, RxSta
   }
   __syncthreads();
   const int nsym = s_first_bad;
+  if (nsym < ntot && cp[nsym] == -2) { if (tid == 0) *need_seq = 1; return; }   // the placement ran out of precomputed lags: sequential tracker
   // the closed form below needs every phase-increment switch to fall inside its call
   for (int s0 = tid; s0 < nsym; s0 += 8 * 1024) {
     int cv[8];
@@ -502,15 +594,17 @@ __global__ __launch_bounds__(1024) void acq_finalize_kernel(FrontParams p, RxSta
   }
   if (tid == 0) {
     st->n_symbols = nsym;
-    if (nsym < ntot) st->status |= (cp[nsym] == -2) ? 8 : 2;
+    if (nsym < ntot) st->status |= 2;
   }
 }
 
 // d_avg after the call in which the tracker lost the lock: the reference re-acquires in the next call with this value
 // (ofdm_sym_acquisition_impl.cc:545-559; d_avg persists).  IIR over the last two windows (see acq_track_par_kernel).
-__global__ void acq_lost_avg_kernel(FrontParams p, RxState *st, const int *__restrict__ cp, const float *__restrict__ lambda)
+__global__ void acq_lost_avg_kernel(FrontParams p, RxState *st, const int *__restrict__ cp, const float *__restrict__ lambda, const int *__restrict__ centre,
+                                    const int *need_seq)
 {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (need_seq && *need_seq) return;                             // the sequential tracker has written avg_lost itself
   st->avg_lost = st->avg;
   if (!(st->status & 2) || (st->status & 1)) return;
   const int f = st->n_symbols, R = p.R, c0 = st->cp_start0;      // f: first call (relative to call0) without a peak
@@ -518,8 +612,9 @@ __global__ void acq_lost_avg_kernel(FrontParams p, RxState *st, const int *__res
   if (f <= 1) { avg = st->avg; w0 = 0; } else { avg = 0.f; w0 = f - 1; }
   for (int ws = w0; ws <= f; ws++) {
     const int cur = ws <= 0 ? c0 : cp[ws - 1];
-    const int rel0 = (cur - 8) - (c0 - R);
-    if (cur < 0 || rel0 < 0 || rel0 + 16 > 2 * R) return;
+    if (cur < 0) return;
+    const int rel0 = (cur - 8) - (centre[st->call0 + ws] - R);
+    if (rel0 < 0 || rel0 + 16 > 2 * R) return;
     const float *lam = lambda + (size_t)(st->call0 + ws) * 2 * R + rel0;
     for (int i = 0; i < 16; i++) avg = 0.9f * lam[i] + (1 - 0.9f) * avg;
   }

@@ -271,7 +271,7 @@ typedef struct {
 
 typedef struct {
   int32_t status;              /* 0 ok; bit0: initial acquisition failed; bit1: CP tracking lost;
-                                  bit2: no superframe start found; bit3: tracking left the precomputed lag range;
+                                  bit2: no superframe start found;
                                   bit4: the stream's TPS disagrees with the configured parameters (tps_mismatch) */
   int32_t n_symbols;           /* OFDM symbols acquired */
   int32_t first_out_symbol;    /* symbol at which superframe_start fired, -1 if none */

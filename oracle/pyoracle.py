@@ -177,6 +177,26 @@ def stream_slice(c, n_sf, seed, begin=0, end=None, lead_in=STREAM_LEAD_IN):
     return out
 
 
+def clock_offset(iq, ppm, taps=16):
+    """The stream as a receiver whose sample clock is off by `ppm` sees it: y[n] = x(n (1 + ppm 1e-6)), windowed-sinc interpolation
+    (test utility: a slowly sliding symbol timing for the drift tests)."""
+    iq = np.ascontiguousarray(iq, dtype=np.complex64)
+    n_out = int((len(iq) - taps - 2) / (1.0 + ppm * 1e-6))
+    out = np.empty(n_out, np.complex64)
+    k = np.arange(-(taps // 2 - 1), taps // 2 + 1)                  # taps around the sampling instant
+    step = 1 << 20
+    for a in range(0, n_out, step):
+        b = min(n_out, a + step)
+        t = np.arange(a, b, dtype=np.float64) * (1.0 + ppm * 1e-6) + (taps // 2)
+        base = np.floor(t).astype(np.int64)
+        frac = (t - base)[:, None]
+        x = k[None, :] - frac
+        h = np.sinc(x) * (0.54 + 0.46 * np.cos(np.pi * x / (taps // 2 + 1)))   # Hamming-windowed sinc
+        idx = base[:, None] + k[None, :]
+        out[a:b] = (iq[idx] * h.astype(np.float32)).sum(axis=1)
+    return out
+
+
 def tx_scale(c):
     """TX multiply_const * RX multiply_const of the demo flowgraphs (apps/dvbt_{tx,rx}_demo*.grc)."""
     return float(np.float32(0.0022097087) * np.float32(0.0022097087 if c.mode == T2k else 0.00055242272))
