@@ -59,7 +59,8 @@ class RxReport(C.Structure):
                 ("ts_first_packet", C.c_int64), ("stream_rs_items", C.c_int64), ("tps_bits", C.c_uint64), ("tps_valid", C.c_int32),
                 ("tps_length_indicator", C.c_int32), ("tps_constellation", C.c_int32), ("tps_hierarchy", C.c_int32),
                 ("tps_code_rate_hp", C.c_int32), ("tps_code_rate_lp", C.c_int32), ("tps_guard_interval", C.c_int32),
-                ("tps_transmission_mode", C.c_int32), ("tps_cell_id", C.c_int32), ("tps_mismatch", C.c_int32)]
+                ("tps_transmission_mode", C.c_int32), ("tps_cell_id", C.c_int32), ("tps_mismatch", C.c_int32),
+                ("n_lock_periods", C.c_int32), ("total_symbols", C.c_int32)]
 
 
 class RxCut(C.Structure):
@@ -90,6 +91,7 @@ def lib():
         L.dvbt_version.restype = C.c_char_p
         L.dvbt_rx_create.argtypes = [C.POINTER(RxParams), C.POINTER(C.c_void_p)]
         L.dvbt_rx_segment_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(RxReport)]
+        L.dvbt_rx_segment_run_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(RxReport)]
         L.dvbt_rx_segment_enqueue_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.dvbt_rx_segment_finish.argtypes = [C.c_void_p, C.POINTER(RxReport)]
         L.dvbt_rx_read_tap.restype = C.c_int64
@@ -153,6 +155,13 @@ class Rx:
         """Declare the following segments as the continuation of a cut stream (include/dvbt_hip.h: dvbt_rx_set_cut)."""
         cut = RxCut(int(stream_symbol_offset))
         _chk(self.L.dvbt_rx_set_cut(self.h, C.byref(cut)))
+
+    def run_device(self, dptr, nsamples, stream=None):
+        """dvbt_rx_segment_run_device: synchronous, follows every loss of the CP lock inside the segment"""
+        rep = RxReport()
+        _chk(self.L.dvbt_rx_segment_run_device(self.h, C.c_void_p(dptr), nsamples, C.c_void_p(stream) if stream else None, C.byref(rep)))
+        self.report = rep
+        return rep
 
     def enqueue_device(self, dptr, nsamples, stream=None):
         _chk(self.L.dvbt_rx_segment_enqueue_device(self.h, C.c_void_p(dptr), nsamples,

@@ -245,11 +245,13 @@ struct dvbt_rx {
   hipEvent_t ev[ST_COUNT]; double acc_ms[ST_COUNT] = {0}; long n_timed = 0; bool ev_ready = false, ev_recorded = false;
   dvbt_rx_report last; bool have_last = false;
   dvbt_rx_cut cut = {0};
+  float2 *tps_prev = nullptr; DescrRun *descr_runs = nullptr; int *descr_nruns = nullptr;
+  int n_periods = 1; size_t seg_offset = 0;
 };
 
 static void rx_free(dvbt_rx *h)
 {
-  void *all[] = {h->centre, h->anchor_pos, h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags, h->trk_eps, h->d_iq, h->rs_iq, h->acq_carry, h->g_init, h->l_init, h->g_trk, h->l_trk, h->meta, h->st, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
+  void *all[] = {h->tps_prev, h->descr_runs, h->descr_nruns, h->centre, h->anchor_pos, h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags, h->trk_eps, h->d_iq, h->rs_iq, h->acq_carry, h->g_init, h->l_init, h->g_trk, h->l_trk, h->meta, h->st, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
                  h->info, h->maj, h->sym_index, h->labels, h->symdeint_tap, h->bitdeint, h->vit, h->deint_tap, h->rs_out, h->ts_out};
   for (void *q : all) if (q) (void)hipFree(q);
   if (h->st_host) (void)hipHostFree(h->st_host);
@@ -293,6 +295,8 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   RXHIP(hipMalloc((void **)&h->meta, sizeof(SymMeta) * C));
   RXHIP(hipMalloc((void **)&h->trk_cp_a, sizeof(int) * C)); RXHIP(hipMalloc((void **)&h->trk_cp_b, sizeof(int) * C));
   RXHIP(hipMalloc((void **)&h->trk_eps, sizeof(float) * C)); RXHIP(hipMalloc((void **)&h->trk_flags, sizeof(int) * 16));
+  RXHIP(hipMalloc((void **)&h->tps_prev, sizeof(float2) * d.n_tps)); RXHIP(hipMemset(h->tps_prev, 0, sizeof(float2) * d.n_tps));
+  RXHIP(hipMalloc((void **)&h->descr_runs, sizeof(DescrRun) * DESCR_MAX_RUNS)); RXHIP(hipMalloc((void **)&h->descr_nruns, sizeof(int)));
   RXHIP(hipMalloc((void **)&h->centre, sizeof(int) * (C + 1))); RXHIP(hipMalloc((void **)&h->anchor_pos, sizeof(int) * (C / ACQ_ANCHOR + 4)));
   RXHIP(hipMalloc((void **)&h->tps_edges, sizeof(TpsEdge) * (C / TPS_SEG + 2))); RXHIP(hipMalloc((void **)&h->st, sizeof(RxState)));
   RXHIP(hipHostMalloc((void **)&h->st_host, sizeof(RxState))); RXHIP(hipMalloc((void **)&h->acq_carry, sizeof(AcqState))); RXHIP(hipMalloc((void **)&h->tps_state, sizeof(TpsState)));
@@ -341,33 +345,80 @@ extern "C" int dvbt_rx_enable_taps(dvbt_rx *h, int enable)
   return DVBT_OK;
 }
 
-// chain_rate: the samples are already at the OFDM elementary rate (a restart inside a resampled segment)
-static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s, bool chain_rate = false, long long hist = 0)
+// How one lock period of a segment is processed.  The asynchronous entry (dvbt_rx_segment_enqueue_device) runs one period with the
+// defaults; the synchronous entries walk the segment's lock periods (segment_periods).
+struct EnqOpt {
+  bool acq_only = false;      // ofdm_sym_acquisition alone (where does the lock start, how long does it hold)
+  bool use_carry = false;     // the peak detector's average is carried in from the call that lost the previous lock (h->acq_carry)
+  long long hist = 0;         // samples of the stream in memory in front of iq[0]
+  bool continuation = false;  // not the first period that reaches demod_reference_signals: its TPS state and the previous symbol's TPS carriers are
+                              // carried over, the first item bears the sync_start tag (demod_reference_signals_impl.cc:115-116)
+  bool keep_last = false;     // a later period delivers items: the last item of this one leaves the demodulator too
+  size_t vit_off = 0;         // where this period's decoded bytes go in the Viterbi stream of the segment
+  bool tail = true;           // byte de-interleaver + RS + descrambler right behind (single period)
+};
+
+// samples at the OFDM elementary rate: the segment itself, or its resampled image (next row 2)
+static int prepare_chain(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s, const float2 **chain, size_t *chain_n)
 {
-  const Dims &d = h->d;
-  if (nsamples > (chain_rate ? h->chain_max : h->max_samples)) return fail(DVBT_ERR_CAPACITY, "segment longer than max_samples");
-  if (h->rsd.ri && !chain_rate) {   // next row 2: the segment arrives at the file rate; resample + scale into the chain's input buffer first
+  if (nsamples > h->max_samples) return fail(DVBT_ERR_CAPACITY, "segment longer than max_samples");
+  *chain = iq; *chain_n = nsamples;
+  if (h->rsd.ri) {   // the segment arrives at the file rate; resample + scale into the chain's input buffer first
     const long long cnt = (long long)(((unsigned long long)nsamples * h->rsd.ri + h->rsd.rd - 1) / h->rsd.rd);
     hipLaunchKernelGGL(resample_scale_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, iq, 0ll, (long long)nsamples, 0ll, cnt, h->rsd.ri, h->rsd.rd,
                        h->rsd.nt, (const float *)h->rsd.br, h->prm.front_scale == 0.f ? 1.0f : h->prm.front_scale, h->rs_iq);
-    iq = h->rs_iq; nsamples = (size_t)cnt;
+    *chain = h->rs_iq; *chain_n = (size_t)cnt;
   }
+  return DVBT_OK;
+}
+
+// A8 + A9 + energy_descramble over the segment's Viterbi stream.  words_fixed < 0: the word count is the device's (one period, no host round trip)
+static int enqueue_tail(dvbt_rx *h, hipStream_t s, long long max_words, long long words_fixed)
+{
+  if (words_fixed >= 0) {   // several periods: the host has laid the stream out and knows its length
+    RxState upd; memset(&upd, 0, sizeof upd);
+    const long long items = (words_fixed / 8) & ~1ll;
+    // n_rs_items / n_rs_words / stream_rs_items sit next to each other; patch them (and the counters) on the device
+    HIPCHK(hipMemcpyAsync(&h->st->n_rs_items, &items, sizeof items, hipMemcpyHostToDevice, s));
+    const long long words = items * 8;
+    HIPCHK(hipMemcpyAsync(&h->st->n_rs_words, &words, sizeof words, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(&h->st->stream_rs_items, &items, sizeof items, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(&h->st->rs_fail, 0, 2 * sizeof(int), s));
+    const long long zero = 0;
+    HIPCHK(hipMemcpyAsync(&h->st->sym_off, &zero, sizeof zero, hipMemcpyHostToDevice, s));
+    (void)upd;
+  }
+  hipLaunchKernelGGL(deint_rs_kernel, dim3((unsigned)((max_words + 63) / 64)), dim3(64), 0, s, (const uint8_t *)h->vit, h->deint_tap, h->rs_out,
+                     h->st, 0ll, 0, 0ll, h->T.rs_tables(), h->prm.rs_oracle_compat, &h->st->rs_fail, &h->st->rs_corr);
+  if (h->prm.descramble) {
+    hipLaunchKernelGGL(descramble_scan_kernel, dim3(1), dim3(1024), 0, s, (const uint8_t *)h->rs_out, h->st, h->descr_runs, h->descr_nruns);
+    hipLaunchKernelGGL(descramble_runs_kernel, dim3(1024), dim3(256), 0, s, (const uint8_t *)h->rs_out, (const uint8_t *)h->T.prbs,
+                       (const RxState *)h->st, (const DescrRun *)h->descr_runs, (const int *)h->descr_nruns, h->ts_out);
+  }
+  return DVBT_OK;
+}
+
+// one lock period of the chain, iq at the OFDM elementary rate
+static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s, const EnqOpt &o = EnqOpt())
+{
+  const Dims &d = h->d;
+  if (nsamples > h->chain_max) return fail(DVBT_ERR_CAPACITY, "segment longer than max_samples");
   if (nsamples < (size_t)(2 * d.N + d.cp + 16)) return fail(DVBT_ERR_INVALID, "segment shorter than one acquisition window");
   FrontParams fp = h->fp;
   fp.ncalls = (int)((nsamples - (2 * d.N + d.cp + 16)) / (d.N + d.cp) + 1);
-  fp.hist = hist;
+  fp.hist = o.hist; fp.keep_last = o.keep_last ? 1 : 0;
   const int C = fp.ncalls, N = d.N;
   h->cur_stream = s;
-  const bool tm = h->timing;
+  const bool tm = h->timing && !o.acq_only;
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_ACQ], s));
-  HIPCHK(hipMemsetAsync(h->tps_state, 0, sizeof(TpsState), s));
+  const AcqState *carry = o.use_carry ? h->acq_carry : nullptr;
   int tries = C < ACQ_INIT_TRIES ? C : ACQ_INIT_TRIES;
   // initial search: the first window normally holds a peak; windows 1..3 are computed and examined only if it did not
   hipLaunchKernelGGL(acq_metric_kernel, dim3((N + 255) / 256, 1), dim3(256), 0, s, iq, fp, (const RxState *)h->st, 0, h->g_init, h->l_init, 0);
-  hipLaunchKernelGGL(acq_init_fsm_kernel, dim3(1), dim3(256), (size_t)N * 5, s, fp, h->st, (const float2 *)h->g_init, (const float *)h->l_init, (const AcqState *)(h->use_carry ? h->acq_carry : nullptr), 0, 1);
+  hipLaunchKernelGGL(acq_init_fsm_kernel, dim3(1), dim3(256), (size_t)N * 5, s, fp, h->st, (const float2 *)h->g_init, (const float *)h->l_init, carry, 0, 1);
   if (tries > 1) {
     hipLaunchKernelGGL(acq_metric_kernel, dim3((N + 255) / 256, tries - 1), dim3(256), 0, s, iq, fp, (const RxState *)h->st, 0, h->g_init, h->l_init, 1);
-    hipLaunchKernelGGL(acq_init_fsm_kernel, dim3(1), dim3(256), (size_t)N * 5, s, fp, h->st, (const float2 *)h->g_init, (const float *)h->l_init, (const AcqState *)(h->use_carry ? h->acq_carry : nullptr), 1, tries);
+    hipLaunchKernelGGL(acq_init_fsm_kernel, dim3(1), dim3(256), (size_t)N * 5, s, fp, h->st, (const float2 *)h->g_init, (const float *)h->l_init, carry, 1, tries);
   }
   HIPCHK(hipMemsetAsync(h->trk_flags, 0, sizeof(int) * 16, s));
   {   // where the tracking metric is computed: CP position predicted per call from coarse estimates every ACQ_ANCHOR calls (sample-clock drift)
@@ -388,22 +439,37 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
                      (const int *)(h->trk_flags + kIters), (AcqState *)nullptr, (const int *)h->centre, iq);
   hipLaunchKernelGGL(acq_lost_avg_kernel, dim3(1), dim3(64), 0, s, fp, h->st, (const int *)h->trk_cp_a, (const float *)h->l_trk, (const int *)h->centre,
                      (const int *)(h->trk_flags + kIters));
+  if (o.acq_only) {
+    HIPCHK(hipMemcpyAsync(h->st_host, h->st, sizeof(RxState), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipGetLastError());
+    return DVBT_OK;
+  }
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_FFT], s));
   // A1 tail + A2 + A3 in one kernel: the FFT item of a symbol never leaves LDS (acq/fft taps are written only when enabled)
   hipLaunchKernelGGL(derot_fft_demod_kernel, dim3(C), dim3(FFT_THREADS), fused_lds_bytes_host(N), s, iq, fp, (const RxState *)h->st, (const SymMeta *)h->meta,
                      (const float2 *)h->T.tw, (const uint16_t *)h->T.perm, h->acq_tap, h->fft_out, h->T.demod_tables(), h->eq, h->tpsval, h->info,
                      h->T.inner_params(d.payload), (const float2 *)h->T.points, (const unsigned char *)h->T.label_tab, h->labels);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_DEMOD], s));
-  hipLaunchKernelGGL(tps_vote_kernel, dim3((C + 63) / 64), dim3(256), 0, s, (const float2 *)h->tpsval, d.n_tps, (const RxState *)h->st, 0,
-                     (const float2 *)nullptr, h->maj);
-  {   // flags[8] = first superframe-start candidate (min), flags[9] = need_seq for the TPS bookkeeping
+  if (!o.continuation) {
+    HIPCHK(hipMemsetAsync(h->tps_state, 0, sizeof(TpsState), s));
+    hipLaunchKernelGGL(tps_vote_kernel, dim3((C + 63) / 64), dim3(256), 0, s, (const float2 *)h->tpsval, d.n_tps, (const RxState *)h->st, 0,
+                       (const float2 *)nullptr, h->maj, fp.keep_last);
+    // flags[8] = first superframe-start candidate (min), flags[9] = need_seq for the TPS bookkeeping
     static const int kInit[2] = {0x7fffffff, 0};
     HIPCHK(hipMemcpyAsync(h->trk_flags + 8, kInit, sizeof kInit, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(tps_fsm_par_kernel, dim3((C + TPS_THREADS * TPS_SEG - 1) / (TPS_THREADS * TPS_SEG)), dim3(TPS_THREADS), 0, s, fp, (const RxState *)h->st, (const SymInfo *)h->info,
                        (const int *)h->maj, h->sym_index, h->tps_edges, h->trk_flags + 8, &h->st->tps_bits);
-    hipLaunchKernelGGL(tps_finalize_kernel, dim3(1), dim3(256), 0, s, h->st, (const TpsEdge *)h->tps_edges, (const int *)(h->trk_flags + 8), h->trk_flags + 9);
+    hipLaunchKernelGGL(tps_finalize_kernel, dim3(1), dim3(256), 0, s, h->st, (const TpsEdge *)h->tps_edges, (const int *)(h->trk_flags + 8), h->trk_flags + 9, fp.keep_last, h->tps_state);
     hipLaunchKernelGGL(tps_fsm_kernel, dim3(1), dim3(256), 0, s, fp, h->st, 0, (const SymInfo *)h->info, (const int *)h->maj, h->tps_state,
                        h->sym_index, (int *)nullptr, (const unsigned char *)nullptr, (const int *)(h->trk_flags + 9));
+  } else {
+    // the pilot engine's members live on (FIFO, symbol and frame counters: reference_signals_impl.h); the sync_start tag on the period's first
+    // item clears d_init (the superframe hunt starts over); DBPSK against the last symbol in front of the gap.  Sequential bookkeeping.
+    HIPCHK(hipMemsetAsync(&h->tps_state->d_init, 0, sizeof(int), s));
+    hipLaunchKernelGGL(tps_vote_kernel, dim3((C + 63) / 64), dim3(256), 0, s, (const float2 *)h->tpsval, d.n_tps, (const RxState *)h->st, 0,
+                       (const float2 *)h->tps_prev, h->maj, fp.keep_last);
+    hipLaunchKernelGGL(tps_fsm_kernel, dim3(1), dim3(256), 0, s, fp, h->st, 0, (const SymInfo *)h->info, (const int *)h->maj, h->tps_state,
+                       h->sym_index, (int *)nullptr, (const unsigned char *)nullptr, (const int *)nullptr);
   }
   hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(64), 0, s, h->st, h->vp, h->prm.descramble, (long long)h->cut.stream_symbol_offset);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_INNER], s));
@@ -417,11 +483,11 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
   VitParams vp = h->vp;
   if (h->prm.viterbi_chunk_bytes <= 0) {
     // chunk size chosen per segment so that the wavefront count is a whole number of "rounds" of the resident
-    // wavefront slots (4 chunks per wavefront, V3_WAVES_PER_CU one-wave workgroups per CU: 3 per SIMD): equal-length chunks then
+    // wavefront slots (4 chunks per wavefront, V3_WAVES_PER_CU one-wave workgroups per CU: 2 per SIMD): equal-length chunks then
     // finish together instead of leaving a partial last round, and longer chunks amortise the warm-up +
     // traceback overlap (V3_WARM + ntraceback - 1 windows per chunk).  Measured on 65 superframes: 3 rounds of
-    // ~2900-byte chunks beat 5 rounds of ~1700 (less overlap) and 1 round of ~8600 (the hardware's static
-    // placement of a single round leaves some SIMDs with one wavefront)
+    // ~2900-byte chunks beat 5 rounds of ~1700 (less overlap) and 1 round of ~8600 (the SIMD's arbiter favours the older of its
+    // two wavefronts, which then finishes long before the other: profiles/r02_viterbi_attribution.jsonl)
     int ncu = 256; (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->prm.device);
     const long long slots = (long long)ncu * V3_WAVES_PER_CU * 4;   // chunks resident at once
     constexpr long long kMaxChunk = 3000;
@@ -431,16 +497,10 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
     if (B < 256) B = 256;
     vp.chunk_bytes = (int)B;
   }
-  launch_viterbi(s, (const uint8_t *)h->bitdeint, h->vit, (const RxState *)h->st, 0ll, vp, 0ll, 0ll, max_vit);
+  if (o.vit_off + (size_t)max_vit > h->vit_cap) return fail(DVBT_ERR_CAPACITY, "Viterbi stream buffer too small for the segment's lock periods");
+  launch_viterbi(s, (const uint8_t *)h->bitdeint, h->vit + o.vit_off, (const RxState *)h->st, 0ll, vp, 0ll, 0ll, max_vit);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_RS], s));
-  long long max_words = max_vit / 204 + 1;
-  hipLaunchKernelGGL(deint_rs_kernel, dim3((unsigned)((max_words + 63) / 64)), dim3(64), 0, s, (const uint8_t *)h->vit, h->deint_tap, h->rs_out,
-                     h->st, 0ll, 0, 0ll, h->T.rs_tables(), h->prm.rs_oracle_compat, &h->st->rs_fail, &h->st->rs_corr);
-  if (h->prm.descramble) {
-    hipLaunchKernelGGL(descramble_find_kernel, dim3(1), dim3(64), 0, s, (const uint8_t *)h->rs_out, h->st);
-    hipLaunchKernelGGL(descramble_apply_kernel, dim3(1024), dim3(256), 0, s, (const uint8_t *)h->rs_out, (const uint8_t *)h->T.prbs,
-                       (const RxState *)h->st, h->ts_out);
-  }
+  if (o.tail) { int r = enqueue_tail(h, s, max_vit / 204 + 1, -1); if (r) return r; }
   if (tm) { HIPCHK(hipEventRecord(h->ev[ST_END], s)); h->ev_recorded = true; }
   HIPCHK(hipMemcpyAsync(h->st_host, h->st, sizeof(RxState), hipMemcpyDeviceToHost, s));
   HIPCHK(hipGetLastError());
@@ -452,22 +512,16 @@ extern "C" int dvbt_rx_segment_enqueue_device(dvbt_rx *h, const void *iq_device,
 {
   if (!h || !iq_device) return fail(DVBT_ERR_INVALID, "null argument");
   HIPCHK(hipSetDevice(h->prm.device));
-  return enqueue(h, (const float2 *)iq_device, nsamples, stream ? (hipStream_t)stream : h->own_stream);
+  hipStream_t s = stream ? (hipStream_t)stream : h->own_stream;
+  const float2 *chain; size_t chain_n;
+  int r = prepare_chain(h, (const float2 *)iq_device, nsamples, s, &chain, &chain_n); if (r) return r;
+  h->n_periods = 1; h->seg_offset = 0;
+  return enqueue(h, chain, chain_n, s);
 }
 
-extern "C" int dvbt_rx_segment_finish(dvbt_rx *h, dvbt_rx_report *rep)
+static void fill_report(dvbt_rx *h, const RxState &s, dvbt_rx_report &r)
 {
-  if (!h) return fail(DVBT_ERR_INVALID, "null handle");
-  if (!h->pending) return fail(DVBT_ERR_STATE, "no segment enqueued");
-  HIPCHK(hipStreamSynchronize(h->cur_stream));
-  h->pending = false;
-  if (h->timing && h->ev_recorded) {
-    for (int i = 0; i < ST_END; i++) { float ms = 0; if (hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]) == hipSuccess) h->acc_ms[i] += ms; }
-    float ms = 0; if (hipEventElapsedTime(&ms, h->ev[0], h->ev[ST_END]) == hipSuccess) h->acc_ms[ST_END] += ms;
-    h->n_timed++; h->ev_recorded = false;
-  }
-  const RxState &s = *h->st_host;
-  dvbt_rx_report r; memset(&r, 0, sizeof r);
+  memset(&r, 0, sizeof r);
   r.status = s.status; r.n_symbols = s.n_symbols; r.first_out_symbol = s.first_out; r.n_out_symbols = s.n_out_symbols;
   r.cp_start0 = s.cp_start0; r.first_call = s.call0;
   // the call that loses the lock consumes half a window (to_consume / 2, ofdm_sym_acquisition_impl.cc:545-559): that half step is
@@ -488,6 +542,111 @@ extern "C" int dvbt_rx_segment_finish(dvbt_rx *h, dvbt_rx_report *rep)
                      (r.tps_guard_interval != q.guard_interval ? 8 : 0) | (r.tps_transmission_mode != q.transmission_mode ? 16 : 0);
     if (r.tps_mismatch) r.status |= 16;
   }
+}
+
+extern "C" int dvbt_rx_segment_finish(dvbt_rx *h, dvbt_rx_report *rep)
+{
+  if (!h) return fail(DVBT_ERR_INVALID, "null handle");
+  if (!h->pending) return fail(DVBT_ERR_STATE, "no segment enqueued");
+  HIPCHK(hipStreamSynchronize(h->cur_stream));
+  h->pending = false;
+  if (h->timing && h->ev_recorded) {
+    for (int i = 0; i < ST_END; i++) { float ms = 0; if (hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]) == hipSuccess) h->acc_ms[i] += ms; }
+    float ms = 0; if (hipEventElapsedTime(&ms, h->ev[0], h->ev[ST_END]) == hipSuccess) h->acc_ms[ST_END] += ms;
+    h->n_timed++; h->ev_recorded = false;
+  }
+  dvbt_rx_report r;
+  fill_report(h, *h->st_host, r);
+  r.n_lock_periods = r.first_out_symbol >= 0 ? 1 : 0;
+  h->last = r; h->have_last = true;
+  if (rep) *rep = r;
+  return DVBT_OK;
+}
+
+// The synchronous entries follow the reference through every loss of the CP lock inside the segment (ofdm_sym_acquisition_impl.cc:545-559;
+// oracle/o_chain.c restates the downstream consequences).  Phase A walks the segment with ofdm_sym_acquisition alone: where each lock period
+// starts, how many symbols it holds, where the search resumes (half a window behind a lost lock; one window after each call that found
+// nothing), d_avg carried along.  Phase B runs the chain over every period that acquired symbols, in order: TPS state carried, the period's last
+// item kept when a later period follows, every period's Viterbi stream appended to the segment's at a multiple of two de-interleaver items.
+// Then the byte de-interleaver, RS and the descrambler run once over the whole stream.
+struct LockPeriod { size_t off; int n_symbols; float avg_in; bool carry; };
+
+static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipStream_t s, dvbt_rx_report *rep)
+{
+  const Dims &d = h->d;
+  const size_t L = (size_t)(d.N + d.cp), win = (size_t)(2 * d.N + d.cp + 16);
+  std::vector<LockPeriod> per;
+  {   // ---- phase A
+    size_t off = 0; bool carry = false; float avg = 0.f;
+    for (int guard = 0; guard < 4096 && off + win <= chain_n; guard++) {
+      if (carry) { AcqState as; memset(&as, 0, sizeof as); as.avg = avg; HIPCHK(hipMemcpyAsync(h->acq_carry, &as, sizeof as, hipMemcpyHostToDevice, s)); }
+      EnqOpt o; o.acq_only = true; o.use_carry = carry; o.hist = (long long)off;
+      int r = enqueue(h, chain + off, chain_n - off, s, o); if (r) return r;
+      HIPCHK(hipStreamSynchronize(s));
+      const RxState &st = *h->st_host;
+      const int tries = (int)std::min<size_t>(ACQ_INIT_TRIES, (chain_n - off - win) / L + 1);
+      if (st.status & 1) {                                       // no peak in these windows: the reference consumes them one by one and searches on
+        off += (size_t)tries * L; avg = st.avg; carry = true;
+        continue;
+      }
+      per.push_back(LockPeriod{off, st.n_symbols, avg, carry});
+      if (!(st.status & 2)) break;                               // the lock held to the end of the segment
+      off += (size_t)(st.call0 + st.n_symbols) * L + L / 2; avg = st.avg_lost; carry = true;
+      if (per.size() >= 1024) break;
+    }
+  }
+  // ---- phase B
+  size_t acc = 0; int delivering = 0, processed = 0; bool any = false;
+  dvbt_rx_report first_rep; memset(&first_rep, 0, sizeof first_rep); first_rep.first_out_symbol = -1;
+  RxState last_st; memset(&last_st, 0, sizeof last_st); last_st.first_out = -1; last_st.status = 1;
+  int total_symbols = 0; size_t last_off = 0;
+  for (size_t p = 0; p < per.size(); p++) {
+    bool later = false;
+    for (size_t q = p + 1; q < per.size(); q++) if (per[q].n_symbols >= 1) later = true;
+    const int usable = per[p].n_symbols - (later ? 0 : 1);       // items that leave the demodulator
+    total_symbols += per[p].n_symbols;
+    if (usable < 1) continue;
+    if (per[p].carry) { AcqState as; memset(&as, 0, sizeof as); as.avg = per[p].avg_in; HIPCHK(hipMemcpyAsync(h->acq_carry, &as, sizeof as, hipMemcpyHostToDevice, s)); }
+    EnqOpt o; o.use_carry = per[p].carry; o.hist = (long long)per[p].off; o.continuation = processed > 0; o.keep_last = later; o.tail = false;
+    o.vit_off = delivering > 0 ? (acc / 3264) * 3264 : 0;         // convolutional_deinterleaver_impl.cc:109-120: the tag realigns the input
+    int r = enqueue(h, chain + per[p].off, chain_n - per[p].off, s, o); if (r) return r;
+    // the TPS carriers of the last demodulated symbol are the DBPSK reference of the next period's first one
+    HIPCHK(hipMemcpyAsync(h->tps_prev, h->tpsval + (size_t)(usable - 1) * d.n_tps, sizeof(float2) * d.n_tps, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    h->pending = false;
+    const RxState &st = *h->st_host;
+    processed++; any = true; last_st = st; last_off = per[p].off;
+    if (st.first_out >= 0) {
+      if (delivering == 0) { fill_report(h, st, first_rep); first_rep.segment_offset = (int64_t)per[p].off; }
+      acc = o.vit_off + (size_t)st.n_vit_bytes; delivering++;
+    }
+  }
+  dvbt_rx_report r;
+  if (!any) {   // nothing was acquired (or single symbols only): report the last acquisition attempt
+    RxState st = *h->st_host; st.first_out = -1; st.n_out_symbols = 0; st.n_vit_bytes = 0; st.n_rs_items = 0; st.n_rs_words = 0; st.n_ts_bytes = 0;
+    st.rs_fail = st.rs_corr = 0; st.tps_bits = 0; st.ts_first_packet = 0; st.stream_rs_items = 0; st.status |= 4;
+    fill_report(h, st, r);
+    h->n_periods = 0; h->seg_offset = 0;
+    h->last = r; h->have_last = true; if (rep) *rep = r;
+    return DVBT_OK;
+  }
+  if (delivering <= 1 && processed == 1 && per.size() >= 1 && acc == (size_t)last_st.n_vit_bytes) {
+    // one period: the device-side plan of that period is already the segment's (cut-stream roundings included)
+    int rr = enqueue_tail(h, s, (long long)(acc / 204 + 1), -1); if (rr) return rr;
+  } else {
+    int rr = enqueue_tail(h, s, (long long)(acc / 204 + 1), (long long)(acc / 204)); if (rr) return rr;
+  }
+  HIPCHK(hipMemcpyAsync(h->st_host, h->st, sizeof(RxState), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  RxState fin = *h->st_host;
+  if (delivering > 1 || processed > 1) fin.n_vit_bytes = (long long)acc;
+  fill_report(h, fin, r);
+  // the front-end fields describe the LAST processed period (the debug taps hold it); the stream fields the whole segment
+  r.segment_offset = (int64_t)last_off;
+  if (r.resume_sample) r.resume_sample += (int64_t)last_off;
+  r.n_lock_periods = delivering; r.total_symbols = total_symbols;
+  if (delivering == 0) { r.first_out_symbol = -1; r.status |= 4; }
+  h->n_periods = delivering; h->seg_offset = last_off;
   h->last = r; h->have_last = true;
   if (rep) *rep = r;
   return DVBT_OK;
@@ -500,34 +659,23 @@ extern "C" int dvbt_rx_segment_run(dvbt_rx *h, const void *iq_host, size_t nsamp
   if (nsamples > h->max_samples) return fail(DVBT_ERR_CAPACITY, "segment longer than max_samples");
   if (!h->d_iq) HIPCHK(hipMalloc((void **)&h->d_iq, sizeof(float2) * h->max_samples));
   HIPCHK(hipMemcpyAsync(h->d_iq, iq_host, sizeof(float2) * nsamples, hipMemcpyHostToDevice, h->own_stream));
-  h->use_carry = false;
-  int r = enqueue(h, h->d_iq, nsamples, h->own_stream); if (r) return r;
-  dvbt_rx_report rp;
-  r = dvbt_rx_segment_finish(h, &rp); if (r) return r;
-  // Start-up transient: a segment that begins with more than one window of silence makes the reference lock on the
-  // leading edge of the signal, lose that lock within a few calls and re-acquire (ofdm_sym_acquisition_impl.cc:545-559).
-  // While no superframe start has been found, do the same: restart at the call after the one that lost the lock, with
-  // the peak detector's average carried over.  (The rotator phase is not carried: it is a common phasor that the
-  // equaliser removes; the ACQ/FFT debug taps of a restarted segment differ from the reference's by that constant.)
-  const float2 *chain = h->rsd.ri ? h->rs_iq : h->d_iq;
-  size_t chain_n = h->rsd.ri ? (size_t)(((unsigned long long)nsamples * h->rsd.ri + h->rsd.rd - 1) / h->rsd.rd) : nsamples;
-  size_t off = 0;
-  for (int attempt = 0; attempt < 8 && (rp.status & 2) && !(rp.status & 1) && rp.first_out_symbol < 0 && rp.resume_sample > 0; attempt++) {
-    off += (size_t)rp.resume_sample;
-    if (off + (size_t)(2 * h->d.N + h->d.cp + 16) > chain_n) break;
-    AcqState as; memset(&as, 0, sizeof as); as.avg = h->st_host->avg_lost;
-    HIPCHK(hipMemcpyAsync(h->acq_carry, &as, sizeof as, hipMemcpyHostToDevice, h->own_stream));
-    h->use_carry = true;
-    r = enqueue(h, chain + off, chain_n - off, h->own_stream, true, (long long)off);   // the stream is already at the chain's rate; `off` samples lie before it
-    h->use_carry = false;
-    if (r) return r;
-    r = dvbt_rx_segment_finish(h, &rp); if (r) return r;
-  }
-  rp.segment_offset = (int64_t)off;
-  if (rp.resume_sample) rp.resume_sample += (int64_t)off;       // in the caller's sample numbering
-  h->last = rp;
-  if (rep) *rep = rp;
-  return DVBT_OK;
+  const float2 *chain; size_t chain_n;
+  int r = prepare_chain(h, h->d_iq, nsamples, h->own_stream, &chain, &chain_n); if (r) return r;
+  if (chain_n < (size_t)(2 * h->d.N + h->d.cp + 16)) return fail(DVBT_ERR_INVALID, "segment shorter than one acquisition window");
+  return segment_periods(h, chain, chain_n, h->own_stream, rep);
+}
+
+// the same on a segment that is already in device memory; synchronous (it reads the acquisition's outcome back between lock periods)
+extern "C" int dvbt_rx_segment_run_device(dvbt_rx *h, const void *iq_device, size_t nsamples, void *stream, dvbt_rx_report *rep)
+{
+  if (!h || !iq_device) return fail(DVBT_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(h->prm.device));
+  hipStream_t s = stream ? (hipStream_t)stream : h->own_stream;
+  const float2 *chain; size_t chain_n;
+  int r = prepare_chain(h, (const float2 *)iq_device, nsamples, s, &chain, &chain_n); if (r) return r;
+  if (chain_n < (size_t)(2 * h->d.N + h->d.cp + 16)) return fail(DVBT_ERR_INVALID, "segment shorter than one acquisition window");
+  h->cur_stream = s;
+  return segment_periods(h, chain, chain_n, s, rep);
 }
 
 static int tap_info(dvbt_rx *h, int tap, void **ptr, size_t *bytes)

@@ -413,33 +413,95 @@ __global__ __launch_bounds__(256) void conv_deint_kernel(const uint8_t *__restri
 }
 
 // ---------------------------------------------------------------- next row: energy_descramble (energy_descramble_impl.cc:108-174)
-__global__ void descramble_find_kernel(const uint8_t *__restrict__ in, RxState *st)
+// The block is restated call by call in the smallest calls it accepts (4 items visible, 2 consumed and delivered: :90,:139-141).
+// Every call first looks at the byte at its offset d_index: no NSYNC (0xB8) there -> search on at 188-byte strides within the first
+// two items (:121-123); nothing found -> offset back to 0, two items dropped, nothing delivered (:129-134).  One workgroup walks the
+// calls: all lanes test the bytes of the coming calls for the current offset at once, the first mismatch (if any) is handled by one
+// lane exactly as above.  What is delivered is a list of runs of whole items (normally one: lock on the first NSYNC, deliver from
+// there to two items before the end); descramble_runs_kernel copies them through the PRBS.
+struct DescrRun { long long src_byte, dst_byte, nbytes; };
+constexpr int DESCR_MAX_RUNS = 1024;
+
+__global__ __launch_bounds__(1024) void descramble_scan_kernel(const uint8_t *__restrict__ in, RxState *st, DescrRun *runs, int *nruns)
 {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  st->n_ts_bytes = 0; st->descr_base = 0; st->descr_index = 0; st->ts_first_packet = 0;
+  __shared__ long long s_first;
+  __shared__ long long s_base, s_written; __shared__ int s_dindex, s_nr, s_stop;
+  const int tid = threadIdx.x;
+  if (tid == 0) { st->n_ts_bytes = 0; st->descr_base = 0; st->descr_index = 0; st->ts_first_packet = 0; *nruns = 0; }
   if (st->sym_off > 0) {
     // continuation of a cut stream: the descrambler of the whole-stream chain locked long ago; this segment delivers
     // every whole 8-packet group from its first NSYNC on (the words before it mix the de-interleaver's zero fill with
     // data, exactly like the first words of a stream; their sync positions hold zeros).  Which of them the stitched
     // stream keeps is the host's decision (gr_dvbt_amd/multi.py::stitch_ts): the two-item hold-back of :139-141
     // belongs to the stream's end, not to a cut.
-    const long long nw = st->n_rs_words;
-    long long q = 0;
-    while (q < nw && in[q * 188] != 0xB8) q++;
-    if (q >= nw) return;
-    st->descr_index = (int)(q * 188); st->ts_first_packet = q;
-    st->n_ts_bytes = ((nw - q) / 8) * 1504;
+    if (tid == 0) {
+      const long long nw = st->n_rs_words;
+      long long q = 0;
+      while (q < nw && in[q * 188] != 0xB8) q++;
+      if (q < nw) {
+        st->descr_index = (int)(q * 188); st->ts_first_packet = q;
+        st->n_ts_bytes = ((nw - q) / 8) * 1504;
+        runs[0].src_byte = q * 188; runs[0].dst_byte = 0; runs[0].nbytes = st->n_ts_bytes; *nruns = st->n_ts_bytes > 0 ? 1 : 0;
+      }
+    }
     return;
   }
-  long long nitems = st->n_rs_items, base = 0; int d_index = 0;
-  while (nitems - base >= 4) {
-    const uint8_t *p = in + base * 1504;
-    while (d_index < 2 * 1504 && p[d_index] != 0xB8) d_index += 188;
-    if (d_index >= 2 * 1504) { d_index = 0; base += 2; continue; }
-    st->descr_base = (int)base; st->descr_index = d_index;
-    st->ts_first_packet = base * 8 + d_index / 188;
-    st->n_ts_bytes = (nitems - base - 2) * 1504;
-    return;
+  const long long nitems = st->n_rs_items;
+  if (tid == 0) { s_base = 0; s_written = 0; s_dindex = 0; s_nr = 0; s_stop = 0; }
+  __syncthreads();
+  while (true) {
+    const long long base = s_base; const int d_index = s_dindex;
+    const long long ncalls = nitems - base >= 4 ? (nitems - base - 4) / 2 + 1 : 0;      // calls that still see 4 items
+    if (ncalls == 0 || s_stop) break;
+    if (tid == 0) s_first = ncalls;
+    __syncthreads();
+    long long mine = ncalls;
+    for (long long k = tid; k < ncalls && k < mine; k += 1024)
+      if (in[(base + 2 * k) * 1504 + d_index] != 0xB8) { mine = k; break; }
+    if (mine < ncalls) atomicMin((unsigned long long *)&s_first, (unsigned long long)mine);
+    __syncthreads();
+    if (tid == 0) {
+      const long long kf = s_first;
+      if (kf > 0) {                                                // kf calls in a row found their NSYNC: one run
+        const int r = s_nr;
+        if (r < DESCR_MAX_RUNS) {
+          if (r == 0) { st->descr_base = (int)base; st->descr_index = d_index; st->ts_first_packet = (base * 1504 + d_index) / 188; }
+          runs[r].src_byte = base * 1504 + d_index; runs[r].dst_byte = s_written; runs[r].nbytes = kf * 2 * 1504; s_nr = r + 1;
+          s_written += kf * 2 * 1504;
+        } else s_stop = 1;
+        s_base = base + 2 * kf;
+      }
+      if (kf < ncalls) {                                           // the call at s_base: search on, or give up and drop two items
+        const uint8_t *p = in + s_base * 1504;
+        int di = d_index;
+        while (di < 2 * 1504 && p[di] != 0xB8) di += 188;
+        if (di >= 2 * 1504) { di = 0; s_base += 2; }
+        s_dindex = di;
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) { st->n_ts_bytes = s_written; *nruns = s_nr; }
+}
+
+// one workgroup pass per 8-packet group (1504 bytes = 376 dwords; every run starts on a multiple of 188 bytes)
+__global__ __launch_bounds__(256) void descramble_runs_kernel(const uint8_t *__restrict__ in, const uint8_t *__restrict__ seq, const RxState *st,
+                                                             const DescrRun *__restrict__ runs, const int *nruns, uint8_t *__restrict__ out)
+{
+  const long long ngroups = st->n_ts_bytes / 1504;
+  const unsigned *sq = reinterpret_cast<const unsigned *>(seq);
+  const int nr = *nruns;
+  for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    const long long dst = g * 1504;
+    int r = 0;
+    while (r + 1 < nr && runs[r + 1].dst_byte <= dst) r++;
+    const unsigned *p = reinterpret_cast<const unsigned *>(in + runs[r].src_byte + (dst - runs[r].dst_byte));
+    unsigned *o = reinterpret_cast<unsigned *>(out + dst);
+    for (int t = threadIdx.x; t < 376; t += 256) {
+      unsigned v = p[t] ^ sq[t];
+      if (t % 47 == 0) v = (v & 0xffffff00u) | 0x47u;              // sync byte restored (:151)
+      o[t] = v;
+    }
   }
 }
 

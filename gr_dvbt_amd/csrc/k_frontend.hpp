@@ -42,6 +42,10 @@ struct FrontParams {
   int ncalls;            // windows available: (ncalls-1)*(N+cp) + 2N+cp+16 <= nsamples
   int R;                 // half-width of the precomputed lag range around the predicted CP position of a call (centre[call])
   float half_rho;        // (float)(rho/2)
+  int keep_last;         // 1: the last acquired symbol is demodulated too.  The reference's demod needs the NEXT item to process one
+                         // (demod_reference_signals_impl.cc:88-94), so the last item of a stream never leaves it; the last item in front of
+                         // a lost lock does, as soon as the re-acquired stream delivers its first item
+  int pad1;
   long long hist;        // samples of the stream that lie BEFORE the segment's first sample in memory (a restart inside a segment): a tracking
                          // window at the left edge of its call reads them, as the reference reads the history of its input buffer
 };
@@ -926,12 +930,12 @@ __global__ __launch_bounds__(256) void demod_kernel(const float2 *__restrict__ f
 
 // DBPSK majority vote per symbol (process_tps_data :929-950): parallel over symbols
 __global__ __launch_bounds__(256) void tps_vote_kernel(const float2 *__restrict__ tpsval, int n_tps, const RxState *st, int nitems_fixed,
-                                                      const float2 *__restrict__ prev0, int *__restrict__ maj)
+                                                      const float2 *__restrict__ prev0, int *__restrict__ maj, int keep_last = 0)
 {
   // four lanes per symbol, each a quarter of the TPS carriers
   const int s = blockIdx.x * 64 + (threadIdx.x >> 2), part = threadIdx.x & 3;
   const int nsym = st ? st->n_symbols : nitems_fixed;
-  const bool act = s + 1 < nsym;
+  const bool act = s + (keep_last ? 0 : 1) < nsym;
   const int per = (n_tps + 3) / 4, k0 = part * per, k1 = k0 + per < n_tps ? k0 + per : n_tps;
   int m = 0;
   if (act)
@@ -982,7 +986,7 @@ __global__ __launch_bounds__(256) void tps_fsm_kernel(FrontParams p, RxState *st
   __shared__ int s_first_out;
   const int tid = threadIdx.x;
   const int nsym = st ? st->n_symbols : nitems_fixed;
-  const int ntot = nsym > 0 ? nsym - 1 : 0;
+  const int ntot = p.keep_last ? nsym : (nsym > 0 ? nsym - 1 : 0);
   if (tid == 0) { s_t = *ts; s_first_out = -1; }
   // sync words s1..s15 as fifo bits 1..15 (only 15 of the 16 are compared: B-11)
   unsigned mask_even = 0, mask_odd = 0;
@@ -1041,7 +1045,7 @@ __global__ __launch_bounds__(256) void tps_fsm_kernel(FrontParams p, RxState *st
     if (st) {
       st->first_out = s_first_out;
       if (s_first_out < 0) { st->status |= 4; st->n_out_symbols = 0; }
-      else st->n_out_symbols = nsym - 1 - s_first_out;
+      else st->n_out_symbols = ntot - s_first_out;
     }
   }
 }
@@ -1129,7 +1133,7 @@ __global__ __launch_bounds__(TPS_THREADS) void tps_fsm_par_kernel(FrontParams p,
   auto pm = [](int i) { return i + (i / TPS_SEG) * 4; };
   auto pj = [](int i) { return i + (i / TPS_SEG) * 2; };
   const int tid = threadIdx.x;
-  const int nsym = st->n_symbols, ntot = nsym > 0 ? nsym - 1 : 0;
+  const int nsym = st->n_symbols, ntot = p.keep_last ? nsym : (nsym > 0 ? nsym - 1 : 0);
   const int blk0 = blockIdx.x * TPS_THREADS * TPS_SEG;
   if (blk0 >= ntot) return;
   const int lo = blk0 - TPS_WARM < 0 ? 0 : blk0 - TPS_WARM;
@@ -1167,11 +1171,11 @@ __global__ __launch_bounds__(TPS_THREADS) void tps_fsm_par_kernel(FrontParams p,
   if (first != 0x7fffffff) atomicMin(first_cand, first);
 }
 
-__global__ __launch_bounds__(256) void tps_finalize_kernel(RxState *st, const TpsEdge *edges, const int *first_cand, int *need_seq)
+__global__ __launch_bounds__(256) void tps_finalize_kernel(RxState *st, const TpsEdge *edges, const int *first_cand, int *need_seq, int keep_last, TpsState *ts)
 {
   __shared__ int s_bad;
   const int tid = threadIdx.x;
-  const int nsym = st->n_symbols, ntot = nsym > 0 ? nsym - 1 : 0;
+  const int nsym = st->n_symbols, ntot = keep_last ? nsym : (nsym > 0 ? nsym - 1 : 0);
   const int nseg = (ntot + TPS_SEG - 1) / TPS_SEG;
   if (tid == 0) s_bad = 0;
   __syncthreads();
@@ -1186,7 +1190,8 @@ __global__ __launch_bounds__(256) void tps_finalize_kernel(RxState *st, const Tp
     if (!s_bad) {
       int fo = *first_cand;
       if (fo == 0x7fffffff) { st->first_out = -1; st->status |= 4; st->n_out_symbols = 0; }
-      else { st->first_out = fo; st->n_out_symbols = nsym - 1 - fo; }
+      else { st->first_out = fo; st->n_out_symbols = ntot - fo; }
+      if (ts && nseg > 0) { TpsState e = edges[nseg - 1].end; e.d_init = fo != 0x7fffffff; *ts = e; }   // the members a later lock period starts from
     }
   }
 }

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(FFT_THREADS, 4) void derot_fft_demod_kernel(const f
   const int s = blockIdx.x;
   const int nsym = st->n_symbols;
   if (s >= nsym) return;
-  const bool last = s + 1 >= nsym;                               // no output for the last item (the reference's demod consumes n+1 items)
+  const bool last = !p.keep_last && s + 1 >= nsym;                               // no output for the last item (the reference's demod consumes n+1 items)
   if (last && !fft_tap && !acq_tap) return;
   const int N = p.N, cp = p.cp, tid = threadIdx.x, zl = p.zl;
   float2 *tw_c = x + (N + N / 32), *tw_f = tw_c + N / 128, *gtab = tw_f + 128;

@@ -302,6 +302,11 @@ typedef struct {
   int32_t tps_length_indicator, tps_constellation, tps_hierarchy, tps_code_rate_hp, tps_code_rate_lp,
           tps_guard_interval, tps_transmission_mode, tps_cell_id;
   int32_t tps_mismatch;        /* bit0 constellation, bit1 hierarchy, bit2 HP code rate, bit3 guard interval, bit4 transmission mode differ */
+  /* lock periods (dvbt_rx_segment_run / _run_device follow the reference through every loss of the CP lock inside the segment) */
+  int32_t n_lock_periods;      /* periods that found a superframe start and delivered items; > 1: the front-end fields above (n_symbols,
+                                  first_out_symbol, cp_start0, first_call, segment_offset, the debug taps) describe the LAST one, the stream
+                                  fields (n_viterbi_bytes .. n_ts_bytes, the VITERBI/DEINT/RS/TS taps) the whole segment */
+  int32_t total_symbols;       /* OFDM symbols acquired over all lock periods */
 } dvbt_rx_report;
 
 typedef enum {
@@ -337,6 +342,13 @@ typedef struct { int64_t stream_symbol_offset; } dvbt_rx_cut;
 int  dvbt_rx_set_cut(dvbt_rx *h, const dvbt_rx_cut *cut);   /* applies to the segments enqueued afterwards */
 /* iq: host pointer to nsamples complex64 (copied to the device first) */
 int  dvbt_rx_segment_run(dvbt_rx *h, const void *iq_host, size_t nsamples, dvbt_rx_report *report);
+/* the same for a segment that is already in device memory (stream: a hipStream_t or NULL).  Like dvbt_rx_segment_run it is synchronous
+ * and follows the reference through every loss of the CP lock inside the segment (ofdm_sym_acquisition_impl.cc:545-559: half a window
+ * consumed, full search again; demod_reference_signals hunts the superframe start again, :115-136; the Viterbi decoder is reset at the
+ * new start and the byte de-interleaver realigned, viterbi_decoder_impl.cc:213-229, convolutional_deinterleaver_impl.cc:109-120; the
+ * descrambler re-searches its NSYNC, energy_descramble_impl.cc:121-141).  dvbt_rx_segment_enqueue_device below never waits for the
+ * device: it decodes the segment's FIRST lock period and reports where the lock ended (status bit 1, resume_sample). */
+int  dvbt_rx_segment_run_device(dvbt_rx *h, const void *iq_device, size_t nsamples, void *stream, dvbt_rx_report *report);
 /* iq_device: device pointer (hipMalloc'd, e.g. a torch tensor's data_ptr). stream: a hipStream_t or NULL.
  * Asynchronous w.r.t. the host: enqueue only.  Use dvbt_rx_segment_finish to wait and fetch the report. */
 int  dvbt_rx_segment_enqueue_device(dvbt_rx *h, const void *iq_device, size_t nsamples, void *stream);

@@ -1,8 +1,18 @@
 /* o_chain.c -- the RX flowgraph of apps/dvbt_rx_demo*.grc, stage after stage, in the
  * "one item per general_work call" scheduling regime.
  * TEST INFRASTRUCTURE (see dvbt_oracle.h): used by tests/ as the checker and by bench.py's
- * cpu_baseline leg as the timed CPU port.  Handles one lock per run (a second sync_start
- * after superframe lock truncates the run; returns 1 in that case). */
+ * cpu_baseline leg as the timed CPU port.
+ *
+ * A lost CP lock is followed the way the reference follows it (ofdm_sym_acquisition_impl.cc:545-559: half a window
+ * consumed, full search again, sync_start on the next item): demod_reference_signals hunts the superframe start again
+ * (demod_reference_signals_impl.cc:115-136) and drops the items in between; the superframe_start tag resets the Viterbi
+ * decoder, which also drops the input bytes between its last whole block and the tag (viterbi_decoder_impl.cc:213-229:
+ * every call handles whole blocks from the previous reset on, so the remainder in front of the tag is what is consumed
+ * undecoded); the byte de-interleaver drops the bytes in front of the tag that do not fill a pair of items and keeps its
+ * FIFOs (convolutional_deinterleaver_impl.cc:109-120); reed_solomon_dec goes on; energy_descramble re-searches the NSYNC
+ * whenever the byte at its offset is not one at the start of a call (energy_descramble_impl.cc:121-141), in calls of the
+ * minimum size (4 items visible, 2 consumed).  Returns the number of lock periods that delivered items, minus one
+ * ("truncated" in the Python binding: 0 for a run with a single lock). */
 #include "dvbt_oracle.h"
 #include <stdlib.h>
 #include <string.h>
@@ -68,6 +78,8 @@ int o_rx_run_cut(const o_cfg *c, const ocf *iq, size_t nsamples, float snr_db, i
 
   /* ---- A3 demod (needs item j and j+1: forecast :88-94) */
   size_t nout = 0;
+  enum { O_MAX_PERIODS = 64 };
+  size_t per_start[O_MAX_PERIODS + 1]; int nper = 0;
   ocf *eq = malloc(sizeof(ocf) * (size_t)P * (nacq + 1));
   int *symidx = malloc(sizeof(int) * (nacq + 1));
   {
@@ -75,10 +87,12 @@ int o_rx_run_cut(const o_cfg *c, const ocf *iq, size_t nsamples, float snr_db, i
     o_demod *d = o_demod_new(c);
     for (size_t j = 0; j + 1 < nacq; j++) {
       int sf, si, info[8];
-      if (sync_tag[j] && t->first_out_symbol >= 0) { truncated = 1; break; }
       int produced = o_demod_work(d, fft + j * (size_t)N, eq + nout * (size_t)P, sync_tag[j], &sf, &si, info);
       if (t->sym_index && j < t->meta_cap) t->sym_index[j] = si;
-      if (sf) t->first_out_symbol = (int)j;
+      if (sf) {
+        if (t->first_out_symbol < 0) t->first_out_symbol = (int)j; else truncated++;
+        if (nper < O_MAX_PERIODS) per_start[nper++] = nout;        /* output item at which this lock period starts */
+      }
       if (produced) symidx[nout++] = si;
     }
     o_demod_free(d);
@@ -117,12 +131,24 @@ int o_rx_run_cut(const o_cfg *c, const ocf *iq, size_t nsamples, float snr_db, i
   t0 = now();
   const long long ibits = (long long)P * c->m * c->k / c->n;            /* decoded bits per OFDM symbol */
   const long long d_nsym = (long long)bsize * c->n / c->m;
-  const long long nblocks_g = (sym_off + (long long)nout) * P / d_nsym;   /* viterbi_decoder_impl.cc:198 in stream coordinates */
-  long long nin_l = nblocks_g * d_nsym - sym_off * P;
-  if (nin_l < 0) nin_l = 0;
-  size_t nvit = o_viterbi_decode_n(c, b2, (size_t)nin_l, vit);
-  long long nb_g = nblocks_g * (long long)c->k * bsize / 8 - o_vit_ntraceback(c->code_rate);
-  if (nb_g < 0) nb_g = 0;
+  /* every lock period is a stream of its own for the decoder (reset at the superframe_start tag); what it delivers in front
+   * of the next tag is cut to whole pairs of de-interleaver items (the tag realigns that block's input) */
+  size_t nvit = 0;
+  long long nb_g = 0;
+  per_start[nper] = nout;
+  for (int pi = 0; pi < nper; pi++) {
+    const long long n_sym_p = (long long)(per_start[pi + 1] - per_start[pi]);
+    const long long off_p = pi == 0 ? sym_off : 0;                   /* a cut stream's offset belongs to its first period */
+    const long long nblocks_g = (off_p + n_sym_p) * P / d_nsym;      /* viterbi_decoder_impl.cc:198 in stream coordinates */
+    long long nin_l = nblocks_g * d_nsym - off_p * P;
+    if (nin_l < 0) nin_l = 0;
+    size_t nv = o_viterbi_decode_n(c, b2 + per_start[pi] * (size_t)P, (size_t)nin_l, vit + nvit);
+    nb_g = nblocks_g * (long long)c->k * bsize / 8 - o_vit_ntraceback(c->code_rate);
+    if (nb_g < 0) nb_g = 0;
+    if (pi + 1 < nper) nv = (nv / 3264) * 3264;                        /* convolutional_deinterleaver_impl.cc:109-120 */
+    nvit += nv;
+  }
+  if (nper > 1) nb_g = (long long)nvit;                              /* several periods: the item count below follows the concatenated stream */
   t->t_stage[6] = now() - t0;
   free(b2);
   if (t->vit_out) { size_t n = nvit < t->vit_cap ? nvit : t->vit_cap; memcpy(t->vit_out, vit, n); t->vit_n = n; }

@@ -76,27 +76,27 @@ size_t o_energy_descramble_groups(const unsigned char *in, size_t ngroups, unsig
   return written;
 }
 
-/* lib/energy_descramble_impl.cc:108-174 with the whole RS output visible in one call
- * sequence: search NSYNC (0xB8) at 188-byte strides within the first 2 items, then
- * descramble groups of 8 packets, always holding back two 1504-byte items. */
+/* lib/energy_descramble_impl.cc:108-174 over the whole RS output, call by call in the smallest calls the block accepts
+ * (noutput_items = 4 items' worth: 4 items visible, 2 consumed, :90,:139-141): every call first checks the byte at its
+ * offset d_index and searches on at 188-byte strides within the first two items when it is not an NSYNC (:121-123); a
+ * search that fails drops two items and starts over at offset 0 (:129-134).  On a stream without sync errors this is:
+ * lock on the first NSYNC, descramble everything from there, hold back the last two items. */
 size_t o_energy_descramble(const unsigned char *in, size_t nitems, unsigned char *out)
 {
   unsigned char seq[1504];
   o_energy_prbs(seq);
   const size_t d_search = 2 * 1504;
-  size_t base = 0, d_index = 0, written = 0;      /* base: item offset consumed so far */
+  size_t base = 0, d_index = 0, written = 0;      /* base: items consumed so far */
   while (nitems - base >= 4) {
     const unsigned char *p = in + base * 1504;
-    size_t avail = nitems - base;
     while (d_index < d_search && p[d_index] != 0xB8) d_index += 188;
     if (d_index >= d_search) { d_index = 0; base += 2; continue; }
-    size_t to_consume = avail - 2;
-    for (size_t i = 0; i < to_consume; i++)
+    for (size_t i = 0; i < 2; i++)
       for (int k = 0; k < 1504; k++) {
         unsigned char b = p[d_index + i * 1504 + k];
         out[written++] = (k % 188 == 0) ? 0x47 : (b ^ seq[k]);
       }
-    base += to_consume;
+    base += 2;
   }
   return written;
 }
