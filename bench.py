@@ -143,12 +143,15 @@ class Job:
             if snr is not None:
                 self.ref_power = float(np.mean(np.abs(head[po.STREAM_LEAD_IN:po.STREAM_LEAD_IN + 100000]) ** 2))
                 head = add_awgn(head, snr, 5, self.ref_power)
-            pre = g.Rx(const, cr, mode, max_samples=len(head), device=local, snr_db=snr_db)
-            rep = pre.run(head)
-            pre.close()
-            if rep.status != 0:
-                raise SystemExit(f"pre-scan failed: status {rep.status}")
-            plan[0], plan[1] = int(rep.segment_offset), int(rep.first_call + rep.first_out_symbol)
+            if os.environ.get("BENCH_SKIP_VERIFY") == "1":       # experiment builds with wrong output: where a correct chain starts is known
+                plan[0], plan[1] = 0, 204 if (const == po.QAM64 and mode == po.T8k) else 272
+            else:
+                pre = g.Rx(const, cr, mode, max_samples=len(head), device=local, snr_db=snr_db)
+                rep = pre.run(head)
+                pre.close()
+                if rep.status != 0:
+                    raise SystemExit(f"pre-scan failed: status {rep.status}")
+                plan[0], plan[1] = int(rep.segment_offset), int(rep.first_call + rep.first_out_symbol)
         if dist:
             dist.broadcast(plan, src=0)
             if snr is not None:
@@ -386,7 +389,7 @@ def main():
     if rank == 0:
         n_stream = job.n_total if not a.from_file_rate else sum(p["n"] for p in job.pieces)
         msps = n_stream * a.steps / dt / 1e6
-        check = job.verify() if not a.from_file_rate else {"verified": None}
+        check = job.verify() if not (a.from_file_rate or os.environ.get("BENCH_SKIP_VERIFY") == "1") else {"verified": None}   # BENCH_SKIP_VERIFY: experiment builds with wrong output (tools/*_attribution.sh)
         ok = check["verified"] is not False
         reps = job.reps
         # dominant kernel = viterbi3_kernel: per launch, algorithmic bytes = bytes in (one per m coded bits) + decoded

@@ -311,6 +311,7 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   h->ev_ready = true;
   RXCHK(set_lds((const void *)derot_fft_demod_kernel, fused_lds_bytes_host((int)N)));
   RXCHK(set_lds((const void *)inner_kernel<6>, inner_lds_bytes(P)));
+  RXCHK(set_lds((const void *)acq_anchor_kernel, acq_anchor_lds_bytes((int)N, d.cp)));
   *out = h;
   return DVBT_OK;
 }
@@ -423,7 +424,7 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
   HIPCHK(hipMemsetAsync(h->trk_flags, 0, sizeof(int) * 16, s));
   {   // where the tracking metric is computed: CP position predicted per call from coarse estimates every ACQ_ANCHOR calls (sample-clock drift)
     const int n_anchors = (C - 1) / ACQ_ANCHOR;
-    if (n_anchors > 0) hipLaunchKernelGGL(acq_anchor_kernel, dim3(n_anchors), dim3(256), 0, s, iq, fp, (const RxState *)h->st, h->anchor_pos);
+    if (n_anchors > 0) hipLaunchKernelGGL(acq_anchor_kernel, dim3(n_anchors), dim3(1024), acq_anchor_lds_bytes(N, d.cp), s, iq, fp, (const RxState *)h->st, h->anchor_pos);
     hipLaunchKernelGGL(acq_centre_kernel, dim3(1), dim3(1024), 0, s, fp, (const RxState *)h->st, h->anchor_pos, n_anchors, h->centre);
   }
   hipLaunchKernelGGL(acq_track_metric_kernel, dim3((C + ACQ_TM_CALLS - 1) / ACQ_TM_CALLS), dim3(256), 0, s, iq, fp, (const RxState *)h->st, (const int *)h->centre, h->g_trk, h->l_trk);

@@ -97,41 +97,50 @@ __global__ __launch_bounds__(256) void acq_metric_kernel(const float2 *__restric
 // If it ever needs a lag outside them (prediction off by more than R-8), the sequential tracker computes that call's metric on the
 // spot (acq_track_kernel), so the result is always the reference's.
 constexpr int ACQ_ANCHOR = 256;                // calls between anchors
-constexpr int ACQ_ANCHOR_LAGS = 32;            // lags per thread in acq_anchor_kernel
+constexpr int ACQ_ANCHOR_LAGS = 8;             // lags per thread in acq_anchor_kernel
 
-__global__ __launch_bounds__(256) void acq_anchor_kernel(const float2 *__restrict__ iq, FrontParams p, const RxState *st, int *__restrict__ anchor_pos)
+// One workgroup per anchor.  The products x[i] conj(x[i-N]) and the energies of the window are formed once (coalesced loads) and kept
+// in LDS; a thread then owns ACQ_ANCHOR_LAGS consecutive lags: direct sum over the cp products of its first lag, sliding sum for the rest.
+__global__ __launch_bounds__(1024) void acq_anchor_kernel(const float2 *__restrict__ iq, FrontParams p, const RxState *st, int *__restrict__ anchor_pos)
 {
-  __shared__ float s_best[256]; __shared__ int s_arg[256];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float2 *s_c = reinterpret_cast<float2 *>(smem_raw);            // [N + cp]  product at sample N + i
+  float *s_e = reinterpret_cast<float *>(s_c + (p.N + p.cp));    // [N + cp]  energy pair
+  __shared__ float s_best[1024]; __shared__ int s_arg[1024];
   const int k = blockIdx.x + 1, tid = threadIdx.x, N = p.N, cp = p.cp;          // anchor 0 is the initial acquisition itself
   if (st->status & 1) return;
   const int call = st->call0 + k * ACQ_ANCHOR;
   if (call >= p.ncalls) { if (tid == 0) anchor_pos[k] = -1; return; }
   const float2 *w = iq + (long long)call * (N + cp);
+  for (int i = tid; i < N + cp - 1; i += 1024) {                  // samples N .. 2N+cp-2 of the window
+    const float2 a = w[N + i], b = w[i];
+    s_c[i] = make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+    s_e[i] = (a.x * a.x + a.y * a.y) + (b.x * b.x + b.y * b.y);
+  }
+  __syncthreads();
   float best = -3.0e38f; int arg = 0;
-  for (int q0 = tid * ACQ_ANCHOR_LAGS; q0 < N; q0 += 256 * ACQ_ANCHOR_LAGS) {
-    // lag q0: direct sums over cp taps; the following lags slide the window by one sample (short runs: no drift of the float sums)
-    const float2 *x = w + (N + cp - 1 + q0);
+  for (int q0 = tid * ACQ_ANCHOR_LAGS; q0 < N; q0 += 1024 * ACQ_ANCHOR_LAGS) {
+    // lag q (sample index N+cp-1+q) sums the products at i = q .. q+cp-1 (i counted from sample N)
     float gr = 0.f, gi = 0.f, phi = 0.f;
-    for (int j = 0; j < cp; j++) {
-      const float2 a = x[-j], b = x[-j - N];
-      gr += a.x * b.x + a.y * b.y; gi += a.y * b.x - a.x * b.y; phi += (a.x * a.x + a.y * a.y) + (b.x * b.x + b.y * b.y);
-    }
+    for (int j = 0; j < cp; j++) { const float2 c = s_c[q0 + j]; gr += c.x; gi += c.y; phi += s_e[q0 + j]; }
     for (int u = 0; u < ACQ_ANCHOR_LAGS && q0 + u < N; u++) {
       const float lam = sqrtf(gr * gr + gi * gi) - phi * p.half_rho;
       if (lam > best) { best = lam; arg = q0 + u; }
-      const float2 a = x[u + 1], b = x[u + 1 - N], c = x[u + 1 - cp], d = x[u + 1 - cp - N];     // enters / leaves
-      gr += (a.x * b.x + a.y * b.y) - (c.x * d.x + c.y * d.y); gi += (a.y * b.x - a.x * b.y) - (c.y * d.x - c.x * d.y);
-      phi += ((a.x * a.x + a.y * a.y) + (b.x * b.x + b.y * b.y)) - ((c.x * c.x + c.y * c.y) + (d.x * d.x + d.y * d.y));
+      if (q0 + u + 1 < N) {
+        const float2 a = s_c[q0 + u + cp], c = s_c[q0 + u];         // enters / leaves
+        gr += a.x - c.x; gi += a.y - c.y; phi += s_e[q0 + u + cp] - s_e[q0 + u];
+      }
     }
   }
   s_best[tid] = best; s_arg[tid] = arg;
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
+  for (int o = 512; o > 0; o >>= 1) {
     if (tid < o && (s_best[tid + o] > s_best[tid] || (s_best[tid + o] == s_best[tid] && s_arg[tid + o] < s_arg[tid]))) { s_best[tid] = s_best[tid + o]; s_arg[tid] = s_arg[tid + o]; }
     __syncthreads();
   }
   if (tid == 0) anchor_pos[k] = s_arg[0] + N + cp - 1;
 }
+inline size_t acq_anchor_lds_bytes(int N, int cp) { return (size_t)(N + cp) * 12 + 64; }
 
 // centre[call] for every call from call0 on.  n_anchors: anchors computed (slots 1..n_anchors of anchor_pos); 0 = none (block API: the
 // window of one work() call is short, every call is centred on the carried CP position)

@@ -17,6 +17,10 @@ namespace dvbt {
 // A4 rides along: every equalised carrier is demapped at once (demap_one: the reference's first strict minimum), so a
 // symbol leaves the kernel as `payload` label bytes in carrier order; the equalised carriers themselves are written
 // only when the EQ tap is enabled.
+#ifndef SYM_EXP
+#define SYM_EXP 0     // experiment builds only (tools/sym_attribution.sh; wrong output): 1 stop after the load + derotation, 2 no FFT, 4 no reorder,
+                      // 8 no integer-CFO / pattern search, 16 no equaliser + demapper
+#endif
 constexpr int SYM_NCP_MAX = 192;           // continual pilots of a mode (177 in 8k)
 inline size_t fused_lds_bytes_host(int N) { return (size_t)(N + N / 32 + N / 128 + 128 + DEMOD_NP) * 8 + 128 + 64 * 8 + 64 + SYM_NCP_MAX * 6; }
 
@@ -85,8 +89,9 @@ __global__ __launch_bounds__(FFT_THREADS, 4) void derot_fft_demod_kernel(const f
     if (acq_tap) acq_tap[(size_t)s * N + n] = v;
   }
   __syncthreads();
-  fft_dif_lds(x, N, tw_c, tw_f, tid);
-  {   // digit-reversed -> natural, fft-shifted order, in place through registers: x[b] = X[(b - N/2) mod N]
+  if (SYM_EXP & 1) { if (x[fpad(tid)].x == 123.f) labels[s] = 1; return; }
+  if (!(SYM_EXP & 2)) fft_dif_lds(x, N, tw_c, tw_f, tid);
+  if (!(SYM_EXP & 4)) {   // digit-reversed -> natural, fft-shifted order, in place through registers: x[b] = X[(b - N/2) mod N]
     constexpr int NR = 8192 / FFT_THREADS;
     unsigned short pos[NR]; float2 r[NR];
 #pragma unroll
@@ -104,7 +109,7 @@ __global__ __launch_bounds__(FFT_THREADS, 4) void derot_fft_demod_kernel(const f
   auto X = [&](int b) -> float2 { return x[fpad(b)]; };
 
   // integer CFO: process_cpilot_data :715-744 -- 16 candidate shifts x (n_cp-1) pilot pairs
-  {
+  if (!(SYM_EXP & 8)) {
     const int cand = (tid >> 4) & 15, sub = tid & 15, i = zl - 8 + cand;
     float sum = 0.f;
     for (int j = sub; j < p.n_cp - 1 && tid < 256; j += 16) {
@@ -117,8 +122,8 @@ __global__ __launch_bounds__(FFT_THREADS, 4) void derot_fft_demod_kernel(const f
   }
   __syncthreads();
   if (tid == 0) {
-    float mx = 0.f; int start = 0;
-    for (int c = 0; c < 16; c++) if (s_sum[c] > mx) { mx = s_sum[c]; start = zl - 8 + c; }
+    float mx = 0.f; int start = zl;
+    for (int c = 0; c < 16 && !(SYM_EXP & 8); c++) if (s_sum[c] > mx) { mx = s_sum[c]; start = zl - 8 + c; }
     s_i[0] = start - zl;
   }
   __syncthreads();
@@ -181,7 +186,7 @@ __global__ __launch_bounds__(FFT_THREADS, 4) void derot_fft_demod_kernel(const f
 #pragma unroll
     for (int it = 0; it < PAY_IT; it++) {
       const int i = tid + it * FFT_THREADS;
-      if (it < nit && i < p.payload) {
+      if (it < nit && i < p.payload && !(SYM_EXP & 16)) {
         const float2 e = cmul(X(xb + tc[it]), gain(tl[it], tr[it], td[it]));
         if (eq_tap) eq_tap[(size_t)s * p.payload + i] = e;
         const int f = demap_fast(e, pts, label_of, ip);
