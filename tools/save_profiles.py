@@ -1,24 +1,38 @@
 """Copy the rocprofv3 outputs of the last gpurun (gpurun_out/) into profiles/ as judged artefacts."""
 import csv, glob, collections, json, os, shutil, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-prof = sorted(glob.glob(os.path.join(root, "gpurun_out", "prof*", "*kernel_stats.csv")), key=os.path.getmtime)[-1]
-shutil.copy(prof, os.path.join(root, "profiles", f"{tag}_kernel_stats_8k_qam64_7_8_65sf.csv"))
-b = json.load(open(os.path.join(root, "gpurun_out", "bench_final.json")))
-json.dump(b, open(os.path.join(root, "profiles", f"{tag}_bench_n1.json"), "w"), indent=1)
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+tag = args[0] if args else "r02"
+pmc_only = "--pmc-only" in sys.argv
+
+
+def kname(n):
+    return n.split("(")[0].replace("void ", "").replace("dvbt::", "").split("<")[0]
+
+
 out = {}
 for f in sorted(glob.glob(os.path.join(root, "gpurun_out", "pmc", "*", "*counter_collection.csv"))):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("dvbt::", "").split("<")[0]
-        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        acc[kname(r["Kernel_Name"])][r["Counter_Name"]].append((int(r["Grid_Size"]), float(r["Counter_Value"])))
     for k in acc:
         for c, v in acc[k].items():
-            out.setdefault(k, {})[c] = sum(v) / len(v)
+            gmax = max(g for g, _ in v)                      # the timed steps' dispatches (the pre-scan's are smaller)
+            big = [x for g, x in v if g == gmax]
+            out.setdefault(k, {})[c] = sum(big) / len(big)
+if pmc_only:
+    for k, d in out.items():
+        if d.get("GRBM_GUI_ACTIVE", 0) > 200000 or "viterbi" in k:
+            print(k, {c: round(v, 1) for c, v in sorted(d.items())})
+    sys.exit(0)
+prof = sorted(glob.glob(os.path.join(root, "gpurun_out", "prof*", "*kernel_stats.csv")), key=os.path.getmtime)[-1]
+shutil.copy(prof, os.path.join(root, "profiles", f"{tag}_kernel_stats_8k_qam64_7_8_65sf.csv"))
+b = json.load(open(os.path.join(root, "gpurun_out", "bench_final.json")))
+json.dump(b, open(os.path.join(root, "profiles", f"{tag}_bench_n1.json"), "w"), indent=1)
 pb = json.load(open(os.path.join(root, "gpurun_out", "pmc", "FETCH_SIZE.json")))
-summary = {"command": "tools/pmc.sh: rocprofv3 --pmc <group> --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --superframes 64 (one pass per counter group: FETCH_SIZE | WRITE_SIZE | SQ issue counters | LDS counters)",
+summary = {"command": "tools/pmc.sh: rocprofv3 --pmc <group> --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --superframes 64 (one pass per counter group: FETCH_SIZE | WRITE_SIZE | SQ issue counters | LDS counters); per kernel the average over its largest dispatches (the timed steps)",
            "workload": pb["config"],
-           "note": "FETCH_SIZE/WRITE_SIZE in KB per dispatch (average over dispatches). gfx950: FETCH_SIZE counts 64 B per 128 B request on coalesced streams, so it is doubled in hbm_bytes_corrected (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported.",
+           "note": "FETCH_SIZE/WRITE_SIZE in KB per dispatch. gfx950: FETCH_SIZE counts 64 B per 128 B request on coalesced streams, so it is doubled in hbm_bytes_corrected (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported. SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* count quad-cycles.",
            "viterbi_algorithmic_bytes": pb["roofline"]["algorithmic_bytes_per_launch"], "kernels": {}}
 for k, c in out.items():
     e = dict(c)
@@ -28,5 +42,5 @@ for k, c in out.items():
 json.dump(summary, open(os.path.join(root, "profiles", f"{tag}_pmc_summary_8k_qam64_7_8_65sf.json"), "w"), indent=1)
 v = summary["kernels"]["viterbi3_kernel"]
 print("viterbi3: hbm", v["hbm_bytes_corrected"] / 1e6, "MB; algorithmic", summary["viterbi_algorithmic_bytes"] / 1e6, "MB")
-for r in list(csv.DictReader(open(prof)))[:14]:
-    print(r["Name"].split("(")[0].replace("void ","").replace("dvbt::","")[:30].ljust(30), r["Calls"].rjust(4), f"{float(r['AverageNs'])/1e3:10.1f} us", r["Percentage"])
+for r in list(csv.DictReader(open(prof)))[:16]:
+    print(kname(r["Name"])[:30].ljust(30), r["Calls"].rjust(5), f"{float(r['AverageNs'])/1e3:10.1f} us", r["Percentage"])
