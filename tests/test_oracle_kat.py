@@ -109,6 +109,12 @@ def test_pilots_8k_first_carriers(po):
         for k, v in exp[s].items():
             assert abs(freq[s, zl + k] - v) < 1e-6, (s, k)
     assert c.zeros_left == 688 and c.payload == 6048
+    # payload carriers (Appendix F): everything that is neither scattered / continual pilot nor TPS carrier, ascending
+    # (reference_signals_impl.cc:1073-1106); in the generator's spectrum they are the bins with a non-zero imaginary part
+    first = [[1, 2, 3, 4, 5, 6], [1, 2, 4, 5, 6, 7], [1, 2, 3, 4, 5, 7], [1, 2, 3, 4, 5, 6]]
+    for s in range(4):
+        pay = [k for k in range(c.Kmax + 1) if abs(freq[s, zl + k].imag) > 1e-3]
+        assert pay[:6] == first[s] and pay[-1] == 6815 and len(pay) == 6048, (s, pay[:8], pay[-1], len(pay))
 
 
 def test_tps_bits_frame0(po):
