@@ -12,6 +12,7 @@
 #include "k_frontend.hpp"
 #include "k_backend.hpp"
 #include "k_symbol.hpp"
+#include "k_symbol8k.hpp"
 #include "k_resample.hpp"
 #include "k_viterbi3.hpp"
 
@@ -247,6 +248,7 @@ struct dvbt_rx {
   dvbt_rx_cut cut = {0};
   float2 *tps_prev = nullptr; DescrRun *descr_runs = nullptr; int *descr_nruns = nullptr;
   int n_periods = 1; size_t seg_offset = 0;
+  int sym_grid = 512;                       // workgroups of symbol8k_kernel (two per CU)
 };
 
 static void rx_free(dvbt_rx *h)
@@ -310,6 +312,8 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   for (int i = 0; i < ST_COUNT; i++) RXHIP(hipEventCreate(&h->ev[i]));
   h->ev_ready = true;
   RXCHK(set_lds((const void *)derot_fft_demod_kernel, fused_lds_bytes_host((int)N)));
+  RXCHK(set_lds((const void *)symbol8k_kernel<false>, S8_LDS_BYTES)); RXCHK(set_lds((const void *)symbol8k_kernel<true>, S8_LDS_BYTES));
+  { int ncu = 256; (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->prm.device); h->sym_grid = s8_grid(ncu); }
   RXCHK(set_lds((const void *)inner_kernel<6>, inner_lds_bytes(P)));
   RXCHK(set_lds((const void *)acq_anchor_kernel, acq_anchor_lds_bytes((int)N, d.cp)));
   *out = h;
@@ -447,9 +451,18 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
   }
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_FFT], s));
   // A1 tail + A2 + A3 in one kernel: the FFT item of a symbol never leaves LDS (acq/fft taps are written only when enabled)
-  hipLaunchKernelGGL(derot_fft_demod_kernel, dim3(C), dim3(FFT_THREADS), fused_lds_bytes_host(N), s, iq, fp, (const RxState *)h->st, (const SymMeta *)h->meta,
-                     (const float2 *)h->T.tw, (const uint16_t *)h->T.perm, h->acq_tap, h->fft_out, h->T.demod_tables(), h->eq, h->tpsval, h->info,
-                     h->T.inner_params(d.payload), (const float2 *)h->T.points, (const unsigned char *)h->T.label_tab, h->labels);
+  if (N == S8_N && !(h->acq_tap || h->fft_out || h->eq))      // 8k: persistent workgroups, two per CU (k_symbol8k.hpp)
+    hipLaunchKernelGGL(symbol8k_kernel<false>, dim3(h->sym_grid), dim3(S8_T), S8_LDS_BYTES, s, iq, fp, (const RxState *)h->st, (const SymMeta *)h->meta,
+                       (const float2 *)h->T.tw, h->acq_tap, h->fft_out, h->T.demod_tables(), h->eq, h->tpsval, h->info,
+                       h->T.inner_params(d.payload), (const float2 *)h->T.points, (const unsigned char *)h->T.label_tab, h->labels);
+  else if (N == S8_N)
+    hipLaunchKernelGGL(symbol8k_kernel<true>, dim3(h->sym_grid), dim3(S8_T), S8_LDS_BYTES, s, iq, fp, (const RxState *)h->st, (const SymMeta *)h->meta,
+                       (const float2 *)h->T.tw, h->acq_tap, h->fft_out, h->T.demod_tables(), h->eq, h->tpsval, h->info,
+                       h->T.inner_params(d.payload), (const float2 *)h->T.points, (const unsigned char *)h->T.label_tab, h->labels);
+  else
+    hipLaunchKernelGGL(derot_fft_demod_kernel, dim3(C), dim3(FFT_THREADS), fused_lds_bytes_host(N), s, iq, fp, (const RxState *)h->st, (const SymMeta *)h->meta,
+                       (const float2 *)h->T.tw, (const uint16_t *)h->T.perm, h->acq_tap, h->fft_out, h->T.demod_tables(), h->eq, h->tpsval, h->info,
+                       h->T.inner_params(d.payload), (const float2 *)h->T.points, (const unsigned char *)h->T.label_tab, h->labels);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_DEMOD], s));
   if (!o.continuation) {
     HIPCHK(hipMemsetAsync(h->tps_state, 0, sizeof(TpsState), s));

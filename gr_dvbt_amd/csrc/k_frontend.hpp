@@ -666,15 +666,47 @@ __device__ __forceinline__ void bfly4(float2 a0, float2 a1, float2 a2, float2 a3
   y3 = make_float2(d02.x - d13.y, d02.y + d13.x);               // d02 + i*d13
 }
 
+// 16-point forward DFT in registers (two radix-4 levels): a[j], j = time index, becomes A[k], k = frequency index
+__device__ __forceinline__ void dft16(float2 (&a)[16])
+{
+  // W16^m = exp(-2 pi i m / 16), m = 0..9 (products r'*k1 with r',k1 <= 3)
+  const float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, h = 0.70710678118654752f;
+  const float2 w16[10] = {{1.f, 0.f}, {c1, -s1}, {h, -h}, {s1, -c1}, {0.f, -1.f}, {-s1, -c1}, {-h, -h}, {-c1, -s1}, {-1.f, 0.f}, {-c1, s1}};
+  float2 t[16];
+#pragma unroll
+  for (int rp = 0; rp < 4; rp++) {                              // level 1: span 16
+    float2 y0, y1, y2, y3;
+    bfly4(a[rp], a[rp + 4], a[rp + 8], a[rp + 12], y0, y1, y2, y3);
+    t[0 * 4 + rp] = y0;
+    t[1 * 4 + rp] = rp ? cmul(y1, w16[rp]) : y1;
+    t[2 * 4 + rp] = rp ? cmul(y2, w16[2 * rp]) : y2;
+    t[3 * 4 + rp] = rp ? cmul(y3, w16[3 * rp]) : y3;
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < 4; k1++) {                              // level 2: span 4 -> A[k1 + 4*k2]
+    float2 y0, y1, y2, y3;
+    bfly4(t[k1 * 4], t[k1 * 4 + 1], t[k1 * 4 + 2], t[k1 * 4 + 3], y0, y1, y2, y3);
+    a[k1] = y0; a[k1 + 4] = y1; a[k1 + 8] = y2; a[k1 + 12] = y3;
+  }
+}
+// a[k] *= w1^k, k = 1..15: the powers by products, at most 4 multiplications deep
+__device__ __forceinline__ void twiddle16(float2 (&a)[16], float2 w1)
+{
+  float2 w[16];
+  w[1] = w1;
+  w[2] = cmul(w[1], w[1]); w[3] = cmul(w[2], w[1]); w[4] = cmul(w[2], w[2]); w[5] = cmul(w[4], w[1]); w[6] = cmul(w[3], w[3]);
+  w[7] = cmul(w[4], w[3]); w[8] = cmul(w[4], w[4]); w[9] = cmul(w[8], w[1]); w[10] = cmul(w[5], w[5]); w[11] = cmul(w[8], w[3]);
+  w[12] = cmul(w[6], w[6]); w[13] = cmul(w[8], w[5]); w[14] = cmul(w[7], w[7]); w[15] = cmul(w[8], w[7]);
+#pragma unroll
+  for (int k = 1; k < 16; k++) a[k] = cmul(a[k], w[k]);
+}
+
 // In-place decimation-in-frequency FFT of the padded LDS image x (N points, natural order in, digit-reversed
 // out; the host-built permutation undoes the reversal).  Radix-16 passes with the 16-point transform held in
 // registers (two radix-4 levels), then a radix-4 and/or radix-2 tail: 8192 = 16.16.16.2, 2048 = 16.16.4.2
 // (dvbt_tables.hpp::fft_radices lists the same sequence).  One __syncthreads per pass.
 __device__ __forceinline__ void fft_dif_lds(float2 *x, int N, const float2 *tw_c, const float2 *tw_f, int tid)
 {
-  // W16^m = exp(-2 pi i m / 16), m = 0..9 (products r'*k1 with r',k1 <= 3)
-  const float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, h = 0.70710678118654752f;
-  const float2 w16[10] = {{1.f, 0.f}, {c1, -s1}, {h, -h}, {s1, -c1}, {0.f, -1.f}, {-s1, -c1}, {-h, -h}, {-c1, -s1}, {-1.f, 0.f}, {-c1, s1}};
   int L = N;
   while (L >= 16) {
     const int Q = L >> 4, tstep = N / L, nblk = (N >> 4) / Q;
@@ -684,34 +716,11 @@ __device__ __forceinline__ void fft_dif_lds(float2 *x, int N, const float2 *tw_c
       const int r = Q <= 2 ? bf / nblk : bf % Q, base = (Q <= 2 ? bf % nblk : bf / Q) * L + r;
       // padded address of element base + j Q: fpad is affine in j here (base % 32 = r < Q for Q < 32, and j Q % 32 = 0 otherwise)
       const int pb = fpad(base);
-      float2 a[16], t[16];
+      float2 a[16];
 #pragma unroll
       for (int j = 0; j < 16; j++) a[j] = x[pb + j * Q + ((j * Q) >> 5)];
-#pragma unroll
-      for (int rp = 0; rp < 4; rp++) {                          // level 1: span 16
-        float2 y0, y1, y2, y3;
-        bfly4(a[rp], a[rp + 4], a[rp + 8], a[rp + 12], y0, y1, y2, y3);
-        t[0 * 4 + rp] = y0;
-        t[1 * 4 + rp] = rp ? cmul(y1, w16[rp]) : y1;
-        t[2 * 4 + rp] = rp ? cmul(y2, w16[2 * rp]) : y2;
-        t[3 * 4 + rp] = rp ? cmul(y3, w16[3 * rp]) : y3;
-      }
-#pragma unroll
-      for (int k1 = 0; k1 < 4; k1++) {                          // level 2: span 4 -> Y[k1 + 4*k2]
-        float2 y0, y1, y2, y3;
-        bfly4(t[k1 * 4], t[k1 * 4 + 1], t[k1 * 4 + 2], t[k1 * 4 + 3], y0, y1, y2, y3);
-        a[k1] = y0; a[k1 + 4] = y1; a[k1 + 8] = y2; a[k1 + 12] = y3;
-      }
-      {
-        // inter-pass twiddles W^(r k tstep), k = 1..15, as powers of w1 = W^(r tstep) (at most 4 multiplications deep)
-        float2 w[16];
-        w[1] = twid(tw_c, tw_f, r * tstep);
-        w[2] = cmul(w[1], w[1]); w[3] = cmul(w[2], w[1]); w[4] = cmul(w[2], w[2]); w[5] = cmul(w[4], w[1]); w[6] = cmul(w[3], w[3]);
-        w[7] = cmul(w[4], w[3]); w[8] = cmul(w[4], w[4]); w[9] = cmul(w[8], w[1]); w[10] = cmul(w[5], w[5]); w[11] = cmul(w[8], w[3]);
-        w[12] = cmul(w[6], w[6]); w[13] = cmul(w[8], w[5]); w[14] = cmul(w[7], w[7]); w[15] = cmul(w[8], w[7]);
-#pragma unroll
-        for (int k = 1; k < 16; k++) a[k] = cmul(a[k], w[k]);
-      }
+      dft16(a);
+      twiddle16(a, twid(tw_c, tw_f, r * tstep));       // inter-pass twiddles W^(r k tstep), k = 1..15
 #pragma unroll
       for (int k = 0; k < 16; k++) x[pb + k * Q + ((k * Q) >> 5)] = a[k];
     }
