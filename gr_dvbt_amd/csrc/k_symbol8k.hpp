@@ -12,7 +12,15 @@
 //  * derotation phasors from per-symbol tables (2 x 16 + 2 x 32 entries per piece) written one phase ahead by 128 threads: one
 //    complex product per thread and piece instead of two sincos;
 //  * the integer-CFO search and the pattern search (for all 16 candidate offsets) run side by side on the two halves of the workgroup,
-//    every thread then takes the two arg-max itself: one barrier instead of four.
+//    every thread then takes the two arg-max itself: one barrier instead of four;
+//  * the kernel is bound by VALU issue (every wave64 instruction of a mixed stream costs ~4 cycles, profiles/r02_ubench_mix.json), so the
+//    arithmetic is written for instruction COUNT: complex products as v_pk_mul_f32 + v_pk_fma_f32 with op_sel / neg modifiers (2 instructions; the
+//    compiler's best is 4 and a third of its FFT passes were register moves), multiplications by the fixed 16th / 32nd roots of unity as
+//    modifier variants of the same pair over four (cos, sin) constants, +-i folded into the butterflies' adds;
+//  * the demapper first tries the cell of the square grid the carrier falls into: when the carrier is farther than 1e-5 of a cell from every
+//    decision boundary (and within 12 cells of the grid) the cell's point is the reference's first strict minimum whatever the rounding of its
+//    float distances (bound: 1.4e-6 of a cell, see s8_demap_cell); the 4-candidate search with the reference's tie rule (demap_fast) and the
+//    exhaustive one (demap_all) remain for the rest, wave by wave.
 // Reference: ofdm_sym_acquisition_impl.cc:285-309,527-534 (derotation), fft_vcc forward + shift (SURVEY C-2),
 // reference_signals_impl.cc:536-689,715-744,1065-1124 (pilot engine), dvbt_demap_impl.cc:167-203.
 #pragma once
@@ -51,8 +59,129 @@ __device__ __forceinline__ void s8_fill_ptab(float2 *pt, const SymMeta &m, int t
   pt[t] = make_float2(cs, sn);
 }
 
+// ---- packed complex arithmetic: a float2 lives in an aligned VGPR pair, one VOP3P instruction works on both halves
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f s8_v(float2 a) { return (v2f){a.x, a.y}; }
+__device__ __forceinline__ float2 s8_f(v2f a) { return make_float2(a.x, a.y); }
+// a * b (2 instructions; the second one is fused: the rounding differs from cmul() in the last bit)
+__device__ __forceinline__ v2f s8_cmul(v2f a, v2f b)
+{
+  v2f p, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(p) : "v"(a), "v"(b));                                        // (a.y b.y, a.y b.x)
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(p));          // (a.x b.x - p.x, a.x b.y + p.y)
+  return r;
+}
+__device__ __forceinline__ v2f s8_add_mi(v2f a, v2f b)    // a - i b
+{ v2f r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ v2f s8_add_pi(v2f a, v2f b)    // a + i b
+{ v2f r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ v2f s8_mul_mi(v2f y)           // -i y = (y.y, -y.x)
+{ v2f r; asm("v_pk_add_f32 %0, %1, 0 op_sel:[1,0] op_sel_hi:[0,1] neg_hi:[1,0]" : "=v"(r) : "v"(y)); return r; }
+// y * w for w built from K = (c, s) = (cos t, sin t): the five sign / swap patterns the 16th and 32nd roots need
+#define S8_MULK(name, m1, m2) \
+  __device__ __forceinline__ v2f name(v2f y, v2f K) { v2f p, r; \
+    asm("v_pk_mul_f32 %0, %1, %2 " m1 : "=v"(p) : "v"(y), "v"(K)); \
+    asm("v_pk_fma_f32 %0, %1, %2, %3 " m2 : "=v"(r) : "v"(y), "v"(K), "v"(p)); return r; }
+S8_MULK(s8_mul_c_ms, "op_sel:[0,0] op_sel_hi:[1,0]", "op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]")                                   // w = ( c, -s)
+S8_MULK(s8_mul_s_mc, "op_sel:[0,1] op_sel_hi:[1,1]", "op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]")                                   // w = ( s, -c)
+S8_MULK(s8_mul_mc_s, "op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]", "op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]")         // w = (-c,  s)
+S8_MULK(s8_mul_ms_mc, "op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]", "op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]")        // w = (-s, -c)
+S8_MULK(s8_mul_mc_ms, "op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]", "op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]")        // w = (-c, -s)
+#undef S8_MULK
+__device__ __forceinline__ v2f s8_mul_h_mh(v2f y, v2f H)  // y * h (1 - i), H = (h, h)
+{
+  v2f t, r;
+  asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(t) : "v"(y));                                    // (y.x + y.y, y.y - y.x)
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(t), "v"(H));
+  return r;
+}
+__device__ __forceinline__ v2f s8_mul_mh_mh(v2f y, v2f H) // y * -h (1 + i)
+{
+  v2f t, r;
+  asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(y));                                    // (y.x - y.y, y.y + y.x)
+  asm("v_pk_mul_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(t), "v"(H));
+  return r;
+}
+// the four constants of the fixed twiddles, in VGPR pairs
+struct S8Roots { v2f K8, K16, K316, H; };   // (cos, sin) of pi/8, pi/16, 3 pi/16; (sqrt 1/2, sqrt 1/2)
+__device__ __forceinline__ S8Roots s8_roots()
+{
+  S8Roots R;
+  R.K8 = (v2f){0.92387953251128674f, 0.38268343236508977f}; R.K16 = (v2f){0.98078528040323043f, 0.19509032201612825f};
+  R.K316 = (v2f){0.83146961230254524f, 0.55557023301960218f}; R.H = (v2f){0.70710678118654752f, 0.70710678118654752f};
+  return R;
+}
+__device__ __forceinline__ void s8_bfly4(v2f a0, v2f a1, v2f a2, v2f a3, v2f &y0, v2f &y1, v2f &y2, v2f &y3)
+{
+  const v2f s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = a1 - a3;
+  y0 = s02 + s13; y2 = s02 - s13; y1 = s8_add_mi(d02, d13); y3 = s8_add_pi(d02, d13);
+}
+// 16-point forward DFT in registers, as dft16() (k_frontend.hpp): 64 adds + 17 instructions of fixed twiddles
+__device__ __forceinline__ void s8_dft16(v2f (&a)[16], const S8Roots &R)
+{
+  v2f t[16];
+#pragma unroll
+  for (int rp = 0; rp < 4; rp++) {
+    v2f y0, y1, y2, y3;
+    s8_bfly4(a[rp], a[rp + 4], a[rp + 8], a[rp + 12], y0, y1, y2, y3);
+    t[rp] = y0;
+    if (rp == 0) { t[4] = y1; t[8] = y2; t[12] = y3; }
+    else if (rp == 1) { t[5] = s8_mul_c_ms(y1, R.K8); t[9] = s8_mul_h_mh(y2, R.H); t[13] = s8_mul_s_mc(y3, R.K8); }            // W16^1, ^2, ^3
+    else if (rp == 2) { t[6] = s8_mul_h_mh(y1, R.H); t[10] = s8_mul_mi(y2); t[14] = s8_mul_mh_mh(y3, R.H); }                   // W16^2, ^4, ^6
+    else { t[7] = s8_mul_s_mc(y1, R.K8); t[11] = s8_mul_mh_mh(y2, R.H); t[15] = s8_mul_mc_s(y3, R.K8); }                       // W16^3, ^6, ^9
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < 4; k1++) {
+    v2f y0, y1, y2, y3;
+    s8_bfly4(t[k1 * 4], t[k1 * 4 + 1], t[k1 * 4 + 2], t[k1 * 4 + 3], y0, y1, y2, y3);
+    a[k1] = y0; a[k1 + 4] = y1; a[k1 + 8] = y2; a[k1 + 12] = y3;
+  }
+}
+// a[k] *= w1^k, k = 1..15 (powers by products, at most 4 deep, as twiddle16)
+__device__ __forceinline__ void s8_twiddle16(v2f (&a)[16], v2f w1)
+{
+  v2f w[16];
+  w[1] = w1;
+  w[2] = s8_cmul(w[1], w[1]); w[3] = s8_cmul(w[2], w[1]); w[4] = s8_cmul(w[2], w[2]); w[5] = s8_cmul(w[4], w[1]); w[6] = s8_cmul(w[3], w[3]);
+  w[7] = s8_cmul(w[4], w[3]); w[8] = s8_cmul(w[4], w[4]); w[9] = s8_cmul(w[8], w[1]); w[10] = s8_cmul(w[5], w[5]); w[11] = s8_cmul(w[8], w[3]);
+  w[12] = s8_cmul(w[6], w[6]); w[13] = s8_cmul(w[8], w[5]); w[14] = s8_cmul(w[7], w[7]); w[15] = s8_cmul(w[8], w[7]);
+#pragma unroll
+  for (int k = 1; k < 16; k++) a[k] = s8_cmul(a[k], w[k]);
+}
+// u * W_32^b for the second half (c = 1) of the last pass, b = 1..15
+template <int B> __device__ __forceinline__ v2f s8_mul_w32(v2f u, const S8Roots &R)
+{
+  if (B == 1) return s8_mul_c_ms(u, R.K16); if (B == 2) return s8_mul_c_ms(u, R.K8); if (B == 3) return s8_mul_c_ms(u, R.K316);
+  if (B == 4) return s8_mul_h_mh(u, R.H);
+  if (B == 5) return s8_mul_s_mc(u, R.K316); if (B == 6) return s8_mul_s_mc(u, R.K8); if (B == 7) return s8_mul_s_mc(u, R.K16);
+  if (B == 8) return s8_mul_mi(u);
+  if (B == 9) return s8_mul_ms_mc(u, R.K16); if (B == 10) return s8_mul_ms_mc(u, R.K8); if (B == 11) return s8_mul_ms_mc(u, R.K316);
+  if (B == 12) return s8_mul_mh_mh(u, R.H);
+  if (B == 13) return s8_mul_mc_ms(u, R.K316); if (B == 14) return s8_mul_mc_ms(u, R.K8); if (B == 15) return s8_mul_mc_ms(u, R.K16);
+  return u;
+}
+
+// A4, first try: the cell of the nlev x nlev grid the carrier falls into.  g = e / step + nlev / 2 puts level j on [j, j + 1); outside the grid the
+// edge cells extend outwards.  The cell's point is the reference's answer (first strict minimum of fl(fl(dx^2) + fl(dy^2)) over all points,
+// dvbt_demap_impl.cc:167-203) whenever the carrier is farther from the cell's boundaries than rounding can reorder two neighbours: t cells inside
+// the nearer boundary the neighbouring level's squared distance is larger by 2 t step^2; against that stand the rounding of dx (2.4e-7 step^2 after
+// the square, |x| <= 8 step), of the squares (1.5e-8 step^2) and of the two sums (6e-8 (ax + ay) each, ay <= 4.5^2 step^2 inside S8_REACH):
+// together < 3e-6 step^2, so t > 1.5e-6 decides; the g computed here is off by <= 1e-6.  S8_MARGIN = 2e-5 (eight times that).
+// Returns false when the carrier is closer than S8_MARGIN to a boundary or farther than S8_REACH cells from the grid: demap_fast / demap_all decide.
+constexpr float S8_MARGIN = 2.0e-5f, S8_REACH = 4.0f;
+__device__ __forceinline__ bool s8_demap_cell(v2f e, float inv_step, float half_n, float top, int &idx)
+{
+  const float gx = __builtin_fmaf(e.x, inv_step, half_n), gy = __builtin_fmaf(e.y, inv_step, half_n);
+  const float cx = __builtin_amdgcn_fmed3f(gx, 0.5f, top), cy = __builtin_amdgcn_fmed3f(gy, 0.5f, top);     // top = nlev - 0.5
+  const float fx = floorf(cx), fy = floorf(cy);
+  const bool ok = fabsf((cx - fx) - 0.5f) < 0.5f - S8_MARGIN && fabsf((cy - fy) - 0.5f) < 0.5f - S8_MARGIN &&
+                  fabsf(gx - cx) < S8_REACH && fabsf(gy - cy) < S8_REACH;
+  idx = (int)fx * 8 + (int)fy;
+  return ok;
+}
+
 // TAPS: the debug taps (derotated samples, spectrum, equalised carriers) are compiled in; the production instantiation has none of that code
-template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(const float2 *__restrict__ iq, FrontParams p, const RxState *st,
+template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(const float2 *__restrict__ iq_, FrontParams p, const RxState *st,
                                                            const SymMeta *__restrict__ meta, const float2 *__restrict__ tw, float2 *__restrict__ acq_tap,
                                                            float2 *__restrict__ fft_tap, DemodTables T, float2 *__restrict__ eq_tap,
                                                            float2 *__restrict__ tpsval, SymInfo *__restrict__ info, InnerParams ip,
@@ -60,15 +189,16 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
                                                            uint8_t *__restrict__ labels)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float2 *x = reinterpret_cast<float2 *>(smem_raw);
-  float2 *gtab = x + S8_N;                                       // LS gains at the estimation carriers
-  float2 *ptab = gtab + DEMOD_NP;                                // [2][128] phasor tables, this symbol's and the next one's
+  v2f *x = reinterpret_cast<v2f *>(smem_raw);
+  v2f *gtab = x + S8_N;                                          // LS gains at the estimation carriers
+  float2 *ptab = reinterpret_cast<float2 *>(gtab + DEMOD_NP);    // [2][128] phasor tables, this symbol's and the next one's
   float2 *pts = ptab + 256;
   float *s_known = reinterpret_cast<float *>(pts + 64);          // 192
   float *s_cfo = s_known + 192;                                  // 16 candidate offsets
   float *s_pat = s_cfo + 16;                                     // [16 candidates][4 patterns]
   short *s_cpil = reinterpret_cast<short *>(s_pat + 64);         // 192
   unsigned char *label_of = reinterpret_cast<unsigned char *>(s_cpil + 192);
+  const v2f *iq = reinterpret_cast<const v2f *>(iq_);
   constexpr int N = S8_N, zl = S8_ZL;
   const int tid0 = threadIdx.x, tid = tid0, G = gridDim.x, cp = p.cp;
   const int nsym = st->n_symbols;
@@ -77,19 +207,19 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
 
   if (tid < 64) { pts[tid] = points[tid]; label_of[tid] = label_tab[tid]; }
   if (tid < S8_NCP) { s_cpil[tid] = T.cpilot[tid]; if (tid < S8_NCP - 1) s_known[tid] = T.known_diff[tid]; }
-  const float2 w1A = tw[tid], w1B = tw[16 * (tid & 31)];         // W_8192^n2 (first pass), W_512^m2 (second pass): the thread's twiddle bases
+  const v2f w1A = s8_v(tw[tid]), w1B = s8_v(tw[16 * (tid & 31)]); // W_8192^n2 (first pass), W_512^m2 (second pass): the thread's twiddle bases
   const int tps_c = tid < S8_NTPS ? T.tps[tid] : 0;
   float pat_ref = 0.f;                                            // reference value of this thread's scattered pilot in the pattern search
   if (tid >= 256) { const int q = tid - 256, j = q & 15, pat = (q >> 4) & 3; if (j < 10) pat_ref = T.pilot_ref[3 * pat + 12 * j]; }
+  const float half_n = 0.5f * (float)ip.nlev, top = (float)ip.nlev - 0.5f;
 
   // per-pattern table rows of this thread, kept across symbols
   int cur_mod = -1;
-  unsigned tcl[S8_IT];                                            // carrier | rank of the left bracketing estimation carrier << 16  (the right one is rank + 1)
-  unsigned tdp[(S8_IT + 3) / 4];                                  // distance to the left estimation carrier, one byte per carrier
+  unsigned tcl[S8_IT];                                            // carrier | rank of the left bracketing estimation carrier << 13 | distance to it << 23 (the right one is rank + 1)
   unsigned est01 = 0, tps_ld = 0; int np = 0;
 
   SymMeta m = meta[s];
-  float2 vin[16];
+  v2f vin[16];
   {
     const long long low = (long long)(st->call0 + s) * (N + cp) + m.cp_start - N + 1;
 #pragma unroll
@@ -101,9 +231,11 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
 
   for (;;) {
     // the thread's index and twiddle bases, opaque to the optimiser: everything derived from them is a handful of instructions, and hoisting it out of
-    // the loop (the 30 twiddle powers, ~80 LDS addresses) costs more registers than the loop has
-    int tid = tid0; float2 wA = w1A, wB = w1B;
-    asm volatile("" : "+v"(tid), "+v"(wA.x), "+v"(wA.y), "+v"(wB.x), "+v"(wB.y));
+    // the loop (the 30 twiddle powers, ~80 LDS addresses, the root constants) costs more registers than the loop has
+    int tid = tid0; v2f wA = w1A, wB = w1B;
+    asm volatile("" : "+v"(tid), "+v"(wA), "+v"(wB));
+    S8Roots R = s8_roots();
+    asm volatile("" : "+v"(R.K8), "+v"(R.K16), "+v"(R.K316), "+v"(R.H));
     const int s_next = s + G;
     const bool more = s_next < nsym;
     const bool last = !p.keep_last && s + 1 >= nsym;             // no output for the last item (the reference's demod consumes n+1 items)
@@ -115,22 +247,23 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
       for (int i = 0; i < 16; i++) vin[i] = iq[low + tid + i * S8_T];
     }
     // ---- A1 tail: derotate (ofdm_sym_acquisition_impl.cc:285-309,527-534), on the registers the loads arrived in
-    float2 a[16];
+    v2f a[16];
     {
-      const float2 *pt = ptab + par * 128;
-      const float2 PA = cmul(pt[32 + (tid >> 5)], pt[64 + (tid & 31)]), PB = cmul(pt[48 + (tid >> 5)], pt[96 + (tid & 31)]);
-      const bool has_sw = m.sw >= 0 && m.sw < N + cp;
+      const v2f *pt = reinterpret_cast<const v2f *>(ptab) + par * 128;
+      const v2f PA = s8_cmul(pt[32 + (tid >> 5)], pt[64 + (tid & 31)]), PB = s8_cmul(pt[48 + (tid >> 5)], pt[96 + (tid & 31)]);
+      const int sw = (m.sw >= 0 && m.sw < N + cp) ? m.sw : 0x7fffffff;
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         const int n = tid + i * S8_T;
-        const bool pieceB = has_sw && n + 1 > m.sw;
-        a[i] = (S8_EXP & 32) ? vin[i] : cmul(cmul(pieceB ? PB : PA, pt[(pieceB ? 16 : 0) + i]), vin[i]);
-        if (TAPS && acq_tap) acq_tap[(size_t)s * N + n] = a[i];
+        const bool pieceB = n + 1 > sw;
+        const v2f P = pieceB ? PB : PA;
+        a[i] = (S8_EXP & 32) ? vin[i] : s8_cmul(s8_cmul(P, pt[(pieceB ? 16 : 0) + i]), vin[i]);
+        if (TAPS && acq_tap) acq_tap[(size_t)s * N + n] = s8_f(a[i]);
       }
     }
     // ---- A2, pass 1: n = n2 + 512 n1 -> Y[k1][n2] W_8192^(n2 k1)
-    dft16(a);
-    twiddle16(a, wA);
+    s8_dft16(a, R);
+    s8_twiddle16(a, wA);
     __syncthreads();                                             // the previous symbol's readers of x are done
     {
       const int b0 = tid ^ ((tid >> 5) & 15);
@@ -144,8 +277,8 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
       const int k1 = tid >> 5, mm = (tid & 31) ^ ((k1 & 1) << 4), rb = k1 * 512;
 #pragma unroll
       for (int m1 = 0; m1 < 16; m1++) a[m1] = x[rb + 32 * m1 + (mm ^ m1)];
-      dft16(a);
-      twiddle16(a, wB);
+      s8_dft16(a, R);
+      s8_twiddle16(a, wB);
 #pragma unroll
       for (int j1 = 0; j1 < 16; j1++) x[rb + 32 * j1 + (mm ^ j1)] = a[j1];
     }
@@ -155,23 +288,18 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
       const int j1 = tid & 15, k1 = (tid >> 4) & 15, c = tid >> 8, jj = j1 ^ ((k1 & 1) << 4), rb = k1 * 512 + 32 * j1;
       if (c == 0) {
 #pragma unroll
-        for (int b = 0; b < 16; b++) a[b] = cadd(x[rb + (b ^ jj)], x[rb + ((b + 16) ^ jj)]);
+        for (int b = 0; b < 16; b++) a[b] = x[rb + (b ^ jj)] + x[rb + ((b + 16) ^ jj)];
       } else {
-        // W_32^b = exp(-2 pi i b / 32)
-        const float2 w32[16] = {{1.f, 0.f}, {0.98078528040323043f, -0.19509032201612825f}, {0.92387953251128674f, -0.38268343236508977f},
-                                {0.83146961230254524f, -0.55557023301960218f}, {0.70710678118654752f, -0.70710678118654752f},
-                                {0.55557023301960218f, -0.83146961230254524f}, {0.38268343236508977f, -0.92387953251128674f},
-                                {0.19509032201612825f, -0.98078528040323043f}, {0.f, -1.f}, {-0.19509032201612825f, -0.98078528040323043f},
-                                {-0.38268343236508977f, -0.92387953251128674f}, {-0.55557023301960218f, -0.83146961230254524f},
-                                {-0.70710678118654752f, -0.70710678118654752f}, {-0.83146961230254524f, -0.55557023301960218f},
-                                {-0.92387953251128674f, -0.38268343236508977f}, {-0.98078528040323043f, -0.19509032201612825f}};
+        v2f u[16];
 #pragma unroll
-        for (int b = 0; b < 16; b++) {
-          const float2 dlt = csub(x[rb + (b ^ jj)], x[rb + ((b + 16) ^ jj)]);
-          a[b] = b ? cmul(dlt, w32[b]) : dlt;
-        }
+        for (int b = 0; b < 16; b++) u[b] = x[rb + (b ^ jj)] - x[rb + ((b + 16) ^ jj)];
+        a[0] = u[0];
+        a[1] = s8_mul_w32<1>(u[1], R); a[2] = s8_mul_w32<2>(u[2], R); a[3] = s8_mul_w32<3>(u[3], R); a[4] = s8_mul_w32<4>(u[4], R);
+        a[5] = s8_mul_w32<5>(u[5], R); a[6] = s8_mul_w32<6>(u[6], R); a[7] = s8_mul_w32<7>(u[7], R); a[8] = s8_mul_w32<8>(u[8], R);
+        a[9] = s8_mul_w32<9>(u[9], R); a[10] = s8_mul_w32<10>(u[10], R); a[11] = s8_mul_w32<11>(u[11], R); a[12] = s8_mul_w32<12>(u[12], R);
+        a[13] = s8_mul_w32<13>(u[13], R); a[14] = s8_mul_w32<14>(u[14], R); a[15] = s8_mul_w32<15>(u[15], R);
       }
-      dft16(a);
+      s8_dft16(a, R);
       __syncthreads();                                           // every row has been read
       const int base2 = (k1 ^ j1) + 16 * j1 + 256 * c;           // s8_swz2 of the shifted bin: out[b] = X[(b - N/2) mod N]
 #pragma unroll
@@ -180,10 +308,10 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
     }
     if (more && tid < 128) s8_fill_ptab(ptab + (par ^ 1) * 128, mn, tid);
     __syncthreads();
-    auto X = [&](int b) -> float2 { return x[s8_swz2(b)]; };
+    auto X = [&](int b) -> v2f { return x[s8_swz2(b)]; };
     if (TAPS && fft_tap) {
 #pragma unroll
-      for (int i = 0; i < 16; i++) { const int b = tid + i * S8_T; fft_tap[(size_t)s * N + b] = X(b); }
+      for (int i = 0; i < 16; i++) { const int b = tid + i * S8_T; fft_tap[(size_t)s * N + b] = s8_f(X(b)); }
     }
     if (last) break;
     if (S8_EXP & 1) {
@@ -205,9 +333,8 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
       const int cand = tid >> 4, sub = tid & 15, i = zl - 8 + cand;
       float sum = 0.f;
       for (int j = sub; j < S8_NCP - 1; j += 16) {
-        const float2 u = X(i + s_cpil[j + 1]), v = X(i + s_cpil[j]);
-        const float dx = u.x - v.x, dy = u.y - v.y;
-        sum += s_known[j] * (dx * dx + dy * dy);
+        const v2f d = X(i + s_cpil[j + 1]) - X(i + s_cpil[j]);
+        sum += s_known[j] * (d.x * d.x + d.y * d.y);
       }
       for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
       if (sub == 0) s_cfo[cand] = sum;
@@ -217,21 +344,24 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
       for (int cc = 0; cc < 4; cc++) {
         const int cand = cg * 4 + cc;
         float cr = 0.f, ci = 0.f;
-        if (j < 10) { const float2 v = X(zl - 8 + cand + 3 * pat + 12 * j); cr = pat_ref * v.x; ci = -pat_ref * v.y; }   // ref * conj(v)
+        if (j < 10) { const v2f v = X(zl - 8 + cand + 3 * pat + 12 * j); cr = pat_ref * v.x; ci = -pat_ref * v.y; }   // ref * conj(v)
         for (int o = 8; o > 0; o >>= 1) { cr += __shfl_xor(cr, o); ci += __shfl_xor(ci, o); }
         if (j == 0) s_pat[cand * 4 + pat] = cr * cr + ci * ci;
       }
     }
     __syncthreads();
+    // the two arg-max (first index of the maximum, if positive: the reference's strict > from 0), by every wavefront for itself
     int fo, mod;
     {
-      float mx = 0.f; int best = 8;
-#pragma unroll
-      for (int c = 0; c < 16; c++) { const float v = s_cfo[c]; if (v > mx) { mx = v; best = c; } }
-      float mp = 0.f; int bm = 0;
-#pragma unroll
-      for (int c = 0; c < 4; c++) { const float v = s_pat[best * 4 + c]; if (v > mp) { mp = v; bm = c; } }
-      fo = __builtin_amdgcn_readfirstlane(best - 8); mod = __builtin_amdgcn_readfirstlane(bm);
+      const int l = tid & 63;
+      float v = s_cfo[l & 15], mx = v;
+      mx = fmaxf(mx, __shfl_xor(mx, 8)); mx = fmaxf(mx, __shfl_xor(mx, 4)); mx = fmaxf(mx, __shfl_xor(mx, 2)); mx = fmaxf(mx, __shfl_xor(mx, 1));
+      const unsigned long long hit = __ballot(v == mx && mx > 0.f && l < 16);
+      const int best = hit ? __builtin_ctzll(hit) : 8;
+      v = s_pat[best * 4 + (l & 3)]; mx = v;
+      mx = fmaxf(mx, __shfl_xor(mx, 2)); mx = fmaxf(mx, __shfl_xor(mx, 1));
+      const unsigned long long hit2 = __ballot(v == mx && mx > 0.f && l < 4);
+      fo = best - 8; mod = hit2 ? __builtin_ctzll(hit2) : 0;
     }
     const int xb = zl + fo;
     if (tid == 0) { SymInfo si; si.freq_offset = fo; si.mod_index = mod; si.cfc = 0.f; si.pad = 0; info[s] = si; }
@@ -245,31 +375,35 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
       cur_mod = mod;
       const size_t tb = (size_t)mod * S8_PAY;
 #pragma unroll
-      for (int it = 0; it < (S8_IT + 3) / 4; it++) tdp[it] = 0;
-#pragma unroll
       for (int it = 0; it < S8_IT; it++) {
         const int i = tid + it * S8_T, ic = i < S8_PAY ? i : S8_PAY - 1;
-        tcl[it] = (unsigned)T.pay_c[tb + ic] | ((unsigned)T.pay_Li[tb + ic] << 16);
-        tdp[it >> 2] |= (unsigned)T.pay_d[tb + ic] << (8 * (it & 3));
+        tcl[it] = (unsigned)T.pay_c[tb + ic] | ((unsigned)T.pay_Li[tb + ic] << 13) | ((unsigned)T.pay_d[tb + ic] << 23);
       }
       np = mod == 0 ? T.np[0] : mod == 1 ? T.np[1] : mod == 2 ? T.np[2] : T.np[3];
       const uint16_t *pk = T.pil_k + (size_t)mod * DEMOD_NP;      // carrier | sign of its reference << 15
       est01 = (unsigned)pk[tid < np ? tid : 0] | ((unsigned)pk[tid + S8_T < np ? tid + S8_T : 0] << 16);
       if (tid < S8_NTPS) { const int q = mod * S8_NTPS + tid; tps_ld = (unsigned)T.tps_Li[q] | ((unsigned)T.tps_d[q] << 16); }
     }
-    // LS gains at the estimation carriers (set_channel_gain :486-490)
+    // LS gains at the estimation carriers (set_channel_gain :486-490): ref / X = ref conj(X) / |X|^2, ref = +-4/3
     {
       const float amp = (float)(4.0 / 3.0);
-      const int e0 = (int)(est01 & 0xffffu), e1 = (int)(est01 >> 16);
-      if (tid < np) gtab[tid] = cdiv(make_float2((e0 & 0x8000) ? -amp : amp, 0.f), X(xb + (e0 & 0x7fff)));
-      if (tid + S8_T < np) gtab[tid + S8_T] = cdiv(make_float2((e1 & 0x8000) ? -amp : amp, 0.f), X(xb + (e1 & 0x7fff)));
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int e = (int)((est01 >> (16 * h)) & 0xffffu), r = tid + h * S8_T;
+        if (r < np) {
+          const v2f v = X(xb + (e & 0x7fff));
+          const float q = ((e & 0x8000) ? -amp : amp) / (v.x * v.x + v.y * v.y);
+          gtab[r] = (v2f){q * v.x, -q * v.y};
+        }
+      }
     }
     __syncthreads();
     // interpolation (:617-642, the constant 11 of :625) + equalise (:1111-1114) + demap
-    auto gain = [&](int Li, int dj) -> float2 {
-      const float2 gl = gtab[Li], gr = gtab[Li + 1];
-      const float k11 = 1.0f / 11.0f, tx = (gr.x - gl.x) * k11, ty = (gr.y - gl.y) * k11, j = (float)dj;
-      return make_float2(gl.x + tx * j, gl.y + ty * j);
+    auto equalise = [&](int c, int Li, int dj) -> v2f {
+      const v2f gl = gtab[Li], gr = gtab[Li + 1];
+      const float k11 = 1.0f / 11.0f, j = (float)dj;
+      const v2f t = (gr - gl) * k11;
+      return s8_cmul(X(xb + c), (v2f){__builtin_fmaf(t.x, j, gl.x), __builtin_fmaf(t.y, j, gl.y)});
     };
     {
       uint8_t *lab = labels + (size_t)s * S8_PAY;
@@ -278,27 +412,30 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
       for (int it = 0; it < S8_IT; it++) {
         const int i = tid + it * S8_T;
         if (i < S8_PAY && !(S8_EXP & 8)) {
-          const float2 e = cmul(X(xb + (int)(tcl[it] & 0xffffu)), gain((int)(tcl[it] >> 16), (int)((tdp[it >> 2] >> (8 * (it & 3))) & 0xffu)));
-          if (TAPS && eq_tap) eq_tap[(size_t)s * S8_PAY + i] = e;
-          const int f = demap_fast(e, pts, label_of, ip);
-          slow |= f < 0;
-          lab[i] = (uint8_t)f;
+          const v2f e = equalise((int)(tcl[it] & 0x1fffu), (int)((tcl[it] >> 13) & 0x3ffu), (int)(tcl[it] >> 23));
+          if (TAPS && eq_tap) eq_tap[(size_t)s * S8_PAY + i] = s8_f(e);
+          int idx;
+          slow |= !s8_demap_cell(e, ip.inv_step, half_n, top, idx);
+          lab[i] = label_of[idx & 63];
         }
       }
-      // samples outside the range of the 4-candidate search (never on a locked signal): the exhaustive search, outside the unrolled loop
+      // carriers within rounding of a decision boundary or far outside the grid: the 4-candidate search with the reference's tie rule, then the
+      // exhaustive one; the wavefront simply takes its carriers again
       if (__any(slow)) {
 #pragma unroll 1
         for (int it = 0; it < S8_IT; it++) {
           const int i = tid + it * S8_T;
           if (i >= S8_PAY) break;
           const size_t tb = (size_t)mod * S8_PAY + i;
-          const float2 e = cmul(X(xb + T.pay_c[tb]), gain(T.pay_Li[tb], T.pay_d[tb]));
-          if (demap_fast(e, pts, label_of, ip) < 0) lab[i] = (uint8_t)demap_all(e, pts, ip.csize);
+          const v2f e = equalise(T.pay_c[tb], T.pay_Li[tb], T.pay_d[tb]);
+          int f = demap_fast(s8_f(e), pts, label_of, ip);
+          if (f < 0) f = demap_all(s8_f(e), pts, ip.csize);
+          lab[i] = (uint8_t)f;
         }
       }
     }
     if (tid < S8_NTPS)    // equalised TPS carriers (process_tps_data :929-931)
-      tpsval[(size_t)s * S8_NTPS + tid] = cmul(X(xb + tps_c), gain((int)(tps_ld & 0xffffu), (int)(tps_ld >> 16)));
+      tpsval[(size_t)s * S8_NTPS + tid] = s8_f(equalise(tps_c, (int)(tps_ld & 0xffffu), (int)(tps_ld >> 16)));
     if (!more) break;
     s = s_next; m = mn; par ^= 1;
   }
