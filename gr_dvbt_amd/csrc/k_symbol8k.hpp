@@ -30,7 +30,7 @@ namespace dvbt {
 
 #ifndef S8_EXP
 #define S8_EXP 0      // experiment builds only (tools/s8_attribution.sh; wrong output): 1 no pilot engine / demapper, 2 no passes 2 and 3, 4 the next symbol's samples are
-                      // loaded at the top of the loop (no prefetch), 8 no equaliser + demapper, 16 no integer-CFO / pattern search, 32 no derotation
+                      // loaded at the top of the loop (no prefetch), 8 no equaliser + demapper, 16 no integer-CFO / pattern search, 32 no derotation, 64 the next symbol's samples are requested after the demapper
 #endif
 constexpr int S8_N = 8192, S8_T = 512, S8_PAY = 6048, S8_NCP = 177, S8_NTPS = 68, S8_ZL = 688;
 constexpr int S8_IT = (S8_PAY + S8_T - 1) / S8_T;             // payload carriers per thread (12)
@@ -160,6 +160,14 @@ template <int B> __device__ __forceinline__ v2f s8_mul_w32(v2f u, const S8Roots 
   if (B == 13) return s8_mul_mc_ms(u, R.K316); if (B == 14) return s8_mul_mc_ms(u, R.K8); if (B == 15) return s8_mul_mc_ms(u, R.K16);
   return u;
 }
+
+// sum / maximum over the 16 lanes of a DPP row (every lane gets it), over a quad
+template <int CTRL> __device__ __forceinline__ float s8_dpp(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true)); }
+__device__ __forceinline__ float s8_row_sum(float v)
+{ v += s8_dpp<0xB1>(v); v += s8_dpp<0x4E>(v); v += s8_dpp<0x141>(v); v += s8_dpp<0x140>(v); return v; }   // quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+__device__ __forceinline__ float s8_row_max(float v)
+{ v = fmaxf(v, s8_dpp<0xB1>(v)); v = fmaxf(v, s8_dpp<0x4E>(v)); v = fmaxf(v, s8_dpp<0x141>(v)); v = fmaxf(v, s8_dpp<0x140>(v)); return v; }
+__device__ __forceinline__ float s8_quad_max(float v) { v = fmaxf(v, s8_dpp<0xB1>(v)); return fmaxf(v, s8_dpp<0x4E>(v)); }
 
 // A4, first try: the cell of the nlev x nlev grid the carrier falls into.  g = e / step + nlev / 2 puts level j on [j, j + 1); outside the grid the
 // edge cells extend outwards.  The cell's point is the reference's answer (first strict minimum of fl(fl(dx^2) + fl(dy^2)) over all points,
@@ -306,7 +314,6 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
       for (int d = 0; d < 16; d++) x[base2 + 512 * (d ^ 8)] = a[d];
     }
     }
-    if (more && tid < 128) s8_fill_ptab(ptab + (par ^ 1) * 128, mn, tid);
     __syncthreads();
     auto X = [&](int b) -> v2f { return x[s8_swz2(b)]; };
     if (TAPS && fft_tap) {
@@ -331,42 +338,48 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
     if (S8_EXP & 16) { if (tid < 80) s_cfo[tid] = tid == 8 ? 1.f : 0.f; }
     else if (tid < 256) {
       const int cand = tid >> 4, sub = tid & 15, i = zl - 8 + cand;
+      constexpr int NJ = (S8_NCP - 1) / 16;                         // 176 pairs = 11 per lane: all reads in flight together
+      int c0[NJ], c1[NJ]; v2f u[NJ], v[NJ];
+#pragma unroll
+      for (int k = 0; k < NJ; k++) { c0[k] = s_cpil[sub + 16 * k]; c1[k] = s_cpil[sub + 16 * k + 1]; }
+#pragma unroll
+      for (int k = 0; k < NJ; k++) { u[k] = X(i + c1[k]); v[k] = X(i + c0[k]); }
       float sum = 0.f;
-      for (int j = sub; j < S8_NCP - 1; j += 16) {
-        const v2f d = X(i + s_cpil[j + 1]) - X(i + s_cpil[j]);
-        sum += s_known[j] * (d.x * d.x + d.y * d.y);
-      }
-      for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+#pragma unroll
+      for (int k = 0; k < NJ; k++) { const v2f d = u[k] - v[k]; sum += s_known[sub + 16 * k] * (d.x * d.x + d.y * d.y); }
+      sum = s8_row_sum(sum);
       if (sub == 0) s_cfo[cand] = sum;
     } else {
       const int q = tid - 256, j = q & 15, pat = (q >> 4) & 3, cg = q >> 6;
+      v2f v[4];
+#pragma unroll
+      for (int cc = 0; cc < 4; cc++) v[cc] = X(zl - 8 + cg * 4 + cc + 3 * pat + 12 * (j < 10 ? j : 0));
 #pragma unroll
       for (int cc = 0; cc < 4; cc++) {
-        const int cand = cg * 4 + cc;
-        float cr = 0.f, ci = 0.f;
-        if (j < 10) { const v2f v = X(zl - 8 + cand + 3 * pat + 12 * j); cr = pat_ref * v.x; ci = -pat_ref * v.y; }   // ref * conj(v)
-        for (int o = 8; o > 0; o >>= 1) { cr += __shfl_xor(cr, o); ci += __shfl_xor(ci, o); }
-        if (j == 0) s_pat[cand * 4 + pat] = cr * cr + ci * ci;
+        const float cr = s8_row_sum(j < 10 ? pat_ref * v[cc].x : 0.f), ci = s8_row_sum(j < 10 ? -pat_ref * v[cc].y : 0.f);   // ref * conj(v)
+        if (j == 0) s_pat[(cg * 4 + cc) * 4 + pat] = cr * cr + ci * ci;
       }
+      // the next symbol's phasor tables, by two wavefronts of the half with the lighter search
+      if (more && q < 128) s8_fill_ptab(ptab + (par ^ 1) * 128, mn, q);
     }
     __syncthreads();
     // the two arg-max (first index of the maximum, if positive: the reference's strict > from 0), by every wavefront for itself
     int fo, mod;
     {
       const int l = tid & 63;
-      float v = s_cfo[l & 15], mx = v;
-      mx = fmaxf(mx, __shfl_xor(mx, 8)); mx = fmaxf(mx, __shfl_xor(mx, 4)); mx = fmaxf(mx, __shfl_xor(mx, 2)); mx = fmaxf(mx, __shfl_xor(mx, 1));
+      float v = s_cfo[l & 15];
+      float mx = s8_row_max(v);
       const unsigned long long hit = __ballot(v == mx && mx > 0.f && l < 16);
       const int best = hit ? __builtin_ctzll(hit) : 8;
-      v = s_pat[best * 4 + (l & 3)]; mx = v;
-      mx = fmaxf(mx, __shfl_xor(mx, 2)); mx = fmaxf(mx, __shfl_xor(mx, 1));
+      v = s_pat[best * 4 + (l & 3)];
+      mx = s8_quad_max(v);
       const unsigned long long hit2 = __ballot(v == mx && mx > 0.f && l < 4);
       fo = best - 8; mod = hit2 ? __builtin_ctzll(hit2) : 0;
     }
     const int xb = zl + fo;
     if (tid == 0) { SymInfo si; si.freq_offset = fo; si.mod_index = mod; si.cfc = 0.f; si.pad = 0; info[s] = si; }
     // the next symbol's samples start travelling now
-    if (more && !(S8_EXP & 4)) {
+    if (more && !(S8_EXP & (4 | 64))) {
       const long long low = (long long)(st->call0 + s_next) * (N + cp) + mn.cp_start - N + 1;
 #pragma unroll
       for (int i = 0; i < 16; i++) vin[i] = iq[low + tid + i * S8_T];
@@ -392,7 +405,7 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
         const int e = (int)((est01 >> (16 * h)) & 0xffffu), r = tid + h * S8_T;
         if (r < np) {
           const v2f v = X(xb + (e & 0x7fff));
-          const float q = ((e & 0x8000) ? -amp : amp) / (v.x * v.x + v.y * v.y);
+          const float q = ((e & 0x8000) ? -amp : amp) * __builtin_amdgcn_rcpf(v.x * v.x + v.y * v.y);
           gtab[r] = (v2f){q * v.x, -q * v.y};
         }
       }
@@ -411,7 +424,7 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
 #pragma unroll
       for (int it = 0; it < S8_IT; it++) {
         const int i = tid + it * S8_T;
-        if (i < S8_PAY && !(S8_EXP & 8)) {
+        if ((it < S8_PAY / S8_T || i < S8_PAY) && !(S8_EXP & 8)) {
           const v2f e = equalise((int)(tcl[it] & 0x1fffu), (int)((tcl[it] >> 13) & 0x3ffu), (int)(tcl[it] >> 23));
           if (TAPS && eq_tap) eq_tap[(size_t)s * S8_PAY + i] = s8_f(e);
           int idx;
@@ -433,6 +446,11 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
           lab[i] = (uint8_t)f;
         }
       }
+    }
+    if (more && (S8_EXP & 64)) {
+      const long long low = (long long)(st->call0 + s_next) * (N + cp) + mn.cp_start - N + 1;
+#pragma unroll
+      for (int i = 0; i < 16; i++) vin[i] = iq[low + tid + i * S8_T];
     }
     if (tid < S8_NTPS)    // equalised TPS carriers (process_tps_data :929-931)
       tpsval[(size_t)s * S8_NTPS + tid] = s8_f(equalise(tps_c, (int)(tps_ld & 0xffffu), (int)(tps_ld >> 16)));

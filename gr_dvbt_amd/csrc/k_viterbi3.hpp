@@ -26,8 +26,15 @@
 //    (kept as that state's cell storage index, bits 5:0) and the two oldest inputs of the window (= top two bits of
 //    the state after step 6, stamped there, bits 7:6).  It rides along with the metric through v_pk_max (metric
 //    fields never tie).  In the LDS ring a hop is one v_and_or: origin = byte & 63, merged with the next row address.
+//  * the tie-break bits are armed THREE STEPS AT A TIME.  Whether a cell holds an upper state at a step depends on one bit of its
+//    index, a different one at every step, and the two cells of a butterfly differ in exactly the bit of the current step.  So the
+//    biases of the next three steps can be written together into bits 6, 7, 8 (the earliest step in the lowest bit; bits 7:6 of
+//    the path byte are free until the stamp of the window's 6th step): at the first step the two candidates agree in bits 8 and 7
+//    and differ in bit 6, whichever wins carries the right bits 8 and 7 into the next step, where bit 7 decides and the stale
+//    bit 6 below it cannot; and so on.  The deltas have zeros in bits 8:0, so the adds leave the three bits alone.  A window of 8
+//    steps re-arms after steps 3, 6 (with the stamp), 7 and 8 (with the origin of the next window): 4 v_and_or instead of 8.
 // Per step and VGPR (two cells): v_perm (both branch-metric deltas from ONE word of four class deltas), pk_add,
-// pk_sub, exchange, pk_max, v_and_or (re-arm bias) -- 3 instructions per cell.
+// pk_sub, exchange, pk_max, and on every second step a v_and_or: 2.75 instructions per cell.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -91,17 +98,17 @@ __device__ __forceinline__ int pk_min(int a, int b) { return ipk(__builtin_eleme
 template <int CTRL> __device__ __forceinline__ int dppb(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
 // a constant the compiler must keep in a VGPR (v_and_or_b32 takes one literal at most)
 __device__ __forceinline__ int vconst(int c) { int x; asm("v_mov_b32 %0, %1" : "=v"(x) : "s"(c)); return x; }
-__device__ __forceinline__ int swap16(int x) { return (int)__builtin_amdgcn_alignbit((unsigned)x, (unsigned)x, 16); }
+// max of a's halves with b's halves SWAPPED (the half exchange of phase 1 rides on the op_sel of the VOP3P encoding)
+__device__ __forceinline__ int pk_max_swap(int a, int b) { int r; asm("v_pk_max_i16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
 struct V3Lane {
   unsigned sel[6][2];   // v_perm selectors: [0, d(class of lo cell), 0, d(class of hi cell)] out of the step word
-  int abit[4];          // logical lane bits a0..a3 at the bias position of both halves
-  int kc[3][2];         // 63 - state of the two cells at window ends (phase 0,2,4)
+  int bias8[6][2];      // tie-break bit of phase P at bit 8 of both halves (1 = the cell holds an upper state at that phase)
+  int kc[3][2];         // (63 - state of the two cells) | (the cell holds a LOWER state) << 8, at window ends (phase 0,2,4)
   int org[2];           // storage index of the two cells, at the path-byte position (bits 5:0)
-  int b2[3][2];         // top two bits of the cells' states at phases 0,2,4
-  int hi_bias;          // 0x01000000: bias of the upper half
-  int nb2[3][2];        // bias of phase 0,2,4 | b2 of that phase   (6th step of a window)
-  int nbo[3][2];        // bias of phase 0,2,4 | org                (last step of a window)
+  int arm_mid[3][2];    // window starting at phase 0,2,4: biases of its steps 3,4,5 at bits 6,7,8              (after the 3rd step)
+  int arm_b2[3][2];     // top two bits of the cells' states after the 6th step at bits 7:6 | bias of step 6 at bit 8 (after the 6th step)
+  int arm_org[3][2];    // NEXT window starting at phase 0,2,4: org | biases of its steps 0,1,2 at bits 6,7,8     (after the last step)
 };
 
 // storage index of a cell in the path-byte table: z = physical lane * 4 + 2r + h (a lane's four bytes are one word)
@@ -110,11 +117,11 @@ __device__ __forceinline__ int v3_log(int p) { const int q = p & 7, a2 = (q >> 2
 __device__ __forceinline__ int v3_cell_of_z(int z) { return ((z & 2) << 4) | ((z & 1) << 4) | v3_log(z >> 2); }
 __device__ __forceinline__ int v3_z_of_cell(int c) { return v3_phys(c & 15) * 4 + ((c >> 5) & 1) * 2 + ((c >> 4) & 1); }
 
+// 1 when cell (r, h, a) holds an upper state (state bit 5 set) at phase P: the state is rotl6(cell, P), its bit 5 is cell bit (5 - P)
+__device__ __forceinline__ int v3_upper(int P, int r, int h, int a) { const int c = (r << 5) | (h << 4) | a; return (c >> (5 - P)) & 1; }
 __device__ inline void v3_init_lane(int pl, V3Lane &L)
 {
   const int a = v3_log(pl);
-  for (int k = 0; k < 4; k++) L.abit[k] = ((a >> k) & 1) * 0x01000100;
-  L.hi_bias = vconst(0x01000000);
   for (int r = 0; r < 2; r++) {
     for (int P = 0; P < 6; P++) {
       unsigned idx[2];
@@ -125,26 +132,30 @@ __device__ inline void v3_init_lane(int pl, V3Lane &L)
         idx[h] = (unsigned)(c0 | (c1 << 1));                          // byte of the step word = label class
       }
       L.sel[P][r] = 0x0c | (idx[0] << 8) | (0x0cu << 16) | (idx[1] << 24);
-    }
-    for (int e = 0; e < 3; e++) {
-      const int s0 = rotl6((r << 5) | a, 2 * e), s1 = rotl6((r << 5) | 16 | a, 2 * e);
-      L.kc[e][r] = (63 - s0) | ((63 - s1) << 16);
-      L.b2[e][r] = ((s0 >> 4) << 6) | (((s1 >> 4) << 6) << 16);   // at bits 7:6 of the path byte
+      L.bias8[P][r] = (v3_upper(P, r, 0, a) << 8) | (v3_upper(P, r, 1, a) << 24);
     }
     L.org[r] = (pl * 4 + 2 * r) | ((pl * 4 + 2 * r + 1) << 16);     // bits 5:0 of the path byte
     for (int e = 0; e < 3; e++) {
-      const int nb = e == 0 ? (r ? 0x01000100 : 0) : e == 1 ? L.abit[3] : L.abit[1];   // bias when the phase is 0, 2, 4
-      L.nb2[e][r] = nb | L.b2[e][r]; L.nbo[e][r] = nb | L.org[r];
+      const int P0 = 2 * e;
+      const int s0 = rotl6((r << 5) | a, P0), s1 = rotl6((r << 5) | 16 | a, P0);
+      L.kc[e][r] = ((63 - s0) | ((63 - s1) << 16)) | (L.bias8[P0][r] ^ 0x01000100);
+      const int b2 = ((s0 >> 4) << 6) | (((s1 >> 4) << 6) << 16);   // top two bits of the cells' states at phase P0, at bits 7:6 of the path byte
+      // a window that starts at phase P0: step u runs at phase (P0 + u) % 6
+      L.arm_mid[e][r] = (L.bias8[(P0 + 3) % 6][r] >> 2) | (L.bias8[(P0 + 4) % 6][r] >> 1) | L.bias8[(P0 + 5) % 6][r];
+      L.arm_org[e][r] = L.org[r] | (L.bias8[P0][r] >> 2) | (L.bias8[P0 + 1][r] >> 1) | L.bias8[(P0 + 2) % 6][r];
+      // after the 6th step of a window that started at phase P0 the phase is P0 again: the stamp and the bias of the 7th step
+      L.arm_b2[e][r] = b2 | L.bias8[P0][r];
     }
   }
 }
 
-// ST: 0 plain step; 1 = the window's 6th step (the two oldest inputs are stamped into the path byte together with
-// the bias); 2 = the window's last step (raw[] keeps the survivors' path bytes for the table, v gets bias AND the
-// origin stamp of the next window in the same v_and_or)
+// ST: what happens to the tie-break bits after the step (see the header): 0 nothing (the bits armed earlier serve the next step too);
+// 3 = the window's 3rd step: the biases of steps 4..6 are armed; 1 = the 6th step: the two oldest inputs are stamped into the path byte
+// together with the bias of the 7th; 4 = the 7th step: the bias of the 8th; 2 = the last step: raw[] keeps the survivors' path bytes for the
+// table, v gets the origin stamp of the next window and the biases of its first three steps in the same v_and_or
 template <int P, int ST> __device__ __forceinline__ void v3_step(int (&v)[2], unsigned W, const V3Lane &L, int (&raw)[2])
 {
-  int X[2], Y[2], Yp[2];
+  int X[2], Y[2], mx[2];
   // The label class of a cell depends on bits 0,1,2,4 of its state (parity taps 0x4f, 0x6d without the MSB).  The
   // VGPR index is cell bit 5 = state bit (5+P)%6: at phases 0 and 4 (state bits 5, 3) both VGPRs have the same
   // deltas, at phases 2 and 3 (state bits 1, 2: both parities flip) VGPR 1 has the negated ones.
@@ -156,24 +167,21 @@ template <int P, int ST> __device__ __forceinline__ void v3_step(int (&v)[2], un
     const int D1 = (int)__builtin_amdgcn_perm(0u, W, L.sel[P][1]);
     X[1] = pk_add(v[1], D1); Y[1] = pk_sub(v[1], D1);
   }
-  if (P == 0) { Yp[0] = Y[1]; Yp[1] = Y[0]; }
-  else if (P == 1) { Yp[0] = swap16(Y[0]); Yp[1] = swap16(Y[1]); }
+  if (P == 0) { mx[0] = pk_max(X[0], Y[1]); mx[1] = pk_max(X[1], Y[0]); }
+  else if (P == 1) { mx[0] = pk_max_swap(X[0], Y[0]); mx[1] = pk_max_swap(X[1], Y[1]); }
   else {
 #pragma unroll
     for (int r = 0; r < 2; r++)
-      Yp[r] = P == 2 ? dppb<DPP_ROR8>(Y[r]) : P == 3 ? dppb<DPP_HALF_MIRROR>(Y[r]) : P == 4 ? dppb<DPP_XOR2>(Y[r]) : dppb<DPP_XOR1>(Y[r]);
+      mx[r] = pk_max(X[r], P == 2 ? dppb<DPP_ROR8>(Y[r]) : P == 3 ? dppb<DPP_HALF_MIRROR>(Y[r]) : P == 4 ? dppb<DPP_XOR2>(Y[r]) : dppb<DPP_XOR1>(Y[r]));
   }
   constexpr int PN = (P + 1) % 6;
 #pragma unroll
   for (int r = 0; r < 2; r++) {
-    const int mx = pk_max(X[r], Yp[r]);
-    if (ST == 1) v[r] = (mx & (int)0xfe3ffe3f) | L.nb2[PN / 2][r];
-    else if (ST == 2) { raw[r] = mx; v[r] = (mx & (int)0xfe00fe00) | L.nbo[PN / 2][r]; }
-    else if (PN == 0) v[r] = r ? (mx | 0x01000100) : (mx & (int)0xfefffeff);      // VGPR 1 holds the upper states
-    else {
-      const int nb = PN == 1 ? L.hi_bias : PN == 2 ? L.abit[3] : PN == 3 ? L.abit[2] : PN == 4 ? L.abit[1] : L.abit[0];
-      v[r] = (mx & (int)0xfefffeff) | nb;
-    }
+    if (ST == 0) v[r] = mx[r];
+    else if (ST == 3) v[r] = (mx[r] & (int)0xfe3ffe3f) | L.arm_mid[((PN + 3) % 6) / 2][r];       // the window started at phase PN - 3
+    else if (ST == 1) v[r] = (mx[r] & (int)0xfe3ffe3f) | L.arm_b2[PN / 2][r];                    // PN = the phase the window started at
+    else if (ST == 4) v[r] = (mx[r] & (int)0xfefffeff) | L.bias8[PN][r];
+    else { raw[r] = mx[r]; v[r] = (mx[r] & (int)0xfe00fe00) | L.arm_org[PN / 2][r]; }
   }
 }
 
@@ -185,9 +193,9 @@ template <int P, int ST> __device__ __forceinline__ void v3_step(int (&v)[2], un
 #endif
 template <int P0> __device__ __forceinline__ void v3_window(int (&v)[2], const unsigned (&W)[8], const V3Lane &L, int (&raw)[2])
 {
-  v3_step<(P0 + 0) % 6, 0>(v, W[0], L, raw); V3_YIELD(); v3_step<(P0 + 1) % 6, 0>(v, W[1], L, raw); V3_YIELD(); v3_step<(P0 + 2) % 6, 0>(v, W[2], L, raw); V3_YIELD();
+  v3_step<(P0 + 0) % 6, 0>(v, W[0], L, raw); V3_YIELD(); v3_step<(P0 + 1) % 6, 0>(v, W[1], L, raw); V3_YIELD(); v3_step<(P0 + 2) % 6, 3>(v, W[2], L, raw); V3_YIELD();
   v3_step<(P0 + 3) % 6, 0>(v, W[3], L, raw); V3_YIELD(); v3_step<(P0 + 4) % 6, 0>(v, W[4], L, raw); V3_YIELD(); v3_step<(P0 + 5) % 6, 1>(v, W[5], L, raw); V3_YIELD();
-  v3_step<(P0 + 6) % 6, 0>(v, W[6], L, raw); V3_YIELD(); v3_step<(P0 + 7) % 6, 2>(v, W[7], L, raw);
+  v3_step<(P0 + 6) % 6, 4>(v, W[6], L, raw); V3_YIELD(); v3_step<(P0 + 7) % 6, 2>(v, W[7], L, raw);
 }
 
 // halves of a packed register as sign-extended 32-bit values
@@ -198,11 +206,11 @@ template <int CTRL> __device__ __forceinline__ int min_dpp(int v) { return min(v
 
 // end of a window: best state = first index of the maximum metric (d_viterbi.c:699-711) and, when asked, the
 // renormalisation.  PE = phase after the window.  Key of a cell = (2M + bias ^ 1) << 8 | 63 - state: among equal M the
-// cells holding a lower state (bias 0) win over the upper ones, then the smaller state; one v_xor + v_and_or per VGPR.
+// cells holding a lower state win over the upper ones, then the smaller state (the flag sits in L.kc); one v_and_or per VGPR.
 // Returns the key's low byte (63 - best state in bits 5:0) in every lane of the row.
 template <int PE, bool RENORM> __device__ __forceinline__ int v3_window_end(int (&v)[2], const V3Lane &L)
 {
-  const int kp = pk_max(((v[0] ^ 0x01000100) & (int)0xff00ff00) | L.kc[PE / 2][0], ((v[1] ^ 0x01000100) & (int)0xff00ff00) | L.kc[PE / 2][1]);
+  const int kp = pk_max((v[0] & (int)0xfe00fe00) | L.kc[PE / 2][0], (v[1] & (int)0xfe00fe00) | L.kc[PE / 2][1]);
   int k = max(lo16(kp), hi16(kp));
   k = max_dpp<DPP_XOR1>(k); k = max_dpp<DPP_XOR2>(k); k = max_dpp<DPP_HALF_MIRROR>(k); k = max_dpp<DPP_MIRROR>(k);
   if (RENORM) {
@@ -350,7 +358,7 @@ template <int NTB> __global__ __launch_bounds__(64) void viterbi3_kernel(const u
   const unsigned long long dbg_t0 = wall_clock64();
 #endif
   V3Lane L; v3_init_lane(pl, L);
-  int v[2] = {L.org[0], 0x01000100 | L.org[1]};                    // phase 0: VGPR 1 holds the upper states; origin stamp of window 0
+  int v[2] = {L.arm_org[0][0], L.arm_org[0][1]};                   // all-zero metrics, origin stamp of window 0, tie-break bits of its first three steps
 
   // ---- staging, first half: where block jb starts in the input (row-uniform) and the load of its bytes
   int ph0 = 0, bo0 = 0, off = 0; uint4 q = make_uint4(0, 0, 0, 0);
