@@ -10,7 +10,9 @@ The batch is ONE stream (1 lead-in superframe + N x --superframes payload superf
 superframe boundaries into N x --segments pieces (gr_dvbt_amd/multi.py::plan_cuts, SURVEY 8e); every
 rank (one process per GPU, torch.distributed / RCCL) generates and decodes only ITS pieces, each on its own
 handle and HIP stream, and the decoded packets travel to rank 0 in the design's single collective per step
-(multi.gather_pieces).  After the timed loop rank 0 stitches the pieces of the last step and compares the TS
+(multi.gather_pieces).  --pipeline steps are in flight per piece (default 3): the piece's handles take its steps in turn, each on
+its own HIP stream, so that the next steps' latency-bound front-end kernels run while the Viterbi decoder of the current step holds the machine
+(one step in flight: --pipeline 1; stage_ms_per_piece_solo has those kernel times).  After the timed loop rank 0 stitches the pieces of the last step and compares the TS
 with the packets that were transmitted: the bench fails (exit 1) when a single byte differs.
 
 Prints ONE JSON line on rank 0.
@@ -119,6 +121,9 @@ def hbm_copy_gbs(torch, device):
     return round(best, 1)
 
 
+STAGES = ("acq", "fft", "demod", "inner", "viterbi", "rs", "total")
+
+
 class Job:
     """One stream cut into world x segments pieces; this rank's pieces resident in HBM, one handle + stream each."""
 
@@ -175,11 +180,16 @@ class Job:
                 iq = po.resample(iq / np.float32(rx_const), 70, 64, 1.0)                # what dvbt_tx_demo writes: the 10 Msps stream
                 kw = {"resample": (64, 70), "front_scale": rx_const}
             d_iq = torch.from_numpy(iq.view(np.float32)).cuda()
-            rx = g.Rx(const, cr, mode, max_samples=len(iq), device=local, viterbi_chunk_bytes=chunk, snr_db=snr_db, **kw)
-            rx.set_cut(cu["sym_off"])
             cap = int(len(iq) * 0.45) + 4096
-            self.pieces.append({"iq": d_iq, "n": len(iq), "rx": rx, "stream": torch.cuda.Stream(), "cut": cu, "cap": cap,
-                                "ts_view": torch.as_tensor(_DevView(rx.tap_device_ptr(g.TAP_TS), cap), device=f"cuda:{local}")})
+            depth = max(1, getattr(a, "pipeline", 1))            # handles (each with its own HIP stream) that take this piece's steps in turn
+            rxs, streams, views = [], [], []
+            for _ in range(depth):
+                rx = g.Rx(const, cr, mode, max_samples=len(iq), device=local, viterbi_chunk_bytes=chunk, snr_db=snr_db, **kw)
+                rx.set_cut(cu["sym_off"])
+                rxs.append(rx); streams.append(torch.cuda.Stream())
+                views.append(torch.as_tensor(_DevView(rx.tap_device_ptr(g.TAP_TS), cap), device=f"cuda:{local}"))
+            self.pieces.append({"iq": d_iq, "n": len(iq), "rxs": rxs, "streams": streams, "views": views, "rx": rxs[0], "stream": streams[0],
+                                "cut": cu, "cap": cap, "ts_view": views[0]})
         # samples of the stream this rank is responsible for (overlaps between pieces are overhead, not throughput)
         self.samples_owned = (cuts[min((rank + 1) * nseg, len(cuts)) - 1]["end"] if rank == world - 1 else cuts[(rank + 1) * nseg]["begin"]) - mine[0]["begin"]
         self.samples_decoded = sum(p["n"] for p in self.pieces)
@@ -196,15 +206,30 @@ class Job:
         self.recv = [[torch.empty(self.slot * nseg, dtype=torch.uint8, device=f"cuda:{local}") for _ in range(world)] for _ in range(2)] if (dist and rank == 0) else [None, None]
         self.pending = [None, None]
         self.nstep = 0
+        self.ngather = 0
+        self.inflight = []
         self.reps = None
 
     def step(self):
-        torch, multi, dist = self.torch, self.multi, self.dist
+        """Enqueue this step on the next handle of every piece, then complete the OLDEST step in flight (depth 1: this one).  With depth 2 the
+        front end of step k+1 (acquisition, symbol kernel, TPS, de-interleavers) runs on its own stream while the Viterbi decoder of step k
+        still holds the machine; drain() completes what is left."""
+        depth = len(self.pieces[0]["rxs"])
+        k = self.nstep % depth
         for p in self.pieces:
-            p["rx"].enqueue_device(p["iq"].data_ptr(), p["n"], p["stream"].cuda_stream)
-        self.reps = [p["rx"].finish() for p in self.pieces]
+            p["rxs"][k].enqueue_device(p["iq"].data_ptr(), p["n"], p["streams"][k].cuda_stream)
+        self.inflight.append(k)
+        if len(self.inflight) >= depth:
+            self._complete(self.inflight.pop(0))
+        self.nstep += 1
+
+    def _complete(self, k):
+        torch, multi, dist = self.torch, self.multi, self.dist
+        self.reps = [p["rxs"][k].finish() for p in self.pieces]
+        for p in self.pieces:
+            p["rx"], p["stream"], p["ts_view"] = p["rxs"][k], p["streams"][k], p["views"][k]
         if dist:
-            b = self.nstep & 1
+            b = self.ngather & 1
             if self.pending[b] is not None:
                 self.pending[b].wait()                 # the buffer pair of two steps ago is free again
             for i, (p, r) in enumerate(zip(self.pieces, self.reps)):
@@ -214,9 +239,11 @@ class Job:
                 p["stream"].wait_event(ev)
             self.pending[b] = multi.gather_pieces(self.send[b], self.recv[b], dst=0, async_op=True)
             self.last_buf = b
-        self.nstep += 1
+            self.ngather += 1
 
     def drain(self):
+        while self.inflight:
+            self._complete(self.inflight.pop(0))
         if self.dist:
             for b in range(2):
                 if self.pending[b] is not None:
@@ -261,9 +288,27 @@ class Job:
             res["packet_error_rate"] = bad_packets / max(npk, 1)
         return res
 
+    def stage_avg(self, name):
+        """HIP-event average over the timed steps (every handle averages its own launches since enable_timing, on the stream they ran on)"""
+        v = [rx.stage_ms(name) for p in self.pieces for rx in p["rxs"]]
+        v = [x for x in v if x >= 0]
+        return sum(v) / max(len(v), 1)
+
+    def solo_stage_ms(self, n=5):
+        """stage times with ONE step in flight (no overlap with the next step's front end): the kernels' own durations"""
+        for p in self.pieces:
+            p["rxs"][0].enable_timing(True)            # a new measurement window on the first handle
+        for _ in range(n):
+            for p in self.pieces:
+                p["rxs"][0].enqueue_device(p["iq"].data_ptr(), p["n"], p["streams"][0].cuda_stream)
+            for p in self.pieces:
+                p["rxs"][0].finish()
+        return {k: round(sum(p["rxs"][0].stage_ms(k) for p in self.pieces) / len(self.pieces), 4) for k in STAGES}
+
     def close(self):
         for p in self.pieces:
-            p["rx"].close()
+            for rx in p["rxs"]:
+                rx.close()
 
 
 def extra_workloads(a, torch, g, local):
@@ -271,6 +316,7 @@ def extra_workloads(a, torch, g, local):
     machinery, shorter streams; each is verified like the main line (config 5: post-RS error rate against the transmitted packets)."""
     class A:
         segments = 1
+        pipeline = 1
     res = {}
     for name, wl, snr, nsf, steps in (("config2_2k_qam16_1_2", "2k_qam16_1_2", None, 64, 100), ("config5_8k_qpsk_7_8_awgn14", "8k_qpsk_7_8", 14.0, 16, 100)):
         job = Job(A, torch, g, None, 0, 1, local, wl, nsf, snr=snr)
@@ -320,7 +366,8 @@ def timed_run(job, steps, warmup):
         job.step()
     job.drain()
     for p in job.pieces:
-        p["rx"].enable_timing(True)
+        for rx in p["rxs"]:
+            rx.enable_timing(True)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -351,6 +398,7 @@ def main():
     ap.add_argument("--superframes", type=int, default=64, help="payload superframes per GPU per step (SURVEY 8d: >= 64 for throughput runs)")
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--segments", type=int, default=1, help="pieces per GPU: the rank's part of the stream is cut again, one handle + HIP stream per piece")
+    ap.add_argument("--pipeline", type=int, default=3, help="steps in flight per piece: handles (own HIP stream each) that take the piece's steps in turn")
     ap.add_argument("--from-file-rate", action="store_true",
                     help="feed the 10 Msps file format: rational_resampler 64/70 + multiply_const run on the device in front of the chain "
                          "(SURVEY 8f row 2; samples are then counted at the 10 Msps input; single piece only)")
@@ -396,7 +444,10 @@ def main():
         # bytes out (6048 + 3969 B per 8k QAM64 7/8 OFDM symbol); launch duration from HIP events
         # recorded on the piece's own stream; averages over this rank's pieces
         d = job.dims
-        vit_ms = sum(p["rx"].stage_ms("viterbi") for p in job.pieces) / nseg
+        depth = len(job.pieces[0]["rxs"])
+        vit_ms = job.stage_avg("viterbi")                         # average over the timed steps' launches
+        stage_avg = {k: round(job.stage_avg(k), 4) for k in STAGES}
+        solo = job.solo_stage_ms() if depth > 1 else None
         alg_bytes = sum(r.n_out_symbols * d.payload_length + r.n_viterbi_bytes for r in reps) / nseg
         achieved = alg_bytes / (vit_ms * 1e-3) / 1e9 if vit_ms > 0 else 0.0
         n_ts = check.get("ts_bytes") or sum(int(r.n_ts_bytes) for r in reps)
@@ -407,20 +458,23 @@ def main():
             "data": "synthetic", "x_realtime": round(msps / REALTIME_MSPS / world, 1), "timed_region_s": round(dt, 3),
             "config": {"workload": f"{a.workload} GI 1/32 RX chain, " + (f"AWGN {a.snr} dB" if a.snr is not None else "clean TX->RX loopback")
                                    + (", input at the 10 Msps file rate (resampler 64/70 + scale on the device)" if a.from_file_rate else ""),
-                       "stream_superframes": job.nsf, "superframes_per_gpu": a.superframes, "pieces_per_gpu": nseg,
+                       "stream_superframes": job.nsf, "superframes_per_gpu": a.superframes, "pieces_per_gpu": nseg, "steps_in_flight": depth,
                        "stream_samples": n_stream, "samples_decoded_per_gpu_per_step": job.samples_decoded,
                        "parallelism": f"one stream cut into {world * nseg} pieces at superframe boundaries, {nseg} per GPU" + (" + one RCCL gather of TS per step" if world > 1 else ""),
                        "ts_bytes_per_step": n_ts, "status": [int(r.status) for r in reps], "rs_fail_words": [int(r.rs_fail_words) for r in reps],
                        **check},
             "roofline": {"bound": "valu", "kernel": "viterbi3_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                         "note": "the dominant kernel is bound by VALU issue, not by HBM: it is made of half-rate instructions (v_pk_*, v_perm, v_and_or, DPP: 4 cycles "
-                                 "per wave64 instruction and SIMD, profiles/r02_ubench_valu.json) and spends 4.5 cycles per instruction (DESIGN.md 5); "
-                                 "achieved/peak/frac are the HBM figures the contract asks for; traffic (PMC) is in profiles/, not measured in this run",
+                         "note": "the dominant kernel is bound by VALU issue, not by HBM: every wave64 instruction of its mix (v_pk_*, v_perm, v_and_or, DPP) occupies the "
+                                 "SIMD for 4 cycles (profiles/r02_ubench_valu.json, r02_ubench_mix.json; DESIGN.md 5); achieved/peak/frac are the HBM figures the contract "
+                                 "asks for, from avg_launch_ms = HIP-event average over the timed steps, during which the next steps' front-end kernels share the machine "
+                                 "(config.steps_in_flight); solo_launch_ms = the same launch with one step in flight; traffic (PMC) is in profiles/, not measured in this run",
                          "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(vit_ms, 4),
+                         "solo_launch_ms": solo["viterbi"] if solo else round(vit_ms, 4),
                          "chain_frac": round(msps / world * 1e6 * (8 + n_ts / n_stream) / 1e9 / HBM_PEAK_GBS, 6),
                          "hbm_copy_gbs": hbm_copy_gbs(torch, f"cuda:{local}")},
-            "stage_ms_per_piece": {k: round(sum(p["rx"].stage_ms(k) for p in job.pieces) / nseg, 4) for k in ("acq", "fft", "demod", "inner", "viterbi", "rs", "total")},
+            "stage_ms_per_piece": stage_avg,
+            "stage_ms_per_piece_solo": solo,
         }
     job.close()
     if rank == 0 and world == 1 and not a.no_extras and not a.from_file_rate:

@@ -80,6 +80,7 @@ struct Tables {          // device lookup tables for one configuration
   int16_t *cpilot = nullptr, *tps = nullptr; float *known = nullptr, *pref = nullptr;
   uint16_t *pay_c = nullptr, *pay_L = nullptr, *pay_R = nullptr, *tps_L = nullptr, *tps_R = nullptr;
   uint16_t *pil_k = nullptr, *pay_Li = nullptr, *pay_Ri = nullptr, *tps_Li = nullptr, *tps_Ri = nullptr; uint8_t *pay_d = nullptr, *tps_d = nullptr; int np[4] = {0, 0, 0, 0};
+  uint32_t *pay_pack = nullptr;              // [4][payload]: carrier | rank of the left estimation carrier << 13 | distance to it << 23 (one word per payload carrier)
   uint16_t *H = nullptr, *Hinv = nullptr; float2 *points = nullptr; uint8_t *label_tab = nullptr; int nlev = 0; float inv_step = 0.f, guard = 0.f;
   uint8_t *mul_alpha = nullptr, *gexp = nullptr, *glog = nullptr, *prbs = nullptr;
   bool front = false, inner = false, rs = false;
@@ -102,6 +103,7 @@ struct Tables {          // device lookup tables for one configuration
     if ((r = upload(c16, &cpilot)) || (r = upload(t16, &tps)) || (r = upload(pr, &pref)) || (r = upload(kn, &known))) return r;
     std::vector<uint16_t> pc, pl, prr, tl, trr, pk((size_t)4 * DEMOD_NP, 0), pli, pri, tli, tri;
     std::vector<uint8_t> pd, td;
+    std::vector<uint32_t> pp;
     for (int s = 0; s < 4; s++) {
       PatternTables pt = pattern_tables(d, s);
       if ((int)pt.pay_c.size() != d.payload) return fail(DVBT_ERR_INVALID, "payload carrier table size mismatch");
@@ -110,6 +112,7 @@ struct Tables {          // device lookup tables for one configuration
       for (size_t i = 0; i < pt.pil_k.size(); i++) pk[(size_t)s * DEMOD_NP + i] = (uint16_t)(pt.pil_k[i] | (pr[pt.pil_k[i]] < 0.f ? 0x8000 : 0));   // carrier | sign of its reference value
       pli.insert(pli.end(), pt.pay_Li.begin(), pt.pay_Li.end()); pri.insert(pri.end(), pt.pay_Ri.begin(), pt.pay_Ri.end());
       pd.insert(pd.end(), pt.pay_d.begin(), pt.pay_d.end());
+      for (size_t i = 0; i < pt.pay_c.size(); i++) pp.push_back((uint32_t)pt.pay_c[i] | ((uint32_t)pt.pay_Li[i] << 13) | ((uint32_t)pt.pay_d[i] << 23));
       tli.insert(tli.end(), pt.tps_Li.begin(), pt.tps_Li.end()); tri.insert(tri.end(), pt.tps_Ri.begin(), pt.tps_Ri.end());
       td.insert(td.end(), pt.tps_d.begin(), pt.tps_d.end());
       pc.insert(pc.end(), pt.pay_c.begin(), pt.pay_c.end()); pl.insert(pl.end(), pt.pay_L.begin(), pt.pay_L.end());
@@ -118,7 +121,7 @@ struct Tables {          // device lookup tables for one configuration
     }
     if ((r = upload(pc, &pay_c)) || (r = upload(pl, &pay_L)) || (r = upload(prr, &pay_R)) || (r = upload(tl, &tps_L)) || (r = upload(trr, &tps_R))) return r;
     if ((r = upload(pk, &pil_k)) || (r = upload(pli, &pay_Li)) || (r = upload(pri, &pay_Ri)) || (r = upload(pd, &pay_d)) || (r = upload(tli, &tps_Li)) ||
-        (r = upload(tri, &tps_Ri)) || (r = upload(td, &tps_d))) return r;
+        (r = upload(tri, &tps_Ri)) || (r = upload(td, &tps_d)) || (r = upload(pp, &pay_pack))) return r;
     front = true;
     return DVBT_OK;
   }
@@ -167,11 +170,11 @@ struct Tables {          // device lookup tables for one configuration
   DemodTables demod_tables() const { DemodTables T; T.cpilot = cpilot; T.known_diff = known; T.tps = tps; T.pilot_ref = pref;
     T.pay_c = pay_c; T.pay_L = pay_L; T.pay_R = pay_R; T.tps_L = tps_L; T.tps_R = tps_R;
     T.pil_k = pil_k; for (int i = 0; i < 4; i++) T.np[i] = np[i];
-    T.pay_Li = pay_Li; T.pay_Ri = pay_Ri; T.pay_d = pay_d; T.tps_Li = tps_Li; T.tps_Ri = tps_Ri; T.tps_d = tps_d; return T; }
+    T.pay_Li = pay_Li; T.pay_Ri = pay_Ri; T.pay_d = pay_d; T.tps_Li = tps_Li; T.tps_Ri = tps_Ri; T.tps_d = tps_d; T.pay_pack = pay_pack; return T; }
   RsTables rs_tables() const { RsTables T; T.div_tab = mul_alpha; T.gexp = gexp; T.glog = glog; return T; }
   ~Tables()
   {
-    void *all[] = {tw, perm, cpilot, tps, known, pref, pay_c, pay_L, pay_R, tps_L, tps_R, pil_k, pay_Li, pay_Ri, pay_d, tps_Li, tps_Ri, tps_d, H, Hinv, points, label_tab, mul_alpha, gexp, glog, prbs};
+    void *all[] = {tw, perm, cpilot, tps, known, pref, pay_c, pay_L, pay_R, tps_L, tps_R, pil_k, pay_Li, pay_Ri, pay_d, tps_Li, tps_Ri, tps_d, pay_pack, H, Hinv, points, label_tab, mul_alpha, gexp, glog, prbs};
     for (void *q : all) if (q) (void)hipFree(q);
   }
 };
@@ -328,7 +331,13 @@ extern "C" int dvbt_rx_set_cut(dvbt_rx *h, const dvbt_rx_cut *cut)
   return DVBT_OK;
 }
 
-extern "C" int dvbt_rx_enable_timing(dvbt_rx *h, int enable) { if (!h) return DVBT_ERR_INVALID; h->timing = enable != 0; return DVBT_OK; }
+extern "C" int dvbt_rx_enable_timing(dvbt_rx *h, int enable)
+{
+  if (!h) return DVBT_ERR_INVALID;
+  h->timing = enable != 0;
+  if (enable) { for (int i = 0; i <= ST_END; i++) h->acc_ms[i] = 0.0; h->n_timed = 0; }     // a new measurement window: dvbt_rx_stage_ms averages from here on
+  return DVBT_OK;
+}
 
 // debug taps that are not pipeline buffers are allocated on first request
 static int ensure_taps(dvbt_rx *h)

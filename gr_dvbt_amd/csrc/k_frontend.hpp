@@ -821,6 +821,7 @@ struct DemodTables {
   int np[4];                               // estimation carriers per pattern
   const uint16_t *pay_Li, *pay_Ri; const uint8_t *pay_d;   // [4][payload]
   const uint16_t *tps_Li, *tps_Ri; const uint8_t *tps_d;   // [4][n_tps]
+  const uint32_t *pay_pack;                // [4][payload]: pay_c | pay_Li << 13 | pay_d << 23 (pay_Ri = pay_Li + 1 always)
 };
 constexpr int DEMOD_NP = 768;              // >= estimation carriers of a symbol (569 scattered + 177 continual - shared)
 struct SymInfo { int freq_offset; int mod_index; float cfc; int pad; };

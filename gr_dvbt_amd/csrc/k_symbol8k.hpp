@@ -4,7 +4,8 @@
 //  * PERSISTENT workgroups (two per CU): workgroup w takes symbols w, w + G, w + 2G, ... and loads the samples of its next symbol
 //    into registers while it equalises the current one, so the HBM latency of a symbol's 64 KB is never exposed;
 //  * with G a multiple of 4 a workgroup meets the same scattered-pilot pattern every time: the equaliser's per-carrier table rows
-//    (carrier, bracketing pilots, distance) stay in registers and are reloaded only when the pattern found differs (lock transients);
+//    (carrier, bracketing pilots, distance: one packed word, L2 resident) are requested for the expected pattern before the pattern search
+//    has run and again only when the pattern found differs (lock transients); the estimation-carrier list stays in registers;
 //  * the FFT is 8192 = 16 x 16 x (2 x 16) with the first radix-16 pass done on the registers the samples were loaded into
 //    (element n = tid + 512 i IS the butterfly of thread tid), and the last pass written in natural, fft-shifted order: no
 //    separate digit-reversal pass, 3 LDS stores + 2 LDS loads per point instead of 6 + 5, and 7 barriers per symbol instead of 13;
@@ -221,9 +222,9 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
   if (tid >= 256) { const int q = tid - 256, j = q & 15, pat = (q >> 4) & 3; if (j < 10) pat_ref = T.pilot_ref[3 * pat + 12 * j]; }
   const float half_n = 0.5f * (float)ip.nlev, top = (float)ip.nlev - 0.5f;
 
-  // per-pattern table rows of this thread, kept across symbols
+  // the pattern (symbol index mod 4) this workgroup expects: with G a multiple of 4 it is the same at every symbol of a locked stream, so the
+  // per-carrier table rows of a symbol (T.pay_pack, L2 resident) are requested before the pattern search has confirmed it
   int cur_mod = -1;
-  unsigned tcl[S8_IT];                                            // carrier | rank of the left bracketing estimation carrier << 13 | distance to it << 23 (the right one is rank + 1)
   unsigned est01 = 0, tps_ld = 0; int np = 0;
 
   SymMeta m = meta[s];
@@ -242,8 +243,7 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
     // the loop (the 30 twiddle powers, ~80 LDS addresses, the root constants) costs more registers than the loop has
     int tid = tid0; v2f wA = w1A, wB = w1B;
     asm volatile("" : "+v"(tid), "+v"(wA), "+v"(wB));
-    S8Roots R = s8_roots();
-    asm volatile("" : "+v"(R.K8), "+v"(R.K16), "+v"(R.K316), "+v"(R.H));
+    const S8Roots R = s8_roots();
     const int s_next = s + G;
     const bool more = s_next < nsym;
     const bool last = !p.keep_last && s + 1 >= nsym;             // no output for the last item (the reference's demod consumes n+1 items)
@@ -316,6 +316,13 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
     }
     __syncthreads();
     auto X = [&](int b) -> v2f { return x[s8_swz2(b)]; };
+    unsigned tcl[S8_IT];                                          // carrier | rank of the left bracketing estimation carrier << 13 | distance to it << 23
+    auto load_rows = [&](int md) {
+      const uint32_t *pp = T.pay_pack + (size_t)md * S8_PAY;
+#pragma unroll
+      for (int it = 0; it < S8_IT; it++) { const int i = tid + it * S8_T; tcl[it] = pp[i < S8_PAY ? i : S8_PAY - 1]; }
+    };
+    if (!last && !(S8_EXP & 1)) load_rows(cur_mod < 0 ? 0 : cur_mod);
     if (TAPS && fft_tap) {
 #pragma unroll
       for (int i = 0; i < 16; i++) { const int b = tid + i * S8_T; fft_tap[(size_t)s * N + b] = s8_f(X(b)); }
@@ -385,13 +392,8 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
       for (int i = 0; i < 16; i++) vin[i] = iq[low + tid + i * S8_T];
     }
     if (mod != cur_mod) {                                         // workgroup-uniform; in lock only at a workgroup's first symbol
+      load_rows(mod);
       cur_mod = mod;
-      const size_t tb = (size_t)mod * S8_PAY;
-#pragma unroll
-      for (int it = 0; it < S8_IT; it++) {
-        const int i = tid + it * S8_T, ic = i < S8_PAY ? i : S8_PAY - 1;
-        tcl[it] = (unsigned)T.pay_c[tb + ic] | ((unsigned)T.pay_Li[tb + ic] << 13) | ((unsigned)T.pay_d[tb + ic] << 23);
-      }
       np = mod == 0 ? T.np[0] : mod == 1 ? T.np[1] : mod == 2 ? T.np[2] : T.np[3];
       const uint16_t *pk = T.pil_k + (size_t)mod * DEMOD_NP;      // carrier | sign of its reference << 15
       est01 = (unsigned)pk[tid < np ? tid : 0] | ((unsigned)pk[tid + S8_T < np ? tid + S8_T : 0] << 16);
@@ -439,8 +441,8 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
         for (int it = 0; it < S8_IT; it++) {
           const int i = tid + it * S8_T;
           if (i >= S8_PAY) break;
-          const size_t tb = (size_t)mod * S8_PAY + i;
-          const v2f e = equalise(T.pay_c[tb], T.pay_Li[tb], T.pay_d[tb]);
+          const unsigned w = T.pay_pack[(size_t)mod * S8_PAY + i];
+          const v2f e = equalise((int)(w & 0x1fffu), (int)((w >> 13) & 0x3ffu), (int)(w >> 23));
           int f = demap_fast(s8_f(e), pts, label_of, ip);
           if (f < 0) f = demap_all(s8_f(e), pts, ip.csize);
           lab[i] = (uint8_t)f;

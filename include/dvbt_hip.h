@@ -357,8 +357,8 @@ int  dvbt_rx_segment_finish(dvbt_rx *h, dvbt_rx_report *report);
 int64_t dvbt_rx_read_tap(dvbt_rx *h, int tap, void *dst_host, size_t cap_bytes);
 /* device pointer of a tap's buffer (for RCCL gathers of the decoded packets) */
 void *dvbt_rx_tap_device_ptr(dvbt_rx *h, int tap);
-/* average device time in ms of the named stage over all enqueues since create (HIP events on the
- * segment's stream); stage names: "acq","fft","demod","inner","viterbi","rs","total" */
+/* average device time in ms of the named stage over the segments finished since the last
+ * dvbt_rx_enable_timing(h, 1) (HIP events on the segment's stream); stage names: "acq","fft","demod","inner","viterbi","rs","total" */
 double dvbt_rx_stage_ms(dvbt_rx *h, const char *stage);
 int  dvbt_rx_enable_timing(dvbt_rx *h, int enable);
 /* allocate (1) / free (0) the debug-only taps ACQ, DEMAP, SYMDEINT, DEINT; the other taps are

@@ -19,18 +19,26 @@ for f in sorted(glob.glob(os.path.join(root, "gpurun_out", "pmc", "*", "*counter
         for c, v in acc[k].items():
             gmax = max(g for g, _ in v)                      # the timed steps' dispatches (the pre-scan's are smaller)
             big = [x for g, x in v if g == gmax]
+            top = max(big)                                   # persistent kernels launch the same grid for the pre-scan's short stream: keep the full-size dispatches
+            big = [x for x in big if x >= 0.5 * top]
             out.setdefault(k, {})[c] = sum(big) / len(big)
 if pmc_only:
     for k, d in out.items():
         if d.get("GRBM_GUI_ACTIVE", 0) > 200000 or "viterbi" in k:
             print(k, {c: round(v, 1) for c, v in sorted(d.items())})
     sys.exit(0)
-prof = sorted(glob.glob(os.path.join(root, "gpurun_out", "prof*", "*kernel_stats.csv")), key=os.path.getmtime)[-1]
-shutil.copy(prof, os.path.join(root, "profiles", f"{tag}_kernel_stats_8k_qam64_7_8_65sf.csv"))
+prof = sorted(glob.glob(os.path.join(root, "gpurun_out", "prof_final", "*kernel_stats.csv")), key=os.path.getmtime)[-1]
+shutil.copy(prof, os.path.join(root, "profiles", f"{tag}_kernel_stats_8k_qam64_7_8_65sf.csv"))                      # the default command (3 steps in flight)
+solo = sorted(glob.glob(os.path.join(root, "gpurun_out", "prof_solo", "*kernel_stats.csv")), key=os.path.getmtime)
+if solo:
+    shutil.copy(solo[-1], os.path.join(root, "profiles", f"{tag}_kernel_stats_8k_qam64_7_8_65sf_one_step_in_flight.csv"))   # bench.py --pipeline 1: the kernels' own durations
+    prof = solo[-1]
+if os.path.exists(os.path.join(root, "gpurun_out", "pipeline_depth.jsonl")):
+    shutil.copy(os.path.join(root, "gpurun_out", "pipeline_depth.jsonl"), os.path.join(root, "profiles", f"{tag}_pipeline_depth.jsonl"))
 b = json.load(open(os.path.join(root, "gpurun_out", "bench_final.json")))
 json.dump(b, open(os.path.join(root, "profiles", f"{tag}_bench_n1.json"), "w"), indent=1)
 pb = json.load(open(os.path.join(root, "gpurun_out", "pmc", "FETCH_SIZE.json")))
-summary = {"command": "tools/pmc.sh: rocprofv3 --pmc <group> --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --superframes 64 (one pass per counter group: FETCH_SIZE | WRITE_SIZE | SQ issue counters | LDS counters); per kernel the average over its largest dispatches (the timed steps)",
+summary = {"command": "tools/pmc.sh: rocprofv3 --pmc <group> --output-format csv -- python bench.py --steps 2 --warmup 1 --pipeline 1 --no-cpu-baseline --no-extras --superframes 64 (one pass per counter group: FETCH_SIZE | WRITE_SIZE | SQ issue counters | LDS counters); per kernel the average over its largest dispatches (the timed steps)",
            "workload": pb["config"],
            "note": "FETCH_SIZE/WRITE_SIZE in KB per dispatch. gfx950: FETCH_SIZE counts 64 B per 128 B request on coalesced streams, so it is doubled in hbm_bytes_corrected (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported. SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* count quad-cycles.",
            "viterbi_algorithmic_bytes": pb["roofline"]["algorithmic_bytes_per_launch"], "kernels": {}}
