@@ -227,7 +227,7 @@ template <int PE, bool RENORM> __device__ __forceinline__ int v3_window_end(int 
 // Two traceback chains per lane: the calls (windows) pl and 16+pl of one block of a decoder.
 struct V3Trace {
   int z[2];             // current cell (storage index)
-  int wsh[2];           // ring row of the window whose table is read next (<< 8) | decoder row
+  int wsh[2];           // ring row of the window whose table is read next (<< 8, counts down past zero: only bits 13:8 are used) | decoder row << 6
   int wlast[2];         // the window a chain ends in (relative index)
   bool ok[2];
   long long ob[2];      // output byte of the call
@@ -239,8 +239,8 @@ __device__ __forceinline__ void v3_hop(V3Trace &T, const unsigned char *tab, int
 #pragma unroll
   for (int q = 0; q < 2; q++) {
     const unsigned t = tab[T.z[q]];                                  // z holds the full LDS index
-    T.wsh[q] = ((T.wsh[q] - 256) & 0x3f00) | rowc;
-    T.z[q] = (int)((t & 63u) | (unsigned)T.wsh[q]);
+    T.wsh[q] -= 256;                                                 // one ring row back; the decoder row rides in bits 7:6, the wrap is the mask below
+    T.z[q] = (T.wsh[q] & 0x3fc0) | ((int)t & ~0x3fc0);               // one v_bfi: ring row and decoder row from wsh, the origin (bits 5:0) from the path byte
   }
 }
 // the decoded byte of a call: (state at the start of the last window of the chain) << 2 | its two oldest inputs.
