@@ -316,7 +316,7 @@ def extra_workloads(a, torch, g, local):
     machinery, shorter streams; each is verified like the main line (config 5: post-RS error rate against the transmitted packets)."""
     class A:
         segments = 1
-        pipeline = 1
+        pipeline = a.pipeline
     res = {}
     for name, wl, snr, nsf, steps in (("config2_2k_qam16_1_2", "2k_qam16_1_2", None, 64, 100), ("config5_8k_qpsk_7_8_awgn14", "8k_qpsk_7_8", 14.0, 16, 100)):
         job = Job(A, torch, g, None, 0, 1, local, wl, nsf, snr=snr)
@@ -324,7 +324,7 @@ def extra_workloads(a, torch, g, local):
         chk = job.verify()
         res[name] = {"value": round(job.n_total * steps / dt / 1e6, 2), "unit": "Msamples/s", "x_realtime": round(job.n_total * steps / dt / 1e6 / REALTIME_MSPS, 1),
                      "ms_per_step": round(dt / steps * 1e3, 3), "stream_superframes": job.nsf, "stream_samples": job.n_total, "steps": steps,
-                     "rs_fail_words": [int(r.rs_fail_words) for r in job.reps], "rs_corrected_symbols": [int(r.rs_corrected_symbols) for r in job.reps], **chk}
+                     "steps_in_flight": a.pipeline, "rs_fail_words": [int(r.rs_fail_words) for r in job.reps], "rs_corrected_symbols": [int(r.rs_corrected_symbols) for r in job.reps], **chk}
         job.close()
     return res
 
