@@ -179,7 +179,7 @@ struct Tables {          // device lookup tables for one configuration
   }
 };
 
-// A7: 4 chunks per wavefront, one-wave workgroups (k_viterbi3.hpp)
+// A7: 4 chunks per wavefront, V3_WGW independent wavefronts per workgroup (k_viterbi3.hpp)
 static void launch_viterbi(hipStream_t s, const uint8_t *in, uint8_t *out, const RxState *st, long long steps_fixed, const VitParams &vp,
                            long long in_base, long long out_lo, long long max_out_bytes)
 {
@@ -506,7 +506,7 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
   VitParams vp = h->vp;
   if (h->prm.viterbi_chunk_bytes <= 0) {
     // chunk size chosen per segment so that the wavefront count is a whole number of "rounds" of the resident
-    // wavefront slots (4 chunks per wavefront, V3_WAVES_PER_CU one-wave workgroups per CU: 2 per SIMD): equal-length chunks then
+    // wavefront slots (4 chunks per wavefront, V3_WAVES_PER_CU wavefronts per CU: 2 per SIMD): equal-length chunks then
     // finish together instead of leaving a partial last round, and longer chunks amortise the warm-up +
     // traceback overlap (V3_WARM + ntraceback - 1 windows per chunk).  Measured on 65 superframes: 3 rounds of
     // ~2900-byte chunks beat 5 rounds of ~1700 (less overlap) and 1 round of ~8600 (the SIMD's arbiter favours the older of its

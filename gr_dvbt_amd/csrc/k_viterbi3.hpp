@@ -69,7 +69,13 @@ inline VitParams make_vit_params(const Dims &d, int bsize, int chunk_bytes)
 
 __device__ __forceinline__ int rotl6(int c, int p) { return ((c << p) | (c >> (6 - p))) & 63; }
 
-constexpr int V3_WGW = 1;          // wavefronts per workgroup (independent: no barrier).  Four-wave workgroups were measured equal (round 2)
+#ifndef V3_WGW_N
+#define V3_WGW_N 4
+#endif
+constexpr int V3_WGW = V3_WGW_N;    // wavefronts per workgroup: independent (no barrier), each with its own slice of the LDS arrays.  Alone on the machine one-wave and
+                                   // four-wave workgroups decode equally fast (3.63 / 3.70 ms); four waves make the workgroup 79 KB of LDS, the size of the symbol kernel's
+                                   // (76 KB), so that with several segments in flight a retiring workgroup of either kernel makes room for one of the other and the two
+                                   // kernels share the CUs instead of queueing: 4.42 against 4.53 ms per step (bench.py --pipeline 3)
 #ifndef V3_EXP
 #define V3_EXP 0                   // tools/vit_kbench.hip only, never the product library (cost attribution; the output is wrong for bits 1..8, 256):
                                    // 1 no traceback, 2 no window end, 4 no path-byte store, 8 stage once, 16 record every wavefront's SIMD and
@@ -79,11 +85,11 @@ constexpr int V3_WGW = 1;          // wavefronts per workgroup (independent: no 
 constexpr int V3_WARM = 72;        // warm-up windows before a chunk's first byte
 constexpr int V3_BLK = 24;         // windows per forward block (multiple of 6: phase cycle x renormalisation cadence)
 constexpr int V3_RINGW = 64;       // windows kept in the LDS ring (power of two, >= 2*V3_BLK - 12 + max ntraceback - 1: the traceback of a
-                                   // block runs during the first 12 windows of the next one).  20 KB of LDS per one-wave workgroup = 2 wavefronts
+                                   // block runs during the first 12 windows of the next one).  20 KB of LDS per wavefront = 2 wavefronts
                                    // per SIMD.  A 32-window ring with traceback groups of six windows (3 wavefronts per SIMD) was built and
                                    // measured in round 2: +14 % instructions for -7 % cycles per instruction, 4.33 ms against 4.03 ms
                                    // (tools/experiments/viterbi_w3_ring32.patch, profiles/r02_viterbi_attribution.json)
-constexpr int V3_WAVES_PER_CU = 4 * 2; // one-wave workgroups resident per CU (3 per SIMD; the kernel is built with amdgpu_waves_per_eu(3, 3))
+constexpr int V3_WAVES_PER_CU = 4 * 2; // wavefronts resident per CU (LDS: 2 per SIMD)
 constexpr int V3_CBW = 17;         // words of compacted received bits per decoder and block (192 steps need <= 384 + 23 bits)
 
 typedef short v3pk __attribute__((ext_vector_type(2)));
@@ -314,12 +320,14 @@ template <bool HOPS, int HOP0, int NTB> __device__ __forceinline__ void v3_fwd_s
 #if V3_EXP & 16
 __device__ unsigned long long *v3_dbg;     // tools/vit_kbench.hip: (hw id, start, end in 100 MHz ticks) per wavefront
 #endif
-template <int NTB> __global__ __launch_bounds__(64) void viterbi3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const RxState *st,
+template <int NTB> __global__ __launch_bounds__(64 * V3_WGW) void viterbi3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const RxState *st,
                                                       long long steps_fixed, VitParams vp, long long in_base, long long out_lo)
 {
-  __shared__ __attribute__((aligned(16))) unsigned char tab[V3_RINGW * 4 * 64];   // path bytes: [window][decoder][cell z]  (the ppresult ring)
-  __shared__ __attribute__((aligned(16))) unsigned wbuf[4 * V3_BLK * 8];          // step words: [decoder][step in block]
-  __shared__ unsigned char bests[4 * V3_RINGW];                                    // best state per window
+  __shared__ __attribute__((aligned(16))) unsigned char tab_[V3_WGW][V3_RINGW * 4 * 64];   // path bytes: [window][decoder][cell z]  (the ppresult ring)
+  __shared__ __attribute__((aligned(16))) unsigned wbuf_[V3_WGW][4 * V3_BLK * 8];          // step words: [decoder][step in block]
+  __shared__ unsigned char bests_[V3_WGW][4 * V3_RINGW];                                    // best state per window
+  const int wv = V3_WGW > 1 ? (int)(threadIdx.x >> 6) : 0;
+  unsigned char *const tab = tab_[wv]; unsigned *const wbuf = wbuf_[wv]; unsigned char *const bests = bests_[wv];
   // compacted received bits per decoder (MSB first): V3_CBW words at the head of the decoder's wbuf row.  stage_words reads them (every
   // lane its two words) before the wavefront writes the block's step words over them, and the previous block's step words are dead by
   // then; a wavefront's LDS operations execute in order.  The overlay keeps the workgroup at 19,776 B of LDS: eight workgroups per CU
@@ -334,7 +342,7 @@ template <int NTB> __global__ __launch_bounds__(64) void viterbi3_kernel(const u
   const long long total_out = total_steps / 8 - vp.ntb;
   const int B = vp.chunk_bytes, m = vp.m;
   constexpr int ntb = NTB;                                         // == vp.ntb (the host picks the instantiation)
-  const long long chunk0 = (long long)blockIdx.x * 4;   // V3_WGW == 1
+  const long long chunk0 = ((long long)blockIdx.x * V3_WGW + wv) * 4;
   if (out_lo + chunk0 * B >= total_out) return;                   // whole wavefront idle
   const long long b0 = out_lo + (chunk0 + dd) * B;                // this lane's decoder
   const bool dec_active = b0 < total_out;
