@@ -36,7 +36,10 @@ namespace dvbt {
 constexpr int S8_N = 8192, S8_T = 512, S8_PAY = 6048, S8_NCP = 177, S8_NTPS = 68, S8_ZL = 688;
 constexpr int S8_IT = (S8_PAY + S8_T - 1) / S8_T;             // payload carriers per thread (12)
 constexpr size_t S8_LDS_BYTES = (size_t)S8_N * 8 + DEMOD_NP * 8 + 2 * 128 * 8 + 64 * 8 + 192 * 4 + 16 * 4 + 64 * 4 + 192 * 2 + 64;
-inline int s8_grid(int cus) { return (2 * cus) & ~3; }        // two workgroups per CU, a multiple of the pattern period
+#ifndef S8_WG_PER_CU
+#define S8_WG_PER_CU 2
+#endif
+inline int s8_grid(int cus) { return (S8_WG_PER_CU * cus) & ~3; }   // two workgroups per CU (what the LDS holds), a multiple of the pattern period
 
 // layout of the first two passes: a = k1 * 512 + (index inside the 512-point sub-transform k1).  Bits 3:0 are XORed with bits 8:5 and bit 4
 // with bit 9, so that 16 rows of 32 (stride 32) and two neighbouring sub-transforms land on 32 distinct bank pairs

@@ -479,7 +479,7 @@ template <int NTB> __global__ __launch_bounds__(64 * V3_WGW) void viterbi3_kerne
     unsigned id, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    unsigned long long *d = v3_dbg + 3 * (long long)blockIdx.x;
+    unsigned long long *d = v3_dbg + 3 * ((long long)blockIdx.x * V3_WGW + wv);
     d[0] = (id & 0xffffu) | ((xcc & 0xfu) << 16); d[1] = dbg_t0; d[2] = wall_clock64();
   }
 #endif
