@@ -252,11 +252,12 @@ struct dvbt_rx {
   float2 *tps_prev = nullptr; DescrRun *descr_runs = nullptr; int *descr_nruns = nullptr;
   int n_periods = 1; size_t seg_offset = 0;
   int sym_grid = 512;                       // workgroups of symbol8k_kernel (two per CU)
+  int *sym_ticket = nullptr;                // its symbol counter
 };
 
 static void rx_free(dvbt_rx *h)
 {
-  void *all[] = {h->tps_prev, h->descr_runs, h->descr_nruns, h->centre, h->anchor_pos, h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags, h->trk_eps, h->d_iq, h->rs_iq, h->acq_carry, h->g_init, h->l_init, h->g_trk, h->l_trk, h->meta, h->st, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
+  void *all[] = {h->tps_prev, h->descr_runs, h->descr_nruns, h->centre, h->anchor_pos, h->sym_ticket, h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags, h->trk_eps, h->d_iq, h->rs_iq, h->acq_carry, h->g_init, h->l_init, h->g_trk, h->l_trk, h->meta, h->st, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
                  h->info, h->maj, h->sym_index, h->labels, h->symdeint_tap, h->bitdeint, h->vit, h->deint_tap, h->rs_out, h->ts_out};
   for (void *q : all) if (q) (void)hipFree(q);
   if (h->st_host) (void)hipHostFree(h->st_host);
@@ -315,6 +316,7 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   for (int i = 0; i < ST_COUNT; i++) RXHIP(hipEventCreate(&h->ev[i]));
   h->ev_ready = true;
   RXCHK(set_lds((const void *)derot_fft_demod_kernel, fused_lds_bytes_host((int)N)));
+  RXHIP(hipMalloc((void **)&h->sym_ticket, 64));
   RXCHK(set_lds((const void *)symbol8k_kernel<false>, S8_LDS_BYTES)); RXCHK(set_lds((const void *)symbol8k_kernel<true>, S8_LDS_BYTES));
   { int ncu = 256; (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->prm.device); h->sym_grid = s8_grid(ncu); }
   RXCHK(set_lds((const void *)inner_kernel<6>, inner_lds_bytes(P)));
@@ -460,14 +462,15 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
   }
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_FFT], s));
   // A1 tail + A2 + A3 in one kernel: the FFT item of a symbol never leaves LDS (acq/fft taps are written only when enabled)
+  if (N == S8_N) HIPCHK(hipMemsetAsync(h->sym_ticket, 0, sizeof(int), s));       // the counter that hands out symbols
   if (N == S8_N && !(h->acq_tap || h->fft_out || h->eq))      // 8k: persistent workgroups, two per CU (k_symbol8k.hpp)
     hipLaunchKernelGGL(symbol8k_kernel<false>, dim3(h->sym_grid), dim3(S8_T), S8_LDS_BYTES, s, iq, fp, (const RxState *)h->st, (const SymMeta *)h->meta,
                        (const float2 *)h->T.tw, h->acq_tap, h->fft_out, h->T.demod_tables(), h->eq, h->tpsval, h->info,
-                       h->T.inner_params(d.payload), (const float2 *)h->T.points, (const unsigned char *)h->T.label_tab, h->labels);
+                       h->T.inner_params(d.payload), (const float2 *)h->T.points, (const unsigned char *)h->T.label_tab, h->labels, h->sym_ticket);
   else if (N == S8_N)
     hipLaunchKernelGGL(symbol8k_kernel<true>, dim3(h->sym_grid), dim3(S8_T), S8_LDS_BYTES, s, iq, fp, (const RxState *)h->st, (const SymMeta *)h->meta,
                        (const float2 *)h->T.tw, h->acq_tap, h->fft_out, h->T.demod_tables(), h->eq, h->tpsval, h->info,
-                       h->T.inner_params(d.payload), (const float2 *)h->T.points, (const unsigned char *)h->T.label_tab, h->labels);
+                       h->T.inner_params(d.payload), (const float2 *)h->T.points, (const unsigned char *)h->T.label_tab, h->labels, h->sym_ticket);
   else
     hipLaunchKernelGGL(derot_fft_demod_kernel, dim3(C), dim3(FFT_THREADS), fused_lds_bytes_host(N), s, iq, fp, (const RxState *)h->st, (const SymMeta *)h->meta,
                        (const float2 *)h->T.tw, (const uint16_t *)h->T.perm, h->acq_tap, h->fft_out, h->T.demod_tables(), h->eq, h->tpsval, h->info,

@@ -1,11 +1,12 @@
 // k_symbol8k.hpp -- the per-OFDM-symbol kernel of the segment path for the 8k mode (A1 tail + A2 + A3 + A4), the
 // configuration the headline metric is quoted on.  Same results as derot_fft_demod_kernel (k_symbol.hpp, which stays the kernel of
 // the 2k mode); what differs is how the symbol moves through the CU:
-//  * PERSISTENT workgroups (two per CU): workgroup w takes symbols w, w + G, w + 2G, ... and loads the samples of its next symbol
+//  * PERSISTENT workgroups (two per CU): a workgroup takes symbol after symbol and loads the samples of its next symbol
 //    into registers while it equalises the current one, so the HBM latency of a symbol's 64 KB is never exposed;
-//  * with G a multiple of 4 a workgroup meets the same scattered-pilot pattern every time: the equaliser's per-carrier table rows
+//  * symbols are handed out by an atomic counter, so a workgroup that starts late (other kernels share the machine when segments are in flight)
+//    takes fewer; the scattered-pilot pattern of a symbol follows from the last one the workgroup saw, and the equaliser's per-carrier table rows
 //    (carrier, bracketing pilots, distance: one packed word, L2 resident) are requested for the expected pattern before the pattern search
-//    has run and again only when the pattern found differs (lock transients); the estimation-carrier list stays in registers;
+//    has run and again only when the pattern found differs (lock transients);
 //  * the FFT is 8192 = 16 x 16 x (2 x 16) with the first radix-16 pass done on the registers the samples were loaded into
 //    (element n = tid + 512 i IS the butterfly of thread tid), and the last pass written in natural, fft-shifted order: no
 //    separate digit-reversal pass, 3 LDS stores + 2 LDS loads per point instead of 6 + 5, and 7 barriers per symbol instead of 13;
@@ -35,7 +36,7 @@ namespace dvbt {
 #endif
 constexpr int S8_N = 8192, S8_T = 512, S8_PAY = 6048, S8_NCP = 177, S8_NTPS = 68, S8_ZL = 688;
 constexpr int S8_IT = (S8_PAY + S8_T - 1) / S8_T;             // payload carriers per thread (12)
-constexpr size_t S8_LDS_BYTES = (size_t)S8_N * 8 + DEMOD_NP * 8 + 2 * 128 * 8 + 64 * 8 + 192 * 4 + 16 * 4 + 64 * 4 + 192 * 2 + 64;
+constexpr size_t S8_LDS_BYTES = (size_t)S8_N * 8 + DEMOD_NP * 8 + 2 * 128 * 8 + 64 * 8 + 192 * 4 + 16 * 4 + 64 * 4 + 192 * 2 + 64 + 16;
 #ifndef S8_WG_PER_CU
 #define S8_WG_PER_CU 2
 #endif
@@ -198,7 +199,7 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
                                                            float2 *__restrict__ fft_tap, DemodTables T, float2 *__restrict__ eq_tap,
                                                            float2 *__restrict__ tpsval, SymInfo *__restrict__ info, InnerParams ip,
                                                            const float2 *__restrict__ points, const unsigned char *__restrict__ label_tab,
-                                                           uint8_t *__restrict__ labels)
+                                                           uint8_t *__restrict__ labels, int *__restrict__ ticket)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   v2f *x = reinterpret_cast<v2f *>(smem_raw);
@@ -210,11 +211,16 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
   float *s_pat = s_cfo + 16;                                     // [16 candidates][4 patterns]
   short *s_cpil = reinterpret_cast<short *>(s_pat + 64);         // 192
   unsigned char *label_of = reinterpret_cast<unsigned char *>(s_cpil + 192);
+  int *s_tkt = reinterpret_cast<int *>(label_of + 64);          // the symbol this workgroup takes next
   const v2f *iq = reinterpret_cast<const v2f *>(iq_);
   constexpr int N = S8_N, zl = S8_ZL;
-  const int tid0 = threadIdx.x, tid = tid0, G = gridDim.x, cp = p.cp;
+  const int tid0 = threadIdx.x, tid = tid0, cp = p.cp;
   const int nsym = st->n_symbols;
-  int s = blockIdx.x;
+  // symbols are handed out by a counter (zeroed by the host before the launch), not by a fixed stride: with other kernels sharing the machine the
+  // workgroups of this launch start at different times, and one that starts late simply takes fewer symbols
+  if (tid == 0) s_tkt[0] = atomicAdd(ticket, 1);
+  __syncthreads();
+  int s = __builtin_amdgcn_readfirstlane(s_tkt[0]);
   if (s >= nsym) return;
 
   if (tid < 64) { pts[tid] = points[tid]; label_of[tid] = label_tab[tid]; }
@@ -225,9 +231,9 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
   if (tid >= 256) { const int q = tid - 256, j = q & 15, pat = (q >> 4) & 3; if (j < 10) pat_ref = T.pilot_ref[3 * pat + 12 * j]; }
   const float half_n = 0.5f * (float)ip.nlev, top = (float)ip.nlev - 0.5f;
 
-  // the pattern (symbol index mod 4) this workgroup expects: with G a multiple of 4 it is the same at every symbol of a locked stream, so the
-  // per-carrier table rows of a symbol (T.pay_pack, L2 resident) are requested before the pattern search has confirmed it
-  int cur_mod = -1;
+  // the pattern (symbol index mod 4) of a symbol of a locked stream follows from the last one's: the per-pattern table rows of a symbol (T.pay_pack
+  // and the estimation-carrier list, L2 resident) are requested before the pattern search has confirmed it
+  int cur_mod = 0, s_prev = s;
   unsigned est01 = 0, tps_ld = 0; int np = 0;
 
   SymMeta m = meta[s];
@@ -247,11 +253,9 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
     int tid = tid0; v2f wA = w1A, wB = w1B;
     asm volatile("" : "+v"(tid), "+v"(wA), "+v"(wB));
     const S8Roots R = s8_roots();
-    const int s_next = s + G;
-    const bool more = s_next < nsym;
+    int tkt = 0;
+    if (tid == 0) tkt = atomicAdd(ticket, 1);                     // the next symbol of this workgroup; published through LDS at the end of the FFT
     const bool last = !p.keep_last && s + 1 >= nsym;             // no output for the last item (the reference's demod consumes n+1 items)
-    SymMeta mn = m;
-    if (more) mn = meta[s_next];
     if ((S8_EXP & 4) && s != (int)blockIdx.x) {
       const long long low = (long long)(st->call0 + s) * (N + cp) + m.cp_start - N + 1;
 #pragma unroll
@@ -317,15 +321,25 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
       for (int d = 0; d < 16; d++) x[base2 + 512 * (d ^ 8)] = a[d];
     }
     }
+    if (tid == 0) s_tkt[1] = tkt;
     __syncthreads();
+    const int s_next = __builtin_amdgcn_readfirstlane(s_tkt[1]);
+    const bool more = s_next < nsym;
+    SymMeta mn = m;
+    if (more) mn = meta[s_next];
     auto X = [&](int b) -> v2f { return x[s8_swz2(b)]; };
     unsigned tcl[S8_IT];                                          // carrier | rank of the left bracketing estimation carrier << 13 | distance to it << 23
-    auto load_rows = [&](int md) {
+    auto load_rows = [&](int md) {                                // the table rows of pattern md
       const uint32_t *pp = T.pay_pack + (size_t)md * S8_PAY;
 #pragma unroll
       for (int it = 0; it < S8_IT; it++) { const int i = tid + it * S8_T; tcl[it] = pp[i < S8_PAY ? i : S8_PAY - 1]; }
+      np = md == 0 ? T.np[0] : md == 1 ? T.np[1] : md == 2 ? T.np[2] : T.np[3];
+      const uint16_t *pk = T.pil_k + (size_t)md * DEMOD_NP;       // carrier | sign of its reference << 15
+      est01 = (unsigned)pk[tid < np ? tid : 0] | ((unsigned)pk[tid + S8_T < np ? tid + S8_T : 0] << 16);
+      if (tid < S8_NTPS) { const int q = md * S8_NTPS + tid; tps_ld = (unsigned)T.tps_Li[q] | ((unsigned)T.tps_d[q] << 16); }
     };
-    if (!last && !(S8_EXP & 1)) load_rows(cur_mod < 0 ? 0 : cur_mod);
+    const int pred = (cur_mod + (s - s_prev)) & 3;                // what a locked stream will show
+    if (!last && !(S8_EXP & 1)) load_rows(pred);
     if (TAPS && fft_tap) {
 #pragma unroll
       for (int i = 0; i < 16; i++) { const int b = tid + i * S8_T; fft_tap[(size_t)s * N + b] = s8_f(X(b)); }
@@ -394,14 +408,8 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
 #pragma unroll
       for (int i = 0; i < 16; i++) vin[i] = iq[low + tid + i * S8_T];
     }
-    if (mod != cur_mod) {                                         // workgroup-uniform; in lock only at a workgroup's first symbol
-      load_rows(mod);
-      cur_mod = mod;
-      np = mod == 0 ? T.np[0] : mod == 1 ? T.np[1] : mod == 2 ? T.np[2] : T.np[3];
-      const uint16_t *pk = T.pil_k + (size_t)mod * DEMOD_NP;      // carrier | sign of its reference << 15
-      est01 = (unsigned)pk[tid < np ? tid : 0] | ((unsigned)pk[tid + S8_T < np ? tid + S8_T : 0] << 16);
-      if (tid < S8_NTPS) { const int q = mod * S8_NTPS + tid; tps_ld = (unsigned)T.tps_Li[q] | ((unsigned)T.tps_d[q] << 16); }
-    }
+    if (mod != pred) load_rows(mod);                              // workgroup-uniform; in lock only at a workgroup's first symbol
+    cur_mod = mod; s_prev = s;
     // LS gains at the estimation carriers (set_channel_gain :486-490): ref / X = ref conj(X) / |X|^2, ref = +-4/3
     {
       const float amp = (float)(4.0 / 3.0);
