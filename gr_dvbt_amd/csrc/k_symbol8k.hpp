@@ -36,6 +36,10 @@ namespace dvbt {
 #endif
 constexpr int S8_N = 8192, S8_T = 512, S8_PAY = 6048, S8_NCP = 177, S8_NTPS = 68, S8_ZL = 688;
 constexpr int S8_IT = (S8_PAY + S8_T - 1) / S8_T;             // payload carriers per thread (12)
+#ifndef S8_TOP_N
+#define S8_TOP_N 6
+#endif
+constexpr int S8_TOP = S8_TOP_N;                              // of a thread's 16 samples the first S8_TOP are requested at the top of the symbol's iteration (and used last), the others one symbol ahead
 constexpr size_t S8_LDS_BYTES = (size_t)S8_N * 8 + DEMOD_NP * 8 + 2 * 128 * 8 + 64 * 8 + 192 * 4 + 16 * 4 + 64 * 4 + 192 * 2 + 64 + 16;
 #ifndef S8_WG_PER_CU
 #define S8_WG_PER_CU 2
@@ -193,6 +197,21 @@ __device__ __forceinline__ bool s8_demap_cell(v2f e, float inv_step, float half_
   return ok;
 }
 
+// The 16 samples of a thread are read through a buffer resource whose base is the symbol's first sample (scalar registers): every load is
+// descriptor + the thread's 32-bit offset + a scalar offset i * 4096, no 64-bit address registers per load (those were what spilled next to the
+// equaliser, each spill behind an s_waitcnt that stalled the wavefront for a memory round trip)
+typedef int s8_i4 __attribute__((ext_vector_type(4)));
+__device__ v2f s8_raw_buffer_load_v2f32(s8_i4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
+__device__ __forceinline__ s8_i4 s8_rsrc(const v2f *base)
+{
+  const unsigned long long a = (unsigned long long)base;
+  s8_i4 r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a); r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32)) & 0xffff;   // 48-bit base, stride 0
+  r.z = 0x7fffffff; r.w = 0x00020000;                                                                                                  // no range limit that matters; gfx9 raw 32-bit format
+  return r;
+}
+__device__ __forceinline__ v2f s8_sample(s8_i4 rsrc, int i, int tid) { return s8_raw_buffer_load_v2f32(rsrc, tid * 8, i * S8_T * 8, 0); }
+
 // TAPS: the debug taps (derotated samples, spectrum, equalised carriers) are compiled in; the production instantiation has none of that code
 template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(const float2 *__restrict__ iq_, FrontParams p, const RxState *st,
                                                            const SymMeta *__restrict__ meta, const float2 *__restrict__ tw, float2 *__restrict__ acq_tap,
@@ -234,14 +253,14 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
   // the pattern (symbol index mod 4) of a symbol of a locked stream follows from the last one's: the per-pattern table rows of a symbol (T.pay_pack
   // and the estimation-carrier list, L2 resident) are requested before the pattern search has confirmed it
   int cur_mod = 0, s_prev = s;
-  unsigned est01 = 0, tps_ld = 0; int np = 0;
 
   SymMeta m = meta[s];
   v2f vin[16];
   {
     const long long low = (long long)(st->call0 + s) * (N + cp) + m.cp_start - N + 1;
+    const s8_i4 rs = s8_rsrc(iq + low);
 #pragma unroll
-    for (int i = 0; i < 16; i++) vin[i] = iq[low + tid + i * S8_T];
+    for (int i = S8_TOP; i < 16; i++) vin[i] = s8_sample(rs, i, tid);
   }
   if (tid < 128) s8_fill_ptab(ptab, m, tid);
   int par = 0;
@@ -250,16 +269,18 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
   for (;;) {
     // the thread's index and twiddle bases, opaque to the optimiser: everything derived from them is a handful of instructions, and hoisting it out of
     // the loop (the 30 twiddle powers, ~80 LDS addresses, the root constants) costs more registers than the loop has
-    int tid = tid0; v2f wA = w1A, wB = w1B;
-    asm volatile("" : "+v"(tid), "+v"(wA), "+v"(wB));
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
     const S8Roots R = s8_roots();
     int tkt = 0;
     if (tid == 0) tkt = atomicAdd(ticket, 1);                     // the next symbol of this workgroup; published through LDS at the end of the FFT
     const bool last = !p.keep_last && s + 1 >= nsym;             // no output for the last item (the reference's demod consumes n+1 items)
-    if ((S8_EXP & 4) && s != (int)blockIdx.x) {
+    {   // the samples that did not fit into the registers next to the equaliser (the compiler spilled them, each behind a full wait): they are
+        // requested now and used last in the derotation below
       const long long low = (long long)(st->call0 + s) * (N + cp) + m.cp_start - N + 1;
+      const s8_i4 rs = s8_rsrc(iq + low);
 #pragma unroll
-      for (int i = 0; i < 16; i++) vin[i] = iq[low + tid + i * S8_T];
+      for (int i = 0; i < ((S8_EXP & 4) ? 16 : S8_TOP); i++) vin[i] = s8_sample(rs, i, tid);
     }
     // ---- A1 tail: derotate (ofdm_sym_acquisition_impl.cc:285-309,527-534), on the registers the loads arrived in
     v2f a[16];
@@ -268,8 +289,8 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
       const v2f PA = s8_cmul(pt[32 + (tid >> 5)], pt[64 + (tid & 31)]), PB = s8_cmul(pt[48 + (tid >> 5)], pt[96 + (tid & 31)]);
       const int sw = (m.sw >= 0 && m.sw < N + cp) ? m.sw : 0x7fffffff;
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
-        const int n = tid + i * S8_T;
+      for (int k = 0; k < 16; k++) {
+        const int i = (k + S8_TOP) & 15, n = tid + i * S8_T;
         const bool pieceB = n + 1 > sw;
         const v2f P = pieceB ? PB : PA;
         a[i] = (S8_EXP & 32) ? vin[i] : s8_cmul(s8_cmul(P, pt[(pieceB ? 16 : 0) + i]), vin[i]);
@@ -278,7 +299,8 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
     }
     // ---- A2, pass 1: n = n2 + 512 n1 -> Y[k1][n2] W_8192^(n2 k1)
     s8_dft16(a, R);
-    s8_twiddle16(a, wA);
+    { v2f wA = w1A; asm volatile("" : "+v"(wA), "+v"(a[15]));   // the power chain starts here, not above the butterfly (its 30 registers do not fit there)
+      s8_twiddle16(a, wA); }
     __syncthreads();                                             // the previous symbol's readers of x are done
     {
       const int b0 = tid ^ ((tid >> 5) & 15);
@@ -293,7 +315,8 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
 #pragma unroll
       for (int m1 = 0; m1 < 16; m1++) a[m1] = x[rb + 32 * m1 + (mm ^ m1)];
       s8_dft16(a, R);
-      s8_twiddle16(a, wB);
+      { v2f wB = w1B; asm volatile("" : "+v"(wB), "+v"(a[15]));
+        s8_twiddle16(a, wB); }
 #pragma unroll
       for (int j1 = 0; j1 < 16; j1++) x[rb + 32 * j1 + (mm ^ j1)] = a[j1];
     }
@@ -329,6 +352,7 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
     if (more) mn = meta[s_next];
     auto X = [&](int b) -> v2f { return x[s8_swz2(b)]; };
     unsigned tcl[S8_IT];                                          // carrier | rank of the left bracketing estimation carrier << 13 | distance to it << 23
+    unsigned est01 = 0, tps_ld = 0; int np = 0;                   // this thread's two estimation carriers, its TPS carrier's brackets, the pattern's estimation-carrier count
     auto load_rows = [&](int md) {                                // the table rows of pattern md
       const uint32_t *pp = T.pay_pack + (size_t)md * S8_PAY;
 #pragma unroll
@@ -348,8 +372,9 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
     if (S8_EXP & 1) {
       if (more) {
         const long long low = (long long)(st->call0 + s_next) * (N + cp) + mn.cp_start - N + 1;
+        const s8_i4 rs = s8_rsrc(iq + low);
 #pragma unroll
-        for (int i = 0; i < 16; i++) vin[i] = iq[low + tid + i * S8_T];
+        for (int i = S8_TOP; i < 16; i++) vin[i] = s8_sample(rs, i, tid);
       }
       if (x[tid].x == 123.f) labels[s] = 1;
       if (!more) break;
@@ -402,11 +427,12 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
     }
     const int xb = zl + fo;
     if (tid == 0) { SymInfo si; si.freq_offset = fo; si.mod_index = mod; si.cfc = 0.f; si.pad = 0; info[s] = si; }
-    // the next symbol's samples start travelling now
+    // the next symbol's samples start travelling now (all but the S8_TOP that are requested at the top of its iteration)
     if (more && !(S8_EXP & (4 | 64))) {
       const long long low = (long long)(st->call0 + s_next) * (N + cp) + mn.cp_start - N + 1;
+      const s8_i4 rs = s8_rsrc(iq + low);
 #pragma unroll
-      for (int i = 0; i < 16; i++) vin[i] = iq[low + tid + i * S8_T];
+      for (int i = S8_TOP; i < 16; i++) vin[i] = s8_sample(rs, i, tid);
     }
     if (mod != pred) load_rows(mod);                              // workgroup-uniform; in lock only at a workgroup's first symbol
     cur_mod = mod; s_prev = s;
@@ -444,6 +470,9 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
           slow |= !s8_demap_cell(e, ip.inv_step, half_n, top, idx);
           lab[i] = label_of[idx & 63];
         }
+#ifdef S8_BATCH
+        if (it % S8_BATCH == S8_BATCH - 1) __builtin_amdgcn_sched_barrier(0);   // carriers in flight together: bounds the registers of this loop next to the prefetched samples
+#endif
       }
       // carriers within rounding of a decision boundary or far outside the grid: the 4-candidate search with the reference's tie rule, then the
       // exhaustive one; the wavefront simply takes its carriers again
@@ -462,8 +491,9 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
     }
     if (more && (S8_EXP & 64)) {
       const long long low = (long long)(st->call0 + s_next) * (N + cp) + mn.cp_start - N + 1;
+      const s8_i4 rs = s8_rsrc(iq + low);
 #pragma unroll
-      for (int i = 0; i < 16; i++) vin[i] = iq[low + tid + i * S8_T];
+      for (int i = S8_TOP; i < 16; i++) vin[i] = s8_sample(rs, i, tid);
     }
     if (tid < S8_NTPS)    // equalised TPS carriers (process_tps_data :929-931)
       tpsval[(size_t)s * S8_NTPS + tid] = s8_f(equalise(tps_c, (int)(tps_ld & 0xffffu), (int)(tps_ld >> 16)));
