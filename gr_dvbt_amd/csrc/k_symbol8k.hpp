@@ -234,7 +234,7 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
   const v2f *iq = reinterpret_cast<const v2f *>(iq_);
   constexpr int N = S8_N, zl = S8_ZL;
   const int tid0 = threadIdx.x, tid = tid0, cp = p.cp;
-  const int nsym = st->n_symbols;
+  const int nsym = st->n_symbols, call0 = st->call0;             // read once: st may alias the stores below, every re-read would be a vector load and a full wait
   // symbols are handed out by a counter (zeroed by the host before the launch), not by a fixed stride: with other kernels sharing the machine the
   // workgroups of this launch start at different times, and one that starts late simply takes fewer symbols
   if (tid == 0) s_tkt[0] = atomicAdd(ticket, 1);
@@ -257,7 +257,7 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
   SymMeta m = meta[s];
   v2f vin[16];
   {
-    const long long low = (long long)(st->call0 + s) * (N + cp) + m.cp_start - N + 1;
+    const long long low = (long long)(call0 + s) * (N + cp) + m.cp_start - N + 1;
     const s8_i4 rs = s8_rsrc(iq + low);
 #pragma unroll
     for (int i = S8_TOP; i < 16; i++) vin[i] = s8_sample(rs, i, tid);
@@ -277,7 +277,7 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
     const bool last = !p.keep_last && s + 1 >= nsym;             // no output for the last item (the reference's demod consumes n+1 items)
     {   // the samples that did not fit into the registers next to the equaliser (the compiler spilled them, each behind a full wait): they are
         // requested now and used last in the derotation below
-      const long long low = (long long)(st->call0 + s) * (N + cp) + m.cp_start - N + 1;
+      const long long low = (long long)(call0 + s) * (N + cp) + m.cp_start - N + 1;
       const s8_i4 rs = s8_rsrc(iq + low);
 #pragma unroll
       for (int i = 0; i < ((S8_EXP & 4) ? 16 : S8_TOP); i++) vin[i] = s8_sample(rs, i, tid);
@@ -352,15 +352,16 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
     if (more) mn = meta[s_next];
     auto X = [&](int b) -> v2f { return x[s8_swz2(b)]; };
     unsigned tcl[S8_IT];                                          // carrier | rank of the left bracketing estimation carrier << 13 | distance to it << 23
-    unsigned est01 = 0, tps_ld = 0; int np = 0;                   // this thread's two estimation carriers, its TPS carrier's brackets, the pattern's estimation-carrier count
+    unsigned est0 = 0, est1 = 0, tps_l = 0, tps_dd = 0; int np = 0; // this thread's two estimation carriers, its TPS carrier's left bracket and distance, the pattern's estimation-carrier count
+                                                                  // (kept apart: packing them would need the loaded values at once, i.e. a full wait right behind the requests)
     auto load_rows = [&](int md) {                                // the table rows of pattern md
       const uint32_t *pp = T.pay_pack + (size_t)md * S8_PAY;
 #pragma unroll
       for (int it = 0; it < S8_IT; it++) { const int i = tid + it * S8_T; tcl[it] = pp[i < S8_PAY ? i : S8_PAY - 1]; }
       np = md == 0 ? T.np[0] : md == 1 ? T.np[1] : md == 2 ? T.np[2] : T.np[3];
       const uint16_t *pk = T.pil_k + (size_t)md * DEMOD_NP;       // carrier | sign of its reference << 15
-      est01 = (unsigned)pk[tid < np ? tid : 0] | ((unsigned)pk[tid + S8_T < np ? tid + S8_T : 0] << 16);
-      if (tid < S8_NTPS) { const int q = md * S8_NTPS + tid; tps_ld = (unsigned)T.tps_Li[q] | ((unsigned)T.tps_d[q] << 16); }
+      est0 = pk[tid < np ? tid : 0]; est1 = pk[tid + S8_T < np ? tid + S8_T : 0];
+      if (tid < S8_NTPS) { const int q = md * S8_NTPS + tid; tps_l = T.tps_Li[q]; tps_dd = T.tps_d[q]; }
     };
     const int pred = (cur_mod + (s - s_prev)) & 3;                // what a locked stream will show
     if (!last && !(S8_EXP & 1)) load_rows(pred);
@@ -371,7 +372,7 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
     if (last) break;
     if (S8_EXP & 1) {
       if (more) {
-        const long long low = (long long)(st->call0 + s_next) * (N + cp) + mn.cp_start - N + 1;
+        const long long low = (long long)(call0 + s_next) * (N + cp) + mn.cp_start - N + 1;
         const s8_i4 rs = s8_rsrc(iq + low);
 #pragma unroll
         for (int i = S8_TOP; i < 16; i++) vin[i] = s8_sample(rs, i, tid);
@@ -429,7 +430,7 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
     if (tid == 0) { SymInfo si; si.freq_offset = fo; si.mod_index = mod; si.cfc = 0.f; si.pad = 0; info[s] = si; }
     // the next symbol's samples start travelling now (all but the S8_TOP that are requested at the top of its iteration)
     if (more && !(S8_EXP & (4 | 64))) {
-      const long long low = (long long)(st->call0 + s_next) * (N + cp) + mn.cp_start - N + 1;
+      const long long low = (long long)(call0 + s_next) * (N + cp) + mn.cp_start - N + 1;
       const s8_i4 rs = s8_rsrc(iq + low);
 #pragma unroll
       for (int i = S8_TOP; i < 16; i++) vin[i] = s8_sample(rs, i, tid);
@@ -441,7 +442,7 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
       const float amp = (float)(4.0 / 3.0);
 #pragma unroll
       for (int h = 0; h < 2; h++) {
-        const int e = (int)((est01 >> (16 * h)) & 0xffffu), r = tid + h * S8_T;
+        const int e = (int)(h ? est1 : est0), r = tid + h * S8_T;
         if (r < np) {
           const v2f v = X(xb + (e & 0x7fff));
           const float q = ((e & 0x8000) ? -amp : amp) * __builtin_amdgcn_rcpf(v.x * v.x + v.y * v.y);
@@ -490,13 +491,13 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
       }
     }
     if (more && (S8_EXP & 64)) {
-      const long long low = (long long)(st->call0 + s_next) * (N + cp) + mn.cp_start - N + 1;
+      const long long low = (long long)(call0 + s_next) * (N + cp) + mn.cp_start - N + 1;
       const s8_i4 rs = s8_rsrc(iq + low);
 #pragma unroll
       for (int i = S8_TOP; i < 16; i++) vin[i] = s8_sample(rs, i, tid);
     }
     if (tid < S8_NTPS)    // equalised TPS carriers (process_tps_data :929-931)
-      tpsval[(size_t)s * S8_NTPS + tid] = s8_f(equalise(tps_c, (int)(tps_ld & 0xffffu), (int)(tps_ld >> 16)));
+      tpsval[(size_t)s * S8_NTPS + tid] = s8_f(equalise(tps_c, (int)tps_l, (int)tps_dd));
     if (!more) break;
     s = s_next; m = mn; par ^= 1;
   }
