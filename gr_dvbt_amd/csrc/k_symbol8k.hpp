@@ -1,8 +1,9 @@
 // k_symbol8k.hpp -- the per-OFDM-symbol kernel of the segment path for the 8k mode (A1 tail + A2 + A3 + A4), the
 // configuration the headline metric is quoted on.  Same results as derot_fft_demod_kernel (k_symbol.hpp, which stays the kernel of
 // the 2k mode); what differs is how the symbol moves through the CU:
-//  * PERSISTENT workgroups (two per CU): a workgroup takes symbol after symbol and loads the samples of its next symbol
-//    into registers while it equalises the current one, so the HBM latency of a symbol's 64 KB is never exposed;
+//  * PERSISTENT workgroups (two per CU): a workgroup takes symbol after symbol and requests most of its next symbol's samples (10 of a thread's 16,
+//    through a buffer resource: no address registers) while it equalises the current one; the other six, for which there are no registers
+//    next to the equaliser, at the top of the next iteration, where they are used last;
 //  * symbols are handed out by an atomic counter, so a workgroup that starts late (other kernels share the machine when segments are in flight)
 //    takes fewer; the scattered-pilot pattern of a symbol follows from the last one the workgroup saw, and the equaliser's per-carrier table rows
 //    (carrier, bracketing pilots, distance: one packed word, L2 resident) are requested for the expected pattern before the pattern search
@@ -19,9 +20,9 @@
 //    arithmetic is written for instruction COUNT: complex products as v_pk_mul_f32 + v_pk_fma_f32 with op_sel / neg modifiers (2 instructions; the
 //    compiler's best is 4 and a third of its FFT passes were register moves), multiplications by the fixed 16th / 32nd roots of unity as
 //    modifier variants of the same pair over four (cos, sin) constants, +-i folded into the butterflies' adds;
-//  * the demapper first tries the cell of the square grid the carrier falls into: when the carrier is farther than 1e-5 of a cell from every
-//    decision boundary (and within 12 cells of the grid) the cell's point is the reference's first strict minimum whatever the rounding of its
-//    float distances (bound: 1.4e-6 of a cell, see s8_demap_cell); the 4-candidate search with the reference's tie rule (demap_fast) and the
+//  * the demapper first tries the cell of the square grid the carrier falls into: when the carrier is farther than 2e-5 of a cell from every
+//    decision boundary (and within 4 cells of the grid) the cell's point is the reference's first strict minimum whatever the rounding of its
+//    float distances (bound: 2.5e-6 of a cell, see s8_demap_cell); the 4-candidate search with the reference's tie rule (demap_fast) and the
 //    exhaustive one (demap_all) remain for the rest, wave by wave.
 // Reference: ofdm_sym_acquisition_impl.cc:285-309,527-534 (derotation), fft_vcc forward + shift (SURVEY C-2),
 // reference_signals_impl.cc:536-689,715-744,1065-1124 (pilot engine), dvbt_demap_impl.cc:167-203.
@@ -44,7 +45,7 @@ constexpr size_t S8_LDS_BYTES = (size_t)S8_N * 8 + DEMOD_NP * 8 + 2 * 128 * 8 + 
 #ifndef S8_WG_PER_CU
 #define S8_WG_PER_CU 2
 #endif
-inline int s8_grid(int cus) { return (S8_WG_PER_CU * cus) & ~3; }   // two workgroups per CU (what the LDS holds), a multiple of the pattern period
+inline int s8_grid(int cus) { return S8_WG_PER_CU * cus; }          // two workgroups per CU (what the LDS holds)
 
 // layout of the first two passes: a = k1 * 512 + (index inside the 512-point sub-transform k1).  Bits 3:0 are XORed with bits 8:5 and bit 4
 // with bit 9, so that 16 rows of 32 (stride 32) and two neighbouring sub-transforms land on 32 distinct bank pairs
