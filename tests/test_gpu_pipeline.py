@@ -1,0 +1,38 @@
+"""Segments in flight (bench.py --pipeline): several handles, each on its own HIP stream, decode at the same time and
+share the machine -- the persistent 8k symbol kernel takes its symbols from an atomic counter and its workgroups start whenever the other
+segments' Viterbi workgroups make room.  Every handle must deliver exactly what a handle that has the GPU to itself delivers."""
+import numpy as np
+import pytest
+import torch
+
+import gr_dvbt_amd as g
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("const,cr,mode,nsf", [(g.QAM64, g.C7_8, g.T8k, 6), (g.QAM16, g.C2_3, g.T8k, 4), (g.QAM16, g.C1_2, g.T2k, 8)])
+def test_handles_in_flight_equal_a_handle_alone(po, const, cr, mode, nsf):
+    c = po.cfg(const, cr, mode)
+    ibits = c.payload * c.m * c.k // c.n
+    # three different streams (so that a buffer mixed up between handles cannot go unnoticed) of the same configuration
+    iqs = [po.tx(c, po.make_ts((272 * ibits * nsf) // (204 * 8), 100 + k), lead_in=500 + 700 * k, tail=3 * c.N) for k in range(3)]
+    alone = []
+    for iq in iqs:
+        rx = g.Rx(const, cr, mode, max_samples=len(iq))
+        rep = rx.run(iq)
+        alone.append((rep.n_symbols, rep.first_out_symbol, int(rep.n_ts_bytes), rx.tap(g.TAP_VITERBI).copy(), rx.tap(g.TAP_TS).copy()))
+        rx.close()
+    devs = [torch.from_numpy(iq.view(np.float32)).cuda() for iq in iqs]
+    torch.cuda.synchronize()
+    rxs = [g.Rx(const, cr, mode, max_samples=len(iq)) for iq in iqs]
+    streams = [torch.cuda.Stream() for _ in iqs]
+    for rnd in range(3):                                       # the handles are reused, as a receiver working through a stream does
+        for rx, d, iq, st in zip(rxs, devs, iqs, streams):
+            rx.enqueue_device(d.data_ptr(), len(iq), st.cuda_stream)
+        for k, rx in enumerate(rxs):
+            rep = rx.finish()
+            n_sym, first, n_ts, vit, ts = alone[k]
+            assert (rep.n_symbols, rep.first_out_symbol, int(rep.n_ts_bytes)) == (n_sym, first, n_ts), (rnd, k)
+            assert (rx.tap(g.TAP_VITERBI) == vit).all() and (rx.tap(g.TAP_TS) == ts).all(), (rnd, k)
+    for rx in rxs:
+        rx.close()
