@@ -13,6 +13,7 @@
 #include "k_backend.hpp"
 #include "k_symbol.hpp"
 #include "k_symbol8k.hpp"
+#include "k_symbol2k.hpp"
 #include "k_resample.hpp"
 #include "k_viterbi3.hpp"
 
@@ -317,7 +318,8 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   h->ev_ready = true;
   RXCHK(set_lds((const void *)derot_fft_demod_kernel, fused_lds_bytes_host((int)N)));
   RXHIP(hipMalloc((void **)&h->sym_ticket, 64));
-  RXCHK(set_lds((const void *)symbol8k_kernel<false>, S8_LDS_BYTES)); RXCHK(set_lds((const void *)symbol8k_kernel<true>, S8_LDS_BYTES));
+  RXCHK(set_lds((const void *)symbol8k_kernel<false>, S8_LDS_BYTES));
+  RXCHK(set_lds((const void *)symbol2k_kernel<false>, S2_LDS_BYTES)); RXCHK(set_lds((const void *)symbol2k_kernel<true>, S2_LDS_BYTES)); RXCHK(set_lds((const void *)symbol8k_kernel<true>, S8_LDS_BYTES));
   { int ncu = 256; (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->prm.device); h->sym_grid = s8_grid(ncu); }
   RXCHK(set_lds((const void *)inner_kernel<6>, inner_lds_bytes(P)));
   RXCHK(set_lds((const void *)acq_anchor_kernel, acq_anchor_lds_bytes((int)N, d.cp)));
@@ -462,13 +464,21 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
   }
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_FFT], s));
   // A1 tail + A2 + A3 in one kernel: the FFT item of a symbol never leaves LDS (acq/fft taps are written only when enabled)
-  if (N == S8_N) HIPCHK(hipMemsetAsync(h->sym_ticket, 0, sizeof(int), s));       // the counter that hands out symbols
+  HIPCHK(hipMemsetAsync(h->sym_ticket, 0, sizeof(int), s));                      // the counter that hands out symbols
   if (N == S8_N && !(h->acq_tap || h->fft_out || h->eq))      // 8k: persistent workgroups, two per CU (k_symbol8k.hpp)
     hipLaunchKernelGGL(symbol8k_kernel<false>, dim3(h->sym_grid), dim3(S8_T), S8_LDS_BYTES, s, iq, fp, (const RxState *)h->st, (const SymMeta *)h->meta,
                        (const float2 *)h->T.tw, h->acq_tap, h->fft_out, h->T.demod_tables(), h->eq, h->tpsval, h->info,
                        h->T.inner_params(d.payload), (const float2 *)h->T.points, (const unsigned char *)h->T.label_tab, h->labels, h->sym_ticket);
   else if (N == S8_N)
     hipLaunchKernelGGL(symbol8k_kernel<true>, dim3(h->sym_grid), dim3(S8_T), S8_LDS_BYTES, s, iq, fp, (const RxState *)h->st, (const SymMeta *)h->meta,
+                       (const float2 *)h->T.tw, h->acq_tap, h->fft_out, h->T.demod_tables(), h->eq, h->tpsval, h->info,
+                       h->T.inner_params(d.payload), (const float2 *)h->T.points, (const unsigned char *)h->T.label_tab, h->labels, h->sym_ticket);
+  else if (N == S2_N && !(h->acq_tap || h->fft_out || h->eq))   // 2k: the same design, four symbols per workgroup (k_symbol2k.hpp)
+    hipLaunchKernelGGL(symbol2k_kernel<false>, dim3(h->sym_grid), dim3(S2_T * S2_Q), S2_LDS_BYTES, s, iq, fp, (const RxState *)h->st, (const SymMeta *)h->meta,
+                       (const float2 *)h->T.tw, h->acq_tap, h->fft_out, h->T.demod_tables(), h->eq, h->tpsval, h->info,
+                       h->T.inner_params(d.payload), (const float2 *)h->T.points, (const unsigned char *)h->T.label_tab, h->labels, h->sym_ticket);
+  else if (N == S2_N)
+    hipLaunchKernelGGL(symbol2k_kernel<true>, dim3(h->sym_grid), dim3(S2_T * S2_Q), S2_LDS_BYTES, s, iq, fp, (const RxState *)h->st, (const SymMeta *)h->meta,
                        (const float2 *)h->T.tw, h->acq_tap, h->fft_out, h->T.demod_tables(), h->eq, h->tpsval, h->info,
                        h->T.inner_params(d.payload), (const float2 *)h->T.points, (const unsigned char *)h->T.label_tab, h->labels, h->sym_ticket);
   else
