@@ -11,7 +11,6 @@
 #include "dvbt_tables.hpp"
 #include "k_frontend.hpp"
 #include "k_backend.hpp"
-#include "k_symbol.hpp"
 #include "k_symbol8k.hpp"
 #include "k_symbol2k.hpp"
 #include "k_resample.hpp"
@@ -316,7 +315,6 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   RXHIP(hipMemset(h->st, 0, sizeof(RxState)));
   for (int i = 0; i < ST_COUNT; i++) RXHIP(hipEventCreate(&h->ev[i]));
   h->ev_ready = true;
-  RXCHK(set_lds((const void *)derot_fft_demod_kernel, fused_lds_bytes_host((int)N)));
   RXHIP(hipMalloc((void **)&h->sym_ticket, 64));
   RXCHK(set_lds((const void *)symbol8k_kernel<false>, S8_LDS_BYTES));
   RXCHK(set_lds((const void *)symbol2k_kernel<false>, S2_LDS_BYTES)); RXCHK(set_lds((const void *)symbol2k_kernel<true>, S2_LDS_BYTES)); RXCHK(set_lds((const void *)symbol8k_kernel<true>, S8_LDS_BYTES));
@@ -481,10 +479,6 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
     hipLaunchKernelGGL(symbol2k_kernel<true>, dim3(h->sym_grid), dim3(S2_T * S2_Q), S2_LDS_BYTES, s, iq, fp, (const RxState *)h->st, (const SymMeta *)h->meta,
                        (const float2 *)h->T.tw, h->acq_tap, h->fft_out, h->T.demod_tables(), h->eq, h->tpsval, h->info,
                        h->T.inner_params(d.payload), (const float2 *)h->T.points, (const unsigned char *)h->T.label_tab, h->labels, h->sym_ticket);
-  else
-    hipLaunchKernelGGL(derot_fft_demod_kernel, dim3(C), dim3(FFT_THREADS), fused_lds_bytes_host(N), s, iq, fp, (const RxState *)h->st, (const SymMeta *)h->meta,
-                       (const float2 *)h->T.tw, (const uint16_t *)h->T.perm, h->acq_tap, h->fft_out, h->T.demod_tables(), h->eq, h->tpsval, h->info,
-                       h->T.inner_params(d.payload), (const float2 *)h->T.points, (const unsigned char *)h->T.label_tab, h->labels);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_DEMOD], s));
   if (!o.continuation) {
     HIPCHK(hipMemsetAsync(h->tps_state, 0, sizeof(TpsState), s));

@@ -13,7 +13,7 @@ constexpr int S2_N = 2048, S2_T = 128, S2_Q = 4, S2_PAY = 1512, S2_NCP = 45, S2_
 constexpr int S2_IT = (S2_PAY + S2_T - 1) / S2_T;             // payload carriers per thread (12)
 constexpr int S2_PT = 104;                                    // phasor table entries per symbol
 constexpr size_t S2_SLOT_BYTES = (size_t)S2_N * 8 + S2_NP * 8 + 2 * S2_PT * 8 + 16 * 4 + 64 * 4;       // per symbol of the four: image, gains, phasor tables x 2, search results
-constexpr size_t S2_LDS_BYTES = S2_Q * S2_SLOT_BYTES + 64 * 8 + 64 + 48 * 4 + 48 * 2 + 16;
+constexpr size_t S2_LDS_BYTES = S2_Q * S2_SLOT_BYTES + 64 * 8 + 64 + 48 * 4 + 48 * 2 + 16 + 40 * 4;
 static_assert(S2_LDS_BYTES <= 81920, "two workgroups per CU");
 
 // first two passes: a = k1 * 128 + (index inside the 128-point sub-transform k1), its low four bits XORed with k1 and bit 4 with k1's lowest
@@ -74,6 +74,7 @@ template <bool TAPS> __global__ __launch_bounds__(S2_T * S2_Q, 4) void symbol2k_
   float *s_known = reinterpret_cast<float *>(label_of + 64);     // 48
   short *s_cpil = reinterpret_cast<short *>(s_known + 48);       // 48
   int *s_tkt = reinterpret_cast<int *>(s_cpil + 48);             // the group of four symbols this workgroup takes next
+  float *s_pref = reinterpret_cast<float *>(s_tkt + 4);          // reference values of the first ten scattered pilots of the four patterns
   const v2f *iq = reinterpret_cast<const v2f *>(iq_);
   constexpr int N = S2_N, zl = S2_ZL;
   const int nsym = st->n_symbols, call0 = st->call0;
@@ -86,10 +87,7 @@ template <bool TAPS> __global__ __launch_bounds__(S2_T * S2_Q, 4) void symbol2k_
   if (tid0 < S2_NCP) { s_cpil[tid0] = T.cpilot[tid0]; if (tid0 < S2_NCP - 1) s_known[tid0] = T.known_diff[tid0]; }
   const v2f w1A = s8_v(tw[t0]), w1B = s8_v(tw[16 * (t0 & 15)]);  // W_2048^n2 (first pass), W_128^m2 (second pass)
   const int tps_c = t0 < S2_NTPS ? T.tps[t0] : 0;
-  float pref[5];                                                  // reference values of this thread's five scattered pilots in the pattern search
-  { const int pat = (t0 >> 1) & 3, half = t0 & 1;
-#pragma unroll
-    for (int j = 0; j < 5; j++) pref[j] = T.pilot_ref[3 * pat + 12 * (5 * half + j)]; }
+  if (tid0 < 40) s_pref[tid0] = T.pilot_ref[3 * (tid0 / 10) + 12 * (tid0 % 10)];
   const float half_n = 0.5f * (float)ip.nlev, top = (float)ip.nlev - 0.5f;
   int cur_mod = 0, s_prev = grp * S2_Q + g;
 
@@ -224,7 +222,7 @@ template <bool TAPS> __global__ __launch_bounds__(S2_T * S2_Q, 4) void symbol2k_
       const int combo = t >> 1, cand = combo >> 2, pat = combo & 3, half = t & 1;
       float cr = 0.f, ci = 0.f;
 #pragma unroll
-      for (int j = 0; j < 5; j++) { const v2f v = X(zl - 8 + cand + 3 * pat + 12 * (5 * half + j)); cr += pref[j] * v.x; ci -= pref[j] * v.y; }   // ref * conj(v)
+      for (int j = 0; j < 5; j++) { const v2f v = X(zl - 8 + cand + 3 * pat + 12 * (5 * half + j)); const float r = s_pref[10 * pat + 5 * half + j]; cr += r * v.x; ci -= r * v.y; }   // ref * conj(v)
       cr += s8_dpp<0xB1>(cr); ci += s8_dpp<0xB1>(ci);
       if (half == 0) s_pat[cand * 4 + pat] = cr * cr + ci * ci;
     }

@@ -1,6 +1,10 @@
 // k_symbol8k.hpp -- the per-OFDM-symbol kernel of the segment path for the 8k mode (A1 tail + A2 + A3 + A4), the
-// configuration the headline metric is quoted on.  Same results as derot_fft_demod_kernel (k_symbol.hpp, which stays the kernel of
-// the 2k mode); what differs is how the symbol moves through the CU:
+// configuration the headline metric is quoted on (k_symbol2k.hpp is the 2k mode's).  One kernel takes a symbol from its baseband samples to
+// its 6048 one-byte labels; the symbol never leaves the CU in between.  Against the demodulator blocks of the block API (demod_kernel,
+// k_frontend.hpp) two things differ, both inside the float tolerance of the equalised-carrier tap: the common phasor of frequency_correction
+// (:793-819) is not applied (it multiplies pilots and payload alike and cancels in x[c] * ref / x[pilot], and with it the only use of the NEXT
+// symbol disappears); the LS gain of an estimation carrier is computed once instead of once per carrier that uses it, and the interpolation
+// step (g[R]-g[L])/11 (:625) is a multiplication by 1/11.  How the symbol moves through the CU:
 //  * PERSISTENT workgroups (two per CU): a workgroup takes symbol after symbol and requests most of its next symbol's samples (10 of a thread's 16,
 //    through a buffer resource: no address registers) while it equalises the current one; the other six, for which there are no registers
 //    next to the equaliser, at the top of the next iteration, where they are used last;
@@ -27,7 +31,8 @@
 // Reference: ofdm_sym_acquisition_impl.cc:285-309,527-534 (derotation), fft_vcc forward + shift (SURVEY C-2),
 // reference_signals_impl.cc:536-689,715-744,1065-1124 (pilot engine), dvbt_demap_impl.cc:167-203.
 #pragma once
-#include "k_symbol.hpp"
+#include "k_frontend.hpp"
+#include "k_backend.hpp"
 
 namespace dvbt {
 
@@ -54,7 +59,8 @@ __device__ __forceinline__ int s8_swz1(int a) { return a ^ ((a >> 5) & 15) ^ (((
 __device__ __forceinline__ int s8_swz2(int b) { return b ^ ((b >> 4) & 15); }
 
 // phasor tables of one symbol (128 entries): [0,16) S_A(i) = expj(512 i incA), [16,32) S_B, [32,48) expj(thA + 32 a incA), [48,64) the same for B,
-// [64,96) expj(b incA), [96,128) for B; sample n = tid + 512 i of piece X has phase th_X + n inc_X (see k_symbol.hpp)
+// [64,96) expj(b incA), [96,128) for B; sample n = tid + 512 i of piece X has phase th_X + n inc_X: the phase is piecewise linear in n (increment incA up to the
+// switch position sw, incB after it, ofdm_sym_acquisition_impl.cc:285-309)
 __device__ __forceinline__ void s8_fill_ptab(float2 *pt, const SymMeta &m, int t)
 {
   const double thA = (double)m.ph_base + m.incA, thB = (double)m.ph_base + (double)m.sw * (m.incA - m.incB) + m.incB;
