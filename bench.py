@@ -318,7 +318,7 @@ def extra_workloads(a, torch, g, local):
         segments = 1
         pipeline = a.pipeline
     res = {}
-    for name, wl, snr, nsf, steps in (("config2_2k_qam16_1_2", "2k_qam16_1_2", None, 64, 100), ("config5_8k_qpsk_7_8_awgn14", "8k_qpsk_7_8", 14.0, 16, 100)):
+    for name, wl, snr, nsf, steps in (("config2_2k_qam16_1_2", "2k_qam16_1_2", None, 64, 400), ("config5_8k_qpsk_7_8_awgn14", "8k_qpsk_7_8", 14.0, 16, 400)):
         job = Job(A, torch, g, None, 0, 1, local, wl, nsf, snr=snr)
         dt = timed_run(job, steps, 3)
         chk = job.verify()
