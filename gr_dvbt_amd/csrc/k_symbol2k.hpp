@@ -12,6 +12,10 @@ namespace dvbt {
 constexpr int S2_N = 2048, S2_T = 128, S2_Q = 4, S2_PAY = 1512, S2_NCP = 45, S2_NTPS = 17, S2_ZL = 172, S2_NP = 192;
 constexpr int S2_IT = (S2_PAY + S2_T - 1) / S2_T;             // payload carriers per thread (12)
 constexpr int S2_PT = 104;                                    // phasor table entries per symbol
+#ifndef S2_TOP_N
+#define S2_TOP_N 7
+#endif
+constexpr int S2_TOP = S2_TOP_N;                              // samples per thread requested at the top of the iteration (see S8_TOP)
 constexpr size_t S2_SLOT_BYTES = (size_t)S2_N * 8 + S2_NP * 8 + 2 * S2_PT * 8 + 16 * 4 + 64 * 4;       // per symbol of the four: image, gains, phasor tables x 2, search results
 constexpr size_t S2_LDS_BYTES = S2_Q * S2_SLOT_BYTES + 64 * 8 + 64 + 48 * 4 + 48 * 2 + 16 + 40 * 4;
 static_assert(S2_LDS_BYTES <= 81920, "two workgroups per CU");
@@ -101,7 +105,7 @@ template <bool TAPS> __global__ __launch_bounds__(S2_T * S2_Q, 4) void symbol2k_
     const long long low = (long long)(call0 + sc) * (N + cp) + m.cp_start - N + 1;
     const s8_i4 rs = s8_rsrc(iq + low);
 #pragma unroll
-    for (int i = S8_TOP; i < 16; i++) vin[i] = s2_sample(rs, i, t0);
+    for (int i = S2_TOP; i < 16; i++) vin[i] = s2_sample(rs, i, t0);
   }
   if (t0 < S2_PT) s2_fill_ptab(ptab, m, t0);
   int par = 0;
@@ -118,7 +122,7 @@ template <bool TAPS> __global__ __launch_bounds__(S2_T * S2_Q, 4) void symbol2k_
       const long long low = (long long)(call0 + sc) * (N + cp) + m.cp_start - N + 1;
       const s8_i4 rs = s8_rsrc(iq + low);
 #pragma unroll
-      for (int i = 0; i < S8_TOP; i++) vin[i] = s2_sample(rs, i, t);
+      for (int i = 0; i < S2_TOP; i++) vin[i] = s2_sample(rs, i, t);
     }
     // ---- A1 tail: derotate
     v2f a[16];
@@ -128,7 +132,7 @@ template <bool TAPS> __global__ __launch_bounds__(S2_T * S2_Q, 4) void symbol2k_
       const int sw = (m.sw >= 0 && m.sw < N + cp) ? m.sw : 0x7fffffff;
 #pragma unroll
       for (int k = 0; k < 16; k++) {
-        const int i = (k + S8_TOP) & 15, n = t + i * S2_T;
+        const int i = (k + S2_TOP) & 15, n = t + i * S2_T;
         const bool pieceB = n + 1 > sw;
         const v2f P = pieceB ? PB : PA;
         a[i] = s8_cmul(s8_cmul(P, pt[(pieceB ? 16 : 0) + i]), vin[i]);
@@ -246,7 +250,7 @@ template <bool TAPS> __global__ __launch_bounds__(S2_T * S2_Q, 4) void symbol2k_
       const long long low = (long long)(call0 + sc_next) * (N + cp) + mn.cp_start - N + 1;
       const s8_i4 rs = s8_rsrc(iq + low);
 #pragma unroll
-      for (int i = S8_TOP; i < 16; i++) vin[i] = s2_sample(rs, i, t);
+      for (int i = S2_TOP; i < 16; i++) vin[i] = s2_sample(rs, i, t);
     }
     if (mod != pred) load_rows(mod);
     cur_mod = mod; s_prev = s;
