@@ -122,6 +122,14 @@ def hbm_copy_gbs(torch, device):
 
 
 STAGES = ("acq", "fft", "demod", "inner", "viterbi", "rs", "total")
+_STREAMS = []                    # HIP streams of the process, reused by every Job: streams map onto a few hardware queues in creation order, and a
+                                 # later Job's fresh streams may land on ONE queue (its steps in flight would then run one after the other)
+
+
+def _stream(torch, k):
+    while len(_STREAMS) <= k:
+        _STREAMS.append(torch.cuda.Stream())
+    return _STREAMS[k]
 
 
 class Job:
@@ -186,7 +194,7 @@ class Job:
             for _ in range(depth):
                 rx = g.Rx(const, cr, mode, max_samples=len(iq), device=local, viterbi_chunk_bytes=chunk, snr_db=snr_db, **kw)
                 rx.set_cut(cu["sym_off"])
-                rxs.append(rx); streams.append(torch.cuda.Stream())
+                rxs.append(rx); streams.append(_stream(torch, i * depth + len(streams)))
                 views.append(torch.as_tensor(_DevView(rx.tap_device_ptr(g.TAP_TS), cap), device=f"cuda:{local}"))
             self.pieces.append({"iq": d_iq, "n": len(iq), "rxs": rxs, "streams": streams, "views": views, "rx": rxs[0], "stream": streams[0],
                                 "cut": cu, "cap": cap, "ts_view": views[0]})
