@@ -20,7 +20,6 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
-import subprocess
 import sys
 import time
 
