@@ -34,6 +34,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md)
 REALTIME_MSPS = 64.0 / 7.0       # OFDM elementary rate at the input of ofdm_sym_acquisition
 SEED = 20240607
+EXPERIMENT_BUILD = False         # set by tools/ab_bench.py alone (attribution builds of the library whose output is wrong on purpose): no verification
 
 WORKLOADS = {"8k_qam64_7_8": ("QAM64", "C7_8", "T8k"), "2k_qam16_1_2": ("QAM16", "C1_2", "T2k"), "8k_qpsk_7_8": ("QPSK", "C7_8", "T8k")}
 
@@ -120,6 +121,22 @@ def hbm_copy_gbs(torch, device):
     return round(best, 1)
 
 
+def profiled_traffic(workload, nsf, alg_bytes):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/rNN_pmc_summary_<workload>_<nsf>sf.json, written by
+    tools/save_profiles.py from `rocprofv3 --pmc` runs of this command; counters cannot be collected from inside the run).  None when no
+    profile of this workload and size is committed or its launch is not the one measured here (algorithmic bytes differ by > 1 %)."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_summary_{workload}_{nsf}sf.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            k = d["kernels"]["viterbi3_kernel"]
+            if abs(d.get("viterbi_algorithmic_bytes", 0) - alg_bytes) <= 0.01 * alg_bytes and "hbm_bytes_corrected" in k:
+                return int(k["hbm_bytes_corrected"]), os.path.relpath(f, ROOT)
+        except Exception:
+            continue
+    return None, None
+
+
 STAGES = ("acq", "fft", "demod", "inner", "viterbi", "rs", "total")
 _STREAMS = []                    # HIP streams of the process, reused by every Job: streams map onto a few hardware queues in creation order, and a
                                  # later Job's fresh streams may land on ONE queue (its steps in flight would then run one after the other)
@@ -155,7 +172,7 @@ class Job:
             if snr is not None:
                 self.ref_power = float(np.mean(np.abs(head[po.STREAM_LEAD_IN:po.STREAM_LEAD_IN + 100000]) ** 2))
                 head = add_awgn(head, snr, 5, self.ref_power)
-            if os.environ.get("BENCH_SKIP_VERIFY") == "1":       # experiment builds with wrong output: where a correct chain starts is known
+            if EXPERIMENT_BUILD:                                 # tools/ab_bench.py only (builds with wrong output): where a correct chain starts is known
                 plan[0], plan[1] = 0, 204 if (const == po.QAM64 and mode == po.T8k) else 272
             else:
                 pre = g.Rx(const, cr, mode, max_samples=len(head), device=local, snr_db=snr_db)
@@ -216,6 +233,9 @@ class Job:
         self.ngather = 0
         self.inflight = []
         self.reps = None
+        self.done_times = []
+        self.step_ms = None
+        self.depth = max(1, getattr(a, "pipeline", 1))
 
     def step(self):
         """Enqueue this step on the next handle of every piece, then complete the OLDEST step in flight (depth 1: this one).  With depth 2 the
@@ -233,6 +253,7 @@ class Job:
     def _complete(self, k):
         torch, multi, dist = self.torch, self.multi, self.dist
         self.reps = [p["rxs"][k].finish() for p in self.pieces]
+        self.done_times.append(time.perf_counter())
         for p in self.pieces:
             p["rx"], p["stream"], p["ts_view"] = p["rxs"][k], p["streams"][k], p["views"][k]
         if dist:
@@ -388,6 +409,13 @@ def timed_run(job, steps, warmup):
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # dispersion: host-side intervals between the completions of consecutive steps (job._complete returns when a step's report is back)
+    done = job.done_times[-steps:]
+    iv = np.diff(np.array([t0] + done)) * 1e3 if len(done) == steps else np.zeros(0)
+    if len(iv) > job.depth:                                   # the first `depth` completions include the pipeline's fill
+        iv = iv[job.depth:]
+    job.step_ms = {"min": round(float(iv.min()), 3), "median": round(float(np.median(iv)), 3), "max": round(float(iv.max()), 3),
+                   "p95": round(float(np.percentile(iv, 95)), 3), "n": int(len(iv))} if len(iv) else None
     if dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{job.local}")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -409,6 +437,7 @@ def main():
     ap.add_argument("--from-file-rate", action="store_true",
                     help="feed the 10 Msps file format: rational_resampler 64/70 + multiply_const run on the device in front of the chain "
                          "(SURVEY 8f row 2; samples are then counted at the 10 Msps input; single piece only)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) and run the gather path even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra workload lines (BASELINE configs 1, 2, 5) and the per-block ABI timing")
     ap.add_argument("--cpu-superframes", type=int, default=23)
@@ -432,7 +461,7 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":
+    if world > 1 or a.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
@@ -444,7 +473,7 @@ def main():
     if rank == 0:
         n_stream = job.n_total if not a.from_file_rate else sum(p["n"] for p in job.pieces)
         msps = n_stream * a.steps / dt / 1e6
-        check = job.verify() if not (a.from_file_rate or os.environ.get("BENCH_SKIP_VERIFY") == "1") else {"verified": None}   # BENCH_SKIP_VERIFY: experiment builds with wrong output (tools/*_attribution.sh)
+        check = job.verify() if not (a.from_file_rate or EXPERIMENT_BUILD) else {"verified": None}
         ok = check["verified"] is not False
         reps = job.reps
         # dominant kernel = viterbi3_kernel: per launch, algorithmic bytes = bytes in (one per m coded bits) + decoded
@@ -456,7 +485,9 @@ def main():
         stage_avg = {k: round(job.stage_avg(k), 4) for k in STAGES}
         solo = job.solo_stage_ms() if depth > 1 else None
         alg_bytes = sum(r.n_out_symbols * d.payload_length + r.n_viterbi_bytes for r in reps) / nseg
-        achieved = alg_bytes / (vit_ms * 1e-3) / 1e9 if vit_ms > 0 else 0.0
+        solo_ms = solo["viterbi"] if solo else vit_ms           # the kernel's own duration: one step in flight
+        achieved = alg_bytes / (solo_ms * 1e-3) / 1e9 if solo_ms > 0 else 0.0
+        traffic, traffic_src = profiled_traffic(a.workload, job.nsf, int(alg_bytes))
         n_ts = check.get("ts_bytes") or sum(int(r.n_ts_bytes) for r in reps)
         out = {
             "metric": "RX Msamples/s (baseband in -> TS out)", "value": round(msps, 2), "unit": "Msamples/s",
@@ -471,15 +502,18 @@ def main():
                        "ts_bytes_per_step": n_ts, "status": [int(r.status) for r in reps], "rs_fail_words": [int(r.rs_fail_words) for r in reps],
                        **check},
             "roofline": {"bound": "valu", "kernel": "viterbi3_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                         "note": "the dominant kernel is bound by VALU issue, not by HBM: every wave64 instruction of its mix (v_pk_*, v_perm, v_and_or, DPP) occupies the "
-                                 "SIMD for 4 cycles (profiles/r02_ubench_valu.json, r02_ubench_mix.json; DESIGN.md 5); achieved/peak/frac are the HBM figures the contract "
-                                 "asks for, from avg_launch_ms = HIP-event average over the timed steps, during which the next steps' front-end kernels share the machine "
-                                 "(config.steps_in_flight); solo_launch_ms = the same launch with one step in flight; traffic (PMC) is in profiles/, not measured in this run",
-                         "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(vit_ms, 4),
-                         "solo_launch_ms": solo["viterbi"] if solo else round(vit_ms, 4),
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "note": "the dominant kernel is bound by VALU issue, not by HBM (DESIGN.md 5: every wave64 instruction of its mix occupies the SIMD for 4 cycles); "
+                                 "achieved / peak / frac are the HBM figures the contract asks for: algorithmic bytes per launch / solo_launch_ms (HIP events on the "
+                                 "launch's own stream with ONE step in flight, measured right after the timed region; agrees with the rocprofv3 kernel-trace average "
+                                 "in profiles/); in_flight_* = the same over the timed steps, where the launch interval also contains the time the stream waited while "
+                                 "config.steps_in_flight steps shared the machine; traffic = PMC bytes per launch (FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE), "
+                                 "taken by separate rocprofv3 --pmc passes of this command: " + str(traffic_src),
+                         "algorithmic_bytes_per_launch": int(alg_bytes), "solo_launch_ms": round(solo_ms, 4),
+                         "in_flight_launch_ms": round(vit_ms, 4), "in_flight_achieved": round(alg_bytes / (vit_ms * 1e-3) / 1e9, 2) if vit_ms > 0 else None,
                          "chain_frac": round(msps / world * 1e6 * (8 + n_ts / n_stream) / 1e9 / HBM_PEAK_GBS, 6),
                          "hbm_copy_gbs": hbm_copy_gbs(torch, f"cuda:{local}")},
+            "ms_per_step_dispersion": job.step_ms,
             "stage_ms_per_piece": stage_avg,
             "stage_ms_per_piece_solo": solo,
         }

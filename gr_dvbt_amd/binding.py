@@ -5,7 +5,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-_SO = os.environ.get("DVBT_HIP_LIB") or os.path.join(_HERE, "lib", "libdvbt_hip.so")   # DVBT_HIP_LIB: A/B builds of the same ABI
+_SO = os.path.join(_HERE, "lib", "libdvbt_hip.so")
 _SRC = os.path.join(_HERE, "csrc", "dvbt_hip.hip")
 
 QPSK, QAM16, QAM64 = 0, 1, 2
@@ -14,7 +14,7 @@ C1_2, C2_3, C3_4, C5_6, C7_8 = 0, 1, 2, 3, 4
 T2k, T8k = 0, 1
 G1_32, G1_16, G1_8, G1_4 = 0, 1, 2, 3
 (TAP_ACQ, TAP_FFT, TAP_EQ, TAP_DEMAP, TAP_SYMDEINT, TAP_BITDEINT, TAP_VITERBI, TAP_DEINT, TAP_RS,
- TAP_TS, TAP_CP_START, TAP_SYMBOL_INDEX) = range(12)
+ TAP_TS, TAP_CP_START, TAP_SYMBOL_INDEX, TAP_FREQ_OFFSET) = range(13)
 
 
 class DvbtError(RuntimeError):
@@ -63,6 +63,11 @@ class RxReport(C.Structure):
                 ("n_lock_periods", C.c_int32), ("total_symbols", C.c_int32)]
 
 
+class LockPeriod(C.Structure):
+    _fields_ = [("offset", C.c_int64), ("first_call", C.c_int32), ("cp_start0", C.c_int32), ("n_symbols", C.c_int32),
+                ("first_out_symbol", C.c_int32)]
+
+
 class RxCut(C.Structure):
     _fields_ = [("stream_symbol_offset", C.c_int64)]
 
@@ -104,6 +109,7 @@ def lib():
         L.dvbt_rx_enable_taps.argtypes = [C.c_void_p, C.c_int]
         L.dvbt_rx_set_cut.argtypes = [C.c_void_p, C.POINTER(RxCut)]
         L.dvbt_rx_destroy.argtypes = [C.c_void_p]
+        L.dvbt_rx_lock_periods.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.dvbt_get_dims.argtypes = [C.c_int] * 5 + [C.POINTER(Dims)]
         _lib = L
     return _lib
@@ -129,7 +135,7 @@ class Rx:
     """Device-resident DVB-T receive chain (segment API of include/dvbt_hip.h)."""
 
     _TAP_DTYPE = {TAP_ACQ: np.complex64, TAP_FFT: np.complex64, TAP_EQ: np.complex64, TAP_CP_START: np.int32,
-                  TAP_SYMBOL_INDEX: np.int32}
+                  TAP_SYMBOL_INDEX: np.int32, TAP_FREQ_OFFSET: np.int32}
 
     def __init__(self, constellation, code_rate, mode, max_samples, guard=G1_32, hierarchy=NH, snr_db=30.0,
                  viterbi_bsize=768, rs_oracle_compat=0, descramble=1, device=0, viterbi_chunk_bytes=0, taps=False,
@@ -180,7 +186,8 @@ class Rx:
                  TAP_EQ: r.n_out_symbols * d.payload_length * 8, TAP_DEMAP: r.n_out_symbols * d.payload_length,
                  TAP_SYMDEINT: r.n_out_symbols * d.payload_length, TAP_BITDEINT: r.n_out_symbols * d.payload_length,
                  TAP_VITERBI: r.n_viterbi_bytes, TAP_DEINT: r.n_rs_bytes // 188 * 204, TAP_RS: r.n_rs_bytes,
-                 TAP_TS: r.n_ts_bytes, TAP_CP_START: r.n_symbols * 4, TAP_SYMBOL_INDEX: max(r.n_symbols - 1, 0) * 4}
+                 TAP_TS: r.n_ts_bytes, TAP_CP_START: r.n_symbols * 4, TAP_SYMBOL_INDEX: max(r.n_symbols - 1, 0) * 4,
+                 TAP_FREQ_OFFSET: max(r.n_symbols - 1, 0) * 4}
         nbytes = max(int(sizes[tap]), 0)
         buf = np.zeros(nbytes, np.uint8)
         if nbytes:
@@ -192,6 +199,13 @@ class Rx:
         elif tap in (TAP_EQ, TAP_DEMAP, TAP_SYMDEINT, TAP_BITDEINT):
             out = out.reshape(-1, d.payload_length)
         return out
+
+    def lock_periods(self):
+        """[(offset, first_call, cp_start0, n_symbols, first_out_symbol)] of the last run() / run_device()"""
+        n = _chk(self.L.dvbt_rx_lock_periods(self.h, None, 0))
+        buf = (LockPeriod * max(n, 1))()
+        _chk(self.L.dvbt_rx_lock_periods(self.h, buf, n))
+        return [(b.offset, b.first_call, b.cp_start0, b.n_symbols, b.first_out_symbol) for b in buf[:n]]
 
     def tap_device_ptr(self, tap):
         return self.L.dvbt_rx_tap_device_ptr(self.h, tap)

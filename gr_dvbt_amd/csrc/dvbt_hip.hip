@@ -62,13 +62,15 @@ template <class T> static int upload(const std::vector<T> &v, T **dptr)
 struct DevBuf {          // growable device scratch
   void *p = nullptr; size_t cap = 0;
   int reserve(size_t n) { if (n <= cap) return DVBT_OK; if (p) (void)hipFree(p); p = nullptr; cap = 0; HIPCHK(hipMalloc(&p, n + 64)); cap = n; return DVBT_OK; }
-  // grow and keep the first `keep` bytes (a block's history at the front of its input buffer)
-  int reserve_keep(size_t n, size_t keep)
+  // grow and keep the first `keep` bytes (a block's history at the front of its input buffer).  The history was written by copies queued on
+  // the call's stream `st` (the *_work_device entries never synchronise), so the move is queued on the same stream, and the old buffer is
+  // released only after that stream has drained (growth happens a handful of times in a handle's life)
+  int reserve_keep(size_t n, size_t keep, hipStream_t st)
   {
     if (n <= cap) return DVBT_OK;
     void *q = nullptr; HIPCHK(hipMalloc(&q, n + 64));
-    if (p && keep) HIPCHK(hipMemcpy(q, p, keep, hipMemcpyDeviceToDevice));
-    if (p) (void)hipFree(p);
+    if (p && keep) HIPCHK(hipMemcpyAsync(q, p, keep, hipMemcpyDeviceToDevice, st));
+    if (p) { HIPCHK(hipStreamSynchronize(st)); (void)hipFree(p); }
     p = q; cap = n; return DVBT_OK;
   }
   ~DevBuf() { if (p) (void)hipFree(p); }
@@ -251,6 +253,7 @@ struct dvbt_rx {
   dvbt_rx_cut cut = {0};
   float2 *tps_prev = nullptr; DescrRun *descr_runs = nullptr; int *descr_nruns = nullptr;
   int n_periods = 1; size_t seg_offset = 0;
+  std::vector<dvbt_lock_period> periods;    // phase A of the last synchronous run
   int sym_grid = 512;                       // workgroups of symbol8k_kernel (two per CU)
   int *sym_ticket = nullptr;                // its symbol counter
 };
@@ -599,7 +602,7 @@ extern "C" int dvbt_rx_segment_finish(dvbt_rx *h, dvbt_rx_report *rep)
 // nothing), d_avg carried along.  Phase B runs the chain over every period that acquired symbols, in order: TPS state carried, the period's last
 // item kept when a later period follows, every period's Viterbi stream appended to the segment's at a multiple of two de-interleaver items.
 // Then the byte de-interleaver, RS and the descrambler run once over the whole stream.
-struct LockPeriod { size_t off; int n_symbols; float avg_in; bool carry; };
+struct LockPeriod { size_t off; int n_symbols; float avg_in; bool carry; int call0, cp_start0; };
 
 static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipStream_t s, dvbt_rx_report *rep)
 {
@@ -619,12 +622,14 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
         off += (size_t)tries * L; avg = st.avg; carry = true;
         continue;
       }
-      per.push_back(LockPeriod{off, st.n_symbols, avg, carry});
+      per.push_back(LockPeriod{off, st.n_symbols, avg, carry, st.call0, st.cp_start0});
       if (!(st.status & 2)) break;                               // the lock held to the end of the segment
       off += (size_t)(st.call0 + st.n_symbols) * L + L / 2; avg = st.avg_lost; carry = true;
       if (per.size() >= 1024) break;
     }
   }
+  h->periods.clear();
+  for (const LockPeriod &q : per) h->periods.push_back(dvbt_lock_period{(int64_t)q.off, q.call0, q.cp_start0, q.n_symbols, 0});
   // ---- phase B
   size_t acc = 0; int delivering = 0, processed = 0; bool any = false;
   dvbt_rx_report first_rep; memset(&first_rep, 0, sizeof first_rep); first_rep.first_out_symbol = -1;
@@ -647,6 +652,7 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
     const RxState &st = *h->st_host;
     processed++; any = true; last_st = st; last_off = per[p].off;
     if (st.first_out >= 0) {
+      h->periods[p].first_out_symbol = st.first_out + 1;
       if (delivering == 0) { fill_report(h, st, first_rep); first_rep.segment_offset = (int64_t)per[p].off; }
       acc = o.vit_off + (size_t)st.n_vit_bytes; delivering++;
     }
@@ -742,6 +748,14 @@ extern "C" int64_t dvbt_rx_read_tap(dvbt_rx *h, int tap, void *dst, size_t cap)
     for (size_t i = 0; i < n; i++) ((int32_t *)dst)[i] = m[i].cp_start;
     return (int64_t)(n * 4);
   }
+  if (tap == DVBT_TAP_FREQ_OFFSET) {   // d_freq_offset of every demodulated symbol (reference_signals_impl.cc:715-744), out of the per-symbol sideband
+    size_t ns = h->have_last && h->last.n_symbols > 1 ? (size_t)h->last.n_symbols - 1 : 0;
+    std::vector<SymInfo> m(ns);
+    if (ns) HIPCHK(hipMemcpy(m.data(), h->info, ns * sizeof(SymInfo), hipMemcpyDeviceToHost));
+    size_t n = ns * 4 <= cap ? ns : cap / 4;
+    for (size_t i = 0; i < n; i++) ((int32_t *)dst)[i] = m[i].freq_offset;
+    return (int64_t)(n * 4);
+  }
   void *p = nullptr; size_t bytes = 0;
   int r = tap_info(h, tap, &p, &bytes); if (r) return r;
   if (!p) return fail(DVBT_ERR_STATE, "tap not enabled (call dvbt_rx_enable_taps before the segment)");
@@ -758,6 +772,14 @@ extern "C" void *dvbt_rx_tap_device_ptr(dvbt_rx *h, int tap)
     case DVBT_TAP_FFT: return h->fft_out; case DVBT_TAP_EQ: return h->eq; case DVBT_TAP_BITDEINT: return h->bitdeint;
     default: return nullptr;
   }
+}
+
+extern "C" int dvbt_rx_lock_periods(dvbt_rx *h, dvbt_lock_period *out, int cap)
+{
+  if (!h) return fail(DVBT_ERR_INVALID, "null handle");
+  const int n = (int)h->periods.size();
+  for (int i = 0; i < n && i < cap && out; i++) out[i] = h->periods[i];
+  return n;
 }
 
 extern "C" double dvbt_rx_stage_ms(dvbt_rx *h, const char *stage)

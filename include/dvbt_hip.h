@@ -321,7 +321,8 @@ typedef enum {
   DVBT_TAP_RS = 8,         /* u8[n_rs_bytes] */
   DVBT_TAP_TS = 9,         /* u8[n_ts_bytes] */
   DVBT_TAP_CP_START = 10,  /* i32[n_symbols] */
-  DVBT_TAP_SYMBOL_INDEX = 11 /* i32[n_symbols] */
+  DVBT_TAP_SYMBOL_INDEX = 11, /* i32[n_symbols - 1] */
+  DVBT_TAP_FREQ_OFFSET = 12  /* i32[n_symbols - 1]  integer carrier offset found for each demodulated symbol (reference_signals_impl.cc:715-744) */
 } dvbt_tap;
 
 typedef struct dvbt_rx dvbt_rx;
@@ -353,6 +354,18 @@ int  dvbt_rx_segment_run_device(dvbt_rx *h, const void *iq_device, size_t nsampl
  * Asynchronous w.r.t. the host: enqueue only.  Use dvbt_rx_segment_finish to wait and fetch the report. */
 int  dvbt_rx_segment_enqueue_device(dvbt_rx *h, const void *iq_device, size_t nsamples, void *stream);
 int  dvbt_rx_segment_finish(dvbt_rx *h, dvbt_rx_report *report);
+/* the CP-lock periods the last dvbt_rx_segment_run / _run_device walked through (ofdm_sym_acquisition alone, in stream order): where the
+ * search that found the lock started, the call and d_cp_start of the initial acquisition, how many symbols the lock held.  A period with
+ * n_symbols == 0 is a peak that the tracking search of the same call already missed (ofdm_sym_acquisition_impl.cc:503-559).  Returns the
+ * number of periods (may exceed cap). */
+typedef struct {
+  int64_t offset;             /* sample of the segment (OFDM elementary rate) at which this search began */
+  int32_t first_call;         /* window (of N+cp samples, from offset) in which the initial acquisition found its peak */
+  int32_t cp_start0;          /* d_cp_start of that call */
+  int32_t n_symbols;          /* items the lock delivered before it was lost (or the segment ended) */
+  int32_t first_out_symbol;   /* 1 + symbol of the period at which superframe_start fired, 0 if it delivered nothing downstream */
+} dvbt_lock_period;
+int  dvbt_rx_lock_periods(dvbt_rx *h, dvbt_lock_period *out, int cap);
 /* copy a tap of the last finished segment to host memory; returns bytes written */
 int64_t dvbt_rx_read_tap(dvbt_rx *h, int tap, void *dst_host, size_t cap_bytes);
 /* device pointer of a tap's buffer (for RCCL gathers of the decoded packets) */

@@ -131,6 +131,10 @@ void   o_acq_free(o_acq *a);
 int o_acq_work(o_acq *a, const ocf *in, ocf *out, int *consumed, int *sync_start,
                int *cp_start, float *epsilon);
 
+/* the same when `hist` samples of the stream lie in memory in front of in[0] (GNU Radio's circular buffer keeps what was consumed) */
+int o_acq_work_hist(o_acq *a, const ocf *in, long long hist, ocf *out, int *consumed, int *sync_start,
+                    int *cp_start, float *epsilon);
+
 /* ---- demod_reference_signals (pilot_gen::parse_input + block logic) ---- */
 typedef struct o_demod o_demod;
 o_demod *o_demod_new(const o_cfg *c);
@@ -170,6 +174,9 @@ typedef struct {
   double t_stage[10];     /* seconds per stage (acq,fft,demod,demap,symd,bitd,vit,deint,rs,descr) */
   long long ts_first_packet;  /* RS word index (of this run) of the first TS packet */
   long long stream_rs_items;  /* byte de-interleaver items in stream coordinates (== rs_n/1504 unless the run continues a cut stream) */
+  int *freq_offset;           /* optional, meta_cap entries: d_freq_offset of every demodulator call (reference_signals_impl.cc:715-744) */
+  long long *call_pos;        /* optional, meta_cap entries: sample at which the general_work call that delivered acquired symbol i began */
+  unsigned char *sync_flag;   /* optional, meta_cap entries: 1 = the item carries the sync_start tag (first item of a lock period) */
 } o_rx_taps;
 
 int o_rx_run(const o_cfg *c, const ocf *iq, size_t nsamples, float snr_db, int bsize,

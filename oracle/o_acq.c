@@ -12,6 +12,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* A tracking window at the very left of a call (cp_start within 8 samples of N+cp-1, where the reference's asserts :152-153 would fire in a
+ * debug build) makes the reference index in[], d_norm[] and d_corr[] up to 8 + ... samples BEFORE their start (:166-186): in[] then is the
+ * stream's history in GNU Radio's circular buffer (the samples consumed by the previous calls), which is what is read here when the caller
+ * says it is there (o_acq_work_hist); samples in front of the stream's first one read 0. */
+#define O_ACQ_BACK 32
 struct o_acq {
   int N, cp;
   float snr, rho;
@@ -20,6 +25,7 @@ struct o_acq {
   int initial_acq, cp_start, to_consume, to_out, freq_count, freq_timeout;
   ocf *gamma, *derot, *corr; float *lambda, *norm, *phi; int *peak_pos;
   float last_eps;
+  long long hist;            /* samples of the stream in memory in front of in[0] of the current call */
 };
 
 o_acq *o_acq_new(const o_cfg *c, float snr_db)
@@ -36,7 +42,7 @@ o_acq *o_acq_new(const o_cfg *c, float snr_db)
   a->derot = calloc(a->N + a->cp, sizeof(ocf));
   /* +16: in tracking the look-up window reaches cp_start + 8, and cp_start may sit at the very end of the 2N+cp samples the
    * reference forecasts (its own d_norm/d_corr are W long: it would write past them there); o_rx_run keeps 16 more samples visible */
-  a->norm = calloc(W + 16, sizeof(float)); a->corr = calloc(W + 16, sizeof(ocf));
+  a->norm = (float *)calloc(W + 16 + O_ACQ_BACK, sizeof(float)) + O_ACQ_BACK; a->corr = (ocf *)calloc(W + 16 + O_ACQ_BACK, sizeof(ocf)) + O_ACQ_BACK;
   return a;
 }
 
@@ -44,7 +50,7 @@ void o_acq_free(o_acq *a)
 {
   if (!a) return;
   free(a->gamma); free(a->lambda); free(a->phi); free(a->peak_pos);
-  free(a->derot); free(a->norm); free(a->corr); free(a);
+  free(a->derot); free(a->norm - O_ACQ_BACK); free(a->corr - O_ACQ_BACK); free(a);
 }
 
 /* :72-146 */
@@ -82,19 +88,19 @@ static void advance_phase(o_acq *a)
   while (a->phase < (float)(-M_PI)) a->phase += (float)(2.0 * M_PI);
 }
 
-/* :148-351.  Samples the reference would read before in[0] (possible only when the CP
- * peak sits within 8+cp samples of the window start, where its asserts would fire) read 0. */
+/* :148-351.  Samples the reference would read before in[0] are the stream's own (a->hist of them are in memory), 0 before the stream. */
 static int ml_sync(o_acq *a, const ocf *in, int lookup_start, int lookup_stop)
 {
   const int N = a->N, cp = a->cp;
+  const int back = a->hist < O_ACQ_BACK ? (int)a->hist : O_ACQ_BACK;      /* how far in front of in[0] there are samples */
   int low = lookup_stop - (cp + N - 1);
-  for (int i = low < 0 ? 0 : low; i <= lookup_start; i++) {
+  for (int i = low < -back ? -back : low; i <= lookup_start; i++) {
     float re = crealf(in[i]), im = cimagf(in[i]);
     a->norm[i] = re * re + im * im;
   }
   low = lookup_stop - cp - 1;
   for (int i = low; i <= lookup_start; i++) {
-    if (i - N < 0) continue;
+    if (i - N < -back) continue;
     a->corr[i - N] = in[i] * conjf(in[i - N]);
   }
   for (int i = lookup_start - 1; i >= lookup_stop; i--) {
@@ -102,7 +108,7 @@ static int ml_sync(o_acq *a, const ocf *in, int lookup_start, int lookup_stop)
     float phi = 0.0f; ocf g = 0.0f;
     for (int j = 0; j < cp; j++) {
       int ci = i - j - N;
-      if (ci < 0) continue;
+      if (ci < -back) continue;
       g += a->corr[ci];
       phi += a->norm[i - j] + a->norm[ci];
     }
@@ -143,7 +149,12 @@ static int ml_sync(o_acq *a, const ocf *in, int lookup_start, int lookup_stop)
 /* :489-568 */
 int o_acq_work(o_acq *a, const ocf *in, ocf *out, int *consumed, int *sync_start,
                int *cp_start, float *epsilon)
+{ return o_acq_work_hist(a, in, 0, out, consumed, sync_start, cp_start, epsilon); }
+
+int o_acq_work_hist(o_acq *a, const ocf *in, long long hist, ocf *out, int *consumed, int *sync_start,
+                    int *cp_start, float *epsilon)
 {
+  a->hist = hist;
   const int N = a->N, cp = a->cp;
   *sync_start = 0;
   if (!a->initial_acq) {

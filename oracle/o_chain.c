@@ -52,12 +52,14 @@ int o_rx_run_cut(const o_cfg *c, const ocf *iq, size_t nsamples, float snr_db, i
     /* forecast :474-481 asks for 2N+cp; 16 more keeps the +-8 tracking window in range */
     while (pos + (size_t)(2 * N + cp) + 16 <= nsamples && nacq < max_sym) {
       int consumed, sync, cps; float eps;
-      int produced = o_acq_work(a, iq + pos, acq + nacq * (size_t)N, &consumed, &sync, &cps, &eps);
+      int produced = o_acq_work_hist(a, iq + pos, (long long)pos, acq + nacq * (size_t)N, &consumed, &sync, &cps, &eps);
       if (sync) pending = 1;
       if (produced) {
         sync_tag[nacq] = (unsigned char)pending; pending = 0;
         if (t->cp_start && nacq < t->meta_cap) t->cp_start[nacq] = cps;
         if (t->epsilon && nacq < t->meta_cap) t->epsilon[nacq] = eps;
+        if (t->call_pos && nacq < t->meta_cap) t->call_pos[nacq] = (long long)pos;
+        if (t->sync_flag && nacq < t->meta_cap) t->sync_flag[nacq] = sync_tag[nacq];
         nacq++;
       }
       pos += (size_t)consumed;
@@ -89,6 +91,7 @@ int o_rx_run_cut(const o_cfg *c, const ocf *iq, size_t nsamples, float snr_db, i
       int sf, si, info[8];
       int produced = o_demod_work(d, fft + j * (size_t)N, eq + nout * (size_t)P, sync_tag[j], &sf, &si, info);
       if (t->sym_index && j < t->meta_cap) t->sym_index[j] = si;
+      if (t->freq_offset && j < t->meta_cap) t->freq_offset[j] = info[0];
       if (sf) {
         if (t->first_out_symbol < 0) t->first_out_symbol = (int)j; else truncated++;
         if (nper < O_MAX_PERIODS) per_start[nper++] = nout;        /* output item at which this lock period starts */

@@ -62,7 +62,8 @@ class Taps(C.Structure):
         ("meta_cap", C.c_size_t),
         ("first_out_symbol", C.c_int), ("n_acquired", C.c_int),
         ("rs_fail", C.c_int), ("rs_corr", C.c_int),
-        ("t_stage", C.c_double * 10), ("ts_first_packet", C.c_longlong), ("stream_rs_items", C.c_longlong)]
+        ("t_stage", C.c_double * 10), ("ts_first_packet", C.c_longlong), ("stream_rs_items", C.c_longlong),
+        ("freq_offset", C.c_void_p), ("call_pos", C.c_void_p), ("sync_flag", C.c_void_p)]
 
 
 _lib = None
@@ -197,6 +198,27 @@ def clock_offset(iq, ppm, taps=16):
     return out
 
 
+def channel(iq, N, cfo=0.0, echoes=(), snr_db=None, seed=5, ref_span=(1000, 101000)):
+    """Test utility: what a real capture does to the loopback baseband.  echoes: (delay in samples, complex amplitude) of static
+    extra paths; cfo: carrier offset in subcarrier spacings (fractional part -> ofdm_sym_acquisition's epsilon, integer part ->
+    pilot_gen::process_cpilot_data); AWGN at snr_db relative to the power of iq[ref_span] after the channel.  Computed in
+    double, returned as complex64."""
+    x = np.asarray(iq).astype(np.complex128)
+    if echoes:
+        y = x.copy()
+        for d, a in echoes:
+            y[d:] += a * x[:-d]
+        x = y
+    if cfo:
+        x *= np.exp(2j * np.pi * cfo / N * np.arange(len(x), dtype=np.float64))
+    if snr_db is not None:
+        rng = np.random.RandomState(seed)
+        p = np.mean(np.abs(x[ref_span[0]:ref_span[1]]) ** 2)
+        sig = np.sqrt(p / (10 ** (snr_db / 10)) / 2)
+        x = x + sig * (rng.randn(len(x)) + 1j * rng.randn(len(x)))
+    return x.astype(np.complex64)
+
+
 def tx_scale(c):
     """TX multiply_const * RX multiply_const of the demo flowgraphs (apps/dvbt_{tx,rx}_demo*.grc)."""
     return float(np.float32(0.0022097087) * np.float32(0.0022097087 if c.mode == T2k else 0.00055242272))
@@ -258,6 +280,9 @@ def rx(c, iq, snr_db=30.0, bsize=768, rs_compat=0, want=("rs",), max_sym_taps=No
     t.cp_start = alloc("cp_start", (nsym,), np.int32)
     t.epsilon = alloc("epsilon", (nsym,), np.float32)
     t.sym_index = alloc("sym_index", (nsym,), np.int32)
+    t.freq_offset = alloc("freq_offset", (nsym,), np.int32)
+    t.call_pos = alloc("call_pos", (nsym,), np.int64)
+    t.sync_flag = alloc("sync_flag", (nsym,), np.uint8)
     t.meta_cap = nsym
     trunc = L.o_rx_run_cut(C.byref(c), _p(iq), len(iq), C.c_float(snr_db), bsize, rs_compat, sym_off, C.byref(t))
     out = {"truncated": trunc, "n_acquired": t.n_acquired, "first_out_symbol": t.first_out_symbol,
@@ -268,8 +293,10 @@ def rx(c, iq, snr_db=30.0, bsize=768, rs_compat=0, want=("rs",), max_sym_taps=No
                  ("rs", t.rs_n), ("ts", t.ts_n)):
         if k in bufs:
             out[k] = bufs[k][:n]
-    for k in ("cp_start", "epsilon", "sym_index"):
+    for k in ("cp_start", "epsilon", "sym_index", "freq_offset", "call_pos", "sync_flag"):
         out[k] = bufs[k][:t.n_acquired]
+    starts = np.flatnonzero(out["sync_flag"])
+    out["lock_periods"] = [(int(out["call_pos"][a]), int(b - a)) for a, b in zip(starts, list(starts[1:]) + [t.n_acquired])]
     return out
 
 

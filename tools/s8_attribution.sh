@@ -7,6 +7,6 @@ if [ "$1" = build ]; then
   for e in $BITS; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -DS8_EXP=$e ${EXTRA} -o gr_dvbt_amd/lib/libdvbt_hip_s8e$e.so gr_dvbt_amd/csrc/dvbt_hip.hip || exit 1; done
 else
   for e in $BITS; do
-    DVBT_HIP_LIB=$PWD/gr_dvbt_amd/lib/libdvbt_hip_s8e$e.so BENCH_SKIP_VERIFY=1 python bench.py --pipeline 1 --steps 10 --warmup 2 --superframes 16 --no-cpu-baseline --no-extras 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'s8_exp': $e, 'fft_stage_ms_17sf': d['stage_ms_per_piece']['fft']}))"
+    python tools/ab_bench.py $PWD/gr_dvbt_amd/lib/libdvbt_hip_s8e$e.so --wrong-output --pipeline 1 --steps 10 --warmup 2 --superframes 16 --no-cpu-baseline --no-extras 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'s8_exp': $e, 'fft_stage_ms_17sf': d['stage_ms_per_piece']['fft']}))"
   done
 fi
