@@ -10,6 +10,7 @@
 #include "../../include/dvbt_hip.h"
 #include "dvbt_tables.hpp"
 #include "k_frontend.hpp"
+#include "k_drift.hpp"
 #include "k_backend.hpp"
 #include "k_symbol8k.hpp"
 #include "k_symbol2k.hpp"
@@ -254,13 +255,14 @@ struct dvbt_rx {
   float2 *tps_prev = nullptr; DescrRun *descr_runs = nullptr; int *descr_nruns = nullptr;
   int n_periods = 1; size_t seg_offset = 0;
   std::vector<dvbt_lock_period> periods;    // phase A of the last synchronous run
+  DriftBufs drift = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; double *drift_mem = nullptr;   // k_drift.hpp
   int sym_grid = 512;                       // workgroups of symbol8k_kernel (two per CU)
   int *sym_ticket = nullptr;                // its symbol counter
 };
 
 static void rx_free(dvbt_rx *h)
 {
-  void *all[] = {h->tps_prev, h->descr_runs, h->descr_nruns, h->centre, h->anchor_pos, h->sym_ticket, h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags, h->trk_eps, h->d_iq, h->rs_iq, h->acq_carry, h->g_init, h->l_init, h->g_trk, h->l_trk, h->meta, h->st, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
+  void *all[] = {h->drift_mem, h->drift.delta, h->drift.flags, h->tps_prev, h->descr_runs, h->descr_nruns, h->centre, h->anchor_pos, h->sym_ticket, h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags, h->trk_eps, h->d_iq, h->rs_iq, h->acq_carry, h->g_init, h->l_init, h->g_trk, h->l_trk, h->meta, h->st, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
                  h->info, h->maj, h->sym_index, h->labels, h->symdeint_tap, h->bitdeint, h->vit, h->deint_tap, h->rs_out, h->ts_out};
   for (void *q : all) if (q) (void)hipFree(q);
   if (h->st_host) (void)hipHostFree(h->st_host);
@@ -319,8 +321,16 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   for (int i = 0; i < ST_COUNT; i++) RXHIP(hipEventCreate(&h->ev[i]));
   h->ev_ready = true;
   RXHIP(hipMalloc((void **)&h->sym_ticket, 64));
-  RXCHK(set_lds((const void *)symbol8k_kernel<false>, S8_LDS_BYTES));
-  RXCHK(set_lds((const void *)symbol2k_kernel<false>, S2_LDS_BYTES)); RXCHK(set_lds((const void *)symbol2k_kernel<true>, S2_LDS_BYTES)); RXCHK(set_lds((const void *)symbol8k_kernel<true>, S8_LDS_BYTES));
+  {   // the float phase accumulator's wander (k_drift.hpp): tables and sums per call, one deviation per 32 samples of every item
+    RXHIP(hipMalloc((void **)&h->drift_mem, sizeof(double) * (C * (DRIFT_TAB + 4) + 8)));
+    h->drift.tabs = h->drift_mem; h->drift.ex_run = h->drift.tabs + C * DRIFT_TAB; h->drift.ex_entry = h->drift.ex_run + C;
+    h->drift.d = h->drift.ex_entry + C; h->drift.S = h->drift.d + C; h->drift.A0 = h->drift.S + C;
+    RXHIP(hipMalloc((void **)&h->drift.delta, sizeof(float) * C * (N / 32))); RXHIP(hipMalloc((void **)&h->drift.flags, 16)); RXHIP(hipMemset(h->drift.flags, 0, 16));
+  }
+  RXCHK(set_lds((const void *)symbol8k_kernel<false, false>, S8_LDS_BYTES)); RXCHK(set_lds((const void *)symbol8k_kernel<false, true>, S8_LDS_BYTES));
+  RXCHK(set_lds((const void *)symbol8k_kernel<true, false>, S8_LDS_BYTES)); RXCHK(set_lds((const void *)symbol8k_kernel<true, true>, S8_LDS_BYTES));
+  RXCHK(set_lds((const void *)symbol2k_kernel<false, false>, S2_LDS_BYTES)); RXCHK(set_lds((const void *)symbol2k_kernel<false, true>, S2_LDS_BYTES));
+  RXCHK(set_lds((const void *)symbol2k_kernel<true, false>, S2_LDS_BYTES)); RXCHK(set_lds((const void *)symbol2k_kernel<true, true>, S2_LDS_BYTES));
   { int ncu = 256; (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->prm.device); h->sym_grid = s8_grid(ncu); }
   RXCHK(set_lds((const void *)inner_kernel<6>, inner_lds_bytes(P)));
   RXCHK(set_lds((const void *)acq_anchor_kernel, acq_anchor_lds_bytes((int)N, d.cp)));
@@ -466,22 +476,38 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_FFT], s));
   // A1 tail + A2 + A3 in one kernel: the FFT item of a symbol never leaves LDS (acq/fft taps are written only when enabled)
   HIPCHK(hipMemsetAsync(h->sym_ticket, 0, sizeof(int), s));                      // the counter that hands out symbols
-  if (N == S8_N && !(h->acq_tap || h->fft_out || h->eq))      // 8k: persistent workgroups, two per CU (k_symbol8k.hpp)
-    hipLaunchKernelGGL(symbol8k_kernel<false>, dim3(h->sym_grid), dim3(S8_T), S8_LDS_BYTES, s, iq, fp, (const RxState *)h->st, (const SymMeta *)h->meta,
-                       (const float2 *)h->T.tw, h->acq_tap, h->fft_out, h->T.demod_tables(), h->eq, h->tpsval, h->info,
-                       h->T.inner_params(d.payload), (const float2 *)h->T.points, (const unsigned char *)h->T.label_tab, h->labels, h->sym_ticket);
-  else if (N == S8_N)
-    hipLaunchKernelGGL(symbol8k_kernel<true>, dim3(h->sym_grid), dim3(S8_T), S8_LDS_BYTES, s, iq, fp, (const RxState *)h->st, (const SymMeta *)h->meta,
-                       (const float2 *)h->T.tw, h->acq_tap, h->fft_out, h->T.demod_tables(), h->eq, h->tpsval, h->info,
-                       h->T.inner_params(d.payload), (const float2 *)h->T.points, (const unsigned char *)h->T.label_tab, h->labels, h->sym_ticket);
-  else if (N == S2_N && !(h->acq_tap || h->fft_out || h->eq))   // 2k: the same design, four symbols per workgroup (k_symbol2k.hpp)
-    hipLaunchKernelGGL(symbol2k_kernel<false>, dim3(h->sym_grid), dim3(S2_T * S2_Q), S2_LDS_BYTES, s, iq, fp, (const RxState *)h->st, (const SymMeta *)h->meta,
-                       (const float2 *)h->T.tw, h->acq_tap, h->fft_out, h->T.demod_tables(), h->eq, h->tpsval, h->info,
-                       h->T.inner_params(d.payload), (const float2 *)h->T.points, (const unsigned char *)h->T.label_tab, h->labels, h->sym_ticket);
-  else if (N == S2_N)
-    hipLaunchKernelGGL(symbol2k_kernel<true>, dim3(h->sym_grid), dim3(S2_T * S2_Q), S2_LDS_BYTES, s, iq, fp, (const RxState *)h->st, (const SymMeta *)h->meta,
-                       (const float2 *)h->T.tw, h->acq_tap, h->fft_out, h->T.demod_tables(), h->eq, h->tpsval, h->info,
-                       h->T.inner_params(d.payload), (const float2 *)h->T.points, (const unsigned char *)h->T.label_tab, h->labels, h->sym_ticket);
+  {
+    // the wander of the reference's float phase accumulator (k_drift.hpp): tables per call, three rounds of the fixed point, the deviations per 32-sample block;
+    // every kernel returns at once when the lock period has no usable carrier offset (drift.flags, device side: no host round trip)
+    const DriftBufs &D = h->drift;
+    HIPCHK(hipMemsetAsync(D.flags, 0, 16, s));
+    hipLaunchKernelGGL(drift_prep_kernel, dim3((C + 255) / 256), dim3(256), 0, s, fp, (const RxState *)h->st, (const SymMeta *)h->meta, D);
+    hipLaunchKernelGGL(drift_exact_kernel, dim3(1), dim3(1024), 0, s, fp, (const RxState *)h->st, (const SymMeta *)h->meta, D);
+    for (int it = 0; it < 3; it++) {
+      hipLaunchKernelGGL(drift_eval_kernel, dim3((C + 255) / 256), dim3(256), 0, s, fp, (const RxState *)h->st, (const SymMeta *)h->meta, D, it == 0 ? 1 : 0);
+      hipLaunchKernelGGL(drift_scan_kernel, dim3(1), dim3(1024), 0, s, (const RxState *)h->st, D);
+    }
+    hipLaunchKernelGGL(drift_table_kernel, dim3(C), dim3(N / 32 < 256 ? N / 32 : 256), 0, s, fp, (const RxState *)h->st, (const SymMeta *)h->meta, D);
+  }
+  const bool taps = h->acq_tap || h->fft_out || h->eq;
+#define SYM_ARGS iq, fp, (const RxState *)h->st, (const SymMeta *)h->meta, (const float2 *)h->T.tw, h->acq_tap, h->fft_out, h->T.demod_tables(), h->eq, h->tpsval, h->info, \
+                 h->T.inner_params(d.payload), (const float2 *)h->T.points, (const unsigned char *)h->T.label_tab, h->labels, h->sym_ticket, (const float *)h->drift.delta, (const int *)h->drift.flags
+  // 8k: persistent workgroups, two per CU (k_symbol8k.hpp); 2k: the same design, four symbols per workgroup (k_symbol2k.hpp).  The plain and the DRIFT
+  // instantiation are both launched: the one that drift.flags[1] does not select returns before it takes a symbol
+  if (N == S8_N && !taps) {
+    hipLaunchKernelGGL((symbol8k_kernel<false, false>), dim3(h->sym_grid), dim3(S8_T), S8_LDS_BYTES, s, SYM_ARGS);
+    hipLaunchKernelGGL((symbol8k_kernel<false, true>), dim3(h->sym_grid), dim3(S8_T), S8_LDS_BYTES, s, SYM_ARGS);
+  } else if (N == S8_N) {
+    hipLaunchKernelGGL((symbol8k_kernel<true, false>), dim3(h->sym_grid), dim3(S8_T), S8_LDS_BYTES, s, SYM_ARGS);
+    hipLaunchKernelGGL((symbol8k_kernel<true, true>), dim3(h->sym_grid), dim3(S8_T), S8_LDS_BYTES, s, SYM_ARGS);
+  } else if (N == S2_N && !taps) {
+    hipLaunchKernelGGL((symbol2k_kernel<false, false>), dim3(h->sym_grid), dim3(S2_T * S2_Q), S2_LDS_BYTES, s, SYM_ARGS);
+    hipLaunchKernelGGL((symbol2k_kernel<false, true>), dim3(h->sym_grid), dim3(S2_T * S2_Q), S2_LDS_BYTES, s, SYM_ARGS);
+  } else if (N == S2_N) {
+    hipLaunchKernelGGL((symbol2k_kernel<true, false>), dim3(h->sym_grid), dim3(S2_T * S2_Q), S2_LDS_BYTES, s, SYM_ARGS);
+    hipLaunchKernelGGL((symbol2k_kernel<true, true>), dim3(h->sym_grid), dim3(S2_T * S2_Q), S2_LDS_BYTES, s, SYM_ARGS);
+  }
+#undef SYM_ARGS
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_DEMOD], s));
   if (!o.continuation) {
     HIPCHK(hipMemsetAsync(h->tps_state, 0, sizeof(TpsState), s));

@@ -758,7 +758,7 @@ __device__ __forceinline__ void fft_dif_lds(float2 *x, int N, const float2 *tw_c
 __global__ __launch_bounds__(FFT_THREADS) void derot_fft_kernel(const float2 *__restrict__ iq, FrontParams p, const RxState *st,
                                                        const SymMeta *__restrict__ meta, const float2 *__restrict__ tw,
                                                        const uint16_t *__restrict__ perm, float2 *__restrict__ acq_tap,
-                                                       float2 *__restrict__ out)
+                                                       float2 *__restrict__ out, const float *__restrict__ drift = nullptr, const int *__restrict__ drift_flags = nullptr)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float2 *x = reinterpret_cast<float2 *>(smem_raw);
@@ -778,6 +778,7 @@ __global__ __launch_bounds__(FFT_THREADS) void derot_fft_kernel(const float2 *__
       float ph = wrap_pi((double)m.ph_base + a * m.incA + b * m.incB);
       float sn, cs; sincosf(ph, &sn, &cs);
       v = cmul(make_float2(cs, sn), v);
+      if (drift && drift_flags[1]) { const float dl = drift[(size_t)s * (N / 32) + (n >> 5)]; v = make_float2(v.x - dl * v.y, v.y + dl * v.x); }   // k_drift.hpp
     }
     x[fpad(n)] = v;
     if (acq_tap) acq_tap[(size_t)s * N + n] = v;

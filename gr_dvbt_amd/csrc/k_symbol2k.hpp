@@ -58,13 +58,15 @@ __device__ __forceinline__ void s8_twiddle8(v2f (&a)[8], v2f w1)
 __device__ __forceinline__ float s8_oct_sum(float v) { v += s8_dpp<0xB1>(v); v += s8_dpp<0x4E>(v); v += s8_dpp<0x141>(v); return v; }   // 8 lanes: quad_perm x 2, row_half_mirror
 __device__ __forceinline__ v2f s2_sample(s8_i4 rsrc, int i, int t) { return s8_raw_buffer_load_v2f32(rsrc, t * 8, i * S2_T * 8, 0); }
 
-template <bool TAPS> __global__ __launch_bounds__(S2_T * S2_Q, 4) void symbol2k_kernel(const float2 *__restrict__ iq_, FrontParams p, const RxState *st,
+template <bool TAPS, bool DRIFT> __global__ __launch_bounds__(S2_T * S2_Q, 4) void symbol2k_kernel(const float2 *__restrict__ iq_, FrontParams p, const RxState *st,
                                                            const SymMeta *__restrict__ meta, const float2 *__restrict__ tw, float2 *__restrict__ acq_tap,
                                                            float2 *__restrict__ fft_tap, DemodTables T, float2 *__restrict__ eq_tap,
                                                            float2 *__restrict__ tpsval, SymInfo *__restrict__ info, InnerParams ip,
                                                            const float2 *__restrict__ points, const unsigned char *__restrict__ label_tab,
-                                                           uint8_t *__restrict__ labels, int *__restrict__ ticket)
+                                                           uint8_t *__restrict__ labels, int *__restrict__ ticket,
+                                                           const float *__restrict__ drift, const int *__restrict__ drift_flags)
 {
+  if ((drift_flags[1] != 0) != DRIFT) return;                   // see symbol8k_kernel
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid0 = threadIdx.x, g = tid0 >> 7, t0 = tid0 & 127, cp = p.cp;          // g: which of the workgroup's four symbols
   unsigned char *slot = smem_raw + (size_t)g * S2_SLOT_BYTES;
@@ -136,6 +138,10 @@ template <bool TAPS> __global__ __launch_bounds__(S2_T * S2_Q, 4) void symbol2k_
         const bool pieceB = n + 1 > sw;
         const v2f P = pieceB ? PB : PA;
         a[i] = s8_cmul(s8_cmul(P, pt[(pieceB ? 16 : 0) + i]), vin[i]);
+        if (DRIFT) {   // x (1 + i delta) of the sample's 32-sample block (k_drift.hpp); sample n = t + 128 i lies in block (t >> 5) + 4 i
+          const float dl = drift[(size_t)sc * (S2_N / 32) + (t >> 5) + 4 * i];
+          a[i] = (v2f){__builtin_fmaf(-dl, a[i].y, a[i].x), __builtin_fmaf(dl, a[i].x, a[i].y)};
+        }
         if (TAPS && acq_tap && act) acq_tap[(size_t)s * N + n] = s8_f(a[i]);
       }
     }

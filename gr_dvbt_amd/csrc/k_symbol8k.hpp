@@ -220,13 +220,18 @@ __device__ __forceinline__ s8_i4 s8_rsrc(const v2f *base)
 __device__ __forceinline__ v2f s8_sample(s8_i4 rsrc, int i, int tid) { return s8_raw_buffer_load_v2f32(rsrc, tid * 8, i * S8_T * 8, 0); }
 
 // TAPS: the debug taps (derotated samples, spectrum, equalised carriers) are compiled in; the production instantiation has none of that code
-template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(const float2 *__restrict__ iq_, FrontParams p, const RxState *st,
+// DRIFT: the instantiation that also reproduces the wander of the reference's float phase accumulator (k_drift.hpp): the derotation phasor of a sample is
+// multiplied by (1 + i delta) of its 32-sample block.  Both instantiations are launched; the device-side flag drift_flags[1] decides which one works
+// (the other returns before it takes a symbol), so the path without a carrier offset keeps its registers and instructions.
+template <bool TAPS, bool DRIFT> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(const float2 *__restrict__ iq_, FrontParams p, const RxState *st,
                                                            const SymMeta *__restrict__ meta, const float2 *__restrict__ tw, float2 *__restrict__ acq_tap,
                                                            float2 *__restrict__ fft_tap, DemodTables T, float2 *__restrict__ eq_tap,
                                                            float2 *__restrict__ tpsval, SymInfo *__restrict__ info, InnerParams ip,
                                                            const float2 *__restrict__ points, const unsigned char *__restrict__ label_tab,
-                                                           uint8_t *__restrict__ labels, int *__restrict__ ticket)
+                                                           uint8_t *__restrict__ labels, int *__restrict__ ticket,
+                                                           const float *__restrict__ drift, const int *__restrict__ drift_flags)
 {
+  if ((drift_flags[1] != 0) != DRIFT) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   v2f *x = reinterpret_cast<v2f *>(smem_raw);
   v2f *gtab = x + S8_N;                                          // LS gains at the estimation carriers
@@ -289,6 +294,12 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
 #pragma unroll
       for (int i = 0; i < ((S8_EXP & 4) ? 16 : S8_TOP); i++) vin[i] = s8_sample(rs, i, tid);
     }
+    float dl[16];
+    if (DRIFT) {
+      const float *dt = drift + (size_t)s * (S8_N / 32) + (tid >> 5);           // sample n = tid + 512 i lies in block (tid >> 5) + 16 i
+#pragma unroll
+      for (int i = 0; i < 16; i++) dl[i] = dt[16 * i];
+    }
     // ---- A1 tail: derotate (ofdm_sym_acquisition_impl.cc:285-309,527-534), on the registers the loads arrived in
     v2f a[16];
     {
@@ -301,6 +312,7 @@ template <bool TAPS> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(
         const bool pieceB = n + 1 > sw;
         const v2f P = pieceB ? PB : PA;
         a[i] = (S8_EXP & 32) ? vin[i] : s8_cmul(s8_cmul(P, pt[(pieceB ? 16 : 0) + i]), vin[i]);
+        if (DRIFT) a[i] = (v2f){__builtin_fmaf(-dl[i], a[i].y, a[i].x), __builtin_fmaf(dl[i], a[i].x, a[i].y)};    // x (1 + i delta), |delta| < 2e-3
         if (TAPS && acq_tap) acq_tap[(size_t)s * N + n] = s8_f(a[i]);
       }
     }

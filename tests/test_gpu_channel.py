@@ -11,8 +11,8 @@ estimation carriers of a frequency-selective channel, reference_signals_impl.cc:
   so that the fall below 0.9 d_avg is missed, ofdm_sym_acquisition_impl.cc:72-146): the same lock periods, the same bytes (possibly none);
 * through the segment API and through the ten blocks driven call by call.
 
-The ACQ / FFT taps are compared per symbol up to a common phasor: the reference accumulates the derotation phase sample by sample in float
-(:285-309), the kernels take it in closed form in double; the difference is one rotation per symbol that the equaliser divides out."""
+The ACQ / FFT taps are compared per symbol up to a common phasor (the accumulated deviation of the reference's float phase accumulator from the exact
+line at the symbol's entry is one rotation per symbol, which the equaliser divides out); the wander INSIDE a symbol is reproduced (k_drift.hpp)."""
 import numpy as np
 import pytest
 
@@ -25,12 +25,13 @@ INT_TAPS = (("demap", g.TAP_DEMAP), ("symdeint", g.TAP_SYMDEINT), ("bitdeint", g
             ("deint", g.TAP_DEINT), ("rs", g.TAP_RS), ("ts", g.TAP_TS))
 WANT = ("acq", "fft", "eq") + tuple(k for k, _ in INT_TAPS)
 
-# A1 / A2 taps under a carrier offset: the reference accumulates the derotation phase in a FLOAT, one addition per sample (:285-309).  Inside a
-# binade the addend is rounded to the accumulator's grid the same way at every step (ulp 2.4e-7 for |phase| in [2, pi]), so the accumulated phase
-# runs at a slightly wrong rate that changes from binade to binade: up to 5e-4 rad of wander inside one 8k symbol at epsilon = 2.3 rad
-# (tests/test_phase_accumulator_model.py replays it on the CPU).  The kernels take the phase in closed form in double and do not reproduce that
-# wander; the oracle does.  The contract's tolerance is the EQ tap's (1e-3 of the constellation spacing) and it holds.
-TOL_DEROT = 1.5e-3
+# A1 / A2 taps: the reference accumulates the derotation phase in a FLOAT, one addition per sample (:285-309); inside a binade every step rounds the same
+# way, so the phase runs at a slightly wrong rate that changes from binade to binade -- up to 5e-4 rad of wander inside one 8k symbol
+# (tests/test_phase_accumulator_model.py).  The kernels reproduce that wander in closed form (k_drift.hpp, tests/test_drift_model.py) whenever the
+# offset has a usable fractional part: the taps then agree to ~2e-6 of the peak and the EQ tap to ~1e-5 of the constellation spacing (2.4e-3 .. 3.7e-3
+# without it: above the contract's 1e-3).  Where the model does not apply (estimates that jitter around zero: echoes without an offset, |epsilon| < 4e-3)
+# the accumulator lives near zero, where its grid is fine; what is left is below 1.2e-4 of the peak, which this bound allows.
+TOL_DEROT = 2e-4
 
 K2 = (g.QAM16, g.C1_2, g.T2k, 4)         # BASELINE config 2
 K8 = (g.QAM64, g.C7_8, g.T8k, 2)         # BASELINE config 3
@@ -64,6 +65,9 @@ CLEAN = [
     ("8k cfo -5 - 0.37", K8, dict(cfo=-5.37)),
     ("8k cfo -7.63", K8, dict(cfo=-7.63)),
     ("8k cfo +7.2", K8, dict(cfo=7.2)),
+    ("8k cfo +0.01", K8, dict(cfo=0.01)),                 # a small constant offset: the float accumulator crawls through its coarse binades
+    ("8k cfo -0.0007", K8, dict(cfo=-0.0007)),            # at the edge of what k_drift.hpp models
+    ("8k cfo +0.0001", K8, dict(cfo=0.0001)),             # below it: granular steps of the accumulator, nothing applied
     ("8k echo 0.3 cp -16 dB", K8, dict(echoes=((77, 0.15),))),
     ("8k echo 0.3 cp -20 dB + cfo 2.2", K8, dict(echoes=((77, 0.1),), cfo=2.2)),
 ]
