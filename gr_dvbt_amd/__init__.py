@@ -5,7 +5,7 @@ fallback: importing works anywhere, but every compute entry point raises unless 
 library is built in-tree (gr_dvbt_amd/lib/libdvbt_hip.so) and a GPU is visible.
 """
 from .binding import (  # noqa: F401
-    lib, build, DvbtError, RxParams, RxReport, Rx, get_dims, device_count, Block, Tag, Sideband,
+    lib, build, DvbtError, RxParams, RxReport, Rx, RxStream, get_dims, device_count, Block, Tag, Sideband,
     TAG_SYNC_START, TAG_SUPERFRAME_START, TAG_SYMBOL_INDEX,
     QPSK, QAM16, QAM64, NH, C1_2, C2_3, C3_4, C5_6, C7_8, T2k, T8k, G1_32, G1_16, G1_8, G1_4,
     TAP_ACQ, TAP_FFT, TAP_EQ, TAP_DEMAP, TAP_SYMDEINT, TAP_BITDEINT, TAP_VITERBI, TAP_DEINT,

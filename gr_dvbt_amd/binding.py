@@ -228,6 +228,79 @@ class Rx:
             pass
 
 
+class StreamParams(C.Structure):
+    _fields_ = [("rx", RxParams), ("segment_superframes", C.c_int)]
+
+
+class StreamInfo(C.Structure):
+    _fields_ = [("status", C.c_int32), ("pieces_in_flight", C.c_int32), ("finished", C.c_int32),
+                ("samples_pushed", C.c_int64), ("ts_bytes_decoded", C.c_int64), ("ts_bytes_ready", C.c_int64), ("ts_bytes_pulled", C.c_int64),
+                ("first_superframe_call", C.c_int64), ("first_ts_packet", C.c_int64)]
+
+
+class RxStream:
+    """dvbt_rx_stream_*: push samples in calls of any size, pull the TS in order; the bytes are those of one chain over the whole stream."""
+
+    def __init__(self, constellation, code_rate, mode, segment_superframes=0, guard=G1_32, hierarchy=NH, snr_db=30.0, viterbi_bsize=768,
+                 rs_oracle_compat=0, device=0):
+        self.L = lib()
+        for fn in ("create", "push", "push_device", "finish", "status"):
+            getattr(self.L, f"dvbt_rx_stream_{fn}").restype = C.c_int
+        self.L.dvbt_rx_stream_create.argtypes = [C.POINTER(StreamParams), C.POINTER(C.c_void_p)]
+        self.L.dvbt_rx_stream_push.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        self.L.dvbt_rx_stream_push_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        self.L.dvbt_rx_stream_pull.restype = C.c_int64
+        self.L.dvbt_rx_stream_pull.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        self.L.dvbt_rx_stream_finish.argtypes = [C.c_void_p]
+        self.L.dvbt_rx_stream_status.argtypes = [C.c_void_p, C.POINTER(StreamInfo)]
+        self.L.dvbt_rx_stream_destroy.argtypes = [C.c_void_p]
+        rx = RxParams(constellation, hierarchy, code_rate, guard, mode, 0, 0, snr_db, viterbi_bsize, rs_oracle_compat, 1, 0, device, 0, 0, 0, 0.0)
+        self.p = StreamParams(rx, segment_superframes)
+        self.h = C.c_void_p()
+        _chk(self.L.dvbt_rx_stream_create(C.byref(self.p), C.byref(self.h)))
+        self._out = np.empty(1 << 22, np.uint8)
+
+    def push(self, iq):
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        _chk(self.L.dvbt_rx_stream_push(self.h, iq.ctypes.data_as(C.c_void_p), len(iq)))
+
+    def push_device(self, dptr, nsamples, stream=None):
+        _chk(self.L.dvbt_rx_stream_push_device(self.h, C.c_void_p(dptr), nsamples, C.c_void_p(stream) if stream else None))
+
+    def pull(self, max_bytes=None):
+        """the TS bytes that are ready (all of them unless max_bytes is given), as a numpy array"""
+        chunks = []
+        left = max_bytes
+        while left is None or left > 0:
+            cap = len(self._out) if left is None else min(len(self._out), left)
+            n = _chk(self.L.dvbt_rx_stream_pull(self.h, self._out.ctypes.data_as(C.c_void_p), cap))
+            if n <= 0:
+                break
+            chunks.append(self._out[:n].copy())
+            if left is not None:
+                left -= n
+        return np.concatenate(chunks) if chunks else np.zeros(0, np.uint8)
+
+    def finish(self):
+        _chk(self.L.dvbt_rx_stream_finish(self.h))
+
+    def info(self):
+        i = StreamInfo()
+        _chk(self.L.dvbt_rx_stream_status(self.h, C.byref(i)))
+        return i
+
+    def close(self):
+        if self.h:
+            self.L.dvbt_rx_stream_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ------------------------------------------------------------------ per-block C ABI (one triple per reference block)
 TAG_SYNC_START, TAG_SUPERFRAME_START, TAG_SYMBOL_INDEX = 1, 2, 3
 

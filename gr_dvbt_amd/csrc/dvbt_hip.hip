@@ -7,6 +7,8 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <deque>
+#include <algorithm>
 #include "../../include/dvbt_hip.h"
 #include "dvbt_tables.hpp"
 #include "k_frontend.hpp"
@@ -818,4 +820,5 @@ extern "C" double dvbt_rx_stage_ms(dvbt_rx *h, const char *stage)
 
 extern "C" void dvbt_rx_destroy(dvbt_rx *h) { if (h) rx_free(h); }
 
+#include "dvbt_stream.inc"
 #include "dvbt_blocks.inc"

@@ -228,8 +228,10 @@ struct RsTables { const uint8_t *div_tab; /* [256][16]: b * g(x) */ const uint8_
 // stops at deg(sigma) roots (:376-403); a zero Forney denominator aborts after the higher-indexed
 // roots have already been patched (:445-486); compat reproduces the as-compiled omega[2t] overflow
 // that redirects the lowest root's correction into the zero padding (SURVEY B-1).
-// syn: 16 syndromes (LDS), cw: the 204 received bytes (LDS, index 0 = codeword index 51),
+// syn: 16 syndromes (LDS, RS_SYN_STRIDE bytes apart: syndrome i of the workgroup's word w is s_syn[i * RS_SYN_STRIDE + w]: an odd stride, so that
+// the lanes of one word's Berlekamp-Massey and the words of one syndrome index both fall on distinct banks), cw: the 204 received bytes (LDS, index 0 = codeword index 51),
 // scr: >= 64 bytes of LDS scratch.  Returns rs_decode's return value in every lane.
+constexpr int RS_SYN_STRIDE = 65;
 __device__ inline int rs_decode_word_wave(uint8_t *cw, const uint8_t *syn, const uint8_t *gexp, const uint8_t *glog,
                                           int compat, uint8_t *scr, int lane)
 {
@@ -239,7 +241,7 @@ __device__ inline int rs_decode_word_wave(uint8_t *cw, const uint8_t *syn, const
   // ---- Berlekamp-Massey: lane i (0..16) holds sigma[i] and b[i]
   int sig = lane == 0 ? 1 : 0, bb = sig, el = 0;
   for (int r = 1; r <= 16; r++) {
-    int term = (lane < r && lane <= 16) ? gmul(sig, syn[r - 1 - lane]) : 0;
+    int term = (lane < r && lane <= 16) ? gmul(sig, syn[(r - 1 - lane) * RS_SYN_STRIDE]) : 0;
     const int discr = __shfl(wxor(term), 0);
     int bup = __shfl_up(bb, 1); if (lane == 0) bup = 0;
     if (discr == 0) bb = bup;
@@ -278,7 +280,7 @@ __device__ inline int rs_decode_word_wave(uint8_t *cw, const uint8_t *syn, const
   // ---- omega = sigma * S mod x^16 (lane i computes omega[i])
   {
     int tmp = 0;
-    if (lane < 16) { int jm = deg_sigma < lane ? deg_sigma : lane; for (int j = jm; j >= 0; j--) tmp ^= gmul(syn[lane - j], s_sig[j]); s_om[lane] = (uint8_t)tmp; }
+    if (lane < 16) { int jm = deg_sigma < lane ? deg_sigma : lane; for (int j = jm; j >= 0; j--) tmp ^= gmul(syn[(lane - j) * RS_SYN_STRIDE], s_sig[j]); s_om[lane] = (uint8_t)tmp; }
     const unsigned long long oz = __ballot(lane < 16 && tmp != 0);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     const int deg_omega = oz ? 63 - __clzll(oz) : 0;
@@ -303,6 +305,125 @@ __device__ inline int rs_decode_word_wave(uint8_t *cw, const uint8_t *syn, const
   }
 }
 
+
+// The same decoder with one WORD PER LANE (rs_decode's steps restated for 64 independent words; every lane walks its own word sequentially, the
+// loops run to the wavefront's largest bound).  The wave-per-word version above costs ~6,000 issue slots of mostly waiting per bad word (dependent
+// LDS look-ups with one wavefront per SIMD): fine for the odd bad word of a clean stream, a collapse when most words carry errors (8 dB QPSK 7/8:
+// 3.7 ms per 344k words against 0.07 ms clean, tools/rs_load.py).  Here a wavefront's 64 words cost ~20,000 instructions together.  `active`: the
+// lane has a word with a non-zero syndrome.  syn / sigma / omega live in registers (all loops over them are unrolled), the roots in a private LDS
+// column (s_root[k * 64 + lane]).  Returns rs_decode's value (-1: uncorrectable, else the number of corrected symbols); inactive lanes return 0.
+__device__ inline int rs_decode_word_lane(uint8_t *cw, const uint8_t *syn_col /* s_syn + lane */, const uint8_t *gexp, const uint8_t *glog, int compat,
+                                          uint8_t *root_col /* s_root + lane */, bool active)
+{
+  auto gmul = [&](int a, int b) -> int { return (a == 0 || b == 0) ? 0 : gexp[glog[a] + glog[b]]; };
+  int syn[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) syn[i] = active ? syn_col[i * RS_SYN_STRIDE] : 0;
+  // ---- Berlekamp-Massey (:315-354)
+  int sg[17], bb[17];
+#pragma unroll
+  for (int i = 0; i < 17; i++) { sg[i] = i == 0 ? 1 : 0; bb[i] = sg[i]; }
+  int el = 0;
+#pragma unroll
+  for (int r = 1; r <= 16; r++) {
+    int discr = 0;
+#pragma unroll
+    for (int i = 0; i < r; i++) discr ^= gmul(sg[i], syn[r - i - 1]);
+    if (__any(discr != 0)) {
+      const int dl = glog[discr];                                  // used only where discr != 0
+      const bool grow = discr != 0 && 2 * el <= r - 1;
+      int T[17];
+      T[0] = sg[0];
+#pragma unroll
+      for (int i = 0; i < 16; i++) T[i + 1] = sg[i + 1] ^ ((discr == 0 || bb[i] == 0) ? 0 : gexp[dl + glog[bb[i]]]);
+#pragma unroll
+      for (int i = 16; i >= 0; i--) {
+        const int shifted = i == 0 ? 0 : bb[i - 1];
+        const int divd = (sg[i] == 0 || discr == 0) ? 0 : gexp[255 + glog[sg[i]] - dl];
+        bb[i] = grow ? divd : shifted;
+      }
+      if (grow) el = r - el;
+#pragma unroll
+      for (int i = 0; i < 17; i++) sg[i] = discr != 0 ? T[i] : sg[i];
+    } else {
+#pragma unroll
+      for (int i = 16; i >= 1; i--) bb[i] = bb[i - 1];
+      bb[0] = 0;
+    }
+  }
+  int deg_sigma = 0;
+#pragma unroll
+  for (int i = 1; i < 17; i++) if (sg[i]) deg_sigma = i;
+  if (!active) deg_sigma = 0;
+  // ---- Chien (:376-403): roots in ascending position, the search stops at deg(sigma) roots.  Term j in the log domain: l_j = log sigma_j + j i (mod 255)
+  int lj[17], mj[17];
+#pragma unroll
+  for (int j = 1; j < 17; j++) { lj[j] = sg[j] ? glog[sg[j]] : 0; mj[j] = (sg[j] && j <= deg_sigma) ? 0xff : 0; }
+  int maxdeg = deg_sigma;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(maxdeg, o); maxdeg = v > maxdeg ? v : maxdeg; }
+  int no_roots = 0;
+  bool done = deg_sigma == 0;                                      // (an active word always has deg >= 1)
+  for (int i = 1; i <= 255; i++) {
+    int q = 1;
+#pragma unroll
+    for (int j = 1; j < 17; j++) {
+      if (j <= maxdeg) {
+        int t = lj[j] + j; t = t >= 255 ? t - 255 : t; lj[j] = t;
+        q ^= gexp[t] & mj[j];
+      }
+    }
+    if (!done && q == 0) {
+      root_col[no_roots * 64] = (uint8_t)i;
+      if (++no_roots == deg_sigma) done = true;
+    }
+    if (__all(done)) break;
+  }
+  bool failed = active && no_roots != deg_sigma;                   // :405-415
+  // ---- omega = sigma S mod x^16 (:419-434)
+  int om[16], deg_omega = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    int tmp = 0;
+#pragma unroll
+    for (int j = 0; j <= i; j++) tmp ^= (j <= deg_sigma) ? gmul(syn[i - j], sg[j]) : 0;
+    om[i] = tmp; if (tmp) deg_omega = i;
+  }
+  int lo[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) lo[i] = om[i] ? glog[om[i]] : -1;
+  int ls[16];                                                      // log sigma_i for odd i (the formal derivative, :466-470)
+#pragma unroll
+  for (int i = 1; i < 16; i += 2) ls[i] = sg[i] ? glog[sg[i]] : -1;
+  // ---- Forney (:445-486): roots from the highest index down; a zero denominator aborts after the higher roots have been patched
+  int nr = (active && !failed) ? no_roots : 0, maxr = nr;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(maxr, o); maxr = v > maxr ? v : maxr; }
+  for (int jj = maxr - 1; jj >= 0; jj--) {
+    const bool on = jj < nr && !failed;
+    const int root = on ? root_col[jj * 64] : 1;
+    int num1 = 0, den = 0, ir = 0;                                  // ir = i * root mod 255
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      if (i <= deg_omega && lo[i] >= 0) { const int e = lo[i] + ir; num1 ^= gexp[e >= 255 ? e - 255 : e]; }
+      if ((i & 1) == 0 && i + 1 < 16 && i + 1 <= deg_sigma && ls[i + 1] >= 0) { const int e = ls[i + 1] + ir; den ^= gexp[e >= 255 ? e - 255 : e]; }   // (i + 1 - 1) * root
+      ir += root; ir = ir >= 255 ? ir - 255 : ir;
+    }
+    if (on) {
+      if (den == 0) failed = true;
+      else {
+        const int num2 = gexp[(255 - root) % 255];
+        const int err = (num1 == 0) ? 0 : gexp[255 + glog[gmul(num1, num2)] - glog[den]];
+        const int loc = (compat && jj == 0) ? 0 : root - 1;
+        if (loc >= 51) cw[loc - 51] ^= (uint8_t)err;               // patches inside the zero padding are not output
+      }
+    }
+  }
+  if (!active) return 0;
+  return failed ? -1 : no_roots;
+}
+
+constexpr int RS_LANE_MIN = 8;                                 // bad words per wavefront from which every lane decodes its own word
 // standalone = 1: input is already de-interleaved items (A9 block alone); 0: gather from the Viterbi stream (A8+A9)
 __global__ __launch_bounds__(64) void deint_rs_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ deint_tap,
                                                      uint8_t *__restrict__ out, RxState *st, long long words_fixed, int standalone,
@@ -315,7 +436,8 @@ __global__ __launch_bounds__(64) void deint_rs_kernel(const uint8_t *__restrict_
   __shared__ __attribute__((aligned(16))) uint8_t s_div[256 * 16];
   __shared__ uint8_t s_exp[512], s_log[256];
   __shared__ uint8_t s_scr[64];
-  __shared__ uint8_t s_syn[64 * 16];
+  __shared__ uint8_t s_syn[RS_SYN_STRIDE * 16];
+  __shared__ uint8_t s_root[17 * 64];                          // rs_decode_word_lane: the roots found, one column per lane
   uint8_t *s_cw = s_rows + 11 * 204;
   const int tid = threadIdx.x;
   const long long nwords = st ? st->n_rs_words : words_fixed;
@@ -377,21 +499,31 @@ __global__ __launch_bounds__(64) void deint_rs_kernel(const uint8_t *__restrict_
       for (int i = 0; i < 16; i++) {
         int sv = 0;
         for (int k = 15; k >= 0; k--) { int c = (Rw[k >> 2] >> (8 * (k & 3))) & 0xff; sv = (sv ? s_exp[(s_log[sv] + i) % 255] : 0) ^ c; }
-        s_syn[tid * 16 + i] = (uint8_t)sv;
+        s_syn[i * RS_SYN_STRIDE + tid] = (uint8_t)sv;
       }
     }
     bad = any != 0;
   }
-  // words with a non-zero syndrome (reed_solomon.cc:299-305 returns early otherwise) are decoded one at a time
-  // by the whole wavefront
+  // words with a non-zero syndrome (reed_solomon.cc:299-305 returns early otherwise): a few of them are decoded one at a time by the whole
+  // wavefront (lowest latency), more than RS_LANE_MIN by every lane for itself (rs_decode_word_lane: ~18x the throughput when most words are bad)
   {
     unsigned long long mask = __ballot(bad);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     int nf = 0, nc = 0;
-    while (mask) {
-      const int wl = __ffsll((long long)mask) - 1; mask &= mask - 1;
-      const int r = rs_decode_word_wave(s_cw + wl * 204, s_syn + wl * 16, s_exp, s_log, compat, s_scr, tid);
-      if (r < 0) nf++; else nc += r;
+    if (__popcll(mask) >= RS_LANE_MIN) {
+      const int r = rs_decode_word_lane(s_cw + tid * 204, s_syn + tid, s_exp, s_log, compat, s_root + tid, bad);
+      const unsigned long long fm = __ballot(bad && r < 0);
+      nf = __popcll(fm);
+      int c = (bad && r > 0) ? r : 0;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+      nc = c;
+    } else {
+      while (mask) {
+        const int wl = __ffsll((long long)mask) - 1; mask &= mask - 1;
+        const int r = rs_decode_word_wave(s_cw + wl * 204, s_syn + wl, s_exp, s_log, compat, s_scr, tid);
+        if (r < 0) nf++; else nc += r;
+      }
     }
     if (tid == 0) { if (nf) atomicAdd(fail_cnt, nf); if (nc) atomicAdd(corr_cnt, nc); }
   }

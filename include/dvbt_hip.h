@@ -379,6 +379,45 @@ int  dvbt_rx_enable_timing(dvbt_rx *h, int enable);
 int  dvbt_rx_enable_taps(dvbt_rx *h, int enable);
 void dvbt_rx_destroy(dvbt_rx *h);
 
+/* ------------------------------------------------------------------ streaming entry: the whole chain behind push / pull
+ * What a C++ host (one gr::block whose work() takes cfloat and gives TS bytes, gr_dvbt_amd/host/gr/rx_hip_impl.cc) needs to decode a
+ * stream of any length at the segment API's speed: samples are pushed in calls of ANY size (complex64 at the OFDM elementary rate, the
+ * input of ofdm_sym_acquisition in apps/dvbt_rx_demo*.grc), the library batches them into pieces of whole superframes with the pre- and
+ * post-roll of SURVEY 8e (one CP lock + one whole TPS frame in front of a piece's first superframe boundary, the byte de-interleaver's
+ * fill and the distance to the next NSYNC behind its last one), decodes every piece device resident on one of two internal chains (the
+ * next piece's samples are copied in while the previous one decodes), trims the pieces and delivers the TS in order.  The bytes are
+ * exactly those of ONE chain over the whole stream (dvbt_rx_segment_run on all samples at once; tests/test_gpu_stream.py), i.e. what the
+ * reference's flowgraph writes to its file sink: this is gr_dvbt_amd/multi.py's plan_cuts / stitch_plan inside the library.
+ * segment_superframes: superframes a piece owns (0 = 16; device memory ~ 2 x (segment_superframes + 3) superframes of samples + the
+ * chains' own buffers).  rx.max_samples, rx.resample_* are ignored / must be 0 (no resampler in front).
+ * Limits: the stream's head must reach its first superframe start within the first piece (segment_superframes + 2 superframes), else that
+ * much of it is dropped (status bit 2, the stream's origin moves); a CP lock lost inside a later piece is reported (status bit 1) and the
+ * stream goes on with the next piece (the packets up to that piece's end are missing: bit 5).
+ * Threading: like every handle, one thread at a time. */
+typedef struct { dvbt_rx_params rx; int segment_superframes; } dvbt_rx_stream_params;
+typedef struct {
+  int32_t status;              /* dvbt_rx_report.status bits of the pieces, OR-ed (bit 1 only when the lock was lost inside a piece) | bit 5: a piece
+                                  delivered fewer packets than its span of the stream | bit 6: a piece's sync byte was not where the stream's packet
+                                  count puts it */
+  int32_t pieces_in_flight, finished;
+  int64_t samples_pushed, ts_bytes_decoded, ts_bytes_ready, ts_bytes_pulled;
+  int64_t first_superframe_call;   /* call (window of N+cp samples) of the stream's first superframe start, -1 before it is known */
+  int64_t first_ts_packet;         /* RS word (counted from that superframe start) of the first TS packet, -1 before it is known */
+} dvbt_rx_stream_info;
+typedef struct dvbt_rx_stream dvbt_rx_stream;
+int  dvbt_rx_stream_create(const dvbt_rx_stream_params *p, dvbt_rx_stream **out);
+/* iq_host: nsamples complex64 in host memory; they have left the caller's buffer when the call returns (the decode has not finished) */
+int  dvbt_rx_stream_push(dvbt_rx_stream *s, const void *iq_host, size_t nsamples);
+/* the same for samples in device memory, ordered behind `stream` (a hipStream_t or NULL); the caller keeps them valid until that copy has run */
+int  dvbt_rx_stream_push_device(dvbt_rx_stream *s, const void *iq_device, size_t nsamples, void *stream);
+/* TS bytes that are ready, in stream order, up to cap; never waits for the device before dvbt_rx_stream_finish.  Returns the bytes written */
+int64_t dvbt_rx_stream_pull(dvbt_rx_stream *s, void *ts_host, size_t cap);
+/* end of the stream: decodes what is left (energy_descramble's two-item hold-back and the block roundings apply here, as at the end of
+ * the reference's run) and waits for it; pull then drains the rest */
+int  dvbt_rx_stream_finish(dvbt_rx_stream *s);
+int  dvbt_rx_stream_status(const dvbt_rx_stream *s, dvbt_rx_stream_info *info);
+void dvbt_rx_stream_destroy(dvbt_rx_stream *s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,119 @@
+"""dvbt_rx_stream_*: the streaming entry of the C ABI.  Samples pushed in calls of arbitrary size (down to a handful of OFDM symbols, sizes that
+do not divide anything), pieces cut, decoded and stitched inside the library; the TS pulled must be, byte for byte, what ONE chain over the whole
+stream delivers (dvbt_rx_segment_run on all samples at once) -- which the other tests tie to the oracle."""
+import numpy as np
+import pytest
+
+import gr_dvbt_amd as g
+
+pytestmark = pytest.mark.gpu
+
+
+def whole(const, cr, mode, iq):
+    rx = g.Rx(const, cr, mode, max_samples=len(iq))
+    rx.run(iq)
+    ts = rx.tap(g.TAP_TS).copy()
+    rx.close()
+    return ts
+
+
+def streamed(const, cr, mode, iq, seg_sf, call, pull_every=7):
+    st = g.RxStream(const, cr, mode, segment_superframes=seg_sf)
+    out, k = [], 0
+    rng = np.random.RandomState(3)
+    pos = 0
+    while pos < len(iq):
+        n = call if isinstance(call, int) else int(rng.randint(call[0], call[1]))
+        st.push(iq[pos:pos + n]); pos += n; k += 1
+        if k % pull_every == 0:
+            out.append(st.pull())
+    st.finish()
+    out.append(st.pull())
+    info = st.info()
+    st.close()
+    return np.concatenate(out), info
+
+
+@pytest.mark.parametrize("const,cr,mode,nsf,seg_sf,call", [
+    (g.QAM16, g.C1_2, g.T2k, 13, 2, 4 * 2112),            # 2k: pieces of 2 superframes, 4 symbols per call
+    (g.QAM16, g.C1_2, g.T2k, 9, 3, (1000, 50000)),         # ragged call sizes
+    (g.QAM64, g.C7_8, g.T8k, 9, 2, 64 * 8448),             # 8k QAM64 7/8 (first superframe start at frame 3): 64 symbols per call
+    (g.QAM64, g.C7_8, g.T8k, 7, 1, 33 * 8448 + 5),         # one superframe per piece, odd call size
+    (g.QPSK, g.C7_8, g.T8k, 8, 2, 16 * 8448),
+    (g.QAM64, g.C3_4, g.T2k, 11, 4, 7777),                 # symbols not byte aligned
+])
+def test_stream_equals_one_chain(po, const, cr, mode, nsf, seg_sf, call):
+    c = po.cfg(const, cr, mode)
+    iq = po.stream_slice(c, nsf, 9)
+    ref = whole(const, cr, mode, iq)
+    ts, info = streamed(const, cr, mode, iq, seg_sf, call)
+    assert info.status & ~2 == 0, info.status
+    assert len(ts) == len(ref) > 0, (len(ts), len(ref))
+    assert (ts == ref).all()
+    assert info.finished and info.ts_bytes_pulled == len(ref) and info.ts_bytes_ready == 0
+
+
+@pytest.mark.parametrize("extra_symbols", [5, 60, 100, 200, 300])
+def test_stream_ends_anywhere(po, extra_symbols):
+    """the end of the stream falls at any distance behind the last piece boundary: a tail too short for a piece of its own extends the piece before"""
+    const, cr, mode = g.QAM16, g.C1_2, g.T2k
+    c = po.cfg(const, cr, mode)
+    L = c.N + c.cp
+    full = po.stream_slice(c, 12, 4)
+    # piece 0 of a 2-superframe plan is 4 superframes + ...: cut the stream so that it ends `extra_symbols` after a later piece's begin
+    for base_sf in (7, 8):
+        n = po.STREAM_LEAD_IN + (272 * base_sf + extra_symbols) * L
+        iq = np.concatenate([full[:n], np.zeros(3 * c.N, np.complex64)])
+        ref = whole(const, cr, mode, iq)
+        ts, info = streamed(const, cr, mode, iq, 2, 10 * L)
+        assert len(ts) == len(ref) > 0 and (ts == ref).all(), (base_sf, extra_symbols, len(ts), len(ref))
+
+
+def test_short_stream_is_one_segment(po):
+    const, cr, mode = g.QAM16, g.C1_2, g.T2k
+    c = po.cfg(const, cr, mode)
+    iq = po.stream_slice(c, 3, 5)
+    ref = whole(const, cr, mode, iq)
+    ts, info = streamed(const, cr, mode, iq, 4, 5000)
+    assert len(ts) == len(ref) > 0 and (ts == ref).all()
+
+
+def test_stream_from_device_memory(po):
+    import torch
+    const, cr, mode = g.QAM64, g.C7_8, g.T8k
+    c = po.cfg(const, cr, mode)
+    iq = po.stream_slice(c, 7, 9)
+    ref = whole(const, cr, mode, iq)
+    dev = torch.from_numpy(iq.view(np.float32)).cuda()
+    torch.cuda.synchronize()
+    st = g.RxStream(const, cr, mode, segment_superframes=2)
+    step, out = 64 * 8448, []
+    for a in range(0, len(iq), step):
+        n = min(step, len(iq) - a)
+        st.push_device(dev.data_ptr() + 8 * a, n)
+        out.append(st.pull())
+    st.finish()
+    out.append(st.pull())
+    st.close()
+    ts = np.concatenate(out)
+    assert len(ts) == len(ref) and (ts == ref).all()
+
+
+def test_noisy_stream_post_rs_equal(po):
+    """AWGN at 22 dB on 8k QAM64 7/8: the Viterbi and RS decoders are busy; the pieces' packets must still be the single chain's"""
+    const, cr, mode = g.QAM64, g.C7_8, g.T8k
+    c = po.cfg(const, cr, mode)
+    iq = po.channel(po.stream_slice(c, 6, 9), c.N, snr_db=24.0)
+    rx = g.Rx(const, cr, mode, max_samples=len(iq), snr_db=24.0)
+    rep = rx.run(iq)
+    ref = rx.tap(g.TAP_TS).copy()
+    rx.close()
+    if rep.n_lock_periods != 1:
+        pytest.skip("the reference's tracker lost the lock on this noise realisation")
+    st = g.RxStream(const, cr, mode, segment_superframes=2, snr_db=24.0)
+    for a in range(0, len(iq), 50 * 8448):
+        st.push(iq[a:a + 50 * 8448])
+    st.finish()
+    ts = st.pull()
+    st.close()
+    assert len(ts) == len(ref) and (ts == ref).all()
