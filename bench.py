@@ -357,6 +357,44 @@ def extra_workloads(a, torch, g, local):
     return res
 
 
+def config5_noise(torch, g, nsf=16, snrs=(9.0, 8.0), reps=5):
+    """BASELINE config 5 at the noise level SURVEY 8d prescribes (pre-Viterbi BER ~ 1e-2 = 8 dB for 8k QPSK 7/8; 9 dB = where the RS decoder still
+    holds): the reference's CP tracker loses the lock again and again there, so the stream goes through dvbt_rx_segment_run_device (synchronous: every
+    lock period is followed inside the library, with a host round trip per period), samples resident in HBM.  ofdm_sym_acquisition's snr parameter = the
+    channel's.  Packet error rate against the transmitted packets; the HIP-vs-oracle comparison of the same sweep is tests/test_gpu_config5.py."""
+    from oracle import pyoracle as po
+    (const, cr, mode), c = workload_cfg("8k_qpsk_7_8")
+    clean = po.stream_slice(c, nsf, SEED)
+    sent = {bytes(p) for p in po.stream_ts(c, 0, nsf, SEED).reshape(-1, 188)}
+    out = {}
+    for snr in snrs:
+        iq = po.channel(clean, c.N, snr_db=snr, seed=5)
+        dev = torch.from_numpy(iq.view(np.float32)).cuda()
+        torch.cuda.synchronize()
+        rx = g.Rx(const, cr, mode, max_samples=len(iq), snr_db=snr)
+        rep = rx.run_device(dev.data_ptr(), len(iq))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            rep = rx.run_device(dev.data_ptr(), len(iq))
+        dt = (time.perf_counter() - t0) / reps
+        ts = rx.tap(g.TAP_TS).reshape(-1, 188)
+        good = sum(1 for p in ts if bytes(p) in sent)
+        rx.close()
+        out[f"awgn_{snr:g}_dB"] = {"value": round(len(iq) / dt / 1e6, 1), "unit": "Msamples/s", "x_realtime": round(len(iq) / dt / 1e6 / REALTIME_MSPS, 1),
+                                   "ms_per_run": round(dt * 1e3, 3), "stream_superframes": nsf, "stream_samples": int(len(iq)), "entry": "dvbt_rx_segment_run_device",
+                                   "lock_periods": int(rep.n_lock_periods), "symbols_acquired": int(rep.total_symbols), "rs_fail_words": int(rep.rs_fail_words),
+                                   "rs_corrected_symbols": int(rep.rs_corrected_symbols), "ts_packets": int(len(ts)), "packet_error_rate": round(1.0 - good / max(len(ts), 1), 5)}
+    return out
+
+
+def stream_abi(g):
+    """The streaming entry of the C ABI (dvbt_rx_stream_push / pull: what the one-block GNU Radio shell gr::dvbt::rx_hip calls) at scheduler-like call sizes"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import stream_bench
+    from oracle import pyoracle as po
+    return [stream_bench.run(po, g, symbols=sym, device=dev) for sym, dev in ((4, False), (64, False), (64, True))]
+
+
 def per_block_abi(g, workload, nsf=4):
     """The drop-in path timed: config `workload` pushed through the ten per-block ABI calls (gr_dvbt_amd/flowgraph.py) at GNU Radio-like
     call sizes, host-pointer entry (dvbt_<blk>_work: H2D + kernels + D2H + synchronise per block, what a gr::block shell does) and
@@ -520,6 +558,8 @@ def main():
     job.close()
     if rank == 0 and world == 1 and not a.no_extras and not a.from_file_rate:
         out["extra_workloads"] = extra_workloads(a, torch, g, local)
+        out["extra_workloads"]["config5_8k_qpsk_7_8_at_the_prescribed_noise"] = config5_noise(torch, g)
+        out["stream_abi"] = stream_abi(g)
         out["per_block_abi"] = per_block_abi(g, a.workload)
     if rank == 0:
         if not a.no_cpu_baseline:

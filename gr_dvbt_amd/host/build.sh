@@ -2,6 +2,7 @@
 # Compile-and-link check of the C++ host mirror against the in-tree libdvbt_hip.so
 set -e
 here="$(cd "$(dirname "$0")" && pwd)"
-g++ -std=c++17 -O2 -Wall -o "$here/rx_flowgraph_example" "$here/rx_flowgraph_example.cpp" \
-    -L"$here/../lib" -ldvbt_hip -Wl,-rpath,"$here/../lib" -Wl,-rpath,/opt/rocm/lib
-echo "built $here/rx_flowgraph_example"
+for ex in rx_flowgraph_example rx_stream_example; do
+  g++ -std=c++17 -O2 -Wall -o "$here/$ex" "$here/$ex.cpp" -L"$here/../lib" -ldvbt_hip -Wl,-rpath,"$here/../lib" -Wl,-rpath,/opt/rocm/lib
+  echo "built $here/$ex"
+done

@@ -129,4 +129,40 @@ DVBT_AMD_BLOCK(energy_descramble, dvbt_energy_descramble_params, (int nblocks), 
 DVBT_AMD_BLOCK(resampler, dvbt_resampler_params, (int interpolation, int decimation, float scale), (dvbt_resampler_params{interpolation, decimation, scale}))
 
 #undef DVBT_AMD_BLOCK
+
+// gr::dvbt::rx_hip (gr_dvbt_amd/host/gr/include/dvbt/rx_hip.h): the ten receive blocks of apps/dvbt_rx_demo*.grc behind one block, over the
+// streaming entry of the C ABI (dvbt_rx_stream_*).  general_work(): samples in (any number), TS bytes out (what is ready); stop(): end of stream.
+class rx_hip {
+ public:
+  typedef std::shared_ptr<rx_hip> sptr;
+  static sptr make(dvbt_constellation_t constellation, dvbt_hierarchy_t hierarchy, dvbt_code_rate_t code_rate, dvbt_guard_interval_t guard_interval,
+                   dvbt_transmission_mode_t transmission_mode, float snr = 30.0f, int bsize = 768, int segment_superframes = 0)
+  { return sptr(new rx_hip(constellation, hierarchy, code_rate, guard_interval, transmission_mode, snr, bsize, segment_superframes)); }
+  ~rx_hip() { if (d_s) dvbt_rx_stream_destroy(d_s); }
+  rx_hip(const rx_hip &) = delete;
+  void forecast(int, std::vector<int> &ninput_items_required) { for (auto &x : ninput_items_required) x = 1; }
+  // in: ninput_items complex64 samples; out: room for noutput_items bytes.  Consumes all of the input; returns the TS bytes produced
+  int general_work(int noutput_items, int ninput_items, const void *in, void *out, int &n_consumed)
+  {
+    check(dvbt_rx_stream_push(d_s, in, (size_t)ninput_items));
+    n_consumed = ninput_items;
+    const long long n = dvbt_rx_stream_pull(d_s, out, (size_t)noutput_items);
+    check((int)(n < 0 ? n : 0));
+    return (int)n;
+  }
+  bool stop() { check(dvbt_rx_stream_finish(d_s)); return true; }
+  // bytes decoded at stop() that no work() call will fetch any more
+  long long drain(void *out, size_t cap) { const long long n = dvbt_rx_stream_pull(d_s, out, cap); check((int)(n < 0 ? n : 0)); return n; }
+  dvbt_rx_stream_info info() const { dvbt_rx_stream_info i; check(dvbt_rx_stream_status(d_s, &i)); return i; }
+ private:
+  rx_hip(dvbt_constellation_t c, dvbt_hierarchy_t h, dvbt_code_rate_t r, dvbt_guard_interval_t g, dvbt_transmission_mode_t m, float snr, int bsize, int seg)
+  {
+    dvbt_rx_stream_params p{};
+    p.rx.constellation = (int)c; p.rx.hierarchy = (int)h; p.rx.code_rate = (int)r; p.rx.guard_interval = (int)g; p.rx.transmission_mode = (int)m;
+    p.rx.snr_db = snr; p.rx.viterbi_bsize = bsize; p.rx.descramble = 1; p.segment_superframes = seg;
+    check(dvbt_rx_stream_create(&p, &d_s));
+  }
+  dvbt_rx_stream *d_s = nullptr;
+};
+
 }}  // namespace gr::dvbt_amd

@@ -24,6 +24,9 @@ namespace gr {
       if (dvbt_get_dims((int)constellation, (int)hierarchy, (int)coderate, 0, 0, &d) < 0) throw std::runtime_error(dvbt_last_error());
       set_relative_rate((double)(d.cr_k * d.m) / (double)(8 * d.cr_n));
       set_output_multiple(bsize * d.cr_k / 8);
+      /* the library emits superframe_start itself (behind the ntraceback delay and the dropped partial block); with the intended rate GNU Radio's
+       * default all-to-all propagation would add a second, misplaced copy of the upstream tag (the reference's rate of 0 sends it to offset 0) */
+      set_tag_propagation_policy(TPP_DONT);
     }
 
   } /* namespace dvbt */

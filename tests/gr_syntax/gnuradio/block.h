@@ -16,10 +16,13 @@ namespace gr {
   class block {
   public:
     enum { WORK_CALLED_PRODUCE = -2, WORK_DONE = -1 };
+    enum tag_propagation_policy_t { TPP_DONT = 0, TPP_ALL_TO_ALL = 1, TPP_ONE_TO_ONE = 2 };
+    void set_tag_propagation_policy(tag_propagation_policy_t p);
     block(const std::string &name, io_signature::sptr in, io_signature::sptr out);
     virtual ~block();
     virtual void forecast(int noutput_items, gr_vector_int &ninput_items_required);
     virtual int general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &output_items);
+    virtual bool stop();
     void consume_each(int how_many_items);
     void set_output_multiple(int multiple);
     void set_relative_rate(double relative_rate);

@@ -117,3 +117,24 @@ def test_noisy_stream_post_rs_equal(po):
     ts = st.pull()
     st.close()
     assert len(ts) == len(ref) and (ts == ref).all()
+
+
+def test_cpp_rx_hip_example(po, tmp_path):
+    """gr_dvbt_amd/host/rx_stream_example: the RX flowgraph with the ten receive blocks replaced by the one block over dvbt_rx_stream_* (the GNU Radio-free
+    mirror of gr::dvbt::rx_hip), a baseband file read 64 symbols per work() call; the TS file must be the single chain's"""
+    import os
+    import subprocess
+    host = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gr_dvbt_amd", "host")
+    exe = os.path.join(host, "rx_stream_example")
+    if not os.path.exists(exe):
+        subprocess.check_call(["bash", os.path.join(host, "build.sh")], stdout=subprocess.DEVNULL)
+    const, cr, mode = g.QAM64, g.C7_8, g.T8k
+    c = po.cfg(const, cr, mode)
+    iq = po.stream_slice(c, 11, 6)
+    ref = whole(const, cr, mode, iq)
+    fin, fout = tmp_path / "bb.cf32", tmp_path / "out.ts"
+    iq.tofile(fin)
+    out = subprocess.check_output([exe, "8k", "qam64", "7/8", str(fin), str(fout)], text=True)
+    got = np.fromfile(fout, np.uint8)
+    assert "status 0" in out, out
+    assert len(got) == len(ref) > 0 and (got == ref).all()

@@ -15,7 +15,7 @@ GR = os.path.join(ROOT, "gr_dvbt_amd", "host", "gr")
 REF_INC = "/root/reference/include"
 
 BLOCKS = ["ofdm_sym_acquisition", "fft_hip", "demod_reference_signals", "dvbt_demap", "symbol_inner_interleaver",
-          "bit_inner_deinterleaver", "viterbi_decoder", "convolutional_deinterleaver", "reed_solomon_dec", "energy_descramble"]
+          "bit_inner_deinterleaver", "viterbi_decoder", "convolutional_deinterleaver", "reed_solomon_dec", "energy_descramble", "rx_hip"]
 
 
 def test_every_receive_block_has_a_shell():
@@ -32,3 +32,18 @@ def test_shell_matches_the_reference_interface(block):
            "-I", os.path.join(GR, "include"), "-I", os.path.join(ROOT, "include"), "-I", GR, os.path.join(GR, block + "_impl.cc")]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert r.returncode == 0, r.stdout.decode()[-3000:]
+
+
+def test_new_blocks_have_grc_and_swig_glue():
+    """dvbt.fft_hip and dvbt.rx_hip are new class names: GRC descriptors and the SWIG lines (pattern: gr-dvbt grc/dvbt_viterbi_decoder.xml:7,
+    swig/dvbt_swig.i:53-71) so that they can be placed in a .grc"""
+    import xml.etree.ElementTree as ET
+    for name, args in (("fft_hip", 3), ("rx_hip", 8)):
+        t = ET.parse(os.path.join(GR, "grc", f"dvbt_{name}.xml")).getroot()
+        assert t.find("key").text == f"dvbt_{name}" and t.find("import").text == "import dvbt"
+        mk = t.find("make").text
+        assert mk.startswith(f"dvbt.{name}(") and mk.count("$") == args
+        keys = {p.find("key").text for p in t.findall("param")}
+        assert all(("$" + k) in mk for k in keys)
+    sw = open(os.path.join(GR, "swig", "dvbt_hip_swig.i")).read()
+    assert "GR_SWIG_BLOCK_MAGIC2(dvbt, fft_hip);" in sw and "GR_SWIG_BLOCK_MAGIC2(dvbt, rx_hip);" in sw
