@@ -200,6 +200,13 @@ static void launch_viterbi(hipStream_t s, const uint8_t *in, uint8_t *out, const
   }
 }
 
+// the plan of A8 + A9 + descrambler for a Viterbi stream that the host has laid out from several lock periods (segment_periods)
+__global__ void tail_patch_kernel(RxState *st, long long items)
+{
+  st->n_rs_items = items; st->n_rs_words = items * 8; st->stream_rs_items = items;
+  st->rs_fail = 0; st->rs_corr = 0; st->rs_list_n = 0; st->sym_off = 0;
+}
+
 static FrontParams make_front_params(const Dims &d, float snr_db)
 {
   FrontParams p; memset(&p, 0, sizeof p);
@@ -249,7 +256,7 @@ struct dvbt_rx {
   int *centre = nullptr, *anchor_pos = nullptr;   // predicted CP position per call / coarse estimates every ACQ_ANCHOR calls
   float2 *acq_tap = nullptr, *fft_out = nullptr, *eq = nullptr, *tpsval = nullptr; SymInfo *info = nullptr; int *maj = nullptr, *sym_index = nullptr;
   uint8_t *labels = nullptr, *symdeint_tap = nullptr, *bitdeint = nullptr, *vit = nullptr, *deint_tap = nullptr, *rs_out = nullptr, *ts_out = nullptr;
-  size_t vit_cap = 0;
+  size_t vit_cap = 0; RsDefer *rs_defer = nullptr; int rs_defer_cap = 0;
   bool timing = false, pending = false;
   hipEvent_t ev[ST_COUNT]; double acc_ms[ST_COUNT] = {0}; long n_timed = 0; bool ev_ready = false, ev_recorded = false;
   dvbt_rx_report last; bool have_last = false;
@@ -264,7 +271,7 @@ struct dvbt_rx {
 
 static void rx_free(dvbt_rx *h)
 {
-  void *all[] = {h->drift_mem, h->drift.delta, h->drift.flags, h->tps_prev, h->descr_runs, h->descr_nruns, h->centre, h->anchor_pos, h->sym_ticket, h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags, h->trk_eps, h->d_iq, h->rs_iq, h->acq_carry, h->g_init, h->l_init, h->g_trk, h->l_trk, h->meta, h->st, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
+  void *all[] = {h->rs_defer, h->drift_mem, h->drift.delta, h->drift.flags, h->tps_prev, h->descr_runs, h->descr_nruns, h->centre, h->anchor_pos, h->sym_ticket, h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags, h->trk_eps, h->d_iq, h->rs_iq, h->acq_carry, h->g_init, h->l_init, h->g_trk, h->l_trk, h->meta, h->st, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
                  h->info, h->maj, h->sym_index, h->labels, h->symdeint_tap, h->bitdeint, h->vit, h->deint_tap, h->rs_out, h->ts_out};
   for (void *q : all) if (q) (void)hipFree(q);
   if (h->st_host) (void)hipHostFree(h->st_host);
@@ -318,6 +325,8 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   RXHIP(hipMalloc((void **)&h->maj, sizeof(int) * C)); RXHIP(hipMalloc((void **)&h->sym_index, sizeof(int) * C));
   RXHIP(hipMalloc((void **)&h->bitdeint, C * P + 64));
   h->vit_cap = C * P * d.m * d.k / (8 * d.n) + 4096;
+  h->rs_defer_cap = (int)((h->vit_cap / 204 / 64 + 2) * (RS_LANE_MIN - 1));
+  RXHIP(hipMalloc((void **)&h->rs_defer, sizeof(RsDefer) * (size_t)h->rs_defer_cap));
   RXHIP(hipMalloc((void **)&h->vit, h->vit_cap)); RXHIP(hipMalloc((void **)&h->rs_out, h->vit_cap)); RXHIP(hipMalloc((void **)&h->ts_out, h->vit_cap));
   RXHIP(hipMemset(h->st, 0, sizeof(RxState)));
   for (int i = 0; i < ST_COUNT; i++) RXHIP(hipEventCreate(&h->ev[i]));
@@ -406,21 +415,15 @@ static int prepare_chain(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStrea
 // A8 + A9 + energy_descramble over the segment's Viterbi stream.  words_fixed < 0: the word count is the device's (one period, no host round trip)
 static int enqueue_tail(dvbt_rx *h, hipStream_t s, long long max_words, long long words_fixed)
 {
-  if (words_fixed >= 0) {   // several periods: the host has laid the stream out and knows its length
-    RxState upd; memset(&upd, 0, sizeof upd);
+  if (words_fixed >= 0) {   // several periods: the host has laid the stream out and knows its length; one small kernel patches the device-side plan
     const long long items = (words_fixed / 8) & ~1ll;
-    // n_rs_items / n_rs_words / stream_rs_items sit next to each other; patch them (and the counters) on the device
-    HIPCHK(hipMemcpyAsync(&h->st->n_rs_items, &items, sizeof items, hipMemcpyHostToDevice, s));
-    const long long words = items * 8;
-    HIPCHK(hipMemcpyAsync(&h->st->n_rs_words, &words, sizeof words, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(&h->st->stream_rs_items, &items, sizeof items, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemsetAsync(&h->st->rs_fail, 0, 2 * sizeof(int), s));
-    const long long zero = 0;
-    HIPCHK(hipMemcpyAsync(&h->st->sym_off, &zero, sizeof zero, hipMemcpyHostToDevice, s));
-    (void)upd;
+    hipLaunchKernelGGL(tail_patch_kernel, dim3(1), dim3(1), 0, s, h->st, items);
   }
   hipLaunchKernelGGL(deint_rs_kernel, dim3((unsigned)((max_words + 63) / 64)), dim3(64), 0, s, (const uint8_t *)h->vit, h->deint_tap, h->rs_out,
-                     h->st, 0ll, 0, 0ll, h->T.rs_tables(), h->prm.rs_oracle_compat, &h->st->rs_fail, &h->st->rs_corr);
+                     h->st, 0ll, 0, 0ll, h->T.rs_tables(), h->prm.rs_oracle_compat, &h->st->rs_fail, &h->st->rs_corr, h->rs_defer, &h->st->rs_list_n, h->rs_defer_cap);
+  // the few bad words of lightly loaded wavefronts, one wavefront each (the deint tap shows the words as received: patches go to the payload only)
+  hipLaunchKernelGGL(rs_fix_kernel, dim3(512), dim3(64), 0, s, (const RsDefer *)h->rs_defer, (const int *)&h->st->rs_list_n, h->rs_defer_cap, h->rs_out,
+                     h->T.rs_tables(), h->prm.rs_oracle_compat, &h->st->rs_fail, &h->st->rs_corr);
   if (h->prm.descramble) {
     hipLaunchKernelGGL(descramble_scan_kernel, dim3(1), dim3(1024), 0, s, (const uint8_t *)h->rs_out, h->st, h->descr_runs, h->descr_nruns);
     hipLaunchKernelGGL(descramble_runs_kernel, dim3(1024), dim3(256), 0, s, (const uint8_t *)h->rs_out, (const uint8_t *)h->T.prbs,
@@ -446,24 +449,22 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
   int tries = C < ACQ_INIT_TRIES ? C : ACQ_INIT_TRIES;
   // initial search: the first window normally holds a peak; windows 1..3 are computed and examined only if it did not
   hipLaunchKernelGGL(acq_metric_kernel, dim3((N + 255) / 256, 1), dim3(256), 0, s, iq, fp, (const RxState *)h->st, 0, h->g_init, h->l_init, 0);
-  hipLaunchKernelGGL(acq_init_fsm_kernel, dim3(1), dim3(256), (size_t)N * 5, s, fp, h->st, (const float2 *)h->g_init, (const float *)h->l_init, carry, 0, 1);
+  // (the first launch also clears the trackers' flag words, the symbol kernel's ticket and, for a period that starts the pilot engine afresh, its state)
+  const AcqReset rz = {h->trk_flags, h->sym_ticket, (o.acq_only || o.continuation) ? nullptr : reinterpret_cast<int *>(h->tps_state), (int)(sizeof(TpsState) / 4)};
+  hipLaunchKernelGGL(acq_init_fsm_kernel, dim3(1), dim3(256), (size_t)N * 5, s, fp, h->st, (const float2 *)h->g_init, (const float *)h->l_init, carry, 0, 1, rz);
   if (tries > 1) {
     hipLaunchKernelGGL(acq_metric_kernel, dim3((N + 255) / 256, tries - 1), dim3(256), 0, s, iq, fp, (const RxState *)h->st, 0, h->g_init, h->l_init, 1);
     hipLaunchKernelGGL(acq_init_fsm_kernel, dim3(1), dim3(256), (size_t)N * 5, s, fp, h->st, (const float2 *)h->g_init, (const float *)h->l_init, carry, 1, tries);
   }
-  HIPCHK(hipMemsetAsync(h->trk_flags, 0, sizeof(int) * 16, s));
   {   // where the tracking metric is computed: CP position predicted per call from coarse estimates every ACQ_ANCHOR calls (sample-clock drift)
     const int n_anchors = (C - 1) / ACQ_ANCHOR;
     if (n_anchors > 0) hipLaunchKernelGGL(acq_anchor_kernel, dim3(n_anchors), dim3(1024), acq_anchor_lds_bytes(N, d.cp), s, iq, fp, (const RxState *)h->st, h->anchor_pos);
     hipLaunchKernelGGL(acq_centre_kernel, dim3(1), dim3(1024), 0, s, fp, (const RxState *)h->st, h->anchor_pos, n_anchors, h->centre);
   }
   hipLaunchKernelGGL(acq_track_metric_kernel, dim3((C + ACQ_TM_CALLS - 1) / ACQ_TM_CALLS), dim3(256), 0, s, iq, fp, (const RxState *)h->st, (const int *)h->centre, h->g_trk, h->l_trk);
-  constexpr int kIters = 4;                     // Jacobi iterations of the window placement; flags[kIters] = need_seq
-  for (int it = 0; it < kIters; it++) {
-    int *cin = (it & 1) ? h->trk_cp_a : h->trk_cp_b, *cout = (it & 1) ? h->trk_cp_b : h->trk_cp_a;
-    hipLaunchKernelGGL(acq_track_par_kernel, dim3((C + 255) / 256), dim3(256), 0, s, fp, (const RxState *)h->st, (const float2 *)h->g_trk,
-                       (const float *)h->l_trk, (const int *)cin, cout, h->trk_eps, h->trk_flags, it, (const int *)h->centre);
-  }
+  constexpr int kIters = TRK_ROUNDS;            // Jacobi iterations of the window placement (one launch); flags[kIters] = need_seq
+  hipLaunchKernelGGL(acq_track_fused_kernel, dim3((C + TRK_OWN - 1) / TRK_OWN), dim3(256), 0, s, fp, (const RxState *)h->st, (const float2 *)h->g_trk,
+                     (const float *)h->l_trk, h->trk_cp_a, h->trk_eps, h->trk_flags, (const int *)h->centre);
   hipLaunchKernelGGL(acq_finalize_kernel, dim3(1), dim3(1024), 0, s, fp, h->st, (const int *)h->trk_cp_a, (const float *)h->trk_eps,
                      (const int *)h->trk_flags, kIters - 1, h->meta, h->trk_flags + kIters);
   hipLaunchKernelGGL(acq_track_kernel, dim3(1), dim3(64), 0, s, fp, h->st, (const float2 *)h->g_trk, (const float *)h->l_trk, h->meta,
@@ -477,18 +478,12 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
   }
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_FFT], s));
   // A1 tail + A2 + A3 in one kernel: the FFT item of a symbol never leaves LDS (acq/fft taps are written only when enabled)
-  HIPCHK(hipMemsetAsync(h->sym_ticket, 0, sizeof(int), s));                      // the counter that hands out symbols
   {
-    // the wander of the reference's float phase accumulator (k_drift.hpp): tables per call, three rounds of the fixed point, the deviations per 32-sample block;
+    // the wander of the reference's float phase accumulator (k_drift.hpp): tables per call, the fixed point (one workgroup), the deviations per 32-sample block;
     // every kernel returns at once when the lock period has no usable carrier offset (drift.flags, device side: no host round trip)
     const DriftBufs &D = h->drift;
-    HIPCHK(hipMemsetAsync(D.flags, 0, 16, s));
     hipLaunchKernelGGL(drift_prep_kernel, dim3((C + 255) / 256), dim3(256), 0, s, fp, (const RxState *)h->st, (const SymMeta *)h->meta, D);
-    hipLaunchKernelGGL(drift_exact_kernel, dim3(1), dim3(1024), 0, s, fp, (const RxState *)h->st, (const SymMeta *)h->meta, D);
-    for (int it = 0; it < 3; it++) {
-      hipLaunchKernelGGL(drift_eval_kernel, dim3((C + 255) / 256), dim3(256), 0, s, fp, (const RxState *)h->st, (const SymMeta *)h->meta, D, it == 0 ? 1 : 0);
-      hipLaunchKernelGGL(drift_scan_kernel, dim3(1), dim3(1024), 0, s, (const RxState *)h->st, D);
-    }
+    hipLaunchKernelGGL(drift_solve_kernel, dim3(1), dim3(1024), 0, s, fp, (const RxState *)h->st, (const SymMeta *)h->meta, D);
     hipLaunchKernelGGL(drift_table_kernel, dim3(C), dim3(N / 32 < 256 ? N / 32 : 256), 0, s, fp, (const RxState *)h->st, (const SymMeta *)h->meta, D);
   }
   const bool taps = h->acq_tap || h->fft_out || h->eq;
@@ -512,12 +507,9 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
 #undef SYM_ARGS
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_DEMOD], s));
   if (!o.continuation) {
-    HIPCHK(hipMemsetAsync(h->tps_state, 0, sizeof(TpsState), s));
     hipLaunchKernelGGL(tps_vote_kernel, dim3((C + 63) / 64), dim3(256), 0, s, (const float2 *)h->tpsval, d.n_tps, (const RxState *)h->st, 0,
                        (const float2 *)nullptr, h->maj, fp.keep_last);
-    // flags[8] = first superframe-start candidate (min), flags[9] = need_seq for the TPS bookkeeping
-    static const int kInit[2] = {0x7fffffff, 0};
-    HIPCHK(hipMemcpyAsync(h->trk_flags + 8, kInit, sizeof kInit, hipMemcpyHostToDevice, s));
+    // flags[8] = first superframe-start candidate (min), flags[9] = need_seq for the TPS bookkeeping (set by acq_init_fsm_kernel's reset)
     hipLaunchKernelGGL(tps_fsm_par_kernel, dim3((C + TPS_THREADS * TPS_SEG - 1) / (TPS_THREADS * TPS_SEG)), dim3(TPS_THREADS), 0, s, fp, (const RxState *)h->st, (const SymInfo *)h->info,
                        (const int *)h->maj, h->sym_index, h->tps_edges, h->trk_flags + 8, &h->st->tps_bits);
     hipLaunchKernelGGL(tps_finalize_kernel, dim3(1), dim3(256), 0, s, h->st, (const TpsEdge *)h->tps_edges, (const int *)(h->trk_flags + 8), h->trk_flags + 9, fp.keep_last, h->tps_state);
@@ -637,9 +629,11 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
   const Dims &d = h->d;
   const size_t L = (size_t)(d.N + d.cp), win = (size_t)(2 * d.N + d.cp + 16);
   std::vector<LockPeriod> per;
+  bool capped = false;                                            // the walk was cut short: the rest of the segment is not decoded (status bit 8)
   {   // ---- phase A
     size_t off = 0; bool carry = false; float avg = 0.f;
-    for (int guard = 0; guard < 4096 && off + win <= chain_n; guard++) {
+    for (int guard = 0; off + win <= chain_n; guard++) {
+      if (guard >= 4096) { capped = true; break; }
       if (carry) { AcqState as; memset(&as, 0, sizeof as); as.avg = avg; HIPCHK(hipMemcpyAsync(h->acq_carry, &as, sizeof as, hipMemcpyHostToDevice, s)); }
       EnqOpt o; o.acq_only = true; o.use_carry = carry; o.hist = (long long)off;
       int r = enqueue(h, chain + off, chain_n - off, s, o); if (r) return r;
@@ -653,7 +647,7 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
       per.push_back(LockPeriod{off, st.n_symbols, avg, carry, st.call0, st.cp_start0});
       if (!(st.status & 2)) break;                               // the lock held to the end of the segment
       off += (size_t)(st.call0 + st.n_symbols) * L + L / 2; avg = st.avg_lost; carry = true;
-      if (per.size() >= 1024) break;
+      if (per.size() >= 1024) { capped = true; break; }
     }
   }
   h->periods.clear();
@@ -690,6 +684,7 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
     RxState st = *h->st_host; st.first_out = -1; st.n_out_symbols = 0; st.n_vit_bytes = 0; st.n_rs_items = 0; st.n_rs_words = 0; st.n_ts_bytes = 0;
     st.rs_fail = st.rs_corr = 0; st.tps_bits = 0; st.ts_first_packet = 0; st.stream_rs_items = 0; st.status |= 4;
     fill_report(h, st, r);
+    if (capped) r.status |= 256;
     h->n_periods = 0; h->seg_offset = 0;
     h->last = r; h->have_last = true; if (rep) *rep = r;
     return DVBT_OK;
@@ -709,6 +704,8 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
   r.segment_offset = (int64_t)last_off;
   if (r.resume_sample) r.resume_sample += (int64_t)last_off;
   r.n_lock_periods = delivering; r.total_symbols = total_symbols;
+  if (capped) r.status |= 256;
+  if (h->cut.stream_symbol_offset != 0 && (delivering > 1 || processed > 1)) r.status |= 128;   // a cut piece that lost the lock: laid out from its own start, not in the stream's coordinates
   if (delivering == 0) { r.first_out_symbol = -1; r.status |= 4; }
   h->n_periods = delivering; h->seg_offset = last_off;
   h->last = r; h->have_last = true;

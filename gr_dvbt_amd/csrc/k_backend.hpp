@@ -210,7 +210,7 @@ __global__ void plan_kernel(RxState *st, VitParams vp, int descramble, long long
   st->n_rs_words = words;
   st->n_rs_items = words / 8;
   st->sym_off = sym_off;
-  st->n_ts_bytes = 0; st->rs_fail = 0; st->rs_corr = 0; st->ts_first_packet = 0;
+  st->n_ts_bytes = 0; st->rs_fail = 0; st->rs_corr = 0; st->ts_first_packet = 0; st->rs_list_n = 0;
   (void)descramble;
 }
 
@@ -423,12 +423,17 @@ __device__ inline int rs_decode_word_lane(uint8_t *cw, const uint8_t *syn_col /*
   return failed ? -1 : no_roots;
 }
 
+// A wavefront with only a few bad words (a clean stream's junction words, the odd error burst) hands them to a second launch, where every bad word gets
+// a wavefront of its own: the 11 undecodable start-up words of a stream (convolutional_deinterleaver_impl.cc:64-65) sit in ONE workgroup and were the
+// critical path of the whole launch (11 x ~8 us in sequence while the other 5,000 workgroups had long finished)
+struct RsDefer { int word; uint8_t syn[16]; uint8_t cw[204]; };   // 224 bytes: the word's index, its syndromes, the received codeword
 constexpr int RS_LANE_MIN = 8;                                 // bad words per wavefront from which every lane decodes its own word
 // standalone = 1: input is already de-interleaved items (A9 block alone); 0: gather from the Viterbi stream (A8+A9)
 __global__ __launch_bounds__(64) void deint_rs_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ deint_tap,
                                                      uint8_t *__restrict__ out, RxState *st, long long words_fixed, int standalone,
                                                      long long hist_words /* words of real history before word 0 (block API) */,
-                                                     RsTables T, int compat, int *fail_cnt, int *corr_cnt)
+                                                     RsTables T, int compat, int *fail_cnt, int *corr_cnt,
+                                                     RsDefer *__restrict__ defer = nullptr, int *defer_n = nullptr, int defer_cap = 0)
 {
   // codewords of the workgroup, one row of 204 bytes each; 11 spare rows on either side absorb the bytes of the 75
   // source words that belong to codewords of the neighbouring workgroups, so the scatter below needs no bounds test
@@ -518,6 +523,22 @@ __global__ __launch_bounds__(64) void deint_rs_kernel(const uint8_t *__restrict_
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
       nc = c;
+    } else if (defer && mask) {
+      // second pass (rs_fix_kernel): the word's index, syndromes and received bytes go to the list; its payload is stored below as received
+      const int cnt = __popcll(mask);
+      int base = 0;
+      if (tid == 0) base = atomicAdd(defer_n, cnt);
+      base = __shfl(base, 0);
+      if (bad) {
+        const int e = base + __popcll(mask & ((1ull << tid) - 1));
+        if (e < defer_cap) {
+          RsDefer *d = defer + e;
+          d->word = (int)(w0 + tid);
+#pragma unroll
+          for (int i = 0; i < 16; i++) d->syn[i] = s_syn[i * RS_SYN_STRIDE + tid];
+          for (int i = 0; i < 51; i++) reinterpret_cast<unsigned *>(d->cw)[i] = reinterpret_cast<const unsigned *>(cw)[i];
+        }
+      }
     } else {
       while (mask) {
         const int wl = __ffsll((long long)mask) - 1; mask &= mask - 1;
@@ -531,6 +552,33 @@ __global__ __launch_bounds__(64) void deint_rs_kernel(const uint8_t *__restrict_
   // coalesced store of 64 x 188 payload bytes as dwords (reed_solomon_dec_impl.cc:102: output regardless of success)
   unsigned *o4 = reinterpret_cast<unsigned *>(out + w0 * 188);
   for (int i = tid; i < nw * 47; i += 64) { const int ww = i / 47, q = i - ww * 47; o4[i] = reinterpret_cast<const unsigned *>(s_cw + ww * 204)[q]; }
+}
+
+// second pass of A9: one wavefront per listed word (rs_decode_word_wave), the corrected payload written over the uncorrected one
+__global__ __launch_bounds__(64) void rs_fix_kernel(const RsDefer *__restrict__ list, const int *__restrict__ list_n, int list_cap, uint8_t *__restrict__ out,
+                                                   RsTables T, int compat, int *fail_cnt, int *corr_cnt)
+{
+  __shared__ __attribute__((aligned(16))) uint8_t s_cw[208];
+  __shared__ uint8_t s_exp[512], s_log[256], s_scr[64], s_syn[RS_SYN_STRIDE * 16];
+  int n = *list_n; if (n > list_cap) n = list_cap;
+  if ((int)blockIdx.x >= n) return;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 512; i += 64) s_exp[i] = T.gexp[i];
+  for (int i = tid; i < 256; i += 64) s_log[i] = T.glog[i];
+  int nf = 0, nc = 0;
+  for (int e = blockIdx.x; e < n; e += gridDim.x) {
+    const RsDefer *d = list + e;
+    __syncthreads();
+    if (tid < 51) reinterpret_cast<unsigned *>(s_cw)[tid] = reinterpret_cast<const unsigned *>(d->cw)[tid];
+    if (tid < 16) s_syn[tid * RS_SYN_STRIDE] = d->syn[tid];
+    __syncthreads();
+    const int r = rs_decode_word_wave(s_cw, s_syn, s_exp, s_log, compat, s_scr, tid);
+    if (r < 0) nf++; else {
+      nc += r;
+      if (tid < 47) reinterpret_cast<unsigned *>(out + (size_t)d->word * 188)[tid] = reinterpret_cast<const unsigned *>(s_cw)[tid];
+    }
+  }
+  if (tid == 0) { if (nf) atomicAdd(fail_cnt, nf); if (nc) atomicAdd(corr_cnt, nc); }
 }
 
 // A8 alone (block API): buf holds `hist` bytes of history followed by the call's n input bytes;

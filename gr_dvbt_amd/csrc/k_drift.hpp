@@ -110,7 +110,7 @@ DRIFT_HD double drift_advance(double inc, double phi0, double n)
 #if defined(__HIPCC__)
 // ------------------------------------------------------------------------------------------------ kernels (segment path)
 // scratch layout (doubles): tabs[C][DRIFT_TAB] | ex_run[C] | ex_entry[C] | d[C] | S[C] | A0[1]
-struct DriftBufs { double *tabs, *ex_run, *ex_entry, *d, *S, *A0; float *delta; int *flags; };   // flags[0]: sign / validity bits, flags[1]: 1 = applied
+struct DriftBufs { double *tabs, *ex_run, *ex_entry, *d, *S, *A0; float *delta; int *flags; };   // flags[0]: sign / validity bits (collected by drift_prep_kernel, cleared by drift_solve_kernel), flags[1]: 1 = applied, flags[2]: 1 = negative increments
 
 __device__ __forceinline__ void drift_load(const double *tabs, int r, double *q, double *tc)
 {
@@ -143,32 +143,7 @@ __global__ __launch_bounds__(256) void drift_prep_kernel(FrontParams p, const Rx
   atomicOr(&B.flags[0], f);
 }
 
-// exact (unrounded) accumulated phase at every call entry and at every run start: prefix sum in double over the calls (one workgroup)
-__global__ __launch_bounds__(1024) void drift_exact_kernel(FrontParams p, const RxState *st, const SymMeta *__restrict__ meta, DriftBufs B)
-{
-  __shared__ double s_tot[1024];
-  const int tid = threadIdx.x, nsym = st->n_symbols, L = p.N + p.cp;
-  const int fl = B.flags[0];
-  const bool on = !(st->status & 1) && nsym >= 2 && (fl == 1 || fl == 2);
-  if (tid == 0) B.flags[1] = on ? 1 : 0;
-  if (!on) return;
-  const int per = (nsym + 1023) / 1024, sbeg = tid * per, cnt = sbeg >= nsym ? 0 : (nsym - sbeg < per ? nsym - sbeg : per);
-  double local = 0.0;
-  for (int i = 0; i < cnt; i++) { const SymMeta m = meta[sbeg + i]; local += m.sw * m.incA + (L - m.sw) * m.incB; }
-  s_tot[tid] = local;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) { const double v = tid >= off ? s_tot[tid - off] : 0.0; __syncthreads(); s_tot[tid] += v; __syncthreads(); }
-  double base = tid == 0 ? 0.0 : s_tot[tid - 1];
-  for (int i = 0; i < cnt; i++) {
-    const SymMeta m = meta[sbeg + i];
-    B.ex_entry[sbeg + i] = base; B.ex_run[sbeg + i] = base + m.sw * m.incA;
-    B.S[sbeg + i] = 0.0;
-    base += m.sw * m.incA + (L - m.sw) * m.incB;
-  }
-  if (tid == 0) { double q[DRIFT_NR], tc[DRIFT_NR + 1]; drift_load(B.tabs, 0, q, tc); B.A0[0] = drift_T(q, tc, fl == 2, 0.0); }   // run 0 starts at phase 0 (increment 0 before it)
-}
-
-// the float phase at the start of run r from the current prefix sums: T_{r-1}(phi_r) = A0 + (n_r - n_0) - S_{r-1}; first round (S = 0 everywhere, `first`): the exact line
+// the float phase at the start of run r from the current prefix sums: T_{r-1}(phi_r) = A0 + (n_r - n_0) - S_{r-1}; first round: the exact line
 __device__ __forceinline__ double drift_phi_run(const DriftBufs &B, const SymMeta *meta, int r, int L, bool neg, bool first)
 {
   if (r == 0) return 0.0;
@@ -179,36 +154,59 @@ __device__ __forceinline__ double drift_phi_run(const DriftBufs &B, const SymMet
   return drift_Tinv(q, tc, neg, B.A0[0] + steps - B.S[r - 1]);
 }
 
-// d_r = T_{r-1}(phi_r) - T_r(phi_r), r >= 1 (d_0 = 0)
-__global__ __launch_bounds__(256) void drift_eval_kernel(FrontParams p, const RxState *st, const SymMeta *__restrict__ meta, DriftBufs B, int first)
-{
-  if (!B.flags[1]) return;
-  const int r = blockIdx.x * 256 + threadIdx.x, nsym = st->n_symbols;
-  if (r >= nsym) return;
-  if (r == 0) { B.d[0] = 0.0; return; }
-  const bool neg = B.flags[0] == 2;
-  const double phi = drift_phi_run(B, meta, r, p.N + p.cp, neg, first != 0);
-  double q[DRIFT_NR], tc[DRIFT_NR + 1];
-  drift_load(B.tabs, r - 1, q, tc);
-  const double a = drift_T(q, tc, neg, phi);
-  drift_load(B.tabs, r, q, tc);
-  B.d[r] = a - drift_T(q, tc, neg, phi);
-}
-
-// S_r = d_1 + ... + d_r (one workgroup)
-__global__ __launch_bounds__(1024) void drift_scan_kernel(const RxState *st, DriftBufs B)
+// One workgroup: (1) the exact (unrounded) accumulated phase at every call entry and run start, a prefix sum in double over the calls; (2) three rounds of
+// the fixed point: d_r = T_{r-1}(phi_r) - T_r(phi_r) at the previous round's phases (r >= 1), S_r = d_1 + ... + d_r.  A thread owns a run of consecutive calls.
+__global__ __launch_bounds__(1024) void drift_solve_kernel(FrontParams p, const RxState *st, const SymMeta *__restrict__ meta, DriftBufs B)
 {
   __shared__ double s_tot[1024];
-  if (!B.flags[1]) return;
-  const int tid = threadIdx.x, nsym = st->n_symbols;
-  const int per = (nsym + 1023) / 1024, sbeg = tid * per, cnt = sbeg >= nsym ? 0 : (nsym - sbeg < per ? nsym - sbeg : per);
-  double local = 0.0;
-  for (int i = 0; i < cnt; i++) local += B.d[sbeg + i];
-  s_tot[tid] = local;
+  const int tid = threadIdx.x, nsym = st->n_symbols, L = p.N + p.cp;
+  const int fl = B.flags[0];
+  const bool on = !(st->status & 1) && nsym >= 2 && (fl == 1 || fl == 2);
   __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) { const double v = tid >= off ? s_tot[tid - off] : 0.0; __syncthreads(); s_tot[tid] += v; __syncthreads(); }
-  double base = tid == 0 ? 0.0 : s_tot[tid - 1];
-  for (int i = 0; i < cnt; i++) { base += B.d[sbeg + i]; B.S[sbeg + i] = base; }
+  if (tid == 0) { B.flags[1] = on ? 1 : 0; B.flags[2] = fl == 2 ? 1 : 0; B.flags[0] = 0; }     // flags[0] is left clear for the next lock period's drift_prep_kernel
+  if (!on) return;
+  const bool neg = fl == 2;
+  const int per = (nsym + 1023) / 1024, sbeg = tid * per, cnt = sbeg >= nsym ? 0 : (nsym - sbeg < per ? nsym - sbeg : per);
+  auto scan = [&](double local) -> double {   // exclusive prefix of the threads' sums
+    s_tot[tid] = local;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) { const double v = tid >= off ? s_tot[tid - off] : 0.0; __syncthreads(); s_tot[tid] += v; __syncthreads(); }
+    const double base = tid == 0 ? 0.0 : s_tot[tid - 1];
+    __syncthreads();
+    return base;
+  };
+  {
+    double local = 0.0;
+    for (int i = 0; i < cnt; i++) { const SymMeta m = meta[sbeg + i]; local += m.sw * m.incA + (L - m.sw) * m.incB; }
+    double base = scan(local);
+    for (int i = 0; i < cnt; i++) {
+      const SymMeta m = meta[sbeg + i];
+      B.ex_entry[sbeg + i] = base; B.ex_run[sbeg + i] = base + m.sw * m.incA;
+      base += m.sw * m.incA + (L - m.sw) * m.incB;
+    }
+    if (tid == 0) { double q[DRIFT_NR], tc[DRIFT_NR + 1]; drift_load(B.tabs, 0, q, tc); B.A0[0] = drift_T(q, tc, neg, 0.0); }   // run 0 starts at phase 0 (increment 0 before it)
+  }
+  __threadfence_block(); __syncthreads();
+  for (int it = 0; it < 3; it++) {
+    double local = 0.0;
+    for (int i = 0; i < cnt; i++) {
+      const int r = sbeg + i;
+      double dr = 0.0;
+      if (r >= 1) {
+        const double phi = drift_phi_run(B, meta, r, L, neg, it == 0);
+        double q[DRIFT_NR], tc[DRIFT_NR + 1];
+        drift_load(B.tabs, r - 1, q, tc);
+        const double a = drift_T(q, tc, neg, phi);
+        drift_load(B.tabs, r, q, tc);
+        dr = a - drift_T(q, tc, neg, phi);
+      }
+      B.d[r] = dr; local += dr;
+    }
+    __syncthreads();                                              // every S of the previous round has been read
+    double base = scan(local);
+    for (int i = 0; i < cnt; i++) { base += B.d[sbeg + i]; B.S[sbeg + i] = base; }
+    __threadfence_block(); __syncthreads();
+  }
 }
 
 // one workgroup per call, one thread per 32-sample block of the item: delta[s][k] = (float phase - exact line) after step 32 k + 17, relative to the call's entry
@@ -218,7 +216,7 @@ __global__ __launch_bounds__(256) void drift_table_kernel(FrontParams p, const R
   __shared__ double s_ent, s_sw;
   const int s = blockIdx.x, k = threadIdx.x, nsym = st->n_symbols, L = p.N + p.cp, nb = p.N / 32;
   if (!B.flags[1] || s >= nsym) return;
-  const bool neg = B.flags[0] == 2;
+  const bool neg = B.flags[2] != 0;
   const SymMeta m = meta[s];
   if (k == 0) {
     double ent = 0.0;

@@ -26,7 +26,7 @@ struct RxState {
   int descr_base, descr_index;
   int rs_fail, rs_corr;
   float avg_lost;        // d_avg after the call that lost the lock (what a re-acquisition starts from)
-  int pad0;
+  int rs_list_n;         // RS words handed to the second pass (rs_fix_kernel) by deint_rs_kernel
   long long sym_off;         // cut stream: OFDM symbols between the stream's first superframe start and this segment's (0: stream start)
   long long n_rs_words;      // RS words decoded (= 8 n_rs_items unless the segment continues a cut stream)
   long long stream_rs_items; // items the byte de-interleaver of a chain over the whole stream has produced up to this segment's end
@@ -296,9 +296,17 @@ __device__ __forceinline__ float wrap_pi(double ph)
 //      are exact by construction).  From it the two threshold tests of sample i (rise: > 0.8 avg, keep: > 0.9 avg).
 //  (2) one lane walks the state machine on the precomputed flags; its only remaining recurrence is the running
 //      maximum of the open peak, so a step costs a few cycles instead of a dependent float chain.
+// reset (segment path, first launch of a lock period): the flag words of the trackers (trk_flags[0..15]; [8], [9] = first superframe-start candidate, need_seq of the
+// TPS bookkeeping), the symbol kernel's ticket and -- for a period that starts the pilot engine afresh -- its state: three memset / copy launches less
+struct AcqReset { int *trk_flags; int *ticket; int *tps_state; int tps_state_words; };
 __global__ __launch_bounds__(256) void acq_init_fsm_kernel(FrontParams p, RxState *st, const float2 *gamma, const float *lambda, const AcqState *as,
-                                                          int t_begin, int t_end)
+                                                          int t_begin, int t_end, AcqReset rz = AcqReset{nullptr, nullptr, nullptr, 0})
 {
+  if (t_begin == 0) {
+    if (rz.trk_flags && threadIdx.x < 16) rz.trk_flags[threadIdx.x] = threadIdx.x == 8 ? 0x7fffffff : 0;
+    if (rz.ticket && threadIdx.x == 16) rz.ticket[0] = 0;
+    if (rz.tps_state) for (int i = threadIdx.x; i < rz.tps_state_words; i += 256) rz.tps_state[i] = 0;
+  }
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float *lam = reinterpret_cast<float *>(smem_raw);
   unsigned char *flg = smem_raw + (size_t)p.N * 4;
@@ -309,7 +317,7 @@ __global__ __launch_bounds__(256) void acq_init_fsm_kernel(FrontParams p, RxStat
   if (tid == 0 && t_begin > 0) { s_done = (st->status & 1) ? 0 : 2; s_avg = st->avg; }   // continuation: only if the earlier windows had no peak
   if (tid == 0 && t_begin == 0) {
     st->status = 1; st->call0 = 0; st->cp_start0 = 0; st->n_symbols = 0; st->first_out = -1; st->n_out_symbols = 0;
-    st->n_vit_in = st->n_vit_steps = st->n_vit_bytes = st->n_rs_items = st->n_ts_bytes = 0; st->rs_fail = st->rs_corr = 0;
+    st->n_vit_in = st->n_vit_steps = st->n_vit_bytes = st->n_rs_items = st->n_ts_bytes = 0; st->rs_fail = st->rs_corr = 0; st->rs_list_n = 0;
     st->n_rs_words = st->stream_rs_items = st->ts_first_packet = 0; st->tps_bits = 0;
     s_done = 0; s_avg = as ? as->avg : 0.f;
     if (as && as->acquired) {          // block API: still locked from the previous work() call, nothing to search
@@ -512,6 +520,63 @@ __global__ __launch_bounds__(256) void acq_track_par_kernel(FrontParams p, const
   cp_out[s] = res; eps_out[s] = eps;
   int old = iter == 0 ? c0 : cp_in[s];
   if (res != old) atomicOr(&changed[iter], 1);
+}
+
+// The four Jacobi rounds in ONE launch.  A round reads the previous round's peaks of the three calls in front of a call, so a workgroup that recomputes
+// 12 calls in front of its own 244 (TRK_HALO = 3 per round) needs nothing from its neighbours: thread t of workgroup b works on call b * 244 - 12 + t, its
+// round-k value is the global one whenever t >= 3 k.  Same results and the same `changed` flags as four launches of acq_track_par_kernel (rounds behind
+// the fixed point reproduce it); the last round's peaks go to cp_out.
+constexpr int TRK_HALO = 12, TRK_OWN = 256 - TRK_HALO, TRK_ROUNDS = 4;
+__global__ __launch_bounds__(256) void acq_track_fused_kernel(FrontParams p, const RxState *st, const float2 *__restrict__ gamma,
+                                                             const float *__restrict__ lambda, int *__restrict__ cp_out, float *__restrict__ eps_out,
+                                                             int *changed, const int *__restrict__ centre)
+{
+  __shared__ int s_cp[2][256];
+  if (st->status & 1) return;
+  const int t = threadIdx.x, s = (int)blockIdx.x * TRK_OWN - TRK_HALO + t;
+  const int call0 = st->call0, call = call0 + s, R = p.R, c0 = st->cp_start0;
+  const bool live = s >= 0 && call < p.ncalls, own = live && (t >= TRK_HALO);
+  int res = c0; float eps = 0.f;
+  for (int iter = 0; iter < TRK_ROUNDS; iter++) {
+    const int *cin = s_cp[(iter + 1) & 1];
+    auto prev_cp = [&](int ss) -> int {                            // peak of call ss - 1 in the previous round
+      if (ss <= 0 || iter == 0) return c0;
+      const int tt = ss - 1 - ((int)blockIdx.x * TRK_OWN - TRK_HALO);
+      return tt >= 0 ? cin[tt] : c0;                               // (tt < 0 only for threads outside the trusted zone)
+    };
+    const int old = res;
+    if (live) {
+      float avg; int first_warm;
+      if (s <= 2) { avg = st->avg; first_warm = 0; } else { avg = 0.f; first_warm = s - 2; }
+      bool bad = false;
+      for (int ws = first_warm; ws < s; ws++) {                    // IIR over the earlier windows (fact 1)
+        const int cur = prev_cp(ws);
+        if (cur < 0) { bad = true; break; }
+        const int rel0 = (cur - 8) - (centre[call0 + ws] - R);
+        if (rel0 < 0 || rel0 + 16 > 2 * R) { bad = true; break; }
+        const float *lam = lambda + (size_t)(call0 + ws) * 2 * R + rel0;
+        for (int i = 0; i < 16; i++) avg = 0.9f * lam[i] + (1 - 0.9f) * avg;
+      }
+      const int cur = prev_cp(s);
+      res = bad ? -2 : -1; eps = 0.f;
+      if (!bad && cur >= 0) {
+        const int rel0 = (cur - 8) - (centre[call] - R);
+        if (rel0 < 0 || rel0 + 16 > 2 * R) res = -2;              // left the precomputed lags: the sequential tracker takes over
+        else {
+          float lam[16];
+          const float *lp = lambda + (size_t)call * 2 * R + rel0;
+          for (int i = 0; i < 16; i++) lam[i] = lp[i];
+          int pos = 0;
+          const int npk = peak_detect(lam, 16, avg, pos);
+          if (npk) { res = pos + cur - 8; const float2 g = gamma[(size_t)call * 2 * R + rel0 + pos]; eps = atan2f(g.y, g.x); }
+        }
+      }
+    }
+    s_cp[iter & 1][t] = res;
+    if (own && res != old) atomicOr(&changed[iter], 1);
+    __syncthreads();
+  }
+  if (own) { cp_out[s] = res; eps_out[s] = eps; }
 }
 
 // bookkeeping after the fixed point: n_symbols = calls before the first miss; derotation phase

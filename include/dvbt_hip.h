@@ -272,7 +272,10 @@ typedef struct {
 typedef struct {
   int32_t status;              /* 0 ok; bit0: initial acquisition failed; bit1: CP tracking lost;
                                   bit2: no superframe start found;
-                                  bit4: the stream's TPS disagrees with the configured parameters (tps_mismatch) */
+                                  bit4: the stream's TPS disagrees with the configured parameters (tps_mismatch);
+                                  bit7: a segment that continues a cut stream (dvbt_rx_set_cut) lost the CP lock: its Viterbi stream was laid out from its own
+                                  lock periods, the cut offset does not apply to its counts (stream_symbol_offset is reported as 0): do not stitch it;
+                                  bit8: dvbt_rx_segment_run gave up walking the segment's lock periods (more than 1024 periods or 4096 searches): the rest is not decoded */
   int32_t n_symbols;           /* OFDM symbols acquired */
   int32_t first_out_symbol;    /* symbol at which superframe_start fired, -1 if none */
   int32_t n_out_symbols;       /* symbols passed downstream */
