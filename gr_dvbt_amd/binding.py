@@ -229,7 +229,7 @@ class Rx:
 
 
 class StreamParams(C.Structure):
-    _fields_ = [("rx", RxParams), ("segment_superframes", C.c_int)]
+    _fields_ = [("rx", RxParams), ("segment_superframes", C.c_int), ("rank", C.c_int), ("world", C.c_int)]
 
 
 class StreamInfo(C.Structure):
@@ -242,7 +242,7 @@ class RxStream:
     """dvbt_rx_stream_*: push samples in calls of any size, pull the TS in order; the bytes are those of one chain over the whole stream."""
 
     def __init__(self, constellation, code_rate, mode, segment_superframes=0, guard=G1_32, hierarchy=NH, snr_db=30.0, viterbi_bsize=768,
-                 rs_oracle_compat=0, device=0):
+                 rs_oracle_compat=0, device=0, rank=0, world=0):
         self.L = lib()
         for fn in ("create", "push", "push_device", "finish", "status"):
             getattr(self.L, f"dvbt_rx_stream_{fn}").restype = C.c_int
@@ -255,7 +255,9 @@ class RxStream:
         self.L.dvbt_rx_stream_status.argtypes = [C.c_void_p, C.POINTER(StreamInfo)]
         self.L.dvbt_rx_stream_destroy.argtypes = [C.c_void_p]
         rx = RxParams(constellation, hierarchy, code_rate, guard, mode, 0, 0, snr_db, viterbi_bsize, rs_oracle_compat, 1, 0, device, 0, 0, 0, 0.0)
-        self.p = StreamParams(rx, segment_superframes)
+        self.p = StreamParams(rx, segment_superframes, rank, world)
+        self.L.dvbt_rx_stream_pull_chunk.restype = C.c_int64
+        self.L.dvbt_rx_stream_pull_chunk.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int64)]
         self.h = C.c_void_p()
         _chk(self.L.dvbt_rx_stream_create(C.byref(self.p), C.byref(self.h)))
         self._out = np.empty(1 << 22, np.uint8)
@@ -280,6 +282,17 @@ class RxStream:
             if left is not None:
                 left -= n
         return np.concatenate(chunks) if chunks else np.zeros(0, np.uint8)
+
+    def pull_chunks(self):
+        """[(first packet index in the stream's TS, uint8 array)] of what is ready: this rank's packets of a sharded stream"""
+        out = []
+        while True:
+            fp = C.c_int64()
+            n = _chk(self.L.dvbt_rx_stream_pull_chunk(self.h, self._out.ctypes.data_as(C.c_void_p), len(self._out) // 188 * 188, C.byref(fp)))
+            if n <= 0:
+                break
+            out.append((fp.value, self._out[:n].copy()))
+        return out
 
     def finish(self):
         _chk(self.L.dvbt_rx_stream_finish(self.h))

@@ -427,7 +427,7 @@ __device__ inline int rs_decode_word_lane(uint8_t *cw, const uint8_t *syn_col /*
 // a wavefront of its own: the 11 undecodable start-up words of a stream (convolutional_deinterleaver_impl.cc:64-65) sit in ONE workgroup and were the
 // critical path of the whole launch (11 x ~8 us in sequence while the other 5,000 workgroups had long finished)
 struct RsDefer { int word; uint8_t syn[16]; uint8_t cw[204]; };   // 224 bytes: the word's index, its syndromes, the received codeword
-constexpr int RS_LANE_MIN = 8;                                 // bad words per wavefront from which every lane decodes its own word
+constexpr int RS_LANE_MIN = 24;                                // bad words per wavefront from which every lane decodes its own word
 // standalone = 1: input is already de-interleaved items (A9 block alone); 0: gather from the Viterbi stream (A8+A9)
 __global__ __launch_bounds__(64) void deint_rs_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ deint_tap,
                                                      uint8_t *__restrict__ out, RxState *st, long long words_fixed, int standalone,

@@ -393,11 +393,20 @@ void dvbt_rx_destroy(dvbt_rx *h);
  * reference's flowgraph writes to its file sink: this is gr_dvbt_amd/multi.py's plan_cuts / stitch_plan inside the library.
  * segment_superframes: superframes a piece owns (0 = 16; device memory ~ 2 x (segment_superframes + 3) superframes of samples + the
  * chains' own buffers).  rx.max_samples, rx.resample_* are ignored / must be 0 (no resampler in front).
+ * A piece is decoded once the stream is known to go on far enough for the next piece to stand on its own (one superframe + 76 symbols behind its begin), so the
+ * TS lags the input by about segment_superframes + 1 superframes.
  * Limits: the stream's head must reach its first superframe start within the first piece (segment_superframes + 2 superframes), else that
  * much of it is dropped (status bit 2, the stream's origin moves); a CP lock lost inside a later piece is reported (status bit 1) and the
  * stream goes on with the next piece (the packets up to that piece's end are missing: bit 5).
  * Threading: like every handle, one thread at a time. */
-typedef struct { dvbt_rx_params rx; int segment_superframes; } dvbt_rx_stream_params;
+typedef struct {
+  dvbt_rx_params rx; int segment_superframes;
+  /* sharding over the GPUs of a node, one stream object per process / GPU: every rank is pushed the SAME stream; piece k >= 1 belongs to rank
+   * k % world, which alone copies its samples to the device and decodes it (piece 0, the plan, is decoded by every rank and delivered by rank 0).  A rank
+   * pulls its own packets with their index in the stream (dvbt_rx_stream_pull_chunk); all ranks' chunks ordered by that index are the single chain's TS:
+   * gathering them is the design's one exchange step (RCCL over xGMI in bench.py / gr_dvbt_amd/multi.py).  world = 0 or 1: no sharding. */
+  int rank, world;
+} dvbt_rx_stream_params;
 typedef struct {
   int32_t status;              /* dvbt_rx_report.status bits of the pieces, OR-ed (bit 1 only when the lock was lost inside a piece) | bit 5: a piece
                                   delivered fewer packets than its span of the stream | bit 6: a piece's sync byte was not where the stream's packet
@@ -415,6 +424,9 @@ int  dvbt_rx_stream_push(dvbt_rx_stream *s, const void *iq_host, size_t nsamples
 int  dvbt_rx_stream_push_device(dvbt_rx_stream *s, const void *iq_device, size_t nsamples, void *stream);
 /* TS bytes that are ready, in stream order, up to cap; never waits for the device before dvbt_rx_stream_finish.  Returns the bytes written */
 int64_t dvbt_rx_stream_pull(dvbt_rx_stream *s, void *ts_host, size_t cap);
+/* one contiguous run of this rank's packets (never across two pieces) and the index of its first packet in the stream's TS (packet 0 = the first packet
+ * the single chain delivers is *first_packet == first_ts_packet of dvbt_rx_stream_info): what a sharded stream's ranks exchange.  cap >= 188 */
+int64_t dvbt_rx_stream_pull_chunk(dvbt_rx_stream *s, void *ts_host, size_t cap, int64_t *first_packet);
 /* end of the stream: decodes what is left (energy_descramble's two-item hold-back and the block roundings apply here, as at the end of
  * the reference's run) and waits for it; pull then drains the rest */
 int  dvbt_rx_stream_finish(dvbt_rx_stream *s);

@@ -119,6 +119,49 @@ def test_noisy_stream_post_rs_equal(po):
     assert len(ts) == len(ref) and (ts == ref).all()
 
 
+@pytest.mark.parametrize("const,cr,mode,nsf,seg_sf,world,call", [
+    (g.QAM16, g.C1_2, g.T2k, 14, 2, 2, 9 * 2112),
+    (g.QAM16, g.C1_2, g.T2k, 11, 1, 3, (1000, 60000)),
+    (g.QAM64, g.C7_8, g.T8k, 9, 1, 4, 64 * 8448),
+    (g.QAM64, g.C7_8, g.T8k, 10, 2, 2, 40 * 8448 + 3),
+])
+def test_sharded_stream_equals_one_chain(po, const, cr, mode, nsf, seg_sf, world, call):
+    """rank / world in the parameters: every rank is pushed the same stream, decodes the pieces k % world == rank and pulls its packets with
+    their index in the stream; the ranks' chunks ordered by that index are the single chain's TS (here: all ranks in one process, on one GPU)"""
+    c = po.cfg(const, cr, mode)
+    iq = po.stream_slice(c, nsf, 9)
+    ref = whole(const, cr, mode, iq)
+    ranks = [g.RxStream(const, cr, mode, segment_superframes=seg_sf, rank=r, world=world) for r in range(world)]
+    chunks = []
+    rng = np.random.RandomState(5)
+    pos = 0
+    while pos < len(iq):
+        n = call if isinstance(call, int) else int(rng.randint(call[0], call[1]))
+        for st in ranks:
+            st.push(iq[pos:pos + n])
+        pos += n
+        for r, st in enumerate(ranks):
+            chunks += [(fp, r, b) for fp, b in st.pull_chunks()]
+    for r, st in enumerate(ranks):
+        st.finish()
+        chunks += [(fp, r, b) for fp, b in st.pull_chunks()]
+    infos = [st.info() for st in ranks]
+    for st in ranks:
+        st.close()
+    assert all(i.status & ~2 == 0 for i in infos), [i.status for i in infos]
+    chunks.sort(key=lambda t: t[0])
+    # contiguous, no packet twice, every rank contributed
+    q0 = infos[0].first_ts_packet
+    assert chunks[0][0] == q0
+    at = q0
+    for fp, r, b in chunks:
+        assert fp == at, (fp, at, r)
+        at += len(b) // 188
+    assert len({r for _, r, _ in chunks}) == world
+    ts = np.concatenate([b for _, _, b in chunks])
+    assert len(ts) == len(ref) > 0 and (ts == ref).all()
+
+
 def test_cpp_rx_hip_example(po, tmp_path):
     """gr_dvbt_amd/host/rx_stream_example: the RX flowgraph with the ten receive blocks replaced by the one block over dvbt_rx_stream_* (the GNU Radio-free
     mirror of gr::dvbt::rx_hip), a baseband file read 64 symbols per work() call; the TS file must be the single chain's"""
