@@ -398,6 +398,19 @@ __global__ __launch_bounds__(256) void acq_init_fsm_kernel(FrontParams p, RxStat
 // tracking FSM over all windows (general_work :512-560 + the phase bookkeeping of ml_sync :285-313).
 // Sequential reference version: one thread walks the calls.
 struct SymMeta { int cp_start; int sw; float eps; float ph_base; double incA, incB; };
+}  // namespace dvbt
+#include "k_drift_math.hpp"
+namespace dvbt {
+
+// d_phase after one call's N + cp additions: the reference's FLOAT accumulator, reproduced binade by binade (k_drift_math.hpp); the increment switches at
+// step `nextpos` when that lies inside the call (:285-309).  The carried value is the accumulator's own (a float), so a call's entry phase is exact
+__device__ inline float acq_phase_advance(float phase, double inc, double next_inc, int nextpos, int L)
+{
+  double x = (double)phase;
+  if (nextpos >= 0 && nextpos < L) x = drift_advance_safe(next_inc, drift_advance_safe(inc, x, (double)nextpos), (double)(L - nextpos));
+  else x = drift_advance_safe(inc, x, (double)L);
+  return (float)drift_wrap(x);
+}
 
 __global__ void acq_track_kernel(FrontParams p, RxState *st, const float2 *gamma, const float *lambda, SymMeta *meta, const int *need_seq,
                                  AcqState *as, const int *__restrict__ centre, const float2 *__restrict__ iq)
@@ -415,10 +428,8 @@ __global__ void acq_track_kernel(FrontParams p, RxState *st, const float2 *gamma
     if (as->acquired) { nextphaseinc = as->nextphaseinc; nextpos = as->nextpos; }
     else {
       // the initial ml_sync of this call ran the phase loop once with the carried increments (:285-313)
-      double tot = (as->nextpos >= 0 && as->nextpos < N + cp) ? as->nextpos * as->phaseinc + (N + cp - as->nextpos) * as->nextphaseinc
-                                                              : (double)(N + cp) * as->phaseinc;
+      phase = acq_phase_advance(phase, as->phaseinc, as->nextphaseinc, as->nextpos, N + cp);
       if (as->nextpos >= 0 && as->nextpos < N + cp) phaseinc = as->nextphaseinc;
-      phase = wrap_pi((double)phase + tot);
     }
   }
   bool lost = false;
@@ -449,10 +460,8 @@ __global__ void acq_track_kernel(FrontParams p, RxState *st, const float2 *gamma
     int peak = pos + cur - 8;
     SymMeta m; m.cp_start = peak; m.eps = eps; m.ph_base = phase; m.incA = phaseinc; m.incB = nextphaseinc; m.sw = nextpos;
     meta[s] = m;
-    double total;
-    if (nextpos >= 0 && nextpos < N + cp) { total = nextpos * phaseinc + (N + cp - nextpos) * nextphaseinc; phaseinc = nextphaseinc; }
-    else total = (double)(N + cp) * phaseinc;
-    phase = wrap_pi((double)phase + total);
+    phase = acq_phase_advance(phase, phaseinc, nextphaseinc, nextpos, N + cp);
+    if (nextpos >= 0 && nextpos < N + cp) phaseinc = nextphaseinc;
     nextphaseinc = (-1.0 / (double)N) * (double)eps;
     nextpos = peak - (N + cp);
     cur = peak;
@@ -461,7 +470,7 @@ __global__ void acq_track_kernel(FrontParams p, RxState *st, const float2 *gamma
   st->avg_lost = lost ? avg : st->avg;                            // d_avg after the call that lost the lock
   if (as) {
     if (lost) {   // the failing call still advanced the phase by N+cp steps without switching (:336-345)
-      phase = wrap_pi((double)phase + (double)(N + cp) * phaseinc);
+      phase = acq_phase_advance(phase, phaseinc, phaseinc, -1, N + cp);
     }
     as->acquired = lost ? 0 : 1; as->lost = lost ? 1 : 0; as->cp_start = cur; as->avg = avg; as->phase = phase;
     as->phaseinc = phaseinc; as->nextphaseinc = nextphaseinc; as->nextpos = nextpos;

@@ -6,7 +6,7 @@
 #include <cmath>
 #include <vector>
 #include <algorithm>
-#include "../../gr_dvbt_amd/csrc/k_drift.hpp"
+#include "../../gr_dvbt_amd/csrc/k_drift_math.hpp"
 using namespace dvbt;
 
 static double wrapd(double x) { x = fmod(x + M_PI, 2 * M_PI); if (x < 0) x += 2 * M_PI; return x - M_PI; }

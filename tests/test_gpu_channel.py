@@ -189,6 +189,8 @@ FLOW = [
     ("2k echo + cfo", K2, dict(echoes=((19, 0.3),), cfo=3.0), "host", 4),
     ("8k cfo +7.2", K8, dict(cfo=7.2), "device", 33),
     ("8k echo 0.3 cp -16 dB", K8, dict(echoes=((77, 0.15),)), "device", 4),
+    ("8k cfo -0.37", K8, dict(cfo=-0.37), "device", 16),
+    ("8k cfo +0.01", K8, dict(cfo=0.01), "device", 8),
 ]
 
 
@@ -197,10 +199,29 @@ def test_block_by_block_on_a_real_channel(po, name, cfgt, chan, mode, call_symbo
     """the drop-in path: ofdm_sym_acquisition -> fft -> demod_reference_signals -> ... driven call by call (k_frontend.hpp::demod_kernel
     applies frequency_correction's phasor and reads the next item, unlike the fused symbol kernels)"""
     c, iq = _stream(po, cfgt, **chan)
-    ref = po.rx(c, iq, want=("ts",))["ts"]
+    o = po.rx(c, iq, want=("acq", "eq", "ts"))
+    ref = o["ts"]
     fg = RxFlowgraph(cfgt[0], cfgt[1], cfgt[2], len(iq), mode=mode, call_symbols=call_symbols)
     ts = fg.run(iq)
+
+    def items(k, dtype, width):
+        st = fg.stages[k]
+        buf = st.out[:st.produced * st.out_item]
+        buf = buf.cpu().numpy() if mode == "device" else np.asarray(buf)
+        return buf.view(dtype).reshape(-1, width)
+    acq, eq = items(0, np.complex64, c.N), items(2, np.complex64, c.payload)
     fg.close()
     n = min(len(ts), len(ref))
     assert n > 0.9 * len(ref) and abs(len(ts) - len(ref)) <= 64 * 1504
     assert (ts[:n] == ref[:n]).all()
+    # the float taps of the single blocks: ofdm_sym_acquisition's items up to one rotation per item, demod_reference_signals' items within the
+    # contract's tolerance (the tracker of the block carries the float phase accumulator's own value from call to call: k_drift.hpp)
+    na = min(len(acq), len(o["acq"]))
+    assert na > 0.9 * len(o["acq"])
+    e_acq = np.abs(_unrotate(acq[:na], o["acq"][:na]) - acq[:na]).max() / np.abs(acq[:na]).max()
+    ne = min(len(eq), len(o["eq"]))
+    assert ne > 0.9 * len(o["eq"])
+    d = eq[:ne] - o["eq"][:ne]
+    e_eq = max(np.abs(d.real).max(), np.abs(d.imag).max()) / (2 * c.norm)
+    print(f"\n[blocks: {name}] acq {e_acq:.2e} of the peak; eq {e_eq:.2e} of the constellation spacing (tolerance 1e-3)")
+    assert e_acq <= TOL_DEROT and e_eq <= 1e-3
