@@ -622,7 +622,7 @@ extern "C" int dvbt_rx_segment_finish(dvbt_rx *h, dvbt_rx_report *rep)
 // nothing), d_avg carried along.  Phase B runs the chain over every period that acquired symbols, in order: TPS state carried, the period's last
 // item kept when a later period follows, every period's Viterbi stream appended to the segment's at a multiple of two de-interleaver items.
 // Then the byte de-interleaver, RS and the descrambler run once over the whole stream.
-struct LockPeriod { size_t off; int n_symbols; float avg_in; bool carry; int call0, cp_start0; };
+struct LockPeriod { size_t off; int n_symbols; float avg_in; bool carry; int call0, cp_start0; bool lost; };
 
 static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipStream_t s, dvbt_rx_report *rep)
 {
@@ -636,15 +636,22 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
       if (guard >= 4096) { capped = true; break; }
       if (carry) { AcqState as; memset(&as, 0, sizeof as); as.avg = avg; HIPCHK(hipMemcpyAsync(h->acq_carry, &as, sizeof as, hipMemcpyHostToDevice, s)); }
       EnqOpt o; o.acq_only = true; o.use_carry = carry; o.hist = (long long)off;
-      int r = enqueue(h, chain + off, chain_n - off, s, o); if (r) return r;
-      HIPCHK(hipStreamSynchronize(s));
+      // the search and the tracker look at a window of the rest of the segment that grows while the lock holds to its end: a segment with many lock
+      // periods costs its length a few times over, not its length times the number of periods (a call's outcome depends on the samples before it only)
+      size_t look = std::min(chain_n - off, win + (size_t)767 * L);
+      for (;;) {
+        int r = enqueue(h, chain + off, look, s, o); if (r) return r;
+        HIPCHK(hipStreamSynchronize(s));
+        if ((h->st_host->status & 3) || look >= chain_n - off) break;
+        look = std::min(chain_n - off, win + 4 * (look - win) + 3 * L);
+      }
       const RxState &st = *h->st_host;
       const int tries = (int)std::min<size_t>(ACQ_INIT_TRIES, (chain_n - off - win) / L + 1);
       if (st.status & 1) {                                       // no peak in these windows: the reference consumes them one by one and searches on
         off += (size_t)tries * L; avg = st.avg; carry = true;
         continue;
       }
-      per.push_back(LockPeriod{off, st.n_symbols, avg, carry, st.call0, st.cp_start0});
+      per.push_back(LockPeriod{off, st.n_symbols, avg, carry, st.call0, st.cp_start0, (st.status & 2) != 0});
       if (!(st.status & 2)) break;                               // the lock held to the end of the segment
       off += (size_t)(st.call0 + st.n_symbols) * L + L / 2; avg = st.avg_lost; carry = true;
       if (per.size() >= 1024) { capped = true; break; }
@@ -666,7 +673,10 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
     if (per[p].carry) { AcqState as; memset(&as, 0, sizeof as); as.avg = per[p].avg_in; HIPCHK(hipMemcpyAsync(h->acq_carry, &as, sizeof as, hipMemcpyHostToDevice, s)); }
     EnqOpt o; o.use_carry = per[p].carry; o.hist = (long long)per[p].off; o.continuation = processed > 0; o.keep_last = later; o.tail = false;
     o.vit_off = delivering > 0 ? (acc / 3264) * 3264 : 0;         // convolutional_deinterleaver_impl.cc:109-120: the tag realigns the input
-    int r = enqueue(h, chain + per[p].off, chain_n - per[p].off, s, o); if (r) return r;
+    // a period that ends in a lost lock is decoded over its own calls and the one that lost the lock, not over the whole rest of the segment
+    size_t span = chain_n - per[p].off;
+    if (per[p].lost) span = std::min(span, win + (size_t)(per[p].call0 + per[p].n_symbols) * L);
+    int r = enqueue(h, chain + per[p].off, span, s, o); if (r) return r;
     // the TPS carriers of the last demodulated symbol are the DBPSK reference of the next period's first one
     HIPCHK(hipMemcpyAsync(h->tps_prev, h->tpsval + (size_t)(usable - 1) * d.n_tps, sizeof(float2) * d.n_tps, hipMemcpyDeviceToDevice, s));
     HIPCHK(hipStreamSynchronize(s));

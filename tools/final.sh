@@ -9,4 +9,7 @@ rm -rf gpurun_out/prof_final gpurun_out/prof_solo
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_final -o r -- python bench.py --no-cpu-baseline --no-extras > gpurun_out/bench_prof.json 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_solo -o r -- python bench.py --pipeline 1 --no-cpu-baseline --no-extras > gpurun_out/bench_prof_solo.json 2> /dev/null
 for pd in 1 2 4; do python bench.py --pipeline $pd --steps 200 --no-cpu-baseline --no-extras 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'steps_in_flight': $pd, 'value': d['value'], 'ms_per_step': d['ms_per_step'], 'verified': d['config']['verified']}))"; done | tee gpurun_out/pipeline_depth.jsonl
+python tools/snr_sweep.py 3 > gpurun_out/snr_sweep.jsonl 2>/dev/null; wc -l gpurun_out/snr_sweep.jsonl
+python tools/rs_load.py > gpurun_out/rs_load.jsonl 2>/dev/null; wc -l gpurun_out/rs_load.jsonl
+./tools/ubench_mfma > gpurun_out/ubench_mfma.json 2>/dev/null
 bash tools/pmc.sh > gpurun_out/pmc.log 2>&1; tail -3 gpurun_out/pmc.log | cut -c1-300

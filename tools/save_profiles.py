@@ -2,7 +2,7 @@
 import csv, glob, collections, json, os, shutil, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
-tag = args[0] if args else "r02"
+tag = args[0] if args else "r03"
 pmc_only = "--pmc-only" in sys.argv
 
 
@@ -35,6 +35,9 @@ if solo:
     prof = solo[-1]
 if os.path.exists(os.path.join(root, "gpurun_out", "pipeline_depth.jsonl")):
     shutil.copy(os.path.join(root, "gpurun_out", "pipeline_depth.jsonl"), os.path.join(root, "profiles", f"{tag}_pipeline_depth.jsonl"))
+for extra in ("snr_sweep.jsonl", "rs_load.jsonl", "ubench_mfma.json"):
+    if os.path.exists(os.path.join(root, "gpurun_out", extra)) and os.path.getsize(os.path.join(root, "gpurun_out", extra)) > 0:
+        shutil.copy(os.path.join(root, "gpurun_out", extra), os.path.join(root, "profiles", f"{tag}_{extra}"))
 b = json.load(open(os.path.join(root, "gpurun_out", "bench_final.json")))
 json.dump(b, open(os.path.join(root, "profiles", f"{tag}_bench_n1.json"), "w"), indent=1)
 pb = json.load(open(os.path.join(root, "gpurun_out", "pmc", "FETCH_SIZE.json")))
