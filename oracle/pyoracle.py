@@ -219,6 +219,68 @@ def channel(iq, N, cfo=0.0, echoes=(), snr_db=None, seed=5, ref_span=(1000, 1010
     return x.astype(np.complex64)
 
 
+def _cos_sin_exact(theta):
+    """cos, sin of a small angle by their Taylor series in plain double arithmetic (+, *, / only: the same bits on every IEEE machine, which
+    libm's and numpy's vectorised cos/sin do not promise)"""
+    c, s, term, k = 1.0, theta, theta, 1
+    t2 = theta * theta
+    cterm = 1.0
+    for k in range(1, 16):
+        cterm = -cterm * t2 / ((2 * k - 1) * (2 * k))
+        c += cterm
+        term = -term * t2 / ((2 * k) * (2 * k + 1))
+        s += term
+    return c, s
+
+
+def channel_exact(iq, N, cfo=0.0, echoes=(), snr_db=None, seed=5, ref_span=(1000, 101000)):
+    """channel() with bit-reproducible arithmetic, for the committed golden fixtures (tests/golden/): every operation is a single IEEE double
+    add / subtract / multiply on real arrays (no complex ufunc, no libm, nothing a SIMD dispatch could fuse or reorder); the carrier offset's
+    phasor comes from a two-level table of powers built by sequential multiplication.  Same model as channel()."""
+    x = np.asarray(iq)
+    xr, xi = x.real.astype(np.float64), x.imag.astype(np.float64)
+    for d, a in echoes:
+        ar, ai = float(np.real(a)), float(np.imag(a))
+        yr, yi = xr.copy(), xi.copy()
+        t = xr[:-d] * ar; u = xi[:-d] * ai; yr[d:] = yr[d:] + (t - u)
+        t = xr[:-d] * ai; u = xi[:-d] * ar; yi[d:] = yi[d:] + (t + u)
+        xr, xi = yr, yi
+    if cfo:
+        theta = 2.0 * 3.141592653589793 * cfo / N
+        n = len(xr)
+        B = 4096
+        wc, ws = _cos_sin_exact(theta)
+        ac, as_ = np.empty(B), np.empty(B)
+        c, s_ = 1.0, 0.0
+        for i in range(B):                                           # w^i, renormalised by nothing: 4096 steps lose ~1e-13
+            ac[i], as_[i] = c, s_
+            c, s_ = c * wc - s_ * ws, c * ws + s_ * wc
+        bc_, bs_ = c, s_                                             # w^4096
+        nb = (n + B - 1) // B
+        kc, ks = np.empty(nb), np.empty(nb)
+        c, s_ = 1.0, 0.0
+        for k in range(nb):
+            kc[k], ks[k] = c, s_
+            c, s_ = c * bc_ - s_ * bs_, c * bs_ + s_ * bc_
+        idx = np.arange(n)
+        hi, lo = idx >> 12, idx & (B - 1)
+        t = kc[hi] * ac[lo]; u = ks[hi] * as_[lo]; pr = t - u
+        t = kc[hi] * as_[lo]; u = ks[hi] * ac[lo]; pi_ = t + u
+        t = xr * pr; u = xi * pi_; yr = t - u
+        t = xr * pi_; u = xi * pr; yi = t + u
+        xr, xi = yr, yi
+    if snr_db is not None:
+        rng = np.random.RandomState(seed)
+        a, b = ref_span
+        t = xr[a:b] * xr[a:b]; u = xi[a:b] * xi[a:b]
+        p = float(np.cumsum(t + u)[-1]) / (b - a)                    # cumsum: one fixed order of additions (a pairwise np.sum may regroup)
+        sig = (p / (10.0 ** (snr_db / 10.0)) / 2.0) ** 0.5
+        xr = xr + sig * rng.randn(len(xr)); xi = xi + sig * rng.randn(len(xi))
+    out = np.empty(len(xr), np.complex64)
+    out.real = xr.astype(np.float32); out.imag = xi.astype(np.float32)
+    return out
+
+
 def tx_scale(c):
     """TX multiply_const * RX multiply_const of the demo flowgraphs (apps/dvbt_{tx,rx}_demo*.grc)."""
     return float(np.float32(0.0022097087) * np.float32(0.0022097087 if c.mode == T2k else 0.00055242272))

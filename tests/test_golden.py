@@ -45,6 +45,27 @@ def test_oracle_chain_taps(po, name):
     assert (o["rs_fail"], o["rs_corr"]) == (e["rs_fail"], e["rs_corr"])
 
 
+CH_CASES = {c[0]: c for c in mg.CHANNEL_CASES}
+
+
+@pytest.mark.parametrize("name", sorted(CH_CASES))
+def test_oracle_channel_taps(po, name):
+    """round 3: carrier offsets, echoes, lock losses (bit-reproducible channel model, oracle/pyoracle.py::channel_exact)"""
+    _, const, cr, mode, nsf, seed, chan = CH_CASES[name]
+    e = TAPS[name]
+    c, iq = mg.make_channel_case(const, cr, mode, nsf, seed, chan)
+    assert len(iq) == e["n_samples"] and mg.sha(iq) == e["iq_sha256"], "seeded generator / channel model drifted"
+    o = po.rx(c, iq, snr_db=30.0 if e["snr_db"] is None else e["snr_db"], want=mg.INT_TAPS)
+    assert o["n_acquired"] == e["n_acquired"] and o["first_out_symbol"] == e["first_out_symbol"]
+    assert [list(x) for x in o["lock_periods"]] == e["lock_periods"]
+    for k in ("cp_start", "sym_index", "freq_offset"):
+        assert mg.sha(o[k].astype(np.int32)) == e[k + "_sha256"], k
+    for t in mg.INT_TAPS:
+        assert o[t].size == e["taps"][t]["n"], t
+        assert mg.sha(o[t]) == e["taps"][t]["sha256"], t
+    assert (o["rs_fail"], o["rs_corr"]) == (e["rs_fail"], e["rs_corr"])
+
+
 def test_oracle_rs_words(po):
     s = np.load(os.path.join(G, "chain_slices.npz"))
     L = po.lib()

@@ -77,6 +77,39 @@ def test_chain_taps_equal_golden(po, g, name):
     rx.close()
 
 
+CH_CASES = {c[0]: c for c in mg.CHANNEL_CASES}
+
+
+@pytest.mark.parametrize("name", sorted(CH_CASES))
+def test_channel_taps_equal_golden(po, g, name):
+    """carrier offsets, echoes, lock losses: the HIP path against the committed hashes (lock periods, per-symbol CP position / integer offset / symbol
+    index, every integer tap; noisy case: the decoded taps)"""
+    _, const, cr, mode, nsf, seed, chan = CH_CASES[name]
+    e = TAPS[name]
+    c, iq = mg.make_channel_case(const, cr, mode, nsf, seed, chan)
+    assert mg.sha(iq) == e["iq_sha256"]
+    rx = g.Rx(const, cr, mode, max_samples=len(iq), taps=True, snr_db=30.0 if e["snr_db"] is None else e["snr_db"])
+    rep = rx.run(iq)
+    L = c.N + c.cp
+    assert rep.total_symbols == e["n_acquired"] and rep.n_lock_periods == e["lock_periods_delivering"]
+    assert [[off + fc * L, n] for (off, fc, cp0, n, fo) in rx.lock_periods() if n > 0] == e["lock_periods"]
+    single = len(e["lock_periods"]) == 1
+    if single:
+        ns = rep.n_symbols - 1
+        assert rep.first_out_symbol == e["first_out_symbol"]
+        assert mg.sha(rx.tap(g.TAP_CP_START).astype(np.int32)) == e["cp_start_sha256"]
+    tapid = {"demap": g.TAP_DEMAP, "symdeint": g.TAP_SYMDEINT, "bitdeint": g.TAP_BITDEINT,
+             "vit": g.TAP_VITERBI, "deint": g.TAP_DEINT, "rs": g.TAP_RS, "ts": g.TAP_TS}
+    names = ("rs", "ts") if e["snr_db"] is not None else (mg.INT_TAPS if single else ("vit", "deint", "rs", "ts"))   # several periods: the per-symbol taps hold the last period only
+    for t in names:
+        a = rx.tap(tapid[t]).reshape(-1)
+        assert a.size == e["taps"][t]["n"], t
+        if a.size:
+            assert mg.sha(a) == e["taps"][t]["sha256"], t
+    assert rep.rs_fail_words == e["rs_fail"]
+    rx.close()
+
+
 @pytest.mark.parametrize("compat", [0, 1])
 def test_rs_words_equal_golden(g, compat):
     s = np.load(os.path.join(G, "chain_slices.npz"))
