@@ -18,6 +18,7 @@
 #include "k_symbol2k.hpp"
 #include "k_resample.hpp"
 #include "k_viterbi3.hpp"
+#include "k_soft.hpp"
 
 using namespace dvbt;
 
@@ -257,6 +258,7 @@ struct dvbt_rx {
   float2 *acq_tap = nullptr, *fft_out = nullptr, *eq = nullptr, *tpsval = nullptr; SymInfo *info = nullptr; int *maj = nullptr, *sym_index = nullptr;
   uint8_t *labels = nullptr, *symdeint_tap = nullptr, *bitdeint = nullptr, *vit = nullptr, *deint_tap = nullptr, *rs_out = nullptr, *ts_out = nullptr;
   size_t vit_cap = 0; RsDefer *rs_defer = nullptr; int rs_defer_cap = 0;
+  float *csi = nullptr; int8_t *soft_a = nullptr, *soft_b = nullptr;   // soft-decision mode (k_soft.hpp): channel state per carrier, soft values before / after the inner de-interleavers
   bool timing = false, pending = false;
   hipEvent_t ev[ST_COUNT]; double acc_ms[ST_COUNT] = {0}; long n_timed = 0; bool ev_ready = false, ev_recorded = false;
   dvbt_rx_report last; bool have_last = false;
@@ -271,7 +273,7 @@ struct dvbt_rx {
 
 static void rx_free(dvbt_rx *h)
 {
-  void *all[] = {h->rs_defer, h->drift_mem, h->drift.delta, h->drift.flags, h->tps_prev, h->descr_runs, h->descr_nruns, h->centre, h->anchor_pos, h->sym_ticket, h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags, h->trk_eps, h->d_iq, h->rs_iq, h->acq_carry, h->g_init, h->l_init, h->g_trk, h->l_trk, h->meta, h->st, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
+  void *all[] = {h->csi, h->soft_a, h->soft_b, h->rs_defer, h->drift_mem, h->drift.delta, h->drift.flags, h->tps_prev, h->descr_runs, h->descr_nruns, h->centre, h->anchor_pos, h->sym_ticket, h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags, h->trk_eps, h->d_iq, h->rs_iq, h->acq_carry, h->g_init, h->l_init, h->g_trk, h->l_trk, h->meta, h->st, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
                  h->info, h->maj, h->sym_index, h->labels, h->symdeint_tap, h->bitdeint, h->vit, h->deint_tap, h->rs_out, h->ts_out};
   for (void *q : all) if (q) (void)hipFree(q);
   if (h->st_host) (void)hipHostFree(h->st_host);
@@ -332,6 +334,10 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   for (int i = 0; i < ST_COUNT; i++) RXHIP(hipEventCreate(&h->ev[i]));
   h->ev_ready = true;
   RXHIP(hipMalloc((void **)&h->sym_ticket, 64));
+  if (p->soft_decision) {
+    RXHIP(hipMalloc((void **)&h->eq, sizeof(float2) * C * P)); RXHIP(hipMalloc((void **)&h->csi, sizeof(float) * C * P));
+    RXHIP(hipMalloc((void **)&h->soft_a, C * P * d.m + 64)); RXHIP(hipMalloc((void **)&h->soft_b, C * P * d.m + 64));
+  }
   {   // the float phase accumulator's wander (k_drift.hpp): tables and sums per call, one deviation per 32 samples of every item
     RXHIP(hipMalloc((void **)&h->drift_mem, sizeof(double) * (C * (DRIFT_TAB + 4) + 8)));
     h->drift.tabs = h->drift_mem; h->drift.ex_run = h->drift.tabs + C * DRIFT_TAB; h->drift.ex_entry = h->drift.ex_run + C;
@@ -488,7 +494,7 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
   }
   const bool taps = h->acq_tap || h->fft_out || h->eq;
 #define SYM_ARGS iq, fp, (const RxState *)h->st, (const SymMeta *)h->meta, (const float2 *)h->T.tw, h->acq_tap, h->fft_out, h->T.demod_tables(), h->eq, h->tpsval, h->info, \
-                 h->T.inner_params(d.payload), (const float2 *)h->T.points, (const unsigned char *)h->T.label_tab, h->labels, h->sym_ticket, (const float *)h->drift.delta, (const int *)h->drift.flags
+                 h->T.inner_params(d.payload), (const float2 *)h->T.points, (const unsigned char *)h->T.label_tab, h->labels, h->sym_ticket, (const float *)h->drift.delta, (const int *)h->drift.flags, h->csi
   // 8k: persistent workgroups, two per CU (k_symbol8k.hpp); 2k: the same design, four symbols per workgroup (k_symbol2k.hpp).  The plain and the DRIFT
   // instantiation are both launched: the one that drift.flags[1] does not select returns before it takes a symbol
   if (N == S8_N && !taps) {
@@ -527,12 +533,25 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
   hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(64), 0, s, h->st, h->vp, h->prm.descramble, (long long)h->cut.stream_symbol_offset);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_INNER], s));
   InnerParams ip = h->T.inner_params(d.payload);
+  long long max_vit = (long long)C * d.payload * d.m * d.k / (8 * d.n) + 1;
+  if (o.vit_off + (size_t)max_vit > h->vit_cap) return fail(DVBT_ERR_CAPACITY, "Viterbi stream buffer too small for the segment's lock periods");
+  if (h->prm.soft_decision) {
+    // soft decisions (k_soft.hpp): LLRs from the equalised carriers and their channel state, A5 + A6 as one gather on the soft values, soft-input decoder
+    const float step = 2.0f * d.norm;
+    hipLaunchKernelGGL(soft_demap_kernel, dim3(C), dim3(256), 0, s, (const float2 *)h->eq, (const float *)h->csi, (const RxState *)h->st, ip, (const float2 *)h->T.points,
+                       1.0f / (step * step), h->soft_a);
+    if (tm) HIPCHK(hipEventRecord(h->ev[ST_VIT], s));
+    hipLaunchKernelGGL(soft_inner_kernel, dim3(C), dim3(256), 0, s, (const int8_t *)h->soft_a, (const RxState *)h->st, ip, (const int *)h->sym_index,
+                       (const uint16_t *)h->T.H, (const uint16_t *)h->T.Hinv, h->soft_b);
+    const long long chunks = (max_vit + SV_B - 1) / SV_B;
+    hipLaunchKernelGGL(viterbi_soft_kernel, dim3((unsigned)((chunks + SV_WAVES - 1) / SV_WAVES)), dim3(64 * SV_WAVES), 0, s, (const int8_t *)h->soft_b, h->vit + o.vit_off,
+                       (const RxState *)h->st, h->vp);
+  } else {
   // A5 + A6 on the label bytes of the symbols from first_out on (A4 ran inside the symbol kernel)
   hipLaunchKernelGGL(inner_kernel<6>, dim3(C), dim3(INNER_THREADS), inner_lds_bytes((size_t)d.payload), s, (const float2 *)nullptr, (const uint8_t *)h->labels, ip,
                      (const RxState *)h->st, 0, (const int *)h->sym_index, (const float2 *)nullptr, (const unsigned char *)nullptr,
                      (const uint16_t *)h->T.H, (const uint16_t *)h->T.Hinv, (uint8_t *)nullptr, h->symdeint_tap, h->bitdeint);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_VIT], s));
-  long long max_vit = (long long)C * d.payload * d.m * d.k / (8 * d.n) + 1;
   VitParams vp = h->vp;
   if (h->prm.viterbi_chunk_bytes <= 0) {
     // chunk size chosen per segment so that the wavefront count is a whole number of "rounds" of the resident
@@ -550,8 +569,8 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
     if (B < 256) B = 256;
     vp.chunk_bytes = (int)B;
   }
-  if (o.vit_off + (size_t)max_vit > h->vit_cap) return fail(DVBT_ERR_CAPACITY, "Viterbi stream buffer too small for the segment's lock periods");
   launch_viterbi(s, (const uint8_t *)h->bitdeint, h->vit + o.vit_off, (const RxState *)h->st, 0ll, vp, 0ll, 0ll, max_vit);
+  }
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_RS], s));
   if (o.tail) { int r = enqueue_tail(h, s, max_vit / 204 + 1, -1); if (r) return r; }
   if (tm) { HIPCHK(hipEventRecord(h->ev[ST_END], s)); h->ev_recorded = true; }

@@ -229,7 +229,7 @@ template <bool TAPS, bool DRIFT> __global__ __launch_bounds__(S8_T, 4) void symb
                                                            float2 *__restrict__ tpsval, SymInfo *__restrict__ info, InnerParams ip,
                                                            const float2 *__restrict__ points, const unsigned char *__restrict__ label_tab,
                                                            uint8_t *__restrict__ labels, int *__restrict__ ticket,
-                                                           const float *__restrict__ drift, const int *__restrict__ drift_flags)
+                                                           const float *__restrict__ drift, const int *__restrict__ drift_flags, float *__restrict__ csi_tap)
 {
   if ((drift_flags[1] != 0) != DRIFT) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -486,6 +486,12 @@ template <bool TAPS, bool DRIFT> __global__ __launch_bounds__(S8_T, 4) void symb
         if ((it < S8_PAY / S8_T || i < S8_PAY) && !(S8_EXP & 8)) {
           const v2f e = equalise((int)(tcl[it] & 0x1fffu), (int)((tcl[it] >> 13) & 0x3ffu), (int)(tcl[it] >> 23));
           if (TAPS && eq_tap) eq_tap[(size_t)s * S8_PAY + i] = s8_f(e);
+          if (TAPS && csi_tap) {   // channel state of the carrier for the soft-decision path (k_soft.hpp): |H|^2 = 1 / |interpolated equaliser gain|^2
+            const int Li = (int)((tcl[it] >> 13) & 0x3ffu); const float j = (float)(tcl[it] >> 23);
+            const v2f gl = gtab[Li], gr = gtab[Li + 1], t2 = (gr - gl) * (1.0f / 11.0f);
+            const float gx = __builtin_fmaf(t2.x, j, gl.x), gy = __builtin_fmaf(t2.y, j, gl.y);
+            csi_tap[(size_t)s * S8_PAY + i] = 1.0f / (gx * gx + gy * gy);
+          }
           int idx;
           slow |= !s8_demap_cell(e, ip.inv_step, half_n, top, idx);
           lab[i] = label_of[idx & 63];

@@ -19,7 +19,7 @@ namespace gr {
       p.rx.constellation = (int)constellation; p.rx.hierarchy = (int)hierarchy; p.rx.code_rate = (int)code_rate; p.rx.guard_interval = (int)guard_interval;
       p.rx.transmission_mode = (int)transmission_mode; p.rx.include_cell_id = 0; p.rx.cell_id = 0; p.rx.snr_db = snr; p.rx.viterbi_bsize = bsize;
       p.rx.rs_oracle_compat = 0; p.rx.descramble = 1; p.rx.max_samples = 0; p.rx.device = 0; p.rx.viterbi_chunk_bytes = 0;
-      p.rx.resample_interp = 0; p.rx.resample_decim = 0; p.rx.front_scale = 0.f;
+      p.rx.resample_interp = 0; p.rx.resample_decim = 0; p.rx.front_scale = 0.f; p.rx.soft_decision = 0;
       p.segment_superframes = segment_superframes; p.rank = 0; p.world = 0;
       if (dvbt_rx_stream_create(&p, &d_stream) < 0) throw std::runtime_error(std::string("libdvbt_hip: ") + dvbt_last_error());
       dvbt_dims d;

@@ -267,6 +267,11 @@ typedef struct {
   int resample_interp, resample_decim;   /* 0,0: the segment is already at the OFDM elementary rate (the north-star tap).
                                             64,70: the segment is the 10 Msps file format; resample + scale run first on the device */
   float front_scale;       /* multiply_const of the flowgraph (used only with resampling; 0 = 1.0) */
+  int soft_decision;       /* 0: the reference's hard-decision demapper and Viterbi decoder (the parity path).  1: soft decisions (gr-dvbt's TODO.txt:25-26, never
+                              built there): per coded bit an 8-bit max-log likelihood ratio weighted with the carrier's channel power, de-interleaved as soft
+                              values, decoded by a soft-input Viterbi decoder; everything behind the decoder unchanged.  No reference exists for it: identical
+                              TS on a clean loopback, lower error rates under noise (tests/test_gpu_soft.py); about 10x slower than the hard decoder.
+                              The DEMAP / SYMDEINT / BITDEINT taps are not filled in this mode. */
 } dvbt_rx_params;
 
 typedef struct {

@@ -171,6 +171,9 @@ def test_channels_that_break_the_cp_lock(po, name, cfgt, chan):
     rx = g.Rx(cfgt[0], cfgt[1], cfgt[2], max_samples=len(iq), snr_db=snr)
     rep = rx.run(iq)
     assert rep.total_symbols == o["n_acquired"], (rep.total_symbols, o["n_acquired"])
+    # every lock period: the sample at which the call that delivered its first item began, and how many items it delivered
+    L = c.N + c.cp
+    assert [(off + fc * L, n) for (off, fc, cp0, n, fo) in rx.lock_periods() if n > 0] == o["lock_periods"]
     delivered = o["truncated"] + 1 if o["first_out_symbol"] >= 0 else 0
     assert rep.n_lock_periods == delivered
     assert rep.n_viterbi_bytes == len(o["vit"]) and rep.n_rs_bytes == len(o["rs"]) and rep.n_ts_bytes == len(o["ts"])
