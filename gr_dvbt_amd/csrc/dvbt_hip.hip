@@ -18,7 +18,7 @@
 #include "k_symbol2k.hpp"
 #include "k_resample.hpp"
 #include "k_viterbi3.hpp"
-#include "k_soft.hpp"
+#include "k_soft4.hpp"
 
 using namespace dvbt;
 
@@ -258,7 +258,7 @@ struct dvbt_rx {
   float2 *acq_tap = nullptr, *fft_out = nullptr, *eq = nullptr, *tpsval = nullptr; SymInfo *info = nullptr; int *maj = nullptr, *sym_index = nullptr;
   uint8_t *labels = nullptr, *symdeint_tap = nullptr, *bitdeint = nullptr, *vit = nullptr, *deint_tap = nullptr, *rs_out = nullptr, *ts_out = nullptr;
   size_t vit_cap = 0; RsDefer *rs_defer = nullptr; int rs_defer_cap = 0;
-  float *csi = nullptr; int8_t *soft_a = nullptr; int *soft_tab = nullptr; unsigned long long *soft_scratch = nullptr;   // soft-decision mode (k_soft.hpp): channel state per carrier, soft values, A5 + A6 gather table, decision slots
+  float *csi = nullptr; int8_t *soft_a = nullptr; uint16_t *soft_tab = nullptr; unsigned *soft_scratch = nullptr;   // soft-decision mode (k_soft.hpp): channel state per carrier, soft values, A5 + A6 gather table, decision slots
   bool timing = false, pending = false;
   hipEvent_t ev[ST_COUNT]; double acc_ms[ST_COUNT] = {0}; long n_timed = 0; bool ev_ready = false, ev_recorded = false;
   dvbt_rx_report last; bool have_last = false;
@@ -336,8 +336,8 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   RXHIP(hipMalloc((void **)&h->sym_ticket, 64));
   if (p->soft_decision) {
     RXHIP(hipMalloc((void **)&h->eq, sizeof(float2) * C * P)); RXHIP(hipMalloc((void **)&h->csi, sizeof(float) * C * P));
-    RXHIP(hipMalloc((void **)&h->soft_a, C * P * d.m + 64)); RXHIP(hipMalloc((void **)&h->soft_tab, sizeof(int) * 2 * P * d.m));
-    RXHIP(hipMalloc((void **)&h->soft_scratch, sizeof(unsigned long long) * SV_SCRATCH_WORDS));
+    RXHIP(hipMalloc((void **)&h->soft_a, C * P * d.m + 64)); RXHIP(hipMalloc((void **)&h->soft_tab, sizeof(uint16_t) * 2 * P * d.m));
+    RXHIP(hipMalloc((void **)&h->soft_scratch, sizeof(unsigned) * S4_SCRATCH_WORDS));
     hipLaunchKernelGGL(soft_tab_kernel, dim3(64), dim3(256), 0, h->own_stream, h->T.inner_params(d.payload), (const uint16_t *)h->T.H, (const uint16_t *)h->T.Hinv, h->soft_tab);
     RXHIP(hipStreamSynchronize(h->own_stream));
   }
@@ -541,15 +541,15 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
   if (h->prm.soft_decision) {
     // soft decisions (k_soft.hpp): LLRs from the equalised carriers and their channel state, A5 + A6 as one gather on the soft values, soft-input decoder
     const float step = 2.0f * d.norm;
-    hipLaunchKernelGGL(soft_demap_kernel, dim3(C), dim3(256), 0, s, (const float2 *)h->eq, (const float *)h->csi, (const RxState *)h->st, ip, (const float2 *)h->T.points,
-                       1.0f / (step * step), h->soft_a);
+    hipLaunchKernelGGL(soft_demap_kernel, dim3(C), dim3(256), (size_t)d.payload * d.m, s, (const float2 *)h->eq, (const float *)h->csi, (const RxState *)h->st, ip, (const float2 *)h->T.points,
+                       1.0f / (step * step), (const int *)h->sym_index, (const uint16_t *)h->soft_tab, h->soft_a);
     if (tm) HIPCHK(hipEventRecord(h->ev[ST_VIT], s));
-    // chunk size: 256 decoded bytes, 128 when that leaves the wavefront slots less than twice filled (short segments)
-    const int B = (max_vit + SV_B - 1) / SV_B >= 2ll * SV_GRID * SV_WAVES ? SV_B : SV_B / 2;
-    const long long chunks = (max_vit + B - 1) / B;
-    const unsigned grid = (unsigned)std::min<long long>(SV_GRID, (chunks + SV_WAVES - 1) / SV_WAVES);
-    hipLaunchKernelGGL(viterbi_soft_kernel, dim3(grid), dim3(64 * SV_WAVES), 0, s, (const int8_t *)h->soft_a, (const int *)h->soft_tab, (const int *)h->sym_index,
-                       h->vit + o.vit_off, (const RxState *)h->st, h->vp, h->soft_scratch, B);
+    // the decoder: four chunks per wavefront, chunk size for whole rounds of the wavefront slots
+    const S4Plan sp = s4_plan(max_vit, d.ntb);
+    const long long tasks = (max_vit + 4ll * sp.B - 1) / (4ll * sp.B);
+    const unsigned grid = (unsigned)std::min<long long>(S4_GRID, (tasks + S4_WAVES - 1) / S4_WAVES);
+    hipLaunchKernelGGL(viterbi_soft4_kernel, dim3(grid), dim3(64 * S4_WAVES), 0, s, (const int8_t *)h->soft_a, h->vit + o.vit_off, (const RxState *)h->st, h->vp,
+                       h->soft_scratch, sp.B, sp.nsteps);
   } else {
   // A5 + A6 on the label bytes of the symbols from first_out on (A4 ran inside the symbol kernel)
   hipLaunchKernelGGL(inner_kernel<6>, dim3(C), dim3(INNER_THREADS), inner_lds_bytes((size_t)d.payload), s, (const float2 *)nullptr, (const uint8_t *)h->labels, ip,

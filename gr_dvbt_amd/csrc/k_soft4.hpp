@@ -1,0 +1,228 @@
+// k_soft4.hpp -- the soft-input decoder on the hard kernel's cell layout (k_viterbi3.hpp): one wavefront decodes FOUR chunks, a chunk owns one DPP row,
+// every lane holds 4 of the 64 path metrics as the 16-bit halves of two VGPRs, the trellis is updated in place (cell c holds state rotl6(c, u mod 6) at
+// relative step u; the six butterfly exchanges are a VGPR swap, a half swap and four DPP controls).  What differs from the hard kernel:
+//   * a cell is a full 16-bit metric (soft values in [-31, 31]: a branch delta is up to +-62, the spread of the 64 metrics up to ~750; the row maximum is
+//     subtracted every 48 steps), so the survivors cannot ride along in a path byte: the DECISION of every cell and step (1 = the survivor came from the
+//     butterfly partner) is the sign of X - Y_partner, shifted into a register per VGPR (v_lshrrev + v_bfi) and, every 8 steps, packed to one dword per
+//     lane (4 cells x 8 steps) and written to the wavefront's slot of a scratch buffer in HBM (256 coalesced bytes per 8 steps: written once, read once);
+//   * the branch deltas of a step are the four correlations +-sx +-sy: one word (A = sx + sy, B = sy - sx) per step and decoder from LDS, its negation,
+//     and the hard kernel's per-lane v_perm selectors pick every cell's class out of the 8 bytes;
+//   * the traceback is four chains (lane k < 4 = decoder k): the cell walks in PHYSICAL coordinates z = r : h : row : lane-in-row, where every butterfly
+//     partner is an XOR with a constant (0x80, 0x40, 8, 7, 2, 1 for phases 0..5); ds_bpermute fetches the decision dword of the cell's lane.
+// The soft values arrive de-interleaved from soft_demap_kernel; the staging of a block depunctures them (viterbi_decoder_impl.cc:241-256, erasures = 0).
+// The first version of the soft decoder (one wavefront per chunk, a lane per state, two ds_bpermute per step; 5.0 ms on 17 superframes of 8k QAM64 7/8
+// after its decisions had moved from LDS to HBM, 27.9 ms before) was bound by the LDS crossbar: 72 cycles per step and SIMD for 8 VALU instructions.
+#pragma once
+#include "k_soft.hpp"
+#ifndef S4_EXP
+#define S4_EXP 0     /* attribution builds (tools/): 1 = no traceback, 2 = no forward pass */
+#endif
+
+namespace dvbt {
+
+constexpr int S4_WARM = 256;               // warm-up steps in front of a chunk
+constexpr int S4_BLK = 48;                 // steps per staged block: a multiple of the 6-step phase cycle and of the 8-step decision group
+constexpr int S4_WAVES = 4;                // wavefronts per workgroup
+constexpr int S4_GRID = 2048;              // workgroups (8 wavefronts per SIMD)
+constexpr int S4_BMAX = 304;               // largest chunk (decoded bytes)
+constexpr int S4_LOOK = 128;               // steps decoded behind a chunk, at least (the reference's depth 8 ntraceback is 40 steps at rate 1/2: the output
+                                           // DELAY stays the reference's, the decision depth need not)
+constexpr int S4_G0 = 30;                  // first decision group that is kept (groups of the warm-up are never traced; a multiple of 3 below S4_WARM / 8)
+constexpr int S4_MAXSTEPS = ((S4_WARM + 8 * S4_BMAX + 8 * 24 + 16 + S4_BLK - 1) / S4_BLK) * S4_BLK;
+constexpr size_t S4_SLOT_WORDS = (size_t)(S4_MAXSTEPS / 8 - S4_G0) * 64;    // dwords of decisions per wavefront
+constexpr size_t S4_SCRATCH_WORDS = (size_t)S4_GRID * S4_WAVES * S4_SLOT_WORDS;
+
+// host: chunk size and steps per decoder for a stream of total_out bytes: whole rounds of the wavefront slots; the steps are rounded up to whole blocks
+// (the look-ahead grows by up to 40 steps)
+struct S4Plan { int B, nsteps; };
+inline S4Plan s4_plan(long long total_out, int ntb)
+{
+  const long long per_round = 4ll * S4_GRID * S4_WAVES;             // decoders resident
+  long long rounds = (total_out + per_round * 256 / 2) / (per_round * 256); if (rounds < 1) rounds = 1;
+  long long B;
+  for (;;) {
+    B = (total_out + rounds * per_round - 1) / (rounds * per_round);
+    if (B < 64) B = 64;
+    if (B <= S4_BMAX) break;
+    rounds++;
+  }
+  const int look = 8 * ntb > S4_LOOK ? 8 * ntb : S4_LOOK;
+  S4Plan p; p.B = (int)B; p.nsteps = ((S4_WARM + 8 * p.B + look + S4_BLK - 1) / S4_BLK) * S4_BLK;
+  return p;
+}
+
+struct S4Lane { unsigned sel[6][2]; };     // v_perm selectors: the 16-bit class delta of the lo / hi cell of VGPR r at phase P out of [A, B, -A, -B]
+__device__ inline void s4_init_lane(int pl, S4Lane &L)
+{
+  const int a = v3_log(pl);
+  for (int r = 0; r < 2; r++)
+    for (int P = 0; P < 6; P++) {
+      unsigned b[2];
+      for (int h = 0; h < 2; h++) {
+        const int c = (r << 5) | (h << 4) | a, i = rotl6(c, P) & 31;
+        const int c0 = ((i >> 2) ^ (i >> 1) ^ i) & 1;                 // parity(2i & 0x4f)
+        const int c1 = ((i >> 4) ^ (i >> 2) ^ (i >> 1)) & 1;          // parity(2i & 0x6d)
+        // class 0: sx + sy = A (bytes 0,1) | class 1 (c0 = 1): -sx + sy = B (2,3) | class 2 (c1 = 1): sx - sy = -B (6,7) | class 3: -A (4,5)
+        const int cls = c0 | (c1 << 1);
+        b[h] = cls == 0 ? 0u : cls == 1 ? 2u : cls == 2 ? 6u : 4u;
+      }
+      L.sel[P][r] = b[0] | ((b[0] + 1) << 8) | (b[1] << 16) | ((b[1] + 1) << 24);
+    }
+}
+
+// one step at phase P: W = A | B << 16 of this lane's decoder
+template <int P> __device__ __forceinline__ void s4_step(int (&v)[2], int (&dacc)[2], unsigned W, const S4Lane &L)
+{
+  const unsigned nW = (unsigned)pk_sub(0, (int)W);
+  int X[2], Y[2], Yp[2];
+  const int D0 = (int)__builtin_amdgcn_perm(nW, W, L.sel[P][0]);
+  X[0] = pk_add(v[0], D0); Y[0] = pk_sub(v[0], D0);
+  // VGPR index = cell bit 5 = state bit (5 + P) % 6: at phases 0 and 4 both VGPRs have the same deltas, at phases 2 and 3 VGPR 1 the negated ones (k_viterbi3.hpp)
+  if (P == 0 || P == 4) { X[1] = pk_add(v[1], D0); Y[1] = pk_sub(v[1], D0); }
+  else if (P == 2 || P == 3) { X[1] = pk_sub(v[1], D0); Y[1] = pk_add(v[1], D0); }
+  else {
+    const int D1 = (int)__builtin_amdgcn_perm(nW, W, L.sel[P][1]);
+    X[1] = pk_add(v[1], D1); Y[1] = pk_sub(v[1], D1);
+  }
+  if (P == 0) { Yp[0] = Y[1]; Yp[1] = Y[0]; }
+  else {
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+      Yp[r] = P == 1 ? (int)__builtin_amdgcn_alignbit((unsigned)Y[r], (unsigned)Y[r], 16) : P == 2 ? dppb<DPP_ROR8>(Y[r]) : P == 3 ? dppb<DPP_HALF_MIRROR>(Y[r])
+                     : P == 4 ? dppb<DPP_XOR2>(Y[r]) : dppb<DPP_XOR1>(Y[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    const int diff = pk_sub(X[r], Yp[r]);                            // sign set: the partner's offer wins
+    v[r] = pk_max(X[r], Yp[r]);
+    dacc[r] = (int)((((unsigned)dacc[r] >> 1) & 0x7fff7fffu) | ((unsigned)diff & 0x80008000u));
+  }
+}
+template <int P0> __device__ __forceinline__ void s4_group(int (&v)[2], int (&dacc)[2], const unsigned *w, const S4Lane &L)
+{
+  s4_step<(P0 + 0) % 6>(v, dacc, w[0], L); s4_step<(P0 + 1) % 6>(v, dacc, w[1], L); s4_step<(P0 + 2) % 6>(v, dacc, w[2], L); s4_step<(P0 + 3) % 6>(v, dacc, w[3], L);
+  s4_step<(P0 + 4) % 6>(v, dacc, w[4], L); s4_step<(P0 + 5) % 6>(v, dacc, w[5], L); s4_step<(P0 + 6) % 6>(v, dacc, w[6], L); s4_step<(P0 + 7) % 6>(v, dacc, w[7], L);
+}
+
+// traceback of 24 steps (three decision groups, phases static), lane k < 4 = the chain of decoder k: z = physical cell (lane | h << 6 | r << 7) after step 23,
+// updated to the cell before step 0; bytes: the three decoded bytes (group gi at bits 8 gi .. 8 gi + 7, MSB of a byte = its first step).  The decision dword
+// of the cell's lane comes through ds_bpermute; it is fetched again only when the lane can have changed (the previous flip was a DPP phase) or the group has.
+// (A first version walked the four chains with scalar instructions and v_readlane: ~7 SALU per step and chain, and the scalar unit issues one instruction
+// per four cycles and SIMD like the vector unit does -- 2.65 ms of traceback against 1.66 ms of forward pass on 17 superframes.)
+template <int J> __device__ __forceinline__ void s4_back(int &z, unsigned &bytes, const int (&w)[3], int &word)
+{
+  constexpr int P = J % 6, P1 = (J + 1) % 6, gi = J >> 3, jj = J & 7;
+  // decoded bit of step J = LSB of the state after it = cell bit (6 - P1) % 6 of the cell after it: a0, r, h, a3, a2, a1 for P1 = 0..5
+  const unsigned zz = (unsigned)z;
+  const unsigned bit = P1 == 0 ? (zz ^ (zz >> 2)) & 1u : P1 == 1 ? (zz >> 7) & 1u : P1 == 2 ? (zz >> 6) & 1u : P1 == 3 ? (zz >> 3) & 1u : P1 == 4 ? (zz >> 2) & 1u
+                                                                                                                                       : ((zz >> 1) ^ (zz >> 2)) & 1u;
+  bytes |= bit << (8 * gi + 7 - jj);
+  if (J == 23 || jj == 7 || P1 >= 2) word = __builtin_amdgcn_ds_bpermute((z & 63) << 2, w[gi]);
+  const unsigned d = ((unsigned)word >> ((zz >> 6) * 8 + jj)) & 1u;
+  constexpr unsigned mask = P == 0 ? 0x80 : P == 1 ? 0x40 : P == 2 ? 8 : P == 3 ? 7 : P == 4 ? 2 : 1;
+  z ^= (int)(d * mask);
+  if constexpr (J > 0) s4_back<J - 1>(z, bytes, w, word);
+}
+
+__global__ __launch_bounds__(64 * S4_WAVES) void viterbi_soft4_kernel(const int8_t *__restrict__ soft, uint8_t *__restrict__ out, const RxState *st, VitParams vp,
+                                                                      unsigned *__restrict__ scratch, int B, int nsteps)
+{
+  __shared__ __attribute__((aligned(16))) unsigned wbuf_[S4_WAVES][2][4 * S4_BLK];               // step words [buffer][decoder][step in block]
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, dd = lane >> 4, pl = lane & 15;
+  if (st->first_out < 0) return;
+  const long long total_steps = st->n_vit_steps, total_out = total_steps / 8 - vp.ntb, n_soft = st->n_vit_in * vp.m;
+  const unsigned magic32 = 0xffffffffu / (unsigned)vp.plen + 1u;   // x / plen == umulhi(x, magic32) for x * plen < 2^32
+  unsigned *dec = scratch + ((size_t)blockIdx.x * S4_WAVES + wv) * S4_SLOT_WORDS;
+  unsigned (*wb)[4 * S4_BLK] = wbuf_[wv];
+  S4Lane L; s4_init_lane(pl, L);
+  const int nblk = nsteps / S4_BLK, ngrp = nsteps / 8;
+  const long long nslots = (long long)gridDim.x * S4_WAVES;
+  for (long long task = (long long)blockIdx.x * S4_WAVES + wv; task * 4 * B < total_out; task += nslots) {
+    const long long b0 = (task * 4 + dd) * B;                      // this lane's decoder
+    const long long t0 = 8 * b0 - S4_WARM;                          // its first step (may be < 0: erasures)
+    const bool active = b0 < total_out;
+    // depuncturing relative to the decoder's first real step: one 64-bit locate per task, then 32-bit arithmetic (x < 2^13: x / plen by one multiply)
+    const long long tbase = t0 > 0 ? t0 : 0;
+    const int skip = (int)(tbase - t0);                             // leading steps before the stream's start: erasures
+    const unsigned long long pbit = 2ull * (unsigned long long)tbase, pq = __umul64hi(pbit, vp.magic_plen);
+    const int phb = (int)(pbit - pq * (unsigned)vp.plen);
+    const long long rb = (long long)(pq * (unsigned)vp.n);
+    auto load3 = [&](int blk, int (&q)[3]) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const int ir = blk * S4_BLK + pl + 16 * k - skip;
+        int sx = 0, sy = 0;
+        if (active && ir >= 0 && tbase + ir < total_steps) {
+          const unsigned x = (unsigned)(phb + 2 * ir), dq = __umulhi(x, magic32); const int ph = (int)(x - dq * vp.plen);
+          const long long r = rb + (long long)(dq * (unsigned)vp.n);
+          if ((vp.punct_mask >> ph) & 1) { const long long rr = r + (int)((vp.prefix_nib >> (4 * ph)) & 15); if (rr < n_soft) sx = soft[rr]; }
+          if ((vp.punct_mask >> (ph + 1)) & 1) { const long long rr = r + (int)((vp.prefix_nib >> (4 * (ph + 1))) & 15); if (rr < n_soft) sy = soft[rr]; }
+        }
+        q[k] = (sx & 0xff) | (sy << 8);
+      }
+    };
+    auto put3 = [&](int buf, const int (&q)[3]) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const int sx = (int)(signed char)(q[k] & 0xff), sy = q[k] >> 8;
+        wb[buf][dd * S4_BLK + pl + 16 * k] = (unsigned)((sx + sy) & 0xffff) | ((unsigned)(sy - sx) << 16);
+      }
+    };
+    int v[2] = {0, 0}, dacc[2] = {0, 0};
+    int q[3];
+    load3(0, q); put3(0, q);
+    for (int blk = 0; blk < ((S4_EXP & 2) ? 1 : nblk); blk++) {
+      if (blk + 1 < nblk) load3(blk + 1, q);
+      const unsigned *wrow = &wb[blk & 1][dd * S4_BLK];
+#pragma unroll
+      for (int gi = 0; gi < 6; gi++) {
+        unsigned w[8];
+        { const uint4 *wp = reinterpret_cast<const uint4 *>(wrow + gi * 8); const uint4 x0 = wp[0], x1 = wp[1];
+          w[0] = x0.x; w[1] = x0.y; w[2] = x0.z; w[3] = x0.w; w[4] = x1.x; w[5] = x1.y; w[6] = x1.z; w[7] = x1.w; }
+        if (gi % 3 == 0) s4_group<0>(v, dacc, w, L); else if (gi % 3 == 1) s4_group<2>(v, dacc, w, L); else s4_group<4>(v, dacc, w, L);
+        const int g = blk * 6 + gi;
+        // the four cells' decisions of the group: bit jj of byte 2 r + h = step jj
+        if (g >= S4_G0) dec[(size_t)(g - S4_G0) * 64 + lane] = __builtin_amdgcn_perm((unsigned)dacc[1], (unsigned)dacc[0], 0x07050301u);
+      }
+      {   // the row's best metric back to 0
+        int k = pk_max(v[0], v[1]);
+        k = pk_max(k, dppb<DPP_XOR1>(k)); k = pk_max(k, dppb<DPP_XOR2>(k)); k = pk_max(k, dppb<DPP_HALF_MIRROR>(k)); k = pk_max(k, dppb<DPP_MIRROR>(k));
+        k = pk_max(k, (int)__builtin_amdgcn_alignbit((unsigned)k, (unsigned)k, 16));
+        v[0] = pk_sub(v[0], k); v[1] = pk_sub(v[1], k);
+      }
+      if (blk + 1 < nblk) put3((blk + 1) & 1, q);
+    }
+    // best end cell of every decoder: after the subtraction the best metric is 0 (steps past the stream's end are erasures)
+    const unsigned long long e00 = __ballot((short)(v[0] & 0xffff) == 0), e01 = __ballot((v[0] >> 16) == 0);
+    const unsigned long long e10 = __ballot((short)(v[1] & 0xffff) == 0), e11 = __ballot((v[1] >> 16) == 0);
+    int z = lane;                                                   // lane k < 4: the chain of decoder k
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const unsigned m00 = (unsigned)(e00 >> (16 * k)) & 0xffffu, m01 = (unsigned)(e01 >> (16 * k)) & 0xffffu;
+      const unsigned m10 = (unsigned)(e10 >> (16 * k)) & 0xffffu, m11 = (unsigned)(e11 >> (16 * k)) & 0xffffu;
+      const int zk = m00 ? 16 * k + __builtin_ctz(m00) : m01 ? (16 * k + __builtin_ctz(m01)) | 0x40 : m10 ? (16 * k + __builtin_ctz(m10)) | 0x80
+                         : (16 * k + (__builtin_ctz(m11 | 0x10000u) & 15)) | 0xc0;
+      if (lane == k) z = zk;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    // traceback: 24 steps (three groups) per round, lane k < 4 walks and stores decoder k
+    const long long ob0 = (task * 4 + lane) * B;                    // lane k < 4: first byte of decoder k
+    const long long ob1 = ob0 + B < total_out ? ob0 + B : total_out;
+    for (int g3 = ngrp / 3 - 1; g3 >= ((S4_EXP & 1) ? ngrp / 3 - 1 : S4_G0 / 3); g3--) {
+      int w[3];
+#pragma unroll
+      for (int gi = 0; gi < 3; gi++) w[gi] = (int)__hip_atomic_load(&dec[(size_t)(3 * g3 + gi - S4_G0) * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned mine = 0; int word = 0;
+      s4_back<23>(z, mine, w, word);
+      if (lane < 4) {
+#pragma unroll
+        for (int gi = 0; gi < 3; gi++) {
+          const long long ob = ob0 + (3 * g3 + gi) - S4_WARM / 8;
+          if (ob >= ob0 && ob < ob1) out[ob] = (uint8_t)(mine >> (8 * gi));
+        }
+      }
+    }
+  }
+}
+
+}  // namespace dvbt
