@@ -7,8 +7,9 @@
 //     lane (4 cells x 8 steps) and written to the wavefront's slot of a scratch buffer in HBM (256 coalesced bytes per 8 steps: written once, read once);
 //   * the branch deltas of a step are the four correlations +-sx +-sy: one word (A = sx + sy, B = sy - sx) per step and decoder from LDS, its negation,
 //     and the hard kernel's per-lane v_perm selectors pick every cell's class out of the 8 bytes;
-//   * the traceback is four chains (lane k < 4 = decoder k): the cell walks in PHYSICAL coordinates z = r : h : row : lane-in-row, where every butterfly
-//     partner is an XOR with a constant (0x80, 0x40, 8, 7, 2, 1 for phases 0..5); ds_bpermute fetches the decision dword of the cell's lane.
+//   * the traceback runs as 8 segments per decoder, a lane per segment, each from the best cell recorded at a block end 192 steps behind the segment: the
+//     cell walks in PHYSICAL coordinates z = r : h : row : lane-in-row, where every butterfly partner is an XOR with a constant (0x80, 0x40, 8, 7, 2, 1 for
+//     phases 0..5); the decision rows of the 8 segments pass through LDS.
 // The soft values arrive de-interleaved from soft_demap_kernel; the staging of a block depunctures them (viterbi_decoder_impl.cc:241-256, erasures = 0).
 // The first version of the soft decoder (one wavefront per chunk, a lane per state, two ds_bpermute per step; 5.0 ms on 17 superframes of 8k QAM64 7/8
 // after its decisions had moved from LDS to HBM, 27.9 ms before) was bound by the LDS crossbar: 72 cycles per step and SIMD for 8 VALU instructions.
@@ -27,7 +28,9 @@ constexpr int S4_GRID = 2048;              // workgroups (8 wavefronts per SIMD)
 constexpr int S4_BMAX = 304;               // largest chunk (decoded bytes)
 constexpr int S4_LOOK = 128;               // steps decoded behind a chunk, at least (the reference's depth 8 ntraceback is 40 steps at rate 1/2: the output
                                            // DELAY stays the reference's, the decision depth need not)
-constexpr int S4_G0 = 30;                  // first decision group that is kept (groups of the warm-up are never traced; a multiple of 3 below S4_WARM / 8)
+constexpr int S4_G0 = 30;                  // first decision group that is kept (groups of the warm-up are never traced; a multiple of 6 below S4_WARM / 8)
+constexpr int S4_NSEG = 8;                 // traceback segments per decoder
+constexpr int S4_PRE = 24;                 // groups a segment's chain starts behind the segment's end (192 steps = the reference's depth at rate 7/8)
 constexpr int S4_MAXSTEPS = ((S4_WARM + 8 * S4_BMAX + 8 * 24 + 16 + S4_BLK - 1) / S4_BLK) * S4_BLK;
 constexpr size_t S4_SLOT_WORDS = (size_t)(S4_MAXSTEPS / 8 - S4_G0) * 64;    // dwords of decisions per wavefront
 constexpr size_t S4_SCRATCH_WORDS = (size_t)S4_GRID * S4_WAVES * S4_SLOT_WORDS;
@@ -70,10 +73,12 @@ __device__ inline void s4_init_lane(int pl, S4Lane &L)
     }
 }
 
-// one step at phase P: W = A | B << 16 of this lane's decoder
-template <int P> __device__ __forceinline__ void s4_step(int (&v)[2], int (&dacc)[2], unsigned W, const S4Lane &L)
+// (mask & a) | (~mask & b): one v_bfi_b32 (left to itself the compiler emits v_and + v_and_or)
+__device__ __forceinline__ int s4_bfi(unsigned mask, unsigned a, unsigned b) { int r; asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(mask), "v"(a), "v"(b)); return r; }
+
+// one step at phase P: W = A | B << 16 of this lane's decoder, nW = -A | -B << 16
+template <int P> __device__ __forceinline__ void s4_step(int (&v)[2], int (&dacc)[2], unsigned W, unsigned nW, const S4Lane &L)
 {
-  const unsigned nW = (unsigned)pk_sub(0, (int)W);
   int X[2], Y[2], Yp[2];
   const int D0 = (int)__builtin_amdgcn_perm(nW, W, L.sel[P][0]);
   X[0] = pk_add(v[0], D0); Y[0] = pk_sub(v[0], D0);
@@ -95,45 +100,50 @@ template <int P> __device__ __forceinline__ void s4_step(int (&v)[2], int (&dacc
   for (int r = 0; r < 2; r++) {
     const int diff = pk_sub(X[r], Yp[r]);                            // sign set: the partner's offer wins
     v[r] = pk_max(X[r], Yp[r]);
-    dacc[r] = (int)((((unsigned)dacc[r] >> 1) & 0x7fff7fffu) | ((unsigned)diff & 0x80008000u));
+    dacc[r] = s4_bfi(0x80008000u, (unsigned)diff, (unsigned)dacc[r] >> 1);   // bits 15 and 31 from diff, the older decisions one place down
   }
 }
-template <int P0> __device__ __forceinline__ void s4_group(int (&v)[2], int (&dacc)[2], const unsigned *w, const S4Lane &L)
+template <int P0> __device__ __forceinline__ void s4_group(int (&v)[2], int (&dacc)[2], const unsigned *w, const S4Lane &L)   // w: W, nW of 8 steps
 {
-  s4_step<(P0 + 0) % 6>(v, dacc, w[0], L); s4_step<(P0 + 1) % 6>(v, dacc, w[1], L); s4_step<(P0 + 2) % 6>(v, dacc, w[2], L); s4_step<(P0 + 3) % 6>(v, dacc, w[3], L);
-  s4_step<(P0 + 4) % 6>(v, dacc, w[4], L); s4_step<(P0 + 5) % 6>(v, dacc, w[5], L); s4_step<(P0 + 6) % 6>(v, dacc, w[6], L); s4_step<(P0 + 7) % 6>(v, dacc, w[7], L);
+  s4_step<(P0 + 0) % 6>(v, dacc, w[0], w[1], L); s4_step<(P0 + 1) % 6>(v, dacc, w[2], w[3], L); s4_step<(P0 + 2) % 6>(v, dacc, w[4], w[5], L);
+  s4_step<(P0 + 3) % 6>(v, dacc, w[6], w[7], L); s4_step<(P0 + 4) % 6>(v, dacc, w[8], w[9], L); s4_step<(P0 + 5) % 6>(v, dacc, w[10], w[11], L);
+  s4_step<(P0 + 6) % 6>(v, dacc, w[12], w[13], L); s4_step<(P0 + 7) % 6>(v, dacc, w[14], w[15], L);
 }
 
-// traceback of 24 steps (three decision groups, phases static), lane k < 4 = the chain of decoder k: z = physical cell (lane | h << 6 | r << 7) after step 23,
-// updated to the cell before step 0; bytes: the three decoded bytes (group gi at bits 8 gi .. 8 gi + 7, MSB of a byte = its first step).  The decision dword
-// of the cell's lane comes through ds_bpermute; it is fetched again only when the lane can have changed (the previous flip was a DPP phase) or the group has.
-// (A first version walked the four chains with scalar instructions and v_readlane: ~7 SALU per step and chain, and the scalar unit issues one instruction
-// per four cycles and SIMD like the vector unit does -- 2.65 ms of traceback against 1.66 ms of forward pass on 17 superframes.)
-template <int J> __device__ __forceinline__ void s4_back(int &z, unsigned &bytes, const int (&w)[3], int &word)
+// traceback of the 8 steps of one decision group (GI = group index mod 3: the phases are static): z = physical cell (lane | h << 6 | r << 7) after the
+// group's last step, updated to the cell before its first; returns the decoded byte (MSB = first step).  row = the group's decision dwords in LDS; the dword of
+// the cell's lane is read again only when the lane can have changed (the previous flip was a DPP phase) or the group has.
+// (Earlier versions: four scalar chains with v_readlane -- ~7 SALU per step and chain, and the scalar unit issues one instruction per four cycles and SIMD
+// like the vector unit: 2.65 ms of traceback against 1.66 ms of forward pass on 17 superframes; then lane k < 4 = the whole chain of decoder k with
+// ds_bpermute: 0.75 ms, still 2240 dependent steps x 9 instructions for 4 useful lanes.)
+template <int GI, int JJ> __device__ __forceinline__ void s4_back(int &z, unsigned &byte, const unsigned *row, unsigned &word)
 {
-  constexpr int P = J % 6, P1 = (J + 1) % 6, gi = J >> 3, jj = J & 7;
+  constexpr int J = GI * 8 + JJ, P = J % 6, P1 = (J + 1) % 6;
   // decoded bit of step J = LSB of the state after it = cell bit (6 - P1) % 6 of the cell after it: a0, r, h, a3, a2, a1 for P1 = 0..5
   const unsigned zz = (unsigned)z;
   const unsigned bit = P1 == 0 ? (zz ^ (zz >> 2)) & 1u : P1 == 1 ? (zz >> 7) & 1u : P1 == 2 ? (zz >> 6) & 1u : P1 == 3 ? (zz >> 3) & 1u : P1 == 4 ? (zz >> 2) & 1u
                                                                                                                                        : ((zz >> 1) ^ (zz >> 2)) & 1u;
-  bytes |= bit << (8 * gi + 7 - jj);
-  if (J == 23 || jj == 7 || P1 >= 2) word = __builtin_amdgcn_ds_bpermute((z & 63) << 2, w[gi]);
-  const unsigned d = ((unsigned)word >> ((zz >> 6) * 8 + jj)) & 1u;
+  byte |= bit << (7 - JJ);
+  if (JJ == 7 || P1 >= 2) word = row[z & 63];
+  const unsigned d = (word >> ((zz >> 6) * 8 + JJ)) & 1u;
   constexpr unsigned mask = P == 0 ? 0x80 : P == 1 ? 0x40 : P == 2 ? 8 : P == 3 ? 7 : P == 4 ? 2 : 1;
   z ^= (int)(d * mask);
-  if constexpr (J > 0) s4_back<J - 1>(z, bytes, w, word);
+  if constexpr (JJ > 0) s4_back<GI, JJ - 1>(z, byte, row, word);
 }
 
 __global__ __launch_bounds__(64 * S4_WAVES) void viterbi_soft4_kernel(const int8_t *__restrict__ soft, uint8_t *__restrict__ out, const RxState *st, VitParams vp,
                                                                       unsigned *__restrict__ scratch, int B, int nsteps)
 {
-  __shared__ __attribute__((aligned(16))) unsigned wbuf_[S4_WAVES][2][4 * S4_BLK];               // step words [buffer][decoder][step in block]
+  __shared__ __attribute__((aligned(16))) unsigned wbuf_[S4_WAVES][2][8 * S4_BLK];               // step words W, -W [buffer][decoder][step in block]
+  __shared__ unsigned rows_[S4_WAVES][S4_NSEG * 64];                                             // traceback: one decision row per segment
+  __shared__ unsigned char best_[S4_WAVES][4 * (S4_MAXSTEPS / S4_BLK)];                          // best cell of every decoder after every block
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, dd = lane >> 4, pl = lane & 15;
   if (st->first_out < 0) return;
+  unsigned *rows = rows_[wv]; unsigned char *bests = best_[wv];
   const long long total_steps = st->n_vit_steps, total_out = total_steps / 8 - vp.ntb, n_soft = st->n_vit_in * vp.m;
   const unsigned magic32 = 0xffffffffu / (unsigned)vp.plen + 1u;   // x / plen == umulhi(x, magic32) for x * plen < 2^32
   unsigned *dec = scratch + ((size_t)blockIdx.x * S4_WAVES + wv) * S4_SLOT_WORDS;
-  unsigned (*wb)[4 * S4_BLK] = wbuf_[wv];
+  unsigned (*wb)[8 * S4_BLK] = wbuf_[wv];
   S4Lane L; s4_init_lane(pl, L);
   const int nblk = nsteps / S4_BLK, ngrp = nsteps / 8;
   const long long nslots = (long long)gridDim.x * S4_WAVES;
@@ -165,7 +175,8 @@ __global__ __launch_bounds__(64 * S4_WAVES) void viterbi_soft4_kernel(const int8
 #pragma unroll
       for (int k = 0; k < 3; k++) {
         const int sx = (int)(signed char)(q[k] & 0xff), sy = q[k] >> 8;
-        wb[buf][dd * S4_BLK + pl + 16 * k] = (unsigned)((sx + sy) & 0xffff) | ((unsigned)(sy - sx) << 16);
+        const unsigned W = (unsigned)((sx + sy) & 0xffff) | ((unsigned)(sy - sx) << 16), nW = (unsigned)((-sx - sy) & 0xffff) | ((unsigned)(sx - sy) << 16);
+        *reinterpret_cast<uint2 *>(&wb[buf][2 * (dd * S4_BLK + pl + 16 * k)]) = make_uint2(W, nW);
       }
     };
     int v[2] = {0, 0}, dacc[2] = {0, 0};
@@ -173,12 +184,13 @@ __global__ __launch_bounds__(64 * S4_WAVES) void viterbi_soft4_kernel(const int8
     load3(0, q); put3(0, q);
     for (int blk = 0; blk < ((S4_EXP & 2) ? 1 : nblk); blk++) {
       if (blk + 1 < nblk) load3(blk + 1, q);
-      const unsigned *wrow = &wb[blk & 1][dd * S4_BLK];
+      const unsigned *wrow = &wb[blk & 1][2 * dd * S4_BLK];
 #pragma unroll
       for (int gi = 0; gi < 6; gi++) {
-        unsigned w[8];
-        { const uint4 *wp = reinterpret_cast<const uint4 *>(wrow + gi * 8); const uint4 x0 = wp[0], x1 = wp[1];
-          w[0] = x0.x; w[1] = x0.y; w[2] = x0.z; w[3] = x0.w; w[4] = x1.x; w[5] = x1.y; w[6] = x1.z; w[7] = x1.w; }
+        unsigned w[16];
+        { const uint4 *wp = reinterpret_cast<const uint4 *>(wrow + gi * 16);
+#pragma unroll
+          for (int i4 = 0; i4 < 4; i4++) { const uint4 x = wp[i4]; w[4 * i4] = x.x; w[4 * i4 + 1] = x.y; w[4 * i4 + 2] = x.z; w[4 * i4 + 3] = x.w; } }
         if (gi % 3 == 0) s4_group<0>(v, dacc, w, L); else if (gi % 3 == 1) s4_group<2>(v, dacc, w, L); else s4_group<4>(v, dacc, w, L);
         const int g = blk * 6 + gi;
         // the four cells' decisions of the group: bit jj of byte 2 r + h = step jj
@@ -189,36 +201,49 @@ __global__ __launch_bounds__(64 * S4_WAVES) void viterbi_soft4_kernel(const int8
         k = pk_max(k, dppb<DPP_XOR1>(k)); k = pk_max(k, dppb<DPP_XOR2>(k)); k = pk_max(k, dppb<DPP_HALF_MIRROR>(k)); k = pk_max(k, dppb<DPP_MIRROR>(k));
         k = pk_max(k, (int)__builtin_amdgcn_alignbit((unsigned)k, (unsigned)k, 16));
         v[0] = pk_sub(v[0], k); v[1] = pk_sub(v[1], k);
+        // a best cell of the row (metric 0 now), as a physical cell: the traceback segments start from it.  key = lane-in-row | h << 6 | r << 7, 0x100 = none
+        const int mine = (short)(v[0] & 0xffff) == 0 ? 0 : (v[0] >> 16) == 0 ? 0x40 : (short)(v[1] & 0xffff) == 0 ? 0x80 : (v[1] >> 16) == 0 ? 0xc0 : 0x100;
+        int key = mine | pl;
+        key = min_dpp<DPP_XOR1>(key); key = min_dpp<DPP_XOR2>(key); key = min_dpp<DPP_HALF_MIRROR>(key); key = min_dpp<DPP_MIRROR>(key);
+        if (pl == 0) bests[blk * 4 + dd] = (unsigned char)((key & 0xcf) | (dd << 4));
       }
       if (blk + 1 < nblk) put3((blk + 1) & 1, q);
     }
-    // best end cell of every decoder: after the subtraction the best metric is 0 (steps past the stream's end are erasures)
-    const unsigned long long e00 = __ballot((short)(v[0] & 0xffff) == 0), e01 = __ballot((v[0] >> 16) == 0);
-    const unsigned long long e10 = __ballot((short)(v[1] & 0xffff) == 0), e11 = __ballot((v[1] >> 16) == 0);
-    int z = lane;                                                   // lane k < 4: the chain of decoder k
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const unsigned m00 = (unsigned)(e00 >> (16 * k)) & 0xffffu, m01 = (unsigned)(e01 >> (16 * k)) & 0xffffu;
-      const unsigned m10 = (unsigned)(e10 >> (16 * k)) & 0xffffu, m11 = (unsigned)(e11 >> (16 * k)) & 0xffffu;
-      const int zk = m00 ? 16 * k + __builtin_ctz(m00) : m01 ? (16 * k + __builtin_ctz(m01)) | 0x40 : m10 ? (16 * k + __builtin_ctz(m10)) | 0x80
-                         : (16 * k + (__builtin_ctz(m11 | 0x10000u) & 15)) | 0xc0;
-      if (lane == k) z = zk;
-    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    // traceback: 24 steps (three groups) per round, lane k < 4 walks and stores decoder k
-    const long long ob0 = (task * 4 + lane) * B;                    // lane k < 4: first byte of decoder k
-    const long long ob1 = ob0 + B < total_out ? ob0 + B : total_out;
-    for (int g3 = ngrp / 3 - 1; g3 >= ((S4_EXP & 1) ? ngrp / 3 - 1 : S4_G0 / 3); g3--) {
-      int w[3];
+    // traceback in S4_NSEG segments per decoder, lane = (segment, decoder) (lanes 32..63 duplicate 0..31 and store nothing): a segment of S groups starts
+    // S4_PRE groups behind its end, from the best cell recorded there, so that 32 chains of S + S4_PRE groups replace 4 chains of the whole chunk.  Segment
+    // bounds, S and S4_PRE are multiples of 6 groups (= block ends, and every lane is at the same phase).  Per group: the 8 segments' decision rows go
+    // through LDS (loaded one group ahead), then 8 steps per lane.
+    {
+      const int k = lane & 3, sg = (lane >> 2) & (S4_NSEG - 1);
+      const int S = ((S4_WARM / 8 + B - S4_G0 + S4_NSEG * 6 - 1) / (S4_NSEG * 6)) * 6;
+      auto top_of = [&](int s_) { const int t_ = S4_G0 + (s_ + 1) * S + S4_PRE; return t_ < ngrp ? t_ : ngrp; };
+      const int lo = S4_G0 + sg * S, hi = lo + S, top = top_of(sg);
+      int z = bests[(top / 6 - 1) * 4 + k];
+      const long long ob0 = (task * 4 + k) * B, ob1 = ob0 + B < total_out ? ob0 + B : total_out;
+      const int nsub = (S4_EXP & 1) ? 3 : S + S4_PRE;               // groups per chain
+      unsigned nxt[S4_NSEG];
+      auto load_rows = [&](int sub) {                               // the row of every segment for its group number `sub` from the top
 #pragma unroll
-      for (int gi = 0; gi < 3; gi++) w[gi] = (int)__hip_atomic_load(&dec[(size_t)(3 * g3 + gi - S4_G0) * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      unsigned mine = 0; int word = 0;
-      s4_back<23>(z, mine, w, word);
-      if (lane < 4) {
+        for (int s_ = 0; s_ < S4_NSEG; s_++) {
+          int g = top_of(s_) - 1 - sub; g = g < S4_G0 ? S4_G0 : g;
+          nxt[s_] = __hip_atomic_load(&dec[(size_t)(g - S4_G0) * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      };
+      load_rows(0);
+      for (int sub = 0; sub < nsub; sub += 3) {
 #pragma unroll
-        for (int gi = 0; gi < 3; gi++) {
-          const long long ob = ob0 + (3 * g3 + gi) - S4_WARM / 8;
-          if (ob >= ob0 && ob < ob1) out[ob] = (uint8_t)(mine >> (8 * gi));
+        for (int gi = 2; gi >= 0; gi--) {                           // top - 1 - sub is 2 (mod 3)
+#pragma unroll
+          for (int s_ = 0; s_ < S4_NSEG; s_++) rows[s_ * 64 + lane] = nxt[s_];
+          const int su = sub + (2 - gi);
+          if (su + 1 < nsub) load_rows(su + 1);
+          const int g = top - 1 - su;
+          unsigned byte = 0, word = 0;
+          const unsigned *row = rows + sg * 64;
+          if (gi == 2) s4_back<2, 7>(z, byte, row, word); else if (gi == 1) s4_back<1, 7>(z, byte, row, word); else s4_back<0, 7>(z, byte, row, word);
+          const long long ob = ob0 + g - S4_WARM / 8;
+          if (lane < 32 && g >= lo && g < hi && ob >= ob0 && ob < ob1) out[ob] = (uint8_t)byte;
         }
       }
     }
