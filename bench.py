@@ -151,7 +151,7 @@ def _stream(torch, k):
 class Job:
     """One stream cut into world x segments pieces; this rank's pieces resident in HBM, one handle + stream each."""
 
-    def __init__(self, a, torch, g, dist, rank, world, local, workload, superframes, snr=None, chunk=0, from_file_rate=False):
+    def __init__(self, a, torch, g, dist, rank, world, local, workload, superframes, snr=None, chunk=0, from_file_rate=False, soft=False):
         from oracle import pyoracle as po
         from gr_dvbt_amd import multi
         self.torch, self.g, self.dist, self.rank, self.world, self.local, self.multi, self.po = torch, g, dist, rank, world, local, multi, po
@@ -198,11 +198,11 @@ class Job:
             iq = po.stream_slice(c, self.nsf, self.seed, cu["begin"], cu["end"])       # only this rank's part of THE stream
             if snr is not None:
                 iq = add_awgn(iq, snr, 1000 + rank * nseg + i, self.ref_power)
-            kw = {}
+            kw = {"soft_decision": 1} if soft else {}
             if from_file_rate:
                 rx_const = 0.0022097087 if mode == po.T2k else 0.00055242272           # blocks_multiply_const_vxx_0 of the RX flowgraph
                 iq = po.resample(iq / np.float32(rx_const), 70, 64, 1.0)                # what dvbt_tx_demo writes: the 10 Msps stream
-                kw = {"resample": (64, 70), "front_scale": rx_const}
+                kw.update({"resample": (64, 70), "front_scale": rx_const})
             d_iq = torch.from_numpy(iq.view(np.float32)).cuda()
             cap = int(len(iq) * 0.45) + 4096
             depth = max(1, getattr(a, "pipeline", 1))            # handles (each with its own HIP stream) that take this piece's steps in turn
@@ -346,8 +346,10 @@ def extra_workloads(a, torch, g, local):
         segments = 1
         pipeline = a.pipeline
     res = {}
-    for name, wl, snr, nsf, steps in (("config2_2k_qam16_1_2", "2k_qam16_1_2", None, 64, 400), ("config5_8k_qpsk_7_8_awgn14", "8k_qpsk_7_8", 14.0, 16, 400)):
-        job = Job(A, torch, g, None, 0, 1, local, wl, nsf, snr=snr)
+    # last line: the opt-in soft-decision mode (k_soft.hpp, k_soft4.hpp; no reference counterpart, no parity claim) on the headline configuration
+    for name, wl, snr, nsf, steps, soft in (("config2_2k_qam16_1_2", "2k_qam16_1_2", None, 64, 400, False), ("config5_8k_qpsk_7_8_awgn14", "8k_qpsk_7_8", 14.0, 16, 400, False),
+                                            ("soft_decision_8k_qam64_7_8", "8k_qam64_7_8", None, 32, 100, True)):
+        job = Job(A, torch, g, None, 0, 1, local, wl, nsf, snr=snr, soft=soft)
         dt = timed_run(job, steps, 3)
         chk = job.verify()
         res[name] = {"value": round(job.n_total * steps / dt / 1e6, 2), "unit": "Msamples/s", "x_realtime": round(job.n_total * steps / dt / 1e6 / REALTIME_MSPS, 1),

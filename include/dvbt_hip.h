@@ -270,7 +270,7 @@ typedef struct {
   int soft_decision;       /* 0: the reference's hard-decision demapper and Viterbi decoder (the parity path).  1: soft decisions (gr-dvbt's TODO.txt:25-26, never
                               built there): per coded bit an 8-bit max-log likelihood ratio weighted with the carrier's channel power, de-interleaved as soft
                               values, decoded by a soft-input Viterbi decoder; everything behind the decoder unchanged.  No reference exists for it: identical
-                              TS on a clean loopback, lower error rates under noise (tests/test_gpu_soft.py); about 10x slower than the hard decoder.
+                              TS on a clean loopback, 2-3 dB of gain at the waterfall (tests/test_gpu_soft.py); the chain takes about 1.6x the hard chain's time.
                               The DEMAP / SYMDEINT / BITDEINT taps are not filled in this mode. */
 } dvbt_rx_params;
 

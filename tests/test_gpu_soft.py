@@ -64,3 +64,26 @@ def test_deep_echo_below_the_hard_waterfall(po):
     hard, soft = both(po, g.QAM16, g.C3_4, g.T2k, 8, snr=16.0, echoes=((20, 0.5 + 0j),), rx_snr=10.0)
     assert soft["periods"] == hard["periods"] == 1
     assert hard["per"] > 0.3 and soft["per"] < 0.01
+
+
+@pytest.mark.parametrize("const,cr,mode,nsf,seg_sf,call", [(g.QAM16, g.C1_2, g.T2k, 9, 2, 4 * 2112), (g.QAM64, g.C7_8, g.T8k, 6, 1, 33 * 8448 + 5)])
+def test_soft_mode_through_the_streaming_entry(po, const, cr, mode, nsf, seg_sf, call):
+    """dvbt_rx_stream_* with soft_decision = 1: pieces that continue a cut stream (dvbt_rx_set_cut: sizes in stream coordinates) go through the soft decoder
+    too; on a clean stream the TS pulled is the hard chain's over the whole stream"""
+    c = po.cfg(const, cr, mode)
+    iq = po.stream_slice(c, nsf, 9)
+    rx = g.Rx(const, cr, mode, max_samples=len(iq))
+    rx.run(iq)
+    ref = rx.tap(g.TAP_TS).copy()
+    rx.close()
+    st = g.RxStream(const, cr, mode, segment_superframes=seg_sf, soft_decision=1)
+    out = []
+    for pos in range(0, len(iq), call):
+        st.push(iq[pos:pos + call])
+        out.append(st.pull())
+    st.finish()
+    out.append(st.pull())
+    info = st.info()
+    st.close()
+    ts = np.concatenate(out)
+    assert info.status & ~2 == 0 and len(ts) == len(ref) > 0 and (ts == ref).all()
