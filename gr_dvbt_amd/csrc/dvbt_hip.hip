@@ -661,7 +661,11 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
       EnqOpt o; o.acq_only = true; o.use_carry = carry; o.hist = (long long)off;
       // the search and the tracker look at a window of the rest of the segment that grows while the lock holds to its end: a segment with many lock
       // periods costs its length a few times over, not its length times the number of periods (a call's outcome depends on the samples before it only)
-      size_t look = std::min(chain_n - off, win + (size_t)767 * L);
+      // (first window: 768 calls, or four times the previous period's length when the lock is being lost every few dozen symbols -- the metric, anchor and
+      // tracker launches cost in proportion to the window)
+      size_t look_calls = 767;
+      if (!per.empty()) look_calls = std::min<size_t>(767, std::max<size_t>(47, 4 * (size_t)std::max(per.back().n_symbols, 0)));
+      size_t look = std::min(chain_n - off, win + look_calls * L);
       for (;;) {
         int r = enqueue(h, chain + off, look, s, o); if (r) return r;
         HIPCHK(hipStreamSynchronize(s));
