@@ -12,4 +12,6 @@ for pd in 1 2 4; do python bench.py --pipeline $pd --steps 200 --no-cpu-baseline
 python tools/snr_sweep.py 3 > gpurun_out/snr_sweep.jsonl 2>/dev/null; wc -l gpurun_out/snr_sweep.jsonl
 python tools/rs_load.py > gpurun_out/rs_load.jsonl 2>/dev/null; wc -l gpurun_out/rs_load.jsonl
 ./tools/ubench_mfma > gpurun_out/ubench_mfma.json 2>/dev/null
+rm -rf gpurun_out/prof_soft; rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_soft -o r -- python tools/soft_prof.py > /dev/null 2>&1
+python tools/soft_gain.py > gpurun_out/soft_gain.jsonl 2>/dev/null; wc -l gpurun_out/soft_gain.jsonl
 bash tools/pmc.sh > gpurun_out/pmc.log 2>&1; tail -3 gpurun_out/pmc.log | cut -c1-300

@@ -35,7 +35,10 @@ if solo:
     prof = solo[-1]
 if os.path.exists(os.path.join(root, "gpurun_out", "pipeline_depth.jsonl")):
     shutil.copy(os.path.join(root, "gpurun_out", "pipeline_depth.jsonl"), os.path.join(root, "profiles", f"{tag}_pipeline_depth.jsonl"))
-for extra in ("snr_sweep.jsonl", "rs_load.jsonl", "ubench_mfma.json"):
+soft = sorted(glob.glob(os.path.join(root, "gpurun_out", "prof_soft", "*kernel_stats.csv")), key=os.path.getmtime)
+if soft:
+    shutil.copy(soft[-1], os.path.join(root, "profiles", f"{tag}_kernel_stats_soft_8k_qam64_7_8_17sf.csv"))   # tools/soft_prof.py: the soft-decision chain
+for extra in ("snr_sweep.jsonl", "rs_load.jsonl", "ubench_mfma.json", "soft_gain.jsonl"):
     if os.path.exists(os.path.join(root, "gpurun_out", extra)) and os.path.getsize(os.path.join(root, "gpurun_out", extra)) > 0:
         shutil.copy(os.path.join(root, "gpurun_out", extra), os.path.join(root, "profiles", f"{tag}_{extra}"))
 b = json.load(open(os.path.join(root, "gpurun_out", "bench_final.json")))
