@@ -3,7 +3,7 @@
 // relative step u; the six butterfly exchanges are a VGPR swap, a half swap and four DPP controls).  What differs from the hard kernel:
 //   * a cell is a full 16-bit metric (soft values in [-31, 31]: a branch delta is up to +-62, the spread of the 64 metrics up to ~750; the row maximum is
 //     subtracted every 48 steps), so the survivors cannot ride along in a path byte: the DECISION of every cell and step (1 = the survivor came from the
-//     butterfly partner) is the sign of X - Y_partner, shifted into a register per VGPR (v_lshrrev + v_bfi) and, every 8 steps, packed to one dword per
+//     butterfly partner) is the sign of X - Y_partner, moved to the step's bit of a register per VGPR (v_pk_lshrrev_b16 + v_bfi) and, every 8 steps, packed to one dword per
 //     lane (4 cells x 8 steps) and written to the wavefront's slot of a scratch buffer in HBM (256 coalesced bytes per 8 steps: written once, read once);
 //   * the branch deltas of a step are the four correlations +-sx +-sy: one word (A = sx + sy, B = sy - sx) per step and decoder from LDS, its negation,
 //     and the hard kernel's per-lane v_perm selectors pick every cell's class out of the 8 bytes;
@@ -76,8 +76,11 @@ __device__ inline void s4_init_lane(int pl, S4Lane &L)
 // (mask & a) | (~mask & b): one v_bfi_b32 (left to itself the compiler emits v_and + v_and_or)
 __device__ __forceinline__ int s4_bfi(unsigned mask, unsigned a, unsigned b) { int r; asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(mask), "v"(a), "v"(b)); return r; }
 
+typedef unsigned short s4u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned s4_pk_lshr(unsigned x, int n) { return __builtin_bit_cast(unsigned, __builtin_bit_cast(s4u2, x) >> (unsigned short)n); }   // v_pk_lshrrev_b16
+
 // one step at phase P: W = A | B << 16 of this lane's decoder, nW = -A | -B << 16
-template <int P> __device__ __forceinline__ void s4_step(int (&v)[2], int (&dacc)[2], unsigned W, unsigned nW, const S4Lane &L)
+template <int P, int JJ> __device__ __forceinline__ void s4_step(int (&v)[2], int (&dacc)[2], unsigned W, unsigned nW, const S4Lane &L)   // JJ: step within the group of 8
 {
   int X[2], Y[2], Yp[2];
   const int D0 = (int)__builtin_amdgcn_perm(nW, W, L.sel[P][0]);
@@ -100,14 +103,17 @@ template <int P> __device__ __forceinline__ void s4_step(int (&v)[2], int (&dacc
   for (int r = 0; r < 2; r++) {
     const int diff = pk_sub(X[r], Yp[r]);                            // sign set: the partner's offer wins
     v[r] = pk_max(X[r], Yp[r]);
-    dacc[r] = s4_bfi(0x80008000u, (unsigned)diff, (unsigned)dacc[r] >> 1);   // bits 15 and 31 from diff, the older decisions one place down
+    // the sign of both halves to bit 8 + JJ of its half (bits 8..15 of a half = the group's 8 decisions, oldest lowest): the halves' shift, then v_bfi
+    // replaces exactly that bit (whatever the previous group left there); the last step of a group needs no shift
+    const unsigned sh = JJ == 7 ? (unsigned)diff : s4_pk_lshr((unsigned)diff, 7 - JJ);
+    dacc[r] = s4_bfi(0x01000100u << JJ, sh, (unsigned)dacc[r]);
   }
 }
 template <int P0> __device__ __forceinline__ void s4_group(int (&v)[2], int (&dacc)[2], const unsigned *w, const S4Lane &L)   // w: W, nW of 8 steps
 {
-  s4_step<(P0 + 0) % 6>(v, dacc, w[0], w[1], L); s4_step<(P0 + 1) % 6>(v, dacc, w[2], w[3], L); s4_step<(P0 + 2) % 6>(v, dacc, w[4], w[5], L);
-  s4_step<(P0 + 3) % 6>(v, dacc, w[6], w[7], L); s4_step<(P0 + 4) % 6>(v, dacc, w[8], w[9], L); s4_step<(P0 + 5) % 6>(v, dacc, w[10], w[11], L);
-  s4_step<(P0 + 6) % 6>(v, dacc, w[12], w[13], L); s4_step<(P0 + 7) % 6>(v, dacc, w[14], w[15], L);
+  s4_step<(P0 + 0) % 6, 0>(v, dacc, w[0], w[1], L); s4_step<(P0 + 1) % 6, 1>(v, dacc, w[2], w[3], L); s4_step<(P0 + 2) % 6, 2>(v, dacc, w[4], w[5], L);
+  s4_step<(P0 + 3) % 6, 3>(v, dacc, w[6], w[7], L); s4_step<(P0 + 4) % 6, 4>(v, dacc, w[8], w[9], L); s4_step<(P0 + 5) % 6, 5>(v, dacc, w[10], w[11], L);
+  s4_step<(P0 + 6) % 6, 6>(v, dacc, w[12], w[13], L); s4_step<(P0 + 7) % 6, 7>(v, dacc, w[14], w[15], L);
 }
 
 // traceback of the 8 steps of one decision group (GI = group index mod 3: the phases are static): z = physical cell (lane | h << 6 | r << 7) after the
