@@ -263,7 +263,7 @@ struct dvbt_rx {
   hipEvent_t ev[ST_COUNT]; double acc_ms[ST_COUNT] = {0}; long n_timed = 0; bool ev_ready = false, ev_recorded = false;
   dvbt_rx_report last; bool have_last = false;
   dvbt_rx_cut cut = {0};
-  float2 *tps_prev = nullptr; DescrRun *descr_runs = nullptr; int *descr_nruns = nullptr;
+  float2 *tps_prev = nullptr, *tps_prev_snap = nullptr; TpsState *tps_snap = nullptr; DescrRun *descr_runs = nullptr; int *descr_nruns = nullptr;
   int n_periods = 1; size_t seg_offset = 0;
   std::vector<dvbt_lock_period> periods;    // phase A of the last synchronous run
   DriftBufs drift = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; double *drift_mem = nullptr;   // k_drift.hpp
@@ -273,7 +273,7 @@ struct dvbt_rx {
 
 static void rx_free(dvbt_rx *h)
 {
-  void *all[] = {h->csi, h->soft_a, h->soft_tab, h->soft_scratch, h->rs_defer, h->drift_mem, h->drift.delta, h->drift.flags, h->tps_prev, h->descr_runs, h->descr_nruns, h->centre, h->anchor_pos, h->sym_ticket, h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags, h->trk_eps, h->d_iq, h->rs_iq, h->acq_carry, h->g_init, h->l_init, h->g_trk, h->l_trk, h->meta, h->st, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
+  void *all[] = {h->tps_prev_snap, h->tps_snap, h->csi, h->soft_a, h->soft_tab, h->soft_scratch, h->rs_defer, h->drift_mem, h->drift.delta, h->drift.flags, h->tps_prev, h->descr_runs, h->descr_nruns, h->centre, h->anchor_pos, h->sym_ticket, h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags, h->trk_eps, h->d_iq, h->rs_iq, h->acq_carry, h->g_init, h->l_init, h->g_trk, h->l_trk, h->meta, h->st, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
                  h->info, h->maj, h->sym_index, h->labels, h->symdeint_tap, h->bitdeint, h->vit, h->deint_tap, h->rs_out, h->ts_out};
   for (void *q : all) if (q) (void)hipFree(q);
   if (h->st_host) (void)hipHostFree(h->st_host);
@@ -318,6 +318,7 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   RXHIP(hipMalloc((void **)&h->trk_cp_a, sizeof(int) * C)); RXHIP(hipMalloc((void **)&h->trk_cp_b, sizeof(int) * C));
   RXHIP(hipMalloc((void **)&h->trk_eps, sizeof(float) * C)); RXHIP(hipMalloc((void **)&h->trk_flags, sizeof(int) * 16));
   RXHIP(hipMalloc((void **)&h->tps_prev, sizeof(float2) * d.n_tps)); RXHIP(hipMemset(h->tps_prev, 0, sizeof(float2) * d.n_tps));
+  RXHIP(hipMalloc((void **)&h->tps_prev_snap, sizeof(float2) * d.n_tps)); RXHIP(hipMalloc((void **)&h->tps_snap, sizeof(TpsState)));
   RXHIP(hipMalloc((void **)&h->descr_runs, sizeof(DescrRun) * DESCR_MAX_RUNS)); RXHIP(hipMalloc((void **)&h->descr_nruns, sizeof(int)));
   RXHIP(hipMalloc((void **)&h->centre, sizeof(int) * (C + 1))); RXHIP(hipMalloc((void **)&h->anchor_pos, sizeof(int) * (C / ACQ_ANCHOR + 4)));
   RXHIP(hipMalloc((void **)&h->tps_edges, sizeof(TpsEdge) * (C / TPS_SEG + 2))); RXHIP(hipMalloc((void **)&h->st, sizeof(RxState)));
@@ -398,6 +399,7 @@ extern "C" int dvbt_rx_enable_taps(dvbt_rx *h, int enable)
 // defaults; the synchronous entries walk the segment's lock periods (segment_periods).
 struct EnqOpt {
   bool acq_only = false;      // ofdm_sym_acquisition alone (where does the lock start, how long does it hold)
+  bool skip_acq = false;      // the acquisition results of the acq_only run just before (same iq, same hist, same carry) are still in the handle: go on from there
   bool use_carry = false;     // the peak detector's average is carried in from the call that lost the previous lock (h->acq_carry)
   long long hist = 0;         // samples of the stream in memory in front of iq[0]
   bool continuation = false;  // not the first period that reaches demod_reference_signals: its TPS state and the previous symbol's TPS carriers are
@@ -454,6 +456,10 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
   h->cur_stream = s;
   const bool tm = h->timing && !o.acq_only;
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_ACQ], s));
+  if (o.skip_acq) {
+    // what acq_init_fsm_kernel's reset would have done on top of the acq_only run's (tracker flags and the symbol ticket are still clear)
+    if (!o.continuation) HIPCHK(hipMemsetAsync(h->tps_state, 0, sizeof(TpsState), s));
+  } else {
   const AcqState *carry = o.use_carry ? h->acq_carry : nullptr;
   int tries = C < ACQ_INIT_TRIES ? C : ACQ_INIT_TRIES;
   // initial search: the first window normally holds a peak; windows 1..3 are computed and examined only if it did not
@@ -484,6 +490,7 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
     HIPCHK(hipMemcpyAsync(h->st_host, h->st, sizeof(RxState), hipMemcpyDeviceToHost, s));
     HIPCHK(hipGetLastError());
     return DVBT_OK;
+  }
   }
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_FFT], s));
   // A1 tail + A2 + A3 in one kernel: the FFT item of a symbol never leaves LDS (acq/fft taps are written only when enabled)
@@ -653,7 +660,42 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
   const size_t L = (size_t)(d.N + d.cp), win = (size_t)(2 * d.N + d.cp + 16);
   std::vector<LockPeriod> per;
   bool capped = false;                                            // the walk was cut short: the rest of the segment is not decoded (status bit 8)
-  {   // ---- phase A
+  h->periods.clear();
+  // what the decode of the periods accumulates
+  struct Book {
+    size_t acc = 0; int delivering = 0, processed = 0; bool any = false; dvbt_rx_report first_rep; RxState last_st; int total_symbols = 0; size_t last_off = 0;
+  } bk, snap;
+  memset(&bk.first_rep, 0, sizeof bk.first_rep); bk.first_rep.first_out_symbol = -1;
+  memset(&bk.last_st, 0, sizeof bk.last_st); bk.last_st.first_out = -1; bk.last_st.status = 1;
+  int snap_period = -1;                                           // the last decoded period: `snap` and the device-side copies of the pilot engine's state were taken in front of it
+  // one period through the chain up to the Viterbi decoder.  later: a later period delivers items (the last item of this one leaves the demodulator too);
+  // reuse: the acquisition results of the acq_only run just before are still in the handle (the period is decoded right behind its discovery)
+  auto decode = [&](size_t p, bool later, bool reuse) -> int {
+    const int usable = per[p].n_symbols - (later ? 0 : 1);       // items that leave the demodulator
+    bk.total_symbols += per[p].n_symbols;
+    if (usable < 1) return DVBT_OK;
+    if (!reuse && per[p].carry) { AcqState as; memset(&as, 0, sizeof as); as.avg = per[p].avg_in; HIPCHK(hipMemcpyAsync(h->acq_carry, &as, sizeof as, hipMemcpyHostToDevice, s)); }
+    EnqOpt o; o.use_carry = per[p].carry; o.hist = (long long)per[p].off; o.continuation = bk.processed > 0; o.keep_last = later; o.tail = false; o.skip_acq = reuse;
+    o.vit_off = bk.delivering > 0 ? (bk.acc / 3264) * 3264 : 0;   // convolutional_deinterleaver_impl.cc:109-120: the tag realigns the input
+    // a period that ends in a lost lock is decoded over its own calls and the one that lost the lock, not over the whole rest of the segment
+    size_t span = chain_n - per[p].off;
+    if (per[p].lost) span = std::min(span, win + (size_t)(per[p].call0 + per[p].n_symbols) * L);
+    int r = enqueue(h, chain + per[p].off, span, s, o); if (r) return r;
+    // the TPS carriers of the last demodulated symbol are the DBPSK reference of the next period's first one
+    HIPCHK(hipMemcpyAsync(h->tps_prev, h->tpsval + (size_t)(usable - 1) * d.n_tps, sizeof(float2) * d.n_tps, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    h->pending = false;
+    const RxState &st = *h->st_host;
+    bk.processed++; bk.any = true; bk.last_st = st; bk.last_off = per[p].off;
+    h->periods[p].first_out_symbol = 0;
+    if (st.first_out >= 0) {
+      h->periods[p].first_out_symbol = st.first_out + 1;
+      if (bk.delivering == 0) { fill_report(h, st, bk.first_rep); bk.first_rep.segment_offset = (int64_t)per[p].off; }
+      bk.acc = o.vit_off + (size_t)st.n_vit_bytes; bk.delivering++;
+    }
+    return DVBT_OK;
+  };
+  {   // ---- the walk: find a period (acquisition alone over a growing window), decode it, go on behind the call that lost the lock
     size_t off = 0; bool carry = false; float avg = 0.f;
     for (int guard = 0; off + win <= chain_n; guard++) {
       if (guard >= 4096) { capped = true; break; }
@@ -672,50 +714,57 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
         if ((h->st_host->status & 3) || look >= chain_n - off) break;
         look = std::min(chain_n - off, win + 4 * (look - win) + 3 * L);
       }
-      const RxState &st = *h->st_host;
+      const RxState st = *h->st_host;
       const int tries = (int)std::min<size_t>(ACQ_INIT_TRIES, (chain_n - off - win) / L + 1);
       if (st.status & 1) {                                       // no peak in these windows: the reference consumes them one by one and searches on
         off += (size_t)tries * L; avg = st.avg; carry = true;
         continue;
       }
-      per.push_back(LockPeriod{off, st.n_symbols, avg, carry, st.call0, st.cp_start0, (st.status & 2) != 0});
-      if (!(st.status & 2)) break;                               // the lock held to the end of the segment
+      const bool lost = (st.status & 2) != 0;
+      per.push_back(LockPeriod{off, st.n_symbols, avg, carry, st.call0, st.cp_start0, lost});
+      h->periods.push_back(dvbt_lock_period{(int64_t)off, st.call0, st.cp_start0, st.n_symbols, 0});
+      // Decoded at once, on the acquisition results that are still in the handle.  Whether the period's last item leaves the demodulator depends on a
+      // LATER period having items: a period that ends in a lost lock is decoded as if one did (corrected behind the walk if none does); a lock that
+      // holds to the segment's end makes the last period.
+      if (st.n_symbols - (lost ? 0 : 1) >= 1) {                  // it will be decoded: keep the state in front of it
+        snap = bk; snap_period = (int)per.size() - 1;
+        HIPCHK(hipMemcpyAsync(h->tps_snap, h->tps_state, sizeof(TpsState), hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(h->tps_prev_snap, h->tps_prev, sizeof(float2) * d.n_tps, hipMemcpyDeviceToDevice, s));
+      }
+      { int r = decode(per.size() - 1, lost, true); if (r) return r; }
+      if (!lost) break;                                           // the lock held to the end of the segment
       off += (size_t)(st.call0 + st.n_symbols) * L + L / 2; avg = st.avg_lost; carry = true;
       if (per.size() >= 1024) { capped = true; break; }
     }
-  }
-  h->periods.clear();
-  for (const LockPeriod &q : per) h->periods.push_back(dvbt_lock_period{(int64_t)q.off, q.call0, q.cp_start0, q.n_symbols, 0});
-  // ---- phase B
-  size_t acc = 0; int delivering = 0, processed = 0; bool any = false;
-  dvbt_rx_report first_rep; memset(&first_rep, 0, sizeof first_rep); first_rep.first_out_symbol = -1;
-  RxState last_st; memset(&last_st, 0, sizeof last_st); last_st.first_out = -1; last_st.status = 1;
-  int total_symbols = 0; size_t last_off = 0;
-  for (size_t p = 0; p < per.size(); p++) {
-    bool later = false;
-    for (size_t q = p + 1; q < per.size(); q++) if (per[q].n_symbols >= 1) later = true;
-    const int usable = per[p].n_symbols - (later ? 0 : 1);       // items that leave the demodulator
-    total_symbols += per[p].n_symbols;
-    if (usable < 1) continue;
-    if (per[p].carry) { AcqState as; memset(&as, 0, sizeof as); as.avg = per[p].avg_in; HIPCHK(hipMemcpyAsync(h->acq_carry, &as, sizeof as, hipMemcpyHostToDevice, s)); }
-    EnqOpt o; o.use_carry = per[p].carry; o.hist = (long long)per[p].off; o.continuation = processed > 0; o.keep_last = later; o.tail = false;
-    o.vit_off = delivering > 0 ? (acc / 3264) * 3264 : 0;         // convolutional_deinterleaver_impl.cc:109-120: the tag realigns the input
-    // a period that ends in a lost lock is decoded over its own calls and the one that lost the lock, not over the whole rest of the segment
-    size_t span = chain_n - per[p].off;
-    if (per[p].lost) span = std::min(span, win + (size_t)(per[p].call0 + per[p].n_symbols) * L);
-    int r = enqueue(h, chain + per[p].off, span, s, o); if (r) return r;
-    // the TPS carriers of the last demodulated symbol are the DBPSK reference of the next period's first one
-    HIPCHK(hipMemcpyAsync(h->tps_prev, h->tpsval + (size_t)(usable - 1) * d.n_tps, sizeof(float2) * d.n_tps, hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));
-    h->pending = false;
-    const RxState &st = *h->st_host;
-    processed++; any = true; last_st = st; last_off = per[p].off;
-    if (st.first_out >= 0) {
-      h->periods[p].first_out_symbol = st.first_out + 1;
-      if (delivering == 0) { fill_report(h, st, first_rep); first_rep.segment_offset = (int64_t)per[p].off; }
-      acc = o.vit_off + (size_t)st.n_vit_bytes; delivering++;
+    int last_items = -1;                                          // the last period that has items at all
+    for (size_t q = 0; q < per.size(); q++) if (per[q].n_symbols >= 1) last_items = (int)q;
+    // The byte de-interleaver, the RS decoder and the report read the device-side state of the LAST decoded period, and that period's last item depends on
+    // whether a later one has items.  Both are in order when the last period's lock held to the segment's end (the common case: its decode was the last
+    // launch).  A last decoded period that ended in a lost lock has had searches launched behind it (and, if no period with items follows, was decoded
+    // with an item too many): it is decoded again from the state kept in front of it, acquisition included.  Should that leave nothing to decode
+    // (a single item, not delivered after all) while earlier periods were decoded, all periods are decoded again in order, each with its own acquisition.
+    if (snap_period >= 0 && per[(size_t)snap_period].lost) {
+      const size_t z = (size_t)snap_period;
+      const bool later = last_items > snap_period;
+      bk = snap;
+      HIPCHK(hipMemcpyAsync(h->tps_state, h->tps_snap, sizeof(TpsState), hipMemcpyDeviceToDevice, s));
+      HIPCHK(hipMemcpyAsync(h->tps_prev, h->tps_prev_snap, sizeof(float2) * d.n_tps, hipMemcpyDeviceToDevice, s));
+      h->periods[z].first_out_symbol = 0;
+      const int before = bk.processed;
+      int r = decode(z, later, false); if (r) return r;
+      for (size_t q = z + 1; q < per.size(); q++) bk.total_symbols += per[q].n_symbols;
+      if (bk.processed == before && before > 0) {
+        bk = Book(); memset(&bk.first_rep, 0, sizeof bk.first_rep); bk.first_rep.first_out_symbol = -1;
+        memset(&bk.last_st, 0, sizeof bk.last_st); bk.last_st.first_out = -1; bk.last_st.status = 1;
+        for (size_t q = 0; q < per.size(); q++) {
+          h->periods[q].first_out_symbol = 0;
+          int rr = decode(q, last_items > (int)q, false); if (rr) return rr;
+        }
+      }
     }
   }
+  size_t acc = bk.acc; const int delivering = bk.delivering, processed = bk.processed; const bool any = bk.any;
+  const dvbt_rx_report first_rep = bk.first_rep; const RxState last_st = bk.last_st; const int total_symbols = bk.total_symbols; const size_t last_off = bk.last_off;
   dvbt_rx_report r;
   if (!any) {   // nothing was acquired (or single symbols only): report the last acquisition attempt
     RxState st = *h->st_host; st.first_out = -1; st.n_out_symbols = 0; st.n_vit_bytes = 0; st.n_rs_items = 0; st.n_rs_words = 0; st.n_ts_bytes = 0;

@@ -55,6 +55,7 @@ struct AcqState { int acquired; int cp_start; float avg; float phase; double pha
 
 constexpr int ACQ_R = 16;
 constexpr int ACQ_INIT_TRIES = 4;
+constexpr int ACQ_CP_MAX = 2048;               // longest guard interval (8k, 1/4)
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a*conj(b)
@@ -403,75 +404,130 @@ struct SymMeta { int cp_start; int sw; float eps; float ph_base; double incA, in
 namespace dvbt {
 
 // d_phase after one call's N + cp additions: the reference's FLOAT accumulator, reproduced binade by binade (k_drift_math.hpp); the increment switches at
-// step `nextpos` when that lies inside the call (:285-309).  The carried value is the accumulator's own (a float), so a call's entry phase is exact
-__device__ inline float acq_phase_advance(float phase, double inc, double next_inc, int nextpos, int L)
+// step `nextpos` when that lies inside the call (:285-309).  The carried value is the accumulator's own (a float), so a call's entry phase is exact.
+// The sequential tracker below is ONE wavefront whose lanes all walk the same calls with the same values (uniform control flow, lane 0 stores); the lanes
+// split only what is wide: the 15 regions of an increment's table (a division each) and the 16 lags of a call whose window has left the precomputed ones.
+// Two tables are kept in LDS (the running increment's and the next one's; a call normally brings one new increment).
+__global__ __launch_bounds__(64) void acq_track_kernel(FrontParams p, RxState *st, const float2 *gamma, const float *lambda, SymMeta *meta, const int *need_seq,
+                                                       AcqState *as, const int *__restrict__ centre, const float2 *__restrict__ iq)
 {
-  double x = (double)phase;
-  if (nextpos >= 0 && nextpos < L) x = drift_advance_safe(next_inc, drift_advance_safe(inc, x, (double)nextpos), (double)(L - nextpos));
-  else x = drift_advance_safe(inc, x, (double)L);
-  return (float)drift_wrap(x);
-}
-
-__global__ void acq_track_kernel(FrontParams p, RxState *st, const float2 *gamma, const float *lambda, SymMeta *meta, const int *need_seq,
-                                 AcqState *as, const int *__restrict__ centre, const float2 *__restrict__ iq)
-{
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (st->status & 1) { if (as) { as->avg = st->avg; as->lost = 0; } return; }
+  __shared__ __attribute__((aligned(16))) double s_q[2][16], s_tc[2][18], s_len[16];
+  __shared__ __attribute__((aligned(16))) float s_lam[16]; __shared__ __attribute__((aligned(16))) float2 s_gam[16];
+  __shared__ __attribute__((aligned(16))) float2 s_xa[ACQ_CP_MAX + 16], s_xb[ACQ_CP_MAX + 16];   // a direct call's samples (guard interval up to 1/4 of 8k)
+  const int lane = threadIdx.x;
+  if (blockIdx.x != 0) return;
+  if (st->status & 1) { if (as && lane == 0) { as->avg = st->avg; as->lost = 0; } return; }
   if (need_seq && *need_seq == 0) return;
-  const int N = p.N, cp = p.cp, R = p.R, c0 = st->cp_start0;
-  (void)c0;
+  double tab_inc0 = 0.0, tab_inc1 = 0.0; int tab_last = 1;        // which increments the two tables hold, which one was used last (an increment of 0 never asks for one)
+  // drift_advance_safe on the shared tables: the unwrapped float phase n steps after phi0
+  auto steps = [&](double inc, double phi0, double n) -> double {
+    if (inc == 0.0 || n <= 0.0) return phi0;
+    if (fabs(inc) < DRIFT_MIN_INC) return phi0 + n * inc;
+    int k;
+    if (inc == tab_inc0) k = 0;
+    else if (inc == tab_inc1) k = 1;
+    else {
+      k = 1 - tab_last;
+      __syncthreads();                                             // readers of the table being replaced are done
+      if (lane < DRIFT_NR) {                                       // drift_build, a region per lane: the same expressions
+        const double a = fabs(inc), u = drift_ulp(lane);
+        const double qq = u > 0.0 ? rint(a / u) * u : a;
+        s_q[k][lane] = qq; s_len[lane] = (drift_bnd(lane + 1) - drift_bnd(lane)) / qq;
+      }
+      __syncthreads();
+      if (lane == 0) { double t = 0.0; for (int r = 0; r < DRIFT_NR; r++) { s_tc[k][r] = t; t += s_len[r]; } s_tc[k][DRIFT_NR] = t; }   // summed in drift_build's order
+      __syncthreads();
+      if (k == 0) tab_inc0 = inc; else tab_inc1 = inc;
+    }
+    tab_last = k;
+    return k == 0 ? drift_Tinv(s_q[0], s_tc[0], inc < 0, drift_T(s_q[0], s_tc[0], inc < 0, phi0) + n)
+                  : drift_Tinv(s_q[1], s_tc[1], inc < 0, drift_T(s_q[1], s_tc[1], inc < 0, phi0) + n);
+  };
+  // d_phase after one call's L additions; the increment switches at step `nextpos` when that lies inside the call (:285-309)
+  auto advance = [&](float phase, double inc, double next_inc, int nextpos, int L) -> float {
+    double x = (double)phase;
+    if (nextpos >= 0 && nextpos < L) x = steps(next_inc, steps(inc, x, (double)nextpos), (double)(L - nextpos));
+    else x = steps(inc, x, (double)L);
+    return (float)drift_wrap(x);
+  };
+  const int N = p.N, cp = p.cp, R = p.R, c0 = st->cp_start0, call0 = st->call0;
+  const float eps_init = st->eps_init;
   float avg = st->avg, phase = 0.f;
-  double phaseinc = 0.0, nextphaseinc = (-1.0 / (double)N) * (double)st->eps_init;
+  double phaseinc = 0.0, nextphaseinc = (-1.0 / (double)N) * (double)eps_init;
   int nextpos = c0 - (N + cp), cur = c0, s = 0;
   if (as) {
-    phase = as->phase; phaseinc = as->phaseinc;
-    if (as->acquired) { nextphaseinc = as->nextphaseinc; nextpos = as->nextpos; }
+    const AcqState a0 = *as;
+    phase = a0.phase; phaseinc = a0.phaseinc;
+    if (a0.acquired) { nextphaseinc = a0.nextphaseinc; nextpos = a0.nextpos; }
     else {
       // the initial ml_sync of this call ran the phase loop once with the carried increments (:285-313)
-      phase = acq_phase_advance(phase, as->phaseinc, as->nextphaseinc, as->nextpos, N + cp);
-      if (as->nextpos >= 0 && as->nextpos < N + cp) phaseinc = as->nextphaseinc;
+      phase = advance(phase, a0.phaseinc, a0.nextphaseinc, a0.nextpos, N + cp);
+      if (a0.nextpos >= 0 && a0.nextpos < N + cp) phaseinc = a0.nextphaseinc;
     }
   }
   bool lost = false;
-  for (int call = st->call0; call < p.ncalls; call++, s++) {
-    int rel0 = (cur - 8) - (centre[call] - R);
-    float lam_here[16]; float2 gam_here[16];
-    const bool direct = rel0 < 0 || rel0 + 16 > 2 * R;            // the window left the precomputed lags: this call's metric on the spot
+  // the 2 R precomputed lags of a call (metric and correlation) and its window centre come through LDS, fetched by the lanes one call ahead: the walk itself
+  // then waits for no global load (three dependent ones per call before: 5 us per call, 40 % of a stream's time where the lock is lost every few dozen symbols)
+  __shared__ __attribute__((aligned(16))) float s_rl[2][2 * ACQ_R]; __shared__ __attribute__((aligned(16))) float2 s_rg[2][2 * ACQ_R];
+  float nl = 0.f; float2 ng = make_float2(0.f, 0.f); int ncen = 0;
+  auto fetch_row = [&](int call) {
+    if (call < p.ncalls) { ncen = centre[call]; if (lane < 2 * R) { nl = lambda[(size_t)call * 2 * R + lane]; ng = gamma[(size_t)call * 2 * R + lane]; } }
+  };
+  fetch_row(call0);
+  for (int call = call0; call < p.ncalls; call++, s++) {
+    const int buf = (call - call0) & 1, cen = ncen;
+    __syncthreads();
+    if (lane < 2 * R) { s_rl[buf][lane] = nl; s_rg[buf][lane] = ng; }
+    __syncthreads();
+    fetch_row(call + 1);
+    int rel0 = (cur - 8) - (cen - R);
+    const bool direct = rel0 < 0 || rel0 + 16 > 2 * R;            // the window left the precomputed lags: this call's metric on the spot, a lag per lane
     if (direct) {
-      for (int q = 0; q < 16; q++) {
-        const int lag = cur - 8 + q;
-        float gr = 0.f, gi = 0.f, phi = 0.f;
-        if ((long long)call * (N + cp) + lag - cp + 1 - N < -p.hist) { lam_here[q] = -3.0e38f; gam_here[q] = make_float2(0.f, 0.f); continue; }
-        const float2 *x = iq + (long long)call * (N + cp) + lag;
-        for (int j = 0; j < cp; j++) {                              // the expressions and the order of acq_track_metric_kernel
-          const float2 a = x[-j], b = x[-j - N];
-          gr += a.x * b.x + a.y * b.y; gi += a.y * b.x - a.x * b.y; phi += (a.x * a.x + a.y * a.y) + (b.x * b.x + b.y * b.y);
-        }
-        gam_here[q] = make_float2(gr, gi); lam_here[q] = sqrtf(gr * gr + gi * gi) - phi * p.half_rho;
+      // the cp + 15 samples the 16 lags share, and the same N samples earlier, through LDS (coalesced loads by all lanes); then a lag per lane, summed in
+      // acq_track_metric_kernel's order
+      const long long lo = (long long)call * (N + cp) + cur - 8 - (cp - 1);
+      __syncthreads();
+      for (int t = lane; t < cp + 15; t += 64) {
+        s_xa[t] = lo + t >= -p.hist ? iq[lo + t] : make_float2(0.f, 0.f);
+        s_xb[t] = lo - N + t >= -p.hist ? iq[lo - N + t] : make_float2(0.f, 0.f);
       }
+      __syncthreads();
+      if (lane < 16) {
+        const int lag = cur - 8 + lane;
+        float gr = 0.f, gi = 0.f, phi = 0.f;
+        if ((long long)call * (N + cp) + lag - cp + 1 - N < -p.hist) { s_lam[lane] = -3.0e38f; s_gam[lane] = make_float2(0.f, 0.f); }
+        else {
+          const float2 *xa = s_xa + (cp - 1) + lane, *xb = s_xb + (cp - 1) + lane;
+          for (int j = 0; j < cp; j++) {                            // the expressions and the order of acq_track_metric_kernel
+            const float2 a = xa[-j], b = xb[-j];
+            gr += a.x * b.x + a.y * b.y; gi += a.y * b.x - a.x * b.y; phi += (a.x * a.x + a.y * a.y) + (b.x * b.x + b.y * b.y);
+          }
+          s_gam[lane] = make_float2(gr, gi); s_lam[lane] = sqrtf(gr * gr + gi * gi) - phi * p.half_rho;
+        }
+      }
+      __syncthreads();
       rel0 = 0;
     }
-    const float *lam = direct ? lam_here : lambda + (size_t)call * 2 * R + rel0;
+    const float *lam = direct ? s_lam : &s_rl[buf][rel0];
     int pos = 0;
     int npk = peak_detect(lam, 16, avg, pos);
-    if (!npk) { st->status |= 2; lost = true; break; }   // the reference drops lock and re-acquires (:545-559)
-    float2 g = direct ? gam_here[pos] : gamma[(size_t)call * 2 * R + rel0 + pos];
+    if (!npk) { lost = true; break; }                               // the reference drops lock and re-acquires (:545-559)
+    float2 g = direct ? s_gam[pos] : s_rg[buf][rel0 + pos];
     float eps = atan2f(g.y, g.x);
     int peak = pos + cur - 8;
-    SymMeta m; m.cp_start = peak; m.eps = eps; m.ph_base = phase; m.incA = phaseinc; m.incB = nextphaseinc; m.sw = nextpos;
-    meta[s] = m;
-    phase = acq_phase_advance(phase, phaseinc, nextphaseinc, nextpos, N + cp);
+    if (lane == 0) { SymMeta m; m.cp_start = peak; m.eps = eps; m.ph_base = phase; m.incA = phaseinc; m.incB = nextphaseinc; m.sw = nextpos; meta[s] = m; }
+    phase = advance(phase, phaseinc, nextphaseinc, nextpos, N + cp);
     if (nextpos >= 0 && nextpos < N + cp) phaseinc = nextphaseinc;
     nextphaseinc = (-1.0 / (double)N) * (double)eps;
     nextpos = peak - (N + cp);
     cur = peak;
   }
+  if (as && lost) phase = advance(phase, phaseinc, phaseinc, -1, N + cp);   // the failing call still advanced the phase by N+cp steps without switching (:336-345)
+  if (lane != 0) return;
+  if (lost) st->status |= 2;
   st->n_symbols = s;
   st->avg_lost = lost ? avg : st->avg;                            // d_avg after the call that lost the lock
   if (as) {
-    if (lost) {   // the failing call still advanced the phase by N+cp steps without switching (:336-345)
-      phase = acq_phase_advance(phase, phaseinc, phaseinc, -1, N + cp);
-    }
     as->acquired = lost ? 0 : 1; as->lost = lost ? 1 : 0; as->cp_start = cur; as->avg = avg; as->phase = phase;
     as->phaseinc = phaseinc; as->nextphaseinc = nextphaseinc; as->nextpos = nextpos;
   }
