@@ -401,8 +401,9 @@ void dvbt_rx_destroy(dvbt_rx *h);
  * A piece is decoded once the stream is known to go on far enough for the next piece to stand on its own (one superframe + 76 symbols behind its begin), so the
  * TS lags the input by about segment_superframes + 1 superframes.
  * Limits: the stream's head must reach its first superframe start within the first piece (segment_superframes + 2 superframes), else that
- * much of it is dropped (status bit 2, the stream's origin moves); a CP lock lost inside a later piece is reported (status bit 1) and the
- * stream goes on with the next piece (the packets up to that piece's end are missing: bit 5).
+ * much of it is dropped (status bit 2, the stream's origin moves); a CP lock lost inside a later piece is reported (status bit 1, and bit 5: packets
+ * are missing) and the piece goes on from the next superframe start it can reach from the sample where the reference's search resumes -- one or two
+ * superframes are not delivered (the reference itself loses the acquisition, a TPS frame and the wait for a superframe start there).
  * Threading: like every handle, one thread at a time. */
 typedef struct {
   dvbt_rx_params rx; int segment_superframes;

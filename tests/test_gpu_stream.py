@@ -181,3 +181,28 @@ def test_cpp_rx_hip_example(po, tmp_path):
     got = np.fromfile(fout, np.uint8)
     assert "status 0" in out, out
     assert len(got) == len(ref) > 0 and (got == ref).all()
+
+
+def test_lock_lost_inside_a_piece_is_recovered(po):
+    """a dropout (30 symbols of silence) in the middle of a piece: the reference's tracker loses the lock, searches, locks again and goes on at the next
+    superframe start.  The streaming entry delivers the piece's first lock period, then decodes the rest of the piece from the next superframe start it can
+    reach (stream_recover): every packet it delivers outside the junctions is a transmitted one, and it delivers what one chain over the whole stream
+    delivers but for at most two superframes around the dropout."""
+    const, cr, mode = g.QAM16, g.C1_2, g.T2k
+    c = po.cfg(const, cr, mode)
+    nsf, seg_sf = 15, 4
+    iq = po.stream_slice(c, nsf, 9).copy()
+    L = c.N + c.cp
+    hole = po.STREAM_LEAD_IN + (272 * 8 + 100) * L                     # inside piece 1 (pieces of 4 superframes behind piece 0's 5 or 6)
+    iq[hole:hole + 30 * L] = 0
+    sent = {bytes(p) for p in po.stream_ts(c, 0, nsf, 9).reshape(-1, 188)}
+    ref = whole(const, cr, mode, iq).reshape(-1, 188)                  # one chain, every lock period followed
+    good_ref = sum(1 for p in ref if bytes(p) in sent)
+    ts, info = streamed(const, cr, mode, iq, seg_sf, 64 * L)
+    pk = ts.reshape(-1, 188)
+    good = sum(1 for p in pk if bytes(p) in sent)
+    wsf = 272 * (c.payload * c.m * c.k // c.n) // (8 * 204)             # packets per superframe
+    assert info.status & 2, info.status                                 # the loss is reported
+    assert len(pk) - good <= 2 * 11 + 16                                # junk only at the two junctions (byte de-interleaver fill) and around the loss
+    assert good >= good_ref - 2 * wsf, (good, good_ref, wsf)
+    assert good >= (nsf - 1 - 3) * wsf                                  # and in absolute terms: all but three superframes of the stream
