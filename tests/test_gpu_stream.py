@@ -183,7 +183,8 @@ def test_cpp_rx_hip_example(po, tmp_path):
     assert len(got) == len(ref) > 0 and (got == ref).all()
 
 
-def test_lock_lost_inside_a_piece_is_recovered(po):
+@pytest.mark.parametrize("hole_symbol", [272 * 8 + 100, 272 * 12 + 100], ids=["a piece in the middle", "the final piece"])
+def test_lock_lost_inside_a_piece_is_recovered(po, hole_symbol):
     """a dropout (30 symbols of silence) in the middle of a piece: the reference's tracker loses the lock, searches, locks again and goes on at the next
     superframe start.  The streaming entry delivers the piece's first lock period, then decodes the rest of the piece from the next superframe start it can
     reach (stream_recover): every packet it delivers outside the junctions is a transmitted one, and it delivers what one chain over the whole stream
@@ -193,7 +194,7 @@ def test_lock_lost_inside_a_piece_is_recovered(po):
     nsf, seg_sf = 15, 4
     iq = po.stream_slice(c, nsf, 9).copy()
     L = c.N + c.cp
-    hole = po.STREAM_LEAD_IN + (272 * 8 + 100) * L                     # inside piece 1 (pieces of 4 superframes behind piece 0's 5 or 6)
+    hole = po.STREAM_LEAD_IN + hole_symbol * L                          # inside piece 1 (pieces of 4 superframes behind piece 0's 5 or 6) / inside the last piece
     iq[hole:hole + 30 * L] = 0
     sent = {bytes(p) for p in po.stream_ts(c, 0, nsf, 9).reshape(-1, 188)}
     ref = whole(const, cr, mode, iq).reshape(-1, 188)                  # one chain, every lock period followed
