@@ -59,6 +59,12 @@ def add_awgn(iq, snr_db, seed, ref_power):
     return (iq + np.float32(sig) * n).astype(np.complex64)
 
 
+def add_cfo(iq, cfo, N, first_sample):
+    """carrier offset of `cfo` subcarrier spacings; the phase is that of the stream's sample index, so pieces cut from one stream stay coherent"""
+    n = np.arange(first_sample, first_sample + len(iq), dtype=np.float64)
+    return (iq * np.exp(2j * np.pi * cfo / N * n)).astype(np.complex64)
+
+
 def cpu_baseline(cfg_name, n_superframes=3, all_cores=True):
     """The oracle port (oracle/o_chain.c, -O3 -funroll-loops -msse2) timed on a bounded sample of the same workload on this
     box's host cores: (i) one thread end to end = the reported value; (ii) what a thread-per-block scheduler
@@ -151,7 +157,7 @@ def _stream(torch, k):
 class Job:
     """One stream cut into world x segments pieces; this rank's pieces resident in HBM, one handle + stream each."""
 
-    def __init__(self, a, torch, g, dist, rank, world, local, workload, superframes, snr=None, chunk=0, from_file_rate=False, soft=False):
+    def __init__(self, a, torch, g, dist, rank, world, local, workload, superframes, snr=None, chunk=0, from_file_rate=False, soft=False, cfo=0.0):
         from oracle import pyoracle as po
         from gr_dvbt_amd import multi
         self.torch, self.g, self.dist, self.rank, self.world, self.local, self.multi, self.po = torch, g, dist, rank, world, local, multi, po
@@ -169,6 +175,8 @@ class Job:
         plan = torch.zeros(2, dtype=torch.int64, device=f"cuda:{local}")
         if rank == 0:
             head = po.stream_slice(c, self.nsf, self.seed, 0, po.STREAM_LEAD_IN + 360 * L)
+            if cfo:
+                head = add_cfo(head, cfo, c.N, 0)
             if snr is not None:
                 self.ref_power = float(np.mean(np.abs(head[po.STREAM_LEAD_IN:po.STREAM_LEAD_IN + 100000]) ** 2))
                 head = add_awgn(head, snr, 5, self.ref_power)
@@ -196,6 +204,8 @@ class Job:
         self.pieces = []
         for i, cu in enumerate(mine):
             iq = po.stream_slice(c, self.nsf, self.seed, cu["begin"], cu["end"])       # only this rank's part of THE stream
+            if cfo:
+                iq = add_cfo(iq, cfo, c.N, cu["begin"])
             if snr is not None:
                 iq = add_awgn(iq, snr, 1000 + rank * nseg + i, self.ref_power)
             kw = {"soft_decision": 1} if soft else {}
@@ -347,9 +357,12 @@ def extra_workloads(a, torch, g, local):
         pipeline = a.pipeline
     res = {}
     # last line: the opt-in soft-decision mode (k_soft.hpp, k_soft4.hpp; no reference counterpart, no parity claim) on the headline configuration
-    for name, wl, snr, nsf, steps, soft in (("config2_2k_qam16_1_2", "2k_qam16_1_2", None, 64, 400, False), ("config5_8k_qpsk_7_8_awgn14", "8k_qpsk_7_8", 14.0, 16, 400, False),
-                                            ("soft_decision_8k_qam64_7_8", "8k_qam64_7_8", None, 32, 100, True)):
-        job = Job(A, torch, g, None, 0, 1, local, wl, nsf, snr=snr, soft=soft)
+    # and the headline configuration on what a capture looks like: a carrier offset of 0.2 subcarrier spacings (the float-accumulator path of k_drift.hpp,
+    # the DRIFT instantiation of the symbol kernel) and 25 dB of noise
+    for name, wl, snr, nsf, steps, soft, cfo in (("config2_2k_qam16_1_2", "2k_qam16_1_2", None, 64, 400, False, 0.0), ("config5_8k_qpsk_7_8_awgn14", "8k_qpsk_7_8", 14.0, 16, 400, False, 0.0),
+                                                 ("soft_decision_8k_qam64_7_8", "8k_qam64_7_8", None, 32, 100, True, 0.0),
+                                                 ("8k_qam64_7_8_cfo_0.2_awgn25", "8k_qam64_7_8", 25.0, 32, 100, False, 0.2)):
+        job = Job(A, torch, g, None, 0, 1, local, wl, nsf, snr=snr, soft=soft, cfo=cfo)
         dt = timed_run(job, steps, 3)
         chk = job.verify()
         res[name] = {"value": round(job.n_total * steps / dt / 1e6, 2), "unit": "Msamples/s", "x_realtime": round(job.n_total * steps / dt / 1e6 / REALTIME_MSPS, 1),

@@ -263,7 +263,7 @@ struct dvbt_rx {
   hipEvent_t ev[ST_COUNT]; double acc_ms[ST_COUNT] = {0}; long n_timed = 0; bool ev_ready = false, ev_recorded = false;
   dvbt_rx_report last; bool have_last = false;
   dvbt_rx_cut cut = {0};
-  float2 *tps_prev = nullptr, *tps_prev_snap = nullptr; TpsState *tps_snap = nullptr; DescrRun *descr_runs = nullptr; int *descr_nruns = nullptr;
+  float2 *tps_prev = nullptr, *tps_prev_snap[2] = {nullptr, nullptr}; TpsState *tps_snap[2] = {nullptr, nullptr}; DescrRun *descr_runs = nullptr; int *descr_nruns = nullptr;
   int n_periods = 1; size_t seg_offset = 0;
   std::vector<dvbt_lock_period> periods;    // phase A of the last synchronous run
   DriftBufs drift = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; double *drift_mem = nullptr;   // k_drift.hpp
@@ -273,7 +273,7 @@ struct dvbt_rx {
 
 static void rx_free(dvbt_rx *h)
 {
-  void *all[] = {h->tps_prev_snap, h->tps_snap, h->csi, h->soft_a, h->soft_tab, h->soft_scratch, h->rs_defer, h->drift_mem, h->drift.delta, h->drift.flags, h->tps_prev, h->descr_runs, h->descr_nruns, h->centre, h->anchor_pos, h->sym_ticket, h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags, h->trk_eps, h->d_iq, h->rs_iq, h->acq_carry, h->g_init, h->l_init, h->g_trk, h->l_trk, h->meta, h->st, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
+  void *all[] = {h->tps_prev_snap[0], h->tps_prev_snap[1], h->tps_snap[0], h->tps_snap[1], h->csi, h->soft_a, h->soft_tab, h->soft_scratch, h->rs_defer, h->drift_mem, h->drift.delta, h->drift.flags, h->tps_prev, h->descr_runs, h->descr_nruns, h->centre, h->anchor_pos, h->sym_ticket, h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags, h->trk_eps, h->d_iq, h->rs_iq, h->acq_carry, h->g_init, h->l_init, h->g_trk, h->l_trk, h->meta, h->st, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
                  h->info, h->maj, h->sym_index, h->labels, h->symdeint_tap, h->bitdeint, h->vit, h->deint_tap, h->rs_out, h->ts_out};
   for (void *q : all) if (q) (void)hipFree(q);
   if (h->st_host) (void)hipHostFree(h->st_host);
@@ -318,7 +318,7 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   RXHIP(hipMalloc((void **)&h->trk_cp_a, sizeof(int) * C)); RXHIP(hipMalloc((void **)&h->trk_cp_b, sizeof(int) * C));
   RXHIP(hipMalloc((void **)&h->trk_eps, sizeof(float) * C)); RXHIP(hipMalloc((void **)&h->trk_flags, sizeof(int) * 16));
   RXHIP(hipMalloc((void **)&h->tps_prev, sizeof(float2) * d.n_tps)); RXHIP(hipMemset(h->tps_prev, 0, sizeof(float2) * d.n_tps));
-  RXHIP(hipMalloc((void **)&h->tps_prev_snap, sizeof(float2) * d.n_tps)); RXHIP(hipMalloc((void **)&h->tps_snap, sizeof(TpsState)));
+  for (int i = 0; i < 2; i++) { RXHIP(hipMalloc((void **)&h->tps_prev_snap[i], sizeof(float2) * d.n_tps)); RXHIP(hipMalloc((void **)&h->tps_snap[i], sizeof(TpsState))); }
   RXHIP(hipMalloc((void **)&h->descr_runs, sizeof(DescrRun) * DESCR_MAX_RUNS)); RXHIP(hipMalloc((void **)&h->descr_nruns, sizeof(int)));
   RXHIP(hipMalloc((void **)&h->centre, sizeof(int) * (C + 1))); RXHIP(hipMalloc((void **)&h->anchor_pos, sizeof(int) * (C / ACQ_ANCHOR + 4)));
   RXHIP(hipMalloc((void **)&h->tps_edges, sizeof(TpsEdge) * (C / TPS_SEG + 2))); RXHIP(hipMalloc((void **)&h->st, sizeof(RxState)));
@@ -499,7 +499,13 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
     // every kernel returns at once when the lock period has no usable carrier offset (drift.flags, device side: no host round trip)
     const DriftBufs &D = h->drift;
     hipLaunchKernelGGL(drift_prep_kernel, dim3((C + 255) / 256), dim3(256), 0, s, fp, (const RxState *)h->st, (const SymMeta *)h->meta, D);
-    hipLaunchKernelGGL(drift_solve_kernel, dim3(1), dim3(1024), 0, s, fp, (const RxState *)h->st, (const SymMeta *)h->meta, D);
+    hipLaunchKernelGGL(drift_exact_kernel, dim3(1), dim3(1024), 0, s, fp, (const RxState *)h->st, (const SymMeta *)h->meta, D);
+    // three rounds of the fixed point (d ping-pongs between D.d and D.S), then the prefix sums S the table kernel reads
+    const dim3 rg((C + 255) / 256);
+    hipLaunchKernelGGL(drift_round_kernel<0>, rg, dim3(256), 0, s, fp, (const RxState *)h->st, (const SymMeta *)h->meta, D, (const double *)nullptr, D.d);
+    hipLaunchKernelGGL(drift_round_kernel<1>, rg, dim3(256), 0, s, fp, (const RxState *)h->st, (const SymMeta *)h->meta, D, (const double *)D.d, D.S);
+    hipLaunchKernelGGL(drift_round_kernel<1>, rg, dim3(256), 0, s, fp, (const RxState *)h->st, (const SymMeta *)h->meta, D, (const double *)D.S, D.d);
+    hipLaunchKernelGGL(drift_round_kernel<2>, rg, dim3(256), 0, s, fp, (const RxState *)h->st, (const SymMeta *)h->meta, D, (const double *)D.d, D.S);
     hipLaunchKernelGGL(drift_table_kernel, dim3(C), dim3(N / 32 < 256 ? N / 32 : 256), 0, s, fp, (const RxState *)h->st, (const SymMeta *)h->meta, D);
   }
   const bool taps = h->acq_tap || h->fft_out || h->eq;
@@ -664,10 +670,11 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
   // what the decode of the periods accumulates
   struct Book {
     size_t acc = 0; int delivering = 0, processed = 0; bool any = false; dvbt_rx_report first_rep; RxState last_st; int total_symbols = 0; size_t last_off = 0;
-  } bk, snap;
+  } bk, snap[2];
   memset(&bk.first_rep, 0, sizeof bk.first_rep); bk.first_rep.first_out_symbol = -1;
   memset(&bk.last_st, 0, sizeof bk.last_st); bk.last_st.first_out = -1; bk.last_st.status = 1;
-  int snap_period = -1;                                           // the last decoded period: `snap` and the device-side copies of the pilot engine's state were taken in front of it
+  int snap_period[2] = {-1, -1}, sn = 0;                          // the last two decoded periods: snap[] and the device-side copies of the pilot engine's state were taken in front of
+                                                                  // them (snap[sn]: the last one, snap[sn ^ 1]: the one before)
   // one period through the chain up to the Viterbi decoder.  later: a later period delivers items (the last item of this one leaves the demodulator too);
   // reuse: the acquisition results of the acq_only run just before are still in the handle (the period is decoded right behind its discovery)
   auto decode = [&](size_t p, bool later, bool reuse) -> int {
@@ -727,9 +734,9 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
       // LATER period having items: a period that ends in a lost lock is decoded as if one did (corrected behind the walk if none does); a lock that
       // holds to the segment's end makes the last period.
       if (st.n_symbols - (lost ? 0 : 1) >= 1) {                  // it will be decoded: keep the state in front of it
-        snap = bk; snap_period = (int)per.size() - 1;
-        HIPCHK(hipMemcpyAsync(h->tps_snap, h->tps_state, sizeof(TpsState), hipMemcpyDeviceToDevice, s));
-        HIPCHK(hipMemcpyAsync(h->tps_prev_snap, h->tps_prev, sizeof(float2) * d.n_tps, hipMemcpyDeviceToDevice, s));
+        sn ^= 1; snap[sn] = bk; snap_period[sn] = (int)per.size() - 1;
+        HIPCHK(hipMemcpyAsync(h->tps_snap[sn], h->tps_state, sizeof(TpsState), hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(h->tps_prev_snap[sn], h->tps_prev, sizeof(float2) * d.n_tps, hipMemcpyDeviceToDevice, s));
       }
       { int r = decode(per.size() - 1, lost, true); if (r) return r; }
       if (!lost) break;                                           // the lock held to the end of the segment
@@ -742,23 +749,27 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
     // whether a later one has items.  Both are in order when the last period's lock held to the segment's end (the common case: its decode was the last
     // launch).  A last decoded period that ended in a lost lock has had searches launched behind it (and, if no period with items follows, was decoded
     // with an item too many): it is decoded again from the state kept in front of it, acquisition included.  Should that leave nothing to decode
-    // (a single item, not delivered after all) while earlier periods were decoded, all periods are decoded again in order, each with its own acquisition.
-    if (snap_period >= 0 && per[(size_t)snap_period].lost) {
-      const size_t z = (size_t)snap_period;
-      const bool later = last_items > snap_period;
-      bk = snap;
-      HIPCHK(hipMemcpyAsync(h->tps_state, h->tps_snap, sizeof(TpsState), hipMemcpyDeviceToDevice, s));
-      HIPCHK(hipMemcpyAsync(h->tps_prev, h->tps_prev_snap, sizeof(float2) * d.n_tps, hipMemcpyDeviceToDevice, s));
+    // (a single item, not delivered after all), the period decoded before it is decoded again instead (the state in front of the last TWO is kept).
+    auto again = [&](int k) -> int {                              // period snap_period[k] once more, from the state in front of it, acquisition included
+      const size_t z = (size_t)snap_period[k];
+      bk = snap[k];
+      HIPCHK(hipMemcpyAsync(h->tps_state, h->tps_snap[k], sizeof(TpsState), hipMemcpyDeviceToDevice, s));
+      HIPCHK(hipMemcpyAsync(h->tps_prev, h->tps_prev_snap[k], sizeof(float2) * d.n_tps, hipMemcpyDeviceToDevice, s));
       h->periods[z].first_out_symbol = 0;
-      const int before = bk.processed;
-      int r = decode(z, later, false); if (r) return r;
+      int r = decode(z, last_items > (int)z, false); if (r) return r;
       for (size_t q = z + 1; q < per.size(); q++) bk.total_symbols += per[q].n_symbols;
+      return DVBT_OK;
+    };
+    if (snap_period[sn] >= 0 && per[(size_t)snap_period[sn]].lost) {
+      const int before = snap[sn].processed;
+      { int r = again(sn); if (r) return r; }
       if (bk.processed == before && before > 0) {
-        bk = Book(); memset(&bk.first_rep, 0, sizeof bk.first_rep); bk.first_rep.first_out_symbol = -1;
-        memset(&bk.last_st, 0, sizeof bk.last_st); bk.last_st.first_out = -1; bk.last_st.status = 1;
-        for (size_t q = 0; q < per.size(); q++) {
-          h->periods[q].first_out_symbol = 0;
-          int rr = decode(q, last_items > (int)q, false); if (rr) return rr;
+        // the last period's single item is not delivered after all: the period decoded before it is the last one, and its device-side state is stale too
+        if (snap_period[sn ^ 1] >= 0) { int r = again(sn ^ 1); if (r) return r; }
+        else {                                                     // (cannot happen: `before` > 0 means an earlier period was decoded)
+          bk = Book(); memset(&bk.first_rep, 0, sizeof bk.first_rep); bk.first_rep.first_out_symbol = -1;
+          memset(&bk.last_st, 0, sizeof bk.last_st); bk.last_st.first_out = -1; bk.last_st.status = 1;
+          for (size_t q = 0; q < per.size(); q++) { h->periods[q].first_out_symbol = 0; int rr = decode(q, last_items > (int)q, false); if (rr) return rr; }
         }
       }
     }

@@ -32,7 +32,7 @@ namespace dvbt {
 #if defined(__HIPCC__)
 // ------------------------------------------------------------------------------------------------ kernels (segment path)
 // scratch layout (doubles): tabs[C][DRIFT_TAB] | ex_run[C] | ex_entry[C] | d[C] | S[C] | A0[1]
-struct DriftBufs { double *tabs, *ex_run, *ex_entry, *d, *S, *A0; float *delta; int *flags; };   // flags[0]: sign / validity bits (collected by drift_prep_kernel, cleared by drift_solve_kernel), flags[1]: 1 = applied, flags[2]: 1 = negative increments
+struct DriftBufs { double *tabs, *ex_run, *ex_entry, *d, *S, *A0; float *delta; int *flags; };   // flags[0]: sign / validity bits (collected by drift_prep_kernel, cleared by drift_exact_kernel), flags[1]: 1 = applied, flags[2]: 1 = negative increments
 
 __device__ __forceinline__ void drift_load(const double *tabs, int r, double *q, double *tc)
 {
@@ -76,9 +76,9 @@ __device__ __forceinline__ double drift_phi_run(const DriftBufs &B, const SymMet
   return drift_Tinv(q, tc, neg, B.A0[0] + steps - B.S[r - 1]);
 }
 
-// One workgroup: (1) the exact (unrounded) accumulated phase at every call entry and run start, a prefix sum in double over the calls; (2) three rounds of
-// the fixed point: d_r = T_{r-1}(phi_r) - T_r(phi_r) at the previous round's phases (r >= 1), S_r = d_1 + ... + d_r.  A thread owns a run of consecutive calls.
-__global__ __launch_bounds__(1024) void drift_solve_kernel(FrontParams p, const RxState *st, const SymMeta *__restrict__ meta, DriftBufs B)
+// One workgroup: the exact (unrounded) accumulated phase at every call entry and run start, a prefix sum in double over the calls (a thread owns a run of
+// consecutive calls); decides whether the period is inside the model and says so to the kernels behind (flags[1], flags[2]).
+__global__ __launch_bounds__(1024) void drift_exact_kernel(FrontParams p, const RxState *st, const SymMeta *__restrict__ meta, DriftBufs B)
 {
   __shared__ double s_tot[1024];
   const int tid = threadIdx.x, nsym = st->n_symbols, L = p.N + p.cp;
@@ -89,46 +89,61 @@ __global__ __launch_bounds__(1024) void drift_solve_kernel(FrontParams p, const 
   if (!on) return;
   const bool neg = fl == 2;
   const int per = (nsym + 1023) / 1024, sbeg = tid * per, cnt = sbeg >= nsym ? 0 : (nsym - sbeg < per ? nsym - sbeg : per);
-  auto scan = [&](double local) -> double {   // exclusive prefix of the threads' sums
-    s_tot[tid] = local;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) { const double v = tid >= off ? s_tot[tid - off] : 0.0; __syncthreads(); s_tot[tid] += v; __syncthreads(); }
-    const double base = tid == 0 ? 0.0 : s_tot[tid - 1];
-    __syncthreads();
-    return base;
-  };
-  {
-    double local = 0.0;
-    for (int i = 0; i < cnt; i++) { const SymMeta m = meta[sbeg + i]; local += m.sw * m.incA + (L - m.sw) * m.incB; }
-    double base = scan(local);
-    for (int i = 0; i < cnt; i++) {
-      const SymMeta m = meta[sbeg + i];
-      B.ex_entry[sbeg + i] = base; B.ex_run[sbeg + i] = base + m.sw * m.incA;
-      base += m.sw * m.incA + (L - m.sw) * m.incB;
-    }
-    if (tid == 0) { double q[DRIFT_NR], tc[DRIFT_NR + 1]; drift_load(B.tabs, 0, q, tc); B.A0[0] = drift_T(q, tc, neg, 0.0); }   // run 0 starts at phase 0 (increment 0 before it)
+  double local = 0.0;
+  for (int i = 0; i < cnt; i++) { const SymMeta m = meta[sbeg + i]; local += m.sw * m.incA + (L - m.sw) * m.incB; }
+  s_tot[tid] = local;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) { const double v = tid >= off ? s_tot[tid - off] : 0.0; __syncthreads(); s_tot[tid] += v; __syncthreads(); }
+  double base = tid == 0 ? 0.0 : s_tot[tid - 1];
+  for (int i = 0; i < cnt; i++) {
+    const SymMeta m = meta[sbeg + i];
+    B.ex_entry[sbeg + i] = base; B.ex_run[sbeg + i] = base + m.sw * m.incA;
+    base += m.sw * m.incA + (L - m.sw) * m.incB;
   }
-  __threadfence_block(); __syncthreads();
-  for (int it = 0; it < 3; it++) {
-    double local = 0.0;
-    for (int i = 0; i < cnt; i++) {
-      const int r = sbeg + i;
-      double dr = 0.0;
-      if (r >= 1) {
-        const double phi = drift_phi_run(B, meta, r, L, neg, it == 0);
-        double q[DRIFT_NR], tc[DRIFT_NR + 1];
-        drift_load(B.tabs, r - 1, q, tc);
-        const double a = drift_T(q, tc, neg, phi);
-        drift_load(B.tabs, r, q, tc);
-        dr = a - drift_T(q, tc, neg, phi);
-      }
-      B.d[r] = dr; local += dr;
-    }
-    __syncthreads();                                              // every S of the previous round has been read
-    double base = scan(local);
-    for (int i = 0; i < cnt; i++) { base += B.d[sbeg + i]; B.S[sbeg + i] = base; }
-    __threadfence_block(); __syncthreads();
+  if (tid == 0) { double q[DRIFT_NR], tc[DRIFT_NR + 1]; drift_load(B.tabs, 0, q, tc); B.A0[0] = drift_T(q, tc, neg, 0.0); }   // run 0 starts at phase 0 (increment 0 before it)
+}
+
+// One round of the fixed point, a thread per run, 256 runs per workgroup (the single-workgroup version of round 3's first build spent 0.4 ms on 4,624
+// calls -- 1.5 ms on a 65-superframe segment -- loading three 31-double tables per run and round on ONE compute unit):
+//   d_r = T_{r-1}(phi_r) - T_r(phi_r) at the previous round's phases (MODE 0: the exact line), S_r = d_1 + ... + d_r.
+// The prefix S of the previous round's d is formed here: the workgroup sums everything in front of its 256 runs (at most nsym doubles from L2) and scans
+// its own.  MODE 2: that prefix alone, written out for drift_table_kernel.  d_prev / d_next ping-pong between B.d and B.S.
+template <int MODE> __global__ __launch_bounds__(256) void drift_round_kernel(FrontParams p, const RxState *st, const SymMeta *__restrict__ meta, DriftBufs B,
+                                                                              const double *__restrict__ d_prev, double *__restrict__ d_next)
+{
+  __shared__ double s_red[256];
+  if (!B.flags[1]) return;
+  const int tid = threadIdx.x, nsym = st->n_symbols, L = p.N + p.cp, base = blockIdx.x * 256, r = base + tid;
+  if (base >= nsym) return;
+  const bool neg = B.flags[2] != 0;
+  double s_before = 0.0;                                          // S_{r-1} of the previous round
+  if (MODE != 0) {
+    double acc = 0.0;
+    for (int i = tid; i < base; i += 256) acc += d_prev[i];
+    s_red[tid] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) s_red[tid] += s_red[tid + o]; __syncthreads(); }
+    const double front = s_red[0];
+    __syncthreads();
+    const double v = r < nsym ? d_prev[r] : 0.0;
+    s_red[tid] = v;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) { const double u = tid >= off ? s_red[tid - off] : 0.0; __syncthreads(); s_red[tid] += u; __syncthreads(); }
+    const double incl = front + s_red[tid];
+    s_before = incl - v;
+    if (MODE == 2) { if (r < nsym) d_next[r] = incl; return; }
   }
+  if (r >= nsym) return;
+  double dr = 0.0;
+  if (r >= 1) {
+    double q[DRIFT_NR], tc[DRIFT_NR + 1];
+    drift_load(B.tabs, r - 1, q, tc);
+    const double phi = MODE == 0 ? B.ex_run[r] : drift_Tinv(q, tc, neg, B.A0[0] + ((double)r * L + meta[r].sw - meta[0].sw) - s_before);
+    const double a = drift_T(q, tc, neg, phi);
+    drift_load(B.tabs, r, q, tc);
+    dr = a - drift_T(q, tc, neg, phi);
+  }
+  d_next[r] = dr;
 }
 
 // one workgroup per call, one thread per 32-sample block of the item: delta[s][k] = (float phase - exact line) after step 32 k + 17, relative to the call's entry

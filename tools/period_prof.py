@@ -1,5 +1,5 @@
 """BASELINE config 5 at the prescribed noise (8k QPSK 7/8, 8 dB by default) through the synchronous entry, for rocprofv3 and for wall-clock timing:
-`python tools/period_prof.py [snr_db] [superframes] [runs]` prints the time per run and the lock structure."""
+`python tools/period_prof.py [snr_db] [superframes] [runs] [stream seed]` prints the time per run and the lock structure."""
 import json
 import os
 import sys
@@ -15,8 +15,9 @@ import gr_dvbt_amd as g
 snr = float(sys.argv[1]) if len(sys.argv) > 1 else 8.0
 nsf = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 runs = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+seed = int(sys.argv[4]) if len(sys.argv) > 4 else 21
 c = po.cfg(g.QPSK, g.C7_8, g.T8k)
-iq = po.channel(po.stream_slice(c, nsf, 21), c.N, snr_db=snr, seed=5)
+iq = po.channel(po.stream_slice(c, nsf, seed), c.N, snr_db=snr, seed=5)
 dev = torch.from_numpy(iq.view(np.float32)).cuda()
 torch.cuda.synchronize()
 rx = g.Rx(g.QPSK, g.C7_8, g.T8k, max_samples=len(iq), snr_db=snr)
