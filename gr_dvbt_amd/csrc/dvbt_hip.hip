@@ -673,6 +673,7 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
   } bk, snap[2];
   memset(&bk.first_rep, 0, sizeof bk.first_rep); bk.first_rep.first_out_symbol = -1;
   memset(&bk.last_st, 0, sizeof bk.last_st); bk.last_st.first_out = -1; bk.last_st.status = 1;
+  bool snap_assumed[2] = {false, false};                          // ... and were decoded on the assumption that a later period has items
   int snap_period[2] = {-1, -1}, sn = 0;                          // the last two decoded periods: snap[] and the device-side copies of the pilot engine's state were taken in front of
                                                                   // them (snap[sn]: the last one, snap[sn ^ 1]: the one before)
   // one period through the chain up to the Viterbi decoder.  later: a later period delivers items (the last item of this one leaves the demodulator too);
@@ -715,6 +716,7 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
       size_t look_calls = 767;
       if (!per.empty()) look_calls = std::min<size_t>(767, std::max<size_t>(47, 4 * (size_t)std::max(per.back().n_symbols, 0)));
       size_t look = std::min(chain_n - off, win + look_calls * L);
+      if (guard == 0) look = chain_n - off;                       // the very first attempt takes the whole segment: a lock that holds to its end (the usual case) is one pass
       for (;;) {
         int r = enqueue(h, chain + off, look, s, o); if (r) return r;
         HIPCHK(hipStreamSynchronize(s));
@@ -732,14 +734,16 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
       h->periods.push_back(dvbt_lock_period{(int64_t)off, st.call0, st.cp_start0, st.n_symbols, 0});
       // Decoded at once, on the acquisition results that are still in the handle.  Whether the period's last item leaves the demodulator depends on a
       // LATER period having items: a period that ends in a lost lock is decoded as if one did (corrected behind the walk if none does); a lock that
-      // holds to the segment's end makes the last period.
-      if (st.n_symbols - (lost ? 0 : 1) >= 1) {                  // it will be decoded: keep the state in front of it
-        sn ^= 1; snap[sn] = bk; snap_period[sn] = (int)per.size() - 1;
+      // holds to the segment's end -- or is lost only where the samples run out -- makes the last period.
+      // a lock that is lost where the samples run out (no room for another window behind it) ends the walk like one that holds to the end
+      const bool final_period = !lost || off + (size_t)(st.call0 + st.n_symbols) * L + L / 2 + win > chain_n;
+      if (st.n_symbols - (final_period ? 1 : 0) >= 1) {          // it will be decoded: keep the state in front of it
+        sn ^= 1; snap[sn] = bk; snap_period[sn] = (int)per.size() - 1; snap_assumed[sn] = !final_period;
         HIPCHK(hipMemcpyAsync(h->tps_snap[sn], h->tps_state, sizeof(TpsState), hipMemcpyDeviceToDevice, s));
         HIPCHK(hipMemcpyAsync(h->tps_prev_snap[sn], h->tps_prev, sizeof(float2) * d.n_tps, hipMemcpyDeviceToDevice, s));
       }
-      { int r = decode(per.size() - 1, lost, true); if (r) return r; }
-      if (!lost) break;                                           // the lock held to the end of the segment
+      { int r = decode(per.size() - 1, !final_period, true); if (r) return r; }
+      if (final_period) break;                                    // the lock held to the end of the segment (or to where its samples end)
       off += (size_t)(st.call0 + st.n_symbols) * L + L / 2; avg = st.avg_lost; carry = true;
       if (per.size() >= 1024) { capped = true; break; }
     }
@@ -760,7 +764,7 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
       for (size_t q = z + 1; q < per.size(); q++) bk.total_symbols += per[q].n_symbols;
       return DVBT_OK;
     };
-    if (snap_period[sn] >= 0 && per[(size_t)snap_period[sn]].lost) {
+    if (snap_period[sn] >= 0 && snap_assumed[sn]) {
       const int before = snap[sn].processed;
       { int r = again(sn); if (r) return r; }
       if (bk.processed == before && before > 0) {
