@@ -263,7 +263,7 @@ struct dvbt_rx {
   hipEvent_t ev[ST_COUNT]; double acc_ms[ST_COUNT] = {0}; long n_timed = 0; bool ev_ready = false, ev_recorded = false;
   dvbt_rx_report last; bool have_last = false;
   dvbt_rx_cut cut = {0};
-  float2 *tps_prev = nullptr, *tps_prev_snap[2] = {nullptr, nullptr}; TpsState *tps_snap[2] = {nullptr, nullptr}; DescrRun *descr_runs = nullptr; int *descr_nruns = nullptr;
+  float2 *tps_prev = nullptr, *tps_prev_snap[2] = {nullptr, nullptr}; TpsState *tps_snap[2] = {nullptr, nullptr}; RxState *st_saved = nullptr; DescrRun *descr_runs = nullptr; int *descr_nruns = nullptr;
   int n_periods = 1; size_t seg_offset = 0;
   std::vector<dvbt_lock_period> periods;    // phase A of the last synchronous run
   DriftBufs drift = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; double *drift_mem = nullptr;   // k_drift.hpp
@@ -273,7 +273,7 @@ struct dvbt_rx {
 
 static void rx_free(dvbt_rx *h)
 {
-  void *all[] = {h->tps_prev_snap[0], h->tps_prev_snap[1], h->tps_snap[0], h->tps_snap[1], h->csi, h->soft_a, h->soft_tab, h->soft_scratch, h->rs_defer, h->drift_mem, h->drift.delta, h->drift.flags, h->tps_prev, h->descr_runs, h->descr_nruns, h->centre, h->anchor_pos, h->sym_ticket, h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags, h->trk_eps, h->d_iq, h->rs_iq, h->acq_carry, h->g_init, h->l_init, h->g_trk, h->l_trk, h->meta, h->st, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
+  void *all[] = {h->st_saved, h->tps_prev_snap[0], h->tps_prev_snap[1], h->tps_snap[0], h->tps_snap[1], h->csi, h->soft_a, h->soft_tab, h->soft_scratch, h->rs_defer, h->drift_mem, h->drift.delta, h->drift.flags, h->tps_prev, h->descr_runs, h->descr_nruns, h->centre, h->anchor_pos, h->sym_ticket, h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags, h->trk_eps, h->d_iq, h->rs_iq, h->acq_carry, h->g_init, h->l_init, h->g_trk, h->l_trk, h->meta, h->st, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
                  h->info, h->maj, h->sym_index, h->labels, h->symdeint_tap, h->bitdeint, h->vit, h->deint_tap, h->rs_out, h->ts_out};
   for (void *q : all) if (q) (void)hipFree(q);
   if (h->st_host) (void)hipHostFree(h->st_host);
@@ -318,6 +318,7 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   RXHIP(hipMalloc((void **)&h->trk_cp_a, sizeof(int) * C)); RXHIP(hipMalloc((void **)&h->trk_cp_b, sizeof(int) * C));
   RXHIP(hipMalloc((void **)&h->trk_eps, sizeof(float) * C)); RXHIP(hipMalloc((void **)&h->trk_flags, sizeof(int) * 16));
   RXHIP(hipMalloc((void **)&h->tps_prev, sizeof(float2) * d.n_tps)); RXHIP(hipMemset(h->tps_prev, 0, sizeof(float2) * d.n_tps));
+  RXHIP(hipMalloc((void **)&h->st_saved, sizeof(RxState)));
   for (int i = 0; i < 2; i++) { RXHIP(hipMalloc((void **)&h->tps_prev_snap[i], sizeof(float2) * d.n_tps)); RXHIP(hipMalloc((void **)&h->tps_snap[i], sizeof(TpsState))); }
   RXHIP(hipMalloc((void **)&h->descr_runs, sizeof(DescrRun) * DESCR_MAX_RUNS)); RXHIP(hipMalloc((void **)&h->descr_nruns, sizeof(int)));
   RXHIP(hipMalloc((void **)&h->centre, sizeof(int) * (C + 1))); RXHIP(hipMalloc((void **)&h->anchor_pos, sizeof(int) * (C / ACQ_ANCHOR + 4)));
@@ -674,6 +675,9 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
   memset(&bk.first_rep, 0, sizeof bk.first_rep); bk.first_rep.first_out_symbol = -1;
   memset(&bk.last_st, 0, sizeof bk.last_st); bk.last_st.first_out = -1; bk.last_st.status = 1;
   bool snap_assumed[2] = {false, false};                          // ... and were decoded on the assumption that a later period has items
+  bool need_full = false;
+  int clobber = 0;                                                // launched behind the last decode: 0 nothing, 1 searches that found nothing (they write the state block
+                                                                  // and scratch only), 2 an acquisition that found a period (tracker results, symbol bookkeeping)
   int snap_period[2] = {-1, -1}, sn = 0;                          // the last two decoded periods: snap[] and the device-side copies of the pilot engine's state were taken in front of
                                                                   // them (snap[sn]: the last one, snap[sn ^ 1]: the one before)
   // one period through the chain up to the Viterbi decoder.  later: a later period delivers items (the last item of this one leaves the demodulator too);
@@ -716,7 +720,9 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
       size_t look_calls = 767;
       if (!per.empty()) look_calls = std::min<size_t>(767, std::max<size_t>(47, 4 * (size_t)std::max(per.back().n_symbols, 0)));
       size_t look = std::min(chain_n - off, win + look_calls * L);
-      if (guard == 0) look = chain_n - off;                       // the very first attempt takes the whole segment: a lock that holds to its end (the usual case) is one pass
+      // the first attempts take the whole rest of the segment: a lock that holds to its end (the usual case, possibly behind a start-up transient of a
+      // few symbols) is one pass; only a stream that keeps losing the lock goes over to the short windows
+      if (per.size() < 3 && guard < 8) look = chain_n - off;
       for (;;) {
         int r = enqueue(h, chain + off, look, s, o); if (r) return r;
         HIPCHK(hipStreamSynchronize(s));
@@ -727,8 +733,12 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
       const int tries = (int)std::min<size_t>(ACQ_INIT_TRIES, (chain_n - off - win) / L + 1);
       if (st.status & 1) {                                       // no peak in these windows: the reference consumes them one by one and searches on
         off += (size_t)tries * L; avg = st.avg; carry = true;
+        if (clobber < 1) clobber = 1;
         continue;
       }
+      clobber = 2;
+      // a period with items behind one that was decoded as the last one (the guess near the segment's end, below): everything is decoded again in order
+      if (st.n_symbols >= 1 && snap_period[sn] >= 0 && !snap_assumed[sn]) need_full = true;
       const bool lost = (st.status & 2) != 0;
       per.push_back(LockPeriod{off, st.n_symbols, avg, carry, st.call0, st.cp_start0, lost});
       h->periods.push_back(dvbt_lock_period{(int64_t)off, st.call0, st.cp_start0, st.n_symbols, 0});
@@ -736,13 +746,18 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
       // LATER period having items: a period that ends in a lost lock is decoded as if one did (corrected behind the walk if none does); a lock that
       // holds to the segment's end -- or is lost only where the samples run out -- makes the last period.
       // a lock that is lost where the samples run out (no room for another window behind it) ends the walk like one that holds to the end
-      const bool final_period = !lost || off + (size_t)(st.call0 + st.n_symbols) * L + L / 2 + win > chain_n;
-      if (st.n_symbols - (final_period ? 1 : 0) >= 1) {          // it will be decoded: keep the state in front of it
-        sn ^= 1; snap[sn] = bk; snap_period[sn] = (int)per.size() - 1; snap_assumed[sn] = !final_period;
+      const size_t behind = off + (size_t)(st.call0 + st.n_symbols) * L + L / 2;
+      const bool final_period = !lost || behind + win > chain_n;
+      // ... and with less than 16 symbols left behind the first or second loss of a segment a later period with items is the less likely outcome (a stream
+      // that simply ends; where the lock is being lost all the time, another short period is the likely one)
+      const bool later_guess = !final_period && !(per.size() <= 2 && behind + win + 16 * L > chain_n);
+      if (st.n_symbols - (later_guess ? 0 : 1) >= 1) {           // it will be decoded: keep the state in front of it
+        sn ^= 1; snap[sn] = bk; snap_period[sn] = (int)per.size() - 1; snap_assumed[sn] = later_guess;
         HIPCHK(hipMemcpyAsync(h->tps_snap[sn], h->tps_state, sizeof(TpsState), hipMemcpyDeviceToDevice, s));
         HIPCHK(hipMemcpyAsync(h->tps_prev_snap[sn], h->tps_prev, sizeof(float2) * d.n_tps, hipMemcpyDeviceToDevice, s));
       }
-      { int r = decode(per.size() - 1, !final_period, true); if (r) return r; }
+      { const int before = bk.processed; int r = decode(per.size() - 1, later_guess, true); if (r) return r;
+        if (bk.processed > before) { clobber = 0; HIPCHK(hipMemcpyAsync(h->st_saved, h->st, sizeof(RxState), hipMemcpyDeviceToDevice, s)); } }
       if (final_period) break;                                    // the lock held to the end of the segment (or to where its samples end)
       off += (size_t)(st.call0 + st.n_symbols) * L + L / 2; avg = st.avg_lost; carry = true;
       if (per.size() >= 1024) { capped = true; break; }
@@ -751,8 +766,9 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
     for (size_t q = 0; q < per.size(); q++) if (per[q].n_symbols >= 1) last_items = (int)q;
     // The byte de-interleaver, the RS decoder and the report read the device-side state of the LAST decoded period, and that period's last item depends on
     // whether a later one has items.  Both are in order when the last period's lock held to the segment's end (the common case: its decode was the last
-    // launch).  A last decoded period that ended in a lost lock has had searches launched behind it (and, if no period with items follows, was decoded
-    // with an item too many): it is decoded again from the state kept in front of it, acquisition included.  Should that leave nothing to decode
+    // launch, or the lock was lost where the samples run out).  Behind a last decoded period that ended in a lost lock, launches have followed: if they were
+    // searches that found nothing, its state block is put back from a copy; if an acquisition found a period (without items), or the guess about a later
+    // period with items was wrong, it is decoded again from the state kept in front of it, acquisition included.  Should that leave nothing to decode
     // (a single item, not delivered after all), the period decoded before it is decoded again instead (the state in front of the last TWO is kept).
     auto again = [&](int k) -> int {                              // period snap_period[k] once more, from the state in front of it, acquisition included
       const size_t z = (size_t)snap_period[k];
@@ -764,17 +780,24 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
       for (size_t q = z + 1; q < per.size(); q++) bk.total_symbols += per[q].n_symbols;
       return DVBT_OK;
     };
-    if (snap_period[sn] >= 0 && snap_assumed[sn]) {
+    auto full = [&]() -> int {                                    // every period again in order, each with its own acquisition and the true `later`
+      bk = Book(); memset(&bk.first_rep, 0, sizeof bk.first_rep); bk.first_rep.first_out_symbol = -1;
+      memset(&bk.last_st, 0, sizeof bk.last_st); bk.last_st.first_out = -1; bk.last_st.status = 1;
+      for (size_t q = 0; q < per.size(); q++) { h->periods[q].first_out_symbol = 0; int rr = decode(q, last_items > (int)q, false); if (rr) return rr; }
+      return DVBT_OK;
+    };
+    const bool guess_ok = snap_period[sn] < 0 || snap_assumed[sn] == (last_items > snap_period[sn]);
+    if (need_full) { int r = full(); if (r) return r; }
+    else if (snap_period[sn] >= 0 && guess_ok && clobber == 1) {
+      // only searches that found nothing ran behind the last decode: its state block is put back, everything else of it is untouched
+      HIPCHK(hipMemcpyAsync(h->st, h->st_saved, sizeof(RxState), hipMemcpyDeviceToDevice, s));
+    } else if (snap_period[sn] >= 0 && (!guess_ok || clobber == 2)) {
       const int before = snap[sn].processed;
       { int r = again(sn); if (r) return r; }
       if (bk.processed == before && before > 0) {
         // the last period's single item is not delivered after all: the period decoded before it is the last one, and its device-side state is stale too
         if (snap_period[sn ^ 1] >= 0) { int r = again(sn ^ 1); if (r) return r; }
-        else {                                                     // (cannot happen: `before` > 0 means an earlier period was decoded)
-          bk = Book(); memset(&bk.first_rep, 0, sizeof bk.first_rep); bk.first_rep.first_out_symbol = -1;
-          memset(&bk.last_st, 0, sizeof bk.last_st); bk.last_st.first_out = -1; bk.last_st.status = 1;
-          for (size_t q = 0; q < per.size(); q++) { h->periods[q].first_out_symbol = 0; int rr = decode(q, last_items > (int)q, false); if (rr) return rr; }
-        }
+        else { int r = full(); if (r) return r; }                // (cannot happen: `before` > 0 means an earlier period was decoded)
       }
     }
   }
