@@ -136,8 +136,8 @@ class rx_hip {
  public:
   typedef std::shared_ptr<rx_hip> sptr;
   static sptr make(dvbt_constellation_t constellation, dvbt_hierarchy_t hierarchy, dvbt_code_rate_t code_rate, dvbt_guard_interval_t guard_interval,
-                   dvbt_transmission_mode_t transmission_mode, float snr = 30.0f, int bsize = 768, int segment_superframes = 0)
-  { return sptr(new rx_hip(constellation, hierarchy, code_rate, guard_interval, transmission_mode, snr, bsize, segment_superframes)); }
+                   dvbt_transmission_mode_t transmission_mode, float snr = 30.0f, int bsize = 768, int segment_superframes = 0, bool soft_decision = false)
+  { return sptr(new rx_hip(constellation, hierarchy, code_rate, guard_interval, transmission_mode, snr, bsize, segment_superframes, soft_decision)); }
   ~rx_hip() { if (d_s) dvbt_rx_stream_destroy(d_s); }
   rx_hip(const rx_hip &) = delete;
   void forecast(int, std::vector<int> &ninput_items_required) { for (auto &x : ninput_items_required) x = 1; }
@@ -155,11 +155,11 @@ class rx_hip {
   long long drain(void *out, size_t cap) { const long long n = dvbt_rx_stream_pull(d_s, out, cap); check((int)(n < 0 ? n : 0)); return n; }
   dvbt_rx_stream_info info() const { dvbt_rx_stream_info i; check(dvbt_rx_stream_status(d_s, &i)); return i; }
  private:
-  rx_hip(dvbt_constellation_t c, dvbt_hierarchy_t h, dvbt_code_rate_t r, dvbt_guard_interval_t g, dvbt_transmission_mode_t m, float snr, int bsize, int seg)
+  rx_hip(dvbt_constellation_t c, dvbt_hierarchy_t h, dvbt_code_rate_t r, dvbt_guard_interval_t g, dvbt_transmission_mode_t m, float snr, int bsize, int seg, bool soft)
   {
     dvbt_rx_stream_params p{};
     p.rx.constellation = (int)c; p.rx.hierarchy = (int)h; p.rx.code_rate = (int)r; p.rx.guard_interval = (int)g; p.rx.transmission_mode = (int)m;
-    p.rx.snr_db = snr; p.rx.viterbi_bsize = bsize; p.rx.descramble = 1; p.segment_superframes = seg;
+    p.rx.snr_db = snr; p.rx.viterbi_bsize = bsize; p.rx.descramble = 1; p.rx.soft_decision = soft ? 1 : 0; p.segment_superframes = seg;
     check(dvbt_rx_stream_create(&p, &d_s));
   }
   dvbt_rx_stream *d_s = nullptr;

@@ -20,10 +20,11 @@ namespace gr {
     public:
       typedef boost::shared_ptr<rx_hip> sptr;
       /* snr: ofdm_sym_acquisition's parameter (30 in the demo flowgraphs); bsize: viterbi_decoder's (768);
-       * segment_superframes: superframes decoded per launch sequence (0 = 16) */
+       * segment_superframes: superframes decoded per launch sequence (0 = 16);
+       * soft_decision: soft demapper + soft-input Viterbi instead of the reference's hard decisions (2-3 dB less SNR needed, ~1.6x the time) */
       static sptr make(dvbt_constellation_t constellation, dvbt_hierarchy_t hierarchy, dvbt_code_rate_t code_rate,
                        dvbt_guard_interval_t guard_interval, dvbt_transmission_mode_t transmission_mode,
-                       float snr = 30.0f, int bsize = 768, int segment_superframes = 0);
+                       float snr = 30.0f, int bsize = 768, int segment_superframes = 0, bool soft_decision = false);
     };
 
   } // namespace dvbt

@@ -8,18 +8,18 @@ namespace gr {
 
     rx_hip::sptr
     rx_hip::make(dvbt_constellation_t constellation, dvbt_hierarchy_t hierarchy, dvbt_code_rate_t code_rate, dvbt_guard_interval_t guard_interval,
-                 dvbt_transmission_mode_t transmission_mode, float snr, int bsize, int segment_superframes)
-    { return gnuradio::get_initial_sptr(new rx_hip_impl(constellation, hierarchy, code_rate, guard_interval, transmission_mode, snr, bsize, segment_superframes)); }
+                 dvbt_transmission_mode_t transmission_mode, float snr, int bsize, int segment_superframes, bool soft_decision)
+    { return gnuradio::get_initial_sptr(new rx_hip_impl(constellation, hierarchy, code_rate, guard_interval, transmission_mode, snr, bsize, segment_superframes, soft_decision)); }
 
     rx_hip_impl::rx_hip_impl(dvbt_constellation_t constellation, dvbt_hierarchy_t hierarchy, dvbt_code_rate_t code_rate, dvbt_guard_interval_t guard_interval,
-                             dvbt_transmission_mode_t transmission_mode, float snr, int bsize, int segment_superframes)
+                             dvbt_transmission_mode_t transmission_mode, float snr, int bsize, int segment_superframes, bool soft_decision)
       : block("rx_hip", io_signature::make(1, 1, sizeof(gr_complex)), io_signature::make(1, 1, sizeof(unsigned char))), d_stream(0)
     {
       dvbt_rx_stream_params p;
       p.rx.constellation = (int)constellation; p.rx.hierarchy = (int)hierarchy; p.rx.code_rate = (int)code_rate; p.rx.guard_interval = (int)guard_interval;
       p.rx.transmission_mode = (int)transmission_mode; p.rx.include_cell_id = 0; p.rx.cell_id = 0; p.rx.snr_db = snr; p.rx.viterbi_bsize = bsize;
       p.rx.rs_oracle_compat = 0; p.rx.descramble = 1; p.rx.max_samples = 0; p.rx.device = 0; p.rx.viterbi_chunk_bytes = 0;
-      p.rx.resample_interp = 0; p.rx.resample_decim = 0; p.rx.front_scale = 0.f; p.rx.soft_decision = 0;
+      p.rx.resample_interp = 0; p.rx.resample_decim = 0; p.rx.front_scale = 0.f; p.rx.soft_decision = soft_decision ? 1 : 0;
       p.segment_superframes = segment_superframes; p.rank = 0; p.world = 0;
       if (dvbt_rx_stream_create(&p, &d_stream) < 0) throw std::runtime_error(std::string("libdvbt_hip: ") + dvbt_last_error());
       dvbt_dims d;

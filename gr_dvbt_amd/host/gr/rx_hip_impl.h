@@ -13,7 +13,7 @@ namespace gr {
       ::dvbt_rx_stream *d_stream;
     public:
       rx_hip_impl(dvbt_constellation_t constellation, dvbt_hierarchy_t hierarchy, dvbt_code_rate_t code_rate, dvbt_guard_interval_t guard_interval,
-                  dvbt_transmission_mode_t transmission_mode, float snr, int bsize, int segment_superframes);
+                  dvbt_transmission_mode_t transmission_mode, float snr, int bsize, int segment_superframes, bool soft_decision);
       ~rx_hip_impl();
       void forecast(int noutput_items, gr_vector_int &ninput_items_required);
       int general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &output_items);

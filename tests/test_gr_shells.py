@@ -38,7 +38,7 @@ def test_new_blocks_have_grc_and_swig_glue():
     """dvbt.fft_hip and dvbt.rx_hip are new class names: GRC descriptors and the SWIG lines (pattern: gr-dvbt grc/dvbt_viterbi_decoder.xml:7,
     swig/dvbt_swig.i:53-71) so that they can be placed in a .grc"""
     import xml.etree.ElementTree as ET
-    for name, args in (("fft_hip", 3), ("rx_hip", 8)):
+    for name, args in (("fft_hip", 3), ("rx_hip", 9)):
         t = ET.parse(os.path.join(GR, "grc", f"dvbt_{name}.xml")).getroot()
         assert t.find("key").text == f"dvbt_{name}" and t.find("import").text == "import dvbt"
         mk = t.find("make").text
