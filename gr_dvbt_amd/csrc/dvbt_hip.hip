@@ -253,6 +253,9 @@ struct dvbt_rx {
   AcqState *acq_carry = nullptr; bool use_carry = false;     // peak-detector state carried into a restart after a lost lock   // front-of-chain resample + scale (next row 2): its output buffer
   float2 *g_init = nullptr; float *l_init = nullptr; float2 *g_trk = nullptr; float *l_trk = nullptr;
   SymMeta *meta = nullptr; RxState *st = nullptr, *st_host = nullptr; TpsState *tps_state = nullptr;
+  // two acquisition contexts (state block + per-symbol tracker results): `st` / `meta` point at the one in use.  The lock-period walk searches on in the
+  // other one, so that what the last decoded period left behind stays valid for the byte de-interleaver, the report and the taps (segment_periods)
+  RxState *st_ctx[2] = {nullptr, nullptr}; SymMeta *meta_ctx[2] = {nullptr, nullptr}; int ctx = 0;
   int *trk_cp_a = nullptr, *trk_cp_b = nullptr, *trk_flags = nullptr; float *trk_eps = nullptr; TpsEdge *tps_edges = nullptr;
   int *centre = nullptr, *anchor_pos = nullptr;   // predicted CP position per call / coarse estimates every ACQ_ANCHOR calls
   float2 *acq_tap = nullptr, *fft_out = nullptr, *eq = nullptr, *tpsval = nullptr; SymInfo *info = nullptr; int *maj = nullptr, *sym_index = nullptr;
@@ -263,7 +266,7 @@ struct dvbt_rx {
   hipEvent_t ev[ST_COUNT]; double acc_ms[ST_COUNT] = {0}; long n_timed = 0; bool ev_ready = false, ev_recorded = false;
   dvbt_rx_report last; bool have_last = false;
   dvbt_rx_cut cut = {0};
-  float2 *tps_prev = nullptr, *tps_prev_snap[2] = {nullptr, nullptr}; TpsState *tps_snap[2] = {nullptr, nullptr}; RxState *st_saved = nullptr; DescrRun *descr_runs = nullptr; int *descr_nruns = nullptr;
+  float2 *tps_prev = nullptr, *tps_prev_snap[2] = {nullptr, nullptr}; TpsState *tps_snap[2] = {nullptr, nullptr};  DescrRun *descr_runs = nullptr; int *descr_nruns = nullptr;
   int n_periods = 1; size_t seg_offset = 0;
   std::vector<dvbt_lock_period> periods;    // phase A of the last synchronous run
   DriftBufs drift = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; double *drift_mem = nullptr;   // k_drift.hpp
@@ -273,7 +276,7 @@ struct dvbt_rx {
 
 static void rx_free(dvbt_rx *h)
 {
-  void *all[] = {h->st_saved, h->tps_prev_snap[0], h->tps_prev_snap[1], h->tps_snap[0], h->tps_snap[1], h->csi, h->soft_a, h->soft_tab, h->soft_scratch, h->rs_defer, h->drift_mem, h->drift.delta, h->drift.flags, h->tps_prev, h->descr_runs, h->descr_nruns, h->centre, h->anchor_pos, h->sym_ticket, h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags, h->trk_eps, h->d_iq, h->rs_iq, h->acq_carry, h->g_init, h->l_init, h->g_trk, h->l_trk, h->meta, h->st, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
+  void *all[] = {h->st_ctx[0], h->st_ctx[1], h->meta_ctx[0], h->meta_ctx[1], h->tps_prev_snap[0], h->tps_prev_snap[1], h->tps_snap[0], h->tps_snap[1], h->csi, h->soft_a, h->soft_tab, h->soft_scratch, h->rs_defer, h->drift_mem, h->drift.delta, h->drift.flags, h->tps_prev, h->descr_runs, h->descr_nruns, h->centre, h->anchor_pos, h->sym_ticket, h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags, h->trk_eps, h->d_iq, h->rs_iq, h->acq_carry, h->g_init, h->l_init, h->g_trk, h->l_trk, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
                  h->info, h->maj, h->sym_index, h->labels, h->symdeint_tap, h->bitdeint, h->vit, h->deint_tap, h->rs_out, h->ts_out};
   for (void *q : all) if (q) (void)hipFree(q);
   if (h->st_host) (void)hipHostFree(h->st_host);
@@ -314,15 +317,15 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   const size_t C = (size_t)h->max_calls, N = d.N, P = d.payload;
   RXHIP(hipMalloc((void **)&h->g_init, sizeof(float2) * ACQ_INIT_TRIES * N)); RXHIP(hipMalloc((void **)&h->l_init, sizeof(float) * ACQ_INIT_TRIES * N));
   RXHIP(hipMalloc((void **)&h->g_trk, sizeof(float2) * C * 2 * ACQ_R)); RXHIP(hipMalloc((void **)&h->l_trk, sizeof(float) * C * 2 * ACQ_R));
-  RXHIP(hipMalloc((void **)&h->meta, sizeof(SymMeta) * C));
+  for (int i = 0; i < 2; i++) { RXHIP(hipMalloc((void **)&h->meta_ctx[i], sizeof(SymMeta) * C)); RXHIP(hipMalloc((void **)&h->st_ctx[i], sizeof(RxState))); RXHIP(hipMemset(h->st_ctx[i], 0, sizeof(RxState))); }
+  h->meta = h->meta_ctx[0]; h->st = h->st_ctx[0]; h->ctx = 0;
   RXHIP(hipMalloc((void **)&h->trk_cp_a, sizeof(int) * C)); RXHIP(hipMalloc((void **)&h->trk_cp_b, sizeof(int) * C));
   RXHIP(hipMalloc((void **)&h->trk_eps, sizeof(float) * C)); RXHIP(hipMalloc((void **)&h->trk_flags, sizeof(int) * 16));
   RXHIP(hipMalloc((void **)&h->tps_prev, sizeof(float2) * d.n_tps)); RXHIP(hipMemset(h->tps_prev, 0, sizeof(float2) * d.n_tps));
-  RXHIP(hipMalloc((void **)&h->st_saved, sizeof(RxState)));
   for (int i = 0; i < 2; i++) { RXHIP(hipMalloc((void **)&h->tps_prev_snap[i], sizeof(float2) * d.n_tps)); RXHIP(hipMalloc((void **)&h->tps_snap[i], sizeof(TpsState))); }
   RXHIP(hipMalloc((void **)&h->descr_runs, sizeof(DescrRun) * DESCR_MAX_RUNS)); RXHIP(hipMalloc((void **)&h->descr_nruns, sizeof(int)));
   RXHIP(hipMalloc((void **)&h->centre, sizeof(int) * (C + 1))); RXHIP(hipMalloc((void **)&h->anchor_pos, sizeof(int) * (C / ACQ_ANCHOR + 4)));
-  RXHIP(hipMalloc((void **)&h->tps_edges, sizeof(TpsEdge) * (C / TPS_SEG + 2))); RXHIP(hipMalloc((void **)&h->st, sizeof(RxState)));
+  RXHIP(hipMalloc((void **)&h->tps_edges, sizeof(TpsEdge) * (C / TPS_SEG + 2)));
   RXHIP(hipHostMalloc((void **)&h->st_host, sizeof(RxState))); RXHIP(hipMalloc((void **)&h->acq_carry, sizeof(AcqState))); RXHIP(hipMalloc((void **)&h->tps_state, sizeof(TpsState)));
   RXHIP(hipMalloc((void **)&h->labels, C * P + 64));   // A1..A4 are one kernel: a symbol reaches HBM as label bytes; fft_out and eq exist only as debug taps
   RXHIP(hipMalloc((void **)&h->tpsval, sizeof(float2) * C * d.n_tps)); RXHIP(hipMalloc((void **)&h->info, sizeof(SymInfo) * C));
@@ -676,8 +679,12 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
   memset(&bk.last_st, 0, sizeof bk.last_st); bk.last_st.first_out = -1; bk.last_st.status = 1;
   bool snap_assumed[2] = {false, false};                          // ... and were decoded on the assumption that a later period has items
   bool need_full = false;
-  int clobber = 0;                                                // launched behind the last decode: 0 nothing, 1 searches that found nothing (they write the state block
-                                                                  // and scratch only), 2 an acquisition that found a period (tracker results, symbol bookkeeping)
+  int ctx_last = -1;                                              // acquisition context of the last decoded period (-1: none yet): acquisitions go to the other one
+  auto acq_ctx = [&]() -> int {                                   // switch to the context an acquisition may write; the state block travels along (fields that
+    const int k = ctx_last < 0 ? h->ctx : (ctx_last ^ 1);         // live through the periods of a segment keep doing so)
+    if (k != h->ctx) { HIPCHK(hipMemcpyAsync(h->st_ctx[k], h->st, sizeof(RxState), hipMemcpyDeviceToDevice, s)); h->ctx = k; h->st = h->st_ctx[k]; h->meta = h->meta_ctx[k]; }
+    return DVBT_OK;
+  };
   int snap_period[2] = {-1, -1}, sn = 0;                          // the last two decoded periods: snap[] and the device-side copies of the pilot engine's state were taken in front of
                                                                   // them (snap[sn]: the last one, snap[sn ^ 1]: the one before)
   // one period through the chain up to the Viterbi decoder.  later: a later period delivers items (the last item of this one leaves the demodulator too);
@@ -686,6 +693,7 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
     const int usable = per[p].n_symbols - (later ? 0 : 1);       // items that leave the demodulator
     bk.total_symbols += per[p].n_symbols;
     if (usable < 1) return DVBT_OK;
+    if (!reuse) { int r = acq_ctx(); if (r) return r; }
     if (!reuse && per[p].carry) { AcqState as; memset(&as, 0, sizeof as); as.avg = per[p].avg_in; HIPCHK(hipMemcpyAsync(h->acq_carry, &as, sizeof as, hipMemcpyHostToDevice, s)); }
     EnqOpt o; o.use_carry = per[p].carry; o.hist = (long long)per[p].off; o.continuation = bk.processed > 0; o.keep_last = later; o.tail = false; o.skip_acq = reuse;
     o.vit_off = bk.delivering > 0 ? (bk.acc / 3264) * 3264 : 0;   // convolutional_deinterleaver_impl.cc:109-120: the tag realigns the input
@@ -698,7 +706,7 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
     HIPCHK(hipStreamSynchronize(s));
     h->pending = false;
     const RxState &st = *h->st_host;
-    bk.processed++; bk.any = true; bk.last_st = st; bk.last_off = per[p].off;
+    bk.processed++; bk.any = true; bk.last_st = st; bk.last_off = per[p].off; ctx_last = h->ctx;
     h->periods[p].first_out_symbol = 0;
     if (st.first_out >= 0) {
       h->periods[p].first_out_symbol = st.first_out + 1;
@@ -711,6 +719,7 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
     size_t off = 0; bool carry = false; float avg = 0.f;
     for (int guard = 0; off + win <= chain_n; guard++) {
       if (guard >= 4096) { capped = true; break; }
+      { int r = acq_ctx(); if (r) return r; }
       if (carry) { AcqState as; memset(&as, 0, sizeof as); as.avg = avg; HIPCHK(hipMemcpyAsync(h->acq_carry, &as, sizeof as, hipMemcpyHostToDevice, s)); }
       EnqOpt o; o.acq_only = true; o.use_carry = carry; o.hist = (long long)off;
       // the search and the tracker look at a window of the rest of the segment that grows while the lock holds to its end: a segment with many lock
@@ -733,10 +742,8 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
       const int tries = (int)std::min<size_t>(ACQ_INIT_TRIES, (chain_n - off - win) / L + 1);
       if (st.status & 1) {                                       // no peak in these windows: the reference consumes them one by one and searches on
         off += (size_t)tries * L; avg = st.avg; carry = true;
-        if (clobber < 1) clobber = 1;
         continue;
       }
-      clobber = 2;
       // a period with items behind one that was decoded as the last one (the guess near the segment's end, below): everything is decoded again in order
       if (st.n_symbols >= 1 && snap_period[sn] >= 0 && !snap_assumed[sn]) need_full = true;
       const bool lost = (st.status & 2) != 0;
@@ -756,8 +763,7 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
         HIPCHK(hipMemcpyAsync(h->tps_snap[sn], h->tps_state, sizeof(TpsState), hipMemcpyDeviceToDevice, s));
         HIPCHK(hipMemcpyAsync(h->tps_prev_snap[sn], h->tps_prev, sizeof(float2) * d.n_tps, hipMemcpyDeviceToDevice, s));
       }
-      { const int before = bk.processed; int r = decode(per.size() - 1, later_guess, true); if (r) return r;
-        if (bk.processed > before) { clobber = 0; HIPCHK(hipMemcpyAsync(h->st_saved, h->st, sizeof(RxState), hipMemcpyDeviceToDevice, s)); } }
+      { int r = decode(per.size() - 1, later_guess, true); if (r) return r; }
       if (final_period) break;                                    // the lock held to the end of the segment (or to where its samples end)
       off += (size_t)(st.call0 + st.n_symbols) * L + L / 2; avg = st.avg_lost; carry = true;
       if (per.size() >= 1024) { capped = true; break; }
@@ -766,10 +772,11 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
     for (size_t q = 0; q < per.size(); q++) if (per[q].n_symbols >= 1) last_items = (int)q;
     // The byte de-interleaver, the RS decoder and the report read the device-side state of the LAST decoded period, and that period's last item depends on
     // whether a later one has items.  Both are in order when the last period's lock held to the segment's end (the common case: its decode was the last
-    // launch, or the lock was lost where the samples run out).  Behind a last decoded period that ended in a lost lock, launches have followed: if they were
-    // searches that found nothing, its state block is put back from a copy; if an acquisition found a period (without items), or the guess about a later
-    // period with items was wrong, it is decoded again from the state kept in front of it, acquisition included.  Should that leave nothing to decode
-    // (a single item, not delivered after all), the period decoded before it is decoded again instead (the state in front of the last TWO is kept).
+    // launch, or the lock was lost where the samples run out).  Behind a last decoded period that ended in a lost lock, searches have followed: they ran in
+    // the other acquisition context (acq_ctx), so its state block and tracker results are intact and the handle just switches back to them.  Only when
+    // the guess about a later period with items was wrong is the period decoded again from the state kept in front of it, acquisition included.  Should
+    // that leave nothing to decode (a single item, not delivered after all), the period decoded before it is decoded again instead (the state in front of
+    // the last TWO is kept; its context has been overwritten by the searches behind the last one).
     auto again = [&](int k) -> int {                              // period snap_period[k] once more, from the state in front of it, acquisition included
       const size_t z = (size_t)snap_period[k];
       bk = snap[k];
@@ -787,11 +794,9 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
       return DVBT_OK;
     };
     const bool guess_ok = snap_period[sn] < 0 || snap_assumed[sn] == (last_items > snap_period[sn]);
-    if (need_full) { int r = full(); if (r) return r; }
-    else if (snap_period[sn] >= 0 && guess_ok && clobber == 1) {
-      // only searches that found nothing ran behind the last decode: its state block is put back, everything else of it is untouched
-      HIPCHK(hipMemcpyAsync(h->st, h->st_saved, sizeof(RxState), hipMemcpyDeviceToDevice, s));
-    } else if (snap_period[sn] >= 0 && (!guess_ok || clobber == 2)) {
+    if (need_full) { ctx_last = -1; int r = full(); if (r) return r; }
+    else if (snap_period[sn] >= 0 && !guess_ok) {
+      ctx_last = -1;                                               // nothing to protect: the period is decoded again
       const int before = snap[sn].processed;
       { int r = again(sn); if (r) return r; }
       if (bk.processed == before && before > 0) {
@@ -801,6 +806,7 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
       }
     }
   }
+  if (ctx_last >= 0 && ctx_last != h->ctx) { h->ctx = ctx_last; h->st = h->st_ctx[ctx_last]; h->meta = h->meta_ctx[ctx_last]; }   // the searches behind the last decoded period ran in the other context
   size_t acc = bk.acc; const int delivering = bk.delivering, processed = bk.processed; const bool any = bk.any;
   const dvbt_rx_report first_rep = bk.first_rep; const RxState last_st = bk.last_st; const int total_symbols = bk.total_symbols; const size_t last_off = bk.last_off;
   dvbt_rx_report r;
