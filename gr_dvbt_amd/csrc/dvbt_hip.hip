@@ -315,7 +315,7 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   RXHIP(hipStreamCreate(&h->own_stream));
   if (h->rsd.ri) RXHIP(hipMalloc((void **)&h->rs_iq, sizeof(float2) * (chain_max + 16)));
   const size_t C = (size_t)h->max_calls, N = d.N, P = d.payload;
-  RXHIP(hipMalloc((void **)&h->g_init, sizeof(float2) * ACQ_INIT_TRIES * N)); RXHIP(hipMalloc((void **)&h->l_init, sizeof(float) * ACQ_INIT_TRIES * N));
+  RXHIP(hipMalloc((void **)&h->g_init, sizeof(float2) * ACQ_INIT_TRIES_MAX * N)); RXHIP(hipMalloc((void **)&h->l_init, sizeof(float) * ACQ_INIT_TRIES_MAX * N));
   RXHIP(hipMalloc((void **)&h->g_trk, sizeof(float2) * C * 2 * ACQ_R)); RXHIP(hipMalloc((void **)&h->l_trk, sizeof(float) * C * 2 * ACQ_R));
   for (int i = 0; i < 2; i++) { RXHIP(hipMalloc((void **)&h->meta_ctx[i], sizeof(SymMeta) * C)); RXHIP(hipMalloc((void **)&h->st_ctx[i], sizeof(RxState))); RXHIP(hipMemset(h->st_ctx[i], 0, sizeof(RxState))); }
   h->meta = h->meta_ctx[0]; h->st = h->st_ctx[0]; h->ctx = 0;
@@ -403,6 +403,7 @@ extern "C" int dvbt_rx_enable_taps(dvbt_rx *h, int enable)
 // defaults; the synchronous entries walk the segment's lock periods (segment_periods).
 struct EnqOpt {
   bool acq_only = false;      // ofdm_sym_acquisition alone (where does the lock start, how long does it hold)
+  int init_tries = ACQ_INIT_TRIES;   // windows the initial search examines before it gives up (the reference consumes them one by one)
   bool skip_acq = false;      // the acquisition results of the acq_only run just before (same iq, same hist, same carry) are still in the handle: go on from there
   bool use_carry = false;     // the peak detector's average is carried in from the call that lost the previous lock (h->acq_carry)
   long long hist = 0;         // samples of the stream in memory in front of iq[0]
@@ -465,7 +466,7 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
     if (!o.continuation) HIPCHK(hipMemsetAsync(h->tps_state, 0, sizeof(TpsState), s));
   } else {
   const AcqState *carry = o.use_carry ? h->acq_carry : nullptr;
-  int tries = C < ACQ_INIT_TRIES ? C : ACQ_INIT_TRIES;
+  int tries = C < o.init_tries ? C : o.init_tries;
   // initial search: the first window normally holds a peak; windows 1..3 are computed and examined only if it did not
   hipLaunchKernelGGL(acq_metric_kernel, dim3((N + 255) / 256, 1), dim3(256), 0, s, iq, fp, (const RxState *)h->st, 0, h->g_init, h->l_init, 0);
   // (the first launch also clears the trackers' flag words, the symbol kernel's ticket and, for a period that starts the pilot engine afresh, its state)
@@ -697,6 +698,7 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
     if (!reuse && per[p].carry) { AcqState as; memset(&as, 0, sizeof as); as.avg = per[p].avg_in; HIPCHK(hipMemcpyAsync(h->acq_carry, &as, sizeof as, hipMemcpyHostToDevice, s)); }
     EnqOpt o; o.use_carry = per[p].carry; o.hist = (long long)per[p].off; o.continuation = bk.processed > 0; o.keep_last = later; o.tail = false; o.skip_acq = reuse;
     o.vit_off = bk.delivering > 0 ? (bk.acc / 3264) * 3264 : 0;   // convolutional_deinterleaver_impl.cc:109-120: the tag realigns the input
+    o.init_tries = std::min(ACQ_INIT_TRIES_MAX, std::max(ACQ_INIT_TRIES, per[p].call0 + 1));   // (a second acquisition must reach the window the wide search found the peak in)
     // a period that ends in a lost lock is decoded over its own calls and the one that lost the lock, not over the whole rest of the segment
     size_t span = chain_n - per[p].off;
     if (per[p].lost) span = std::min(span, win + (size_t)(per[p].call0 + per[p].n_symbols) * L);
@@ -716,12 +718,14 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
     return DVBT_OK;
   };
   {   // ---- the walk: find a period (acquisition alone over a growing window), decode it, go on behind the call that lost the lock
-    size_t off = 0; bool carry = false; float avg = 0.f;
+    size_t off = 0; bool carry = false; float avg = 0.f; int fails = 0;
     for (int guard = 0; off + win <= chain_n; guard++) {
       if (guard >= 4096) { capped = true; break; }
       { int r = acq_ctx(); if (r) return r; }
       if (carry) { AcqState as; memset(&as, 0, sizeof as); as.avg = avg; HIPCHK(hipMemcpyAsync(h->acq_carry, &as, sizeof as, hipMemcpyHostToDevice, s)); }
       EnqOpt o; o.acq_only = true; o.use_carry = carry; o.hist = (long long)off;
+      // searches that found nothing are followed by wider ones (4, 8, ... 64 windows per launch): dead air costs a launch sequence per 64 windows, not per 4
+      o.init_tries = std::min(ACQ_INIT_TRIES_MAX, ACQ_INIT_TRIES << std::min(fails, 4));
       // the search and the tracker look at a window of the rest of the segment that grows while the lock holds to its end: a segment with many lock
       // periods costs its length a few times over, not its length times the number of periods (a call's outcome depends on the samples before it only)
       // (first window: 768 calls, or four times the previous period's length when the lock is being lost every few dozen symbols -- the metric, anchor and
@@ -739,11 +743,12 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
         look = std::min(chain_n - off, win + 4 * (look - win) + 3 * L);
       }
       const RxState st = *h->st_host;
-      const int tries = (int)std::min<size_t>(ACQ_INIT_TRIES, (chain_n - off - win) / L + 1);
+      const int tries = (int)std::min<size_t>((size_t)o.init_tries, (look - win) / L + 1);      // what enqueue() examined
       if (st.status & 1) {                                       // no peak in these windows: the reference consumes them one by one and searches on
-        off += (size_t)tries * L; avg = st.avg; carry = true;
+        off += (size_t)tries * L; avg = st.avg; carry = true; fails++;
         continue;
       }
+      fails = 0;
       // a period with items behind one that was decoded as the last one (the guess near the segment's end, below): everything is decoded again in order
       if (st.n_symbols >= 1 && snap_period[sn] >= 0 && !snap_assumed[sn]) need_full = true;
       const bool lost = (st.status & 2) != 0;

@@ -55,6 +55,7 @@ struct AcqState { int acquired; int cp_start; float avg; float phase; double pha
 
 constexpr int ACQ_R = 16;
 constexpr int ACQ_INIT_TRIES = 4;
+constexpr int ACQ_INIT_TRIES_MAX = 64;         // windows one search launch can examine (the lock-period walk asks for more after searches that found nothing)
 constexpr int ACQ_CP_MAX = 2048;               // longest guard interval (8k, 1/4)
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
