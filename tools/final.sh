@@ -11,6 +11,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_solo -o 
 for pd in 1 2 4; do python bench.py --pipeline $pd --steps 200 --no-cpu-baseline --no-extras 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'steps_in_flight': $pd, 'value': d['value'], 'ms_per_step': d['ms_per_step'], 'verified': d['config']['verified']}))"; done | tee gpurun_out/pipeline_depth.jsonl
 python tools/snr_sweep.py 3 > gpurun_out/snr_sweep.jsonl 2>/dev/null; wc -l gpurun_out/snr_sweep.jsonl
 python tools/rs_load.py > gpurun_out/rs_load.jsonl 2>/dev/null; wc -l gpurun_out/rs_load.jsonl
+[ -x tools/ubench_mfma ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/ubench_mfma tools/ubench_mfma.hip 2>/dev/null
 ./tools/ubench_mfma > gpurun_out/ubench_mfma.json 2>/dev/null
 rm -rf gpurun_out/prof_soft; rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_soft -o r -- python tools/soft_prof.py > /dev/null 2>&1
 python tools/soft_gain.py > gpurun_out/soft_gain.jsonl 2>/dev/null; wc -l gpurun_out/soft_gain.jsonl
