@@ -32,6 +32,7 @@ constexpr int S4_G0 = 30;                  // first decision group that is kept 
 constexpr int S4_NSEG = 8;                 // traceback segments per decoder
 constexpr int S4_PRE = 24;                 // groups a segment's chain starts behind the segment's end (192 steps = the reference's depth at rate 7/8)
 constexpr int S4_MAXSTEPS = ((S4_WARM + 8 * S4_BMAX + 8 * 24 + 16 + S4_BLK - 1) / S4_BLK) * S4_BLK;
+static_assert(((S4_WARM + 8 * S4_BMAX + 8 * 24 + S4_BLK - 1) / S4_BLK) * S4_BLK <= S4_MAXSTEPS, "the largest plan (s4_plan: B = S4_BMAX, look = 8 x 24) must fit the decision slots and the best-cell table");
 constexpr size_t S4_SLOT_WORDS = (size_t)(S4_MAXSTEPS / 8 - S4_G0) * 64;    // dwords of decisions per wavefront
 constexpr size_t S4_SCRATCH_WORDS = (size_t)S4_GRID * S4_WAVES * S4_SLOT_WORDS;
 
