@@ -137,3 +137,138 @@ def test_config_dimensions(po):
                                  (po.QPSK, po.C7_8, po.T8k, (8192, 256, 6817, 688, 6048, 2, 7, 8))):
         c = po.cfg(const, cr, mode)
         assert (c.N, c.cp, c.Kmax + 1, c.zeros_left, c.payload, c.m, c.k, c.n) == exp
+
+
+def test_energy_dispersal_prbs_is_the_standards(po):
+    """ETSI EN 300 744 4.3.1: PRBS 1 + X^14 + X^15, register loaded with 100101010000000 at the first (inverted, 0xB8) sync byte of every group of 8
+    packets, its first output bit applied to the first bit behind that sync byte; it keeps running under the other seven sync bytes without being applied.
+    An LFSR written from that text alone (not from the reference, not from the oracle) must reproduce what the oracle's chain carries behind its RS decoder
+    for a TS of zero payload -- and its first bytes are the well-known 0x03 0xF6 0x08 0x34 0x30 0xB8 0xA3 0x93."""
+    def prbs_bytes(n):
+        reg = [1, 0, 0, 1, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0, 0]         # stages 1..15
+        out = []
+        for _ in range(n):
+            b = 0
+            for _ in range(8):
+                bit = reg[13] ^ reg[14]
+                reg = [bit] + reg[:14]
+                b = (b << 1) | bit
+            out.append(b)
+        return out
+    seq = prbs_bytes(8 * 188 - 1)                                      # one group of 8 packets behind its first sync byte
+    assert seq[:8] == [0x03, 0xF6, 0x08, 0x34, 0x30, 0xB8, 0xA3, 0x93]
+    group = [0xB8] + seq[:187]
+    for k in range(1, 8):
+        group += [0x47] + seq[188 * k:188 * k + 187]                   # the PRBS runs on under the sync byte (one byte of it is skipped), not applied
+    group = np.array(group, np.uint8)
+    c = po.cfg(po.QAM16, po.C1_2, po.T2k)
+    npk = po.packets_per_superframe(c) * 3
+    ts = np.zeros(npk * 188, np.uint8)
+    ts[0::188] = 0x47
+    o = po.rx(c, po.tx(c, ts, lead_in=500, tail=3 * c.N), want=("rs", "ts"))
+    rs = o["rs"].reshape(-1, 188)
+    starts = [i for i in range(len(rs) - 8) if rs[i, 0] == 0xB8 and i >= 11]
+    assert len(starts) >= 10 and all(b - a == 8 for a, b in zip(starts, starts[1:]))
+    for i in starts[:10]:
+        assert (rs[i:i + 8].reshape(-1) == group).all()
+    assert (o["ts"].reshape(-1, 188)[:, 1:] == 0).all() and (o["ts"][0::188] == 0x47).all()
+
+
+def test_inner_code_is_the_standards(po):
+    """ETSI EN 300 744 4.3.3: mother code G1 = 171 oct (X), G2 = 133 oct (Y), puncturing patterns of table 4 with the transmitted sequence X1 Y1 | X1 Y1 Y2 |
+    X1 Y1 Y2 X3 | X1 Y1 Y2 X3 Y4 X5 | X1 Y1 Y2 Y3 Y4 X5 Y6 X7.  An encoder written from that text alone, fed with the bytes the oracle's Viterbi decoder
+    delivers on a clean loopback, must reproduce the coded bits the oracle's chain carries INTO that decoder (bit de-interleaver tap, m bits per item, MSB
+    first): polynomials, puncturing phase at the superframe start and bit order in one known answer per code rate."""
+    seqs = {po.C1_2: ("X1", "Y1"), po.C2_3: ("X1", "Y1", "Y2"), po.C3_4: ("X1", "Y1", "Y2", "X3"), po.C5_6: ("X1", "Y1", "Y2", "X3", "Y4", "X5"),
+            po.C7_8: ("X1", "Y1", "Y2", "Y3", "Y4", "X5", "Y6", "X7")}
+    for cr, seq in seqs.items():
+        c = po.cfg(po.QAM16, cr, po.T2k)
+        ts = po.make_ts(po.packets_per_superframe(c) * 3, 5)
+        o = po.rx(c, po.tx(c, ts, lead_in=500, tail=3 * c.N), want=("bitdeint", "vit"))
+        info = np.unpackbits(o["vit"])
+        k = max(int(s[1]) for s in seq)                               # input bits per puncturing period
+        d = np.concatenate([np.zeros(6, np.uint8), info])            # the register in front of the first delivered bit: unknown, the first steps are skipped
+        x = d[6:] ^ d[5:-1] ^ d[4:-2] ^ d[3:-3] ^ d[:-6]              # 171 oct = 1111001: taps at delays 0, 1, 2, 3, 6
+        y = d[6:] ^ d[4:-2] ^ d[3:-3] ^ d[1:-5] ^ d[:-6]              # 133 oct = 1011011: taps at delays 0, 2, 3, 5, 6
+        n = (len(info) // k) * k
+        coded = np.stack([(x if s[0] == "X" else y)[int(s[1]) - 1:n:k] for s in seq], axis=1).reshape(-1)
+        rx_bits = np.unpackbits(o["bitdeint"].reshape(-1, 1), axis=1)[:, 8 - c.m:].reshape(-1)
+        lo, hi = 8 * len(seq), min(len(coded), len(rx_bits)) - 64
+        assert hi > 100000 and (coded[lo:hi] == rx_bits[lo:hi]).all(), cr
+
+
+def test_outer_deinterleaver_is_the_standards(po):
+    """ETSI EN 300 744 4.3.2 (Forney, I = 12, M = 17): the byte at position n of the interleaved stream travels on branch n mod 12; the de-interleaver's branch b
+    delays it by 17 (11 - b) cells of 12 bytes.  Written from that text: deint[n] = vit[n - 204 (11 - n mod 12)] (zero fill in front), counted from the first
+    byte behind a superframe start (a packet start, branch 0).  And the RS code of the words that come out: 16 parity bytes make the remainder of the
+    shortened (204, 188) code vanish -- every word behind the fill is a codeword of g(x) = prod (x + alpha^i), i = 0 .. 15, over GF(256) with p(x) = 0x11d."""
+    c = po.cfg(po.QAM64, po.C2_3, po.T2k)
+    ts = po.make_ts(po.packets_per_superframe(c) * 3, 11)
+    o = po.rx(c, po.tx(c, ts, lead_in=300, tail=3 * c.N), want=("vit", "deint"))
+    vit, de = o["vit"], o["deint"]
+    n = np.arange(len(de))
+    src = n - 204 * (11 - n % 12)
+    want = np.where(src >= 0, vit[np.clip(src, 0, len(vit) - 1)], 0).astype(np.uint8)
+    ok = src < len(vit)
+    assert len(de) > 50000 and (de[ok] == want[ok]).all()
+    # GF(256) from the text: alpha = 2, p(x) = x^8 + x^4 + x^3 + x^2 + 1
+    exp = np.zeros(512, np.int64); log = np.zeros(256, np.int64)
+    v = 1
+    for i in range(255):
+        exp[i] = v; log[v] = i
+        v <<= 1
+        if v & 0x100: v ^= 0x11d
+    exp[255:510] = exp[:255]
+    words = de[204 * 11:(len(de) // 204) * 204].reshape(-1, 204).astype(np.int64)
+    for root in range(16):                                            # a codeword vanishes at alpha^0 .. alpha^15
+        acc = np.zeros(len(words), np.int64)
+        for j in range(204):                                          # Horner, first byte = highest power
+            nz = acc != 0
+            acc = np.where(nz, exp[(log[acc] + root) % 255], 0) ^ words[:, j]
+        assert (acc == 0).all(), root
+
+
+def test_inner_interleavers_are_the_standards(po):
+    """ETSI EN 300 744 4.3.4.  Symbol interleaver: H(q) from the shift register R'_i (2k: new bit R'[0] ^ R'[3]; 8k: R'[0] ^ R'[1] ^ R'[4] ^ R'[6]), the bit
+    permutations of tables 3a / 3b and the alternating top bit, written from that text.  Bit interleaver: demultiplexing x_di -> b_[di mod v div (v/2) +
+    2 (di mod v/2)], di div v and the six interleavers H_e(w) = (w + {0, 63, 105, 42, 21, 84}) mod 126 applied to what the oracle's chain feeds its Viterbi
+    decoder must give the words that leave its symbol de-interleaver."""
+    def etsi_H(mode):
+        nr, nmax, perm = (11, 1512, [0, 7, 5, 1, 8, 2, 6, 9, 3, 4]) if mode == po.T2k else (13, 6048, [5, 11, 3, 0, 10, 8, 6, 9, 2, 4, 1, 7])
+        nb, out, rp = nr - 1, [], 0
+        for i in range(1 << nr):
+            if i < 2:
+                rp = 0
+            elif i == 2:
+                rp = 1
+            else:
+                new = (rp ^ (rp >> 3)) & 1 if mode == po.T2k else (rp ^ (rp >> 1) ^ (rp >> 4) ^ (rp >> 6)) & 1
+                rp = (rp >> 1) | (new << (nb - 1))
+            r = 0
+            for k in range(nb):                                       # table 3: R' bit nb-1-k goes to R bit perm[k]
+                r |= ((rp >> (nb - 1 - k)) & 1) << perm[k]
+            h = ((i & 1) << (nr - 1)) + r
+            if h < nmax:
+                out.append(h)
+        return np.array(out)
+    L = po.lib()
+    for mode, payload in ((po.T2k, 1512), (po.T8k, 6048)):
+        c = po.cfg(po.QAM16, po.C1_2, mode)
+        h = np.zeros(payload, np.int32)
+        L.o_sym_H(C.byref(c), h.ctypes.data_as(C.c_void_p))
+        assert (etsi_H(mode) == h).all()
+    off = [0, 63, 105, 42, 21, 84]
+    for const in (po.QPSK, po.QAM16, po.QAM64):
+        c = po.cfg(const, po.C3_4, po.T2k)
+        v = c.m
+        ts = po.make_ts(po.packets_per_superframe(c) * 2, 3)
+        o = po.rx(c, po.tx(c, ts, lead_in=200, tail=3 * c.N), want=("symdeint", "bitdeint"))
+        x = np.unpackbits(o["bitdeint"].reshape(-1, 1), axis=1)[:, 8 - v:].reshape(-1)      # the coded bits x_di in order
+        nblk = min(len(x) // (126 * v), 2000)
+        x = x[:nblk * 126 * v].reshape(nblk, 126, v)                   # [block][do][di mod v]
+        y = np.zeros((nblk, 126), np.int64)
+        for k in range(v):
+            e = (k % v) // (v // 2) + 2 * (k % (v // 2))
+            w = np.arange(126)
+            y |= x[:, (w + off[e]) % 126, k].astype(np.int64) << (v - 1 - e)           # a_{e,w} = b_{e,H_e(w)}, a_0 = MSB of the word
+        assert (y.reshape(-1) == o["symdeint"].reshape(-1)[:nblk * 126]).all(), const
