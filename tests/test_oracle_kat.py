@@ -272,3 +272,36 @@ def test_inner_interleavers_are_the_standards(po):
             w = np.arange(126)
             y |= x[:, (w + off[e]) % 126, k].astype(np.int64) << (v - 1 - e)           # a_{e,w} = b_{e,H_e(w)}, a_0 = MSB of the word
         assert (y.reshape(-1) == o["symdeint"].reshape(-1)[:nblk * 126]).all(), const
+
+
+def test_pilot_sequence_and_positions_are_the_standards(po):
+    """ETSI EN 300 744 4.5.2 / 4.5.3 / 4.6: reference sequence w_k from the PRBS X^11 + X^2 + 1 (eleven ones loaded, one bit per carrier from k = 0: taps
+    behind delays 9 and 11), pilots at 4/3 (1 - 2 w_k); scattered pilots at k = 3 (l mod 4) + 12 p; the continual pilots and TPS carriers of tables 7 and
+    8 (2k lists).  Written from that text; checked against the spectrum the oracle's generator builds and its w_k table."""
+    s, w = [1] * 11, []
+    for _ in range(6817):
+        w.append(s[10])
+        s = [s[8] ^ s[10]] + s[:10]
+    w = np.array(w)
+    L = po.lib()
+    c8 = po.cfg(po.QAM64, po.C7_8, po.T8k)
+    wk = np.zeros(c8.Kmax + 1, np.int8)
+    L.o_prbs_wk(C.byref(c8), wk.ctypes.data_as(C.c_void_p))
+    assert (wk == w).all()
+    cont = [0, 48, 54, 87, 141, 156, 192, 201, 255, 279, 282, 333, 432, 450, 483, 525, 531, 618, 636, 714, 759, 765, 780, 804, 873, 888, 918, 939, 942, 969,
+            984, 1050, 1101, 1107, 1110, 1137, 1140, 1146, 1206, 1269, 1323, 1377, 1491, 1683, 1704]
+    tps = [34, 50, 209, 346, 413, 569, 595, 688, 790, 901, 1073, 1219, 1262, 1286, 1469, 1594, 1687]
+    c = po.cfg(po.QAM16, po.C1_2, po.T2k)
+    _, freq = po.tx(c, po.make_ts(600, 3), scale=1.0, want_freq=True)
+    zl = c.zeros_left
+    for l in range(8):
+        row = freq[l, zl:zl + c.Kmax + 1]
+        pil = set(cont) | set(range(3 * (l % 4), c.Kmax + 1, 12))
+        for k in sorted(pil):
+            assert abs(row[k] - (4.0 / 3.0) * (1 - 2 * w[k])) < 1e-6, (l, k)
+        # TPS carriers: DBPSK, real, magnitude 1, the same bit on all of them up to the sign of w_k
+        t = np.array([row[k].real * (1 - 2 * w[k]) for k in tps])
+        assert np.allclose(np.abs(t), 1.0, atol=1e-6) and np.allclose([row[k].imag for k in tps], 0.0, atol=1e-6) and abs(t.sum()) == len(tps)
+        # everything else carries data: not on the real axis at pilot power
+        data = [k for k in range(c.Kmax + 1) if k not in pil and k not in tps]
+        assert len(data) == 1512 and min(abs(row[k].imag) for k in data) > 1e-3
