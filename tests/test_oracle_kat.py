@@ -305,3 +305,26 @@ def test_pilot_sequence_and_positions_are_the_standards(po):
         # everything else carries data: not on the real axis at pilot power
         data = [k for k in range(c.Kmax + 1) if k not in pil and k not in tps]
         assert len(data) == 1512 and min(abs(row[k].imag) for k in data) > 1e-3
+
+
+def test_constellations_are_gray_mapped_as_in_the_standard(po):
+    """ETSI EN 300 744 4.3.5, figures 9: y0 is the sign of I and y1 the sign of Q (0 = positive); neighbouring points differ in exactly one bit; the levels are
+    the odd integers (uniform) or alpha + 2 i (hierarchical, alpha = 2, 4), normalised by the table's factor."""
+    L = po.lib()
+    for const, hier in ((po.QPSK, 0), (po.QAM16, 0), (po.QAM64, 0), (po.QAM16, 2), (po.QAM64, 3)):
+        c = po.cfg(const, po.C1_2, po.T2k, hierarchy=hier)
+        m = c.m
+        pts = np.zeros(1 << m, np.complex64)
+        L.o_constellation(C.byref(c), C.c_float(1.0), pts.ctypes.data_as(C.c_void_p))
+        z = (pts / c.norm).astype(np.complex128)
+        lab = np.arange(1 << m)
+        assert (((lab >> (m - 1)) & 1) == (z.real < 0)).all() and (((lab >> (m - 2)) & 1) == (z.imag < 0)).all()
+        alpha = {0: 1, 1: 1, 2: 2, 3: 4}[hier]
+        levels = sorted({round(abs(v), 4) for v in z.real})
+        assert levels == [alpha + 2 * i for i in range(1 << (m // 2 - 1))]
+        for a in range(1 << m):
+            for b in range(a + 1, 1 << m):
+                d = z[a] - z[b]
+                near = (d.imag == 0 and abs(d.real) == min(2, 2 * alpha) or d.real == 0 and abs(d.imag) == min(2, 2 * alpha)) if alpha == 1 else False
+                if near:
+                    assert bin(a ^ b).count("1") == 1, (a, b)
