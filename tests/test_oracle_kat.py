@@ -328,3 +328,27 @@ def test_constellations_are_gray_mapped_as_in_the_standard(po):
                 near = (d.imag == 0 and abs(d.real) == min(2, 2 * alpha) or d.real == 0 and abs(d.imag) == min(2, 2 * alpha)) if alpha == 1 else False
                 if near:
                     assert bin(a ^ b).count("1") == 1, (a, b)
+
+
+def test_tps_frame_is_a_bch_codeword_of_the_standards_generator(po):
+    """ETSI EN 300 744 4.6.3: the 53 information bits s1 .. s53 and 14 parity bits of a TPS frame form a word of the BCH (67, 53, t = 2) code shortened from
+    (127, 113), generator x^14 + x^9 + x^8 + x^6 + x^5 + x^4 + x^2 + x + 1; 4.6.2: synchronisation word 0011010111101110 in frames 1 and 3, its inverse in
+    2 and 4, length indicator 010111 (no cell identification).  Polynomial division written here, not the oracle's checker."""
+    L = po.lib()
+    g = 0b100001101110111
+    for const, cr, mode in ((po.QAM64, po.C7_8, po.T8k), (po.QAM16, po.C1_2, po.T2k), (po.QPSK, po.C3_4, po.T8k)):
+        c = po.cfg(const, cr, mode)
+        wk = np.zeros(c.Kmax + 1, np.int8)
+        L.o_prbs_wk(C.byref(c), wk.ctypes.data_as(C.c_void_p))
+        for frame in range(4):
+            t = np.zeros(68, np.uint8)
+            L.o_tps_format(C.byref(c), frame, wk.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p))
+            sync = "".join(str(b) for b in t[1:17])
+            assert sync == ("0011010111101110" if frame % 2 == 0 else "1100101000010001") and "".join(str(b) for b in t[17:23]) == "010111"
+            assert int(t[23]) * 2 + int(t[24]) == frame                  # frame number, s23 s24
+            r = 0
+            for b in t[1:68]:                                            # s1 first = highest power
+                r = (r << 1) | int(b)
+                if r & (1 << 14):
+                    r ^= g
+            assert r == 0, (const, cr, mode, frame)
