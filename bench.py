@@ -161,6 +161,9 @@ class Job:
         from oracle import pyoracle as po
         from gr_dvbt_amd import multi
         self.torch, self.g, self.dist, self.rank, self.world, self.local, self.multi, self.po = torch, g, dist, rank, world, local, multi, po
+        # where the collectives' tensors live: device memory under RCCL (backend nccl), host memory under gloo (the gather is then staged through pinned host buffers)
+        self.host_staged = bool(dist) and dist.get_backend() == "gloo"
+        self.cdev = "cpu" if self.host_staged else f"cuda:{local}"
         (const, cr, mode), c = workload_cfg(workload)
         self.c, self.workload, self.snr = c, workload, snr
         self.dims = d = g.get_dims(const, cr, mode)
@@ -172,7 +175,7 @@ class Job:
         snr_db = 30.0 if snr is None else snr                   # ofdm_sym_acquisition's snr parameter (30 in the demo flowgraphs)
         self.ref_power = None
         # ---- pre-scan (rank 0): where does the reference's chain start decoding?  Two numbers, broadcast once.
-        plan = torch.zeros(2, dtype=torch.int64, device=f"cuda:{local}")
+        plan = torch.zeros(2, dtype=torch.int64, device=self.cdev if dist else "cpu")
         if rank == 0:
             head = po.stream_slice(c, self.nsf, self.seed, 0, po.STREAM_LEAD_IN + 360 * L)
             if cfo:
@@ -192,7 +195,7 @@ class Job:
         if dist:
             dist.broadcast(plan, src=0)
             if snr is not None:
-                pw = torch.tensor([self.ref_power or 0.0], dtype=torch.float64, device=f"cuda:{local}")
+                pw = torch.tensor([self.ref_power or 0.0], dtype=torch.float64, device=self.cdev)
                 dist.broadcast(pw, src=0)
                 self.ref_power = float(pw.item())
         self.grid0, self.sf_call = int(plan[0]), int(plan[1])
@@ -233,11 +236,12 @@ class Job:
         # the closing barrier of the timed region.
         self.slot = multi.HEADER_BYTES + max(p["cap"] for p in self.pieces)
         if dist:
-            mx = torch.tensor([self.slot], dtype=torch.int64, device=f"cuda:{local}")
+            mx = torch.tensor([self.slot], dtype=torch.int64, device=self.cdev)
             dist.all_reduce(mx, op=dist.ReduceOp.MAX)
             self.slot = int(mx.item())
         self.send = [torch.zeros(self.slot * nseg, dtype=torch.uint8, device=f"cuda:{local}") for _ in range(2)] if dist else None
-        self.recv = [[torch.empty(self.slot * nseg, dtype=torch.uint8, device=f"cuda:{local}") for _ in range(world)] for _ in range(2)] if (dist and rank == 0) else [None, None]
+        self.recv = [[torch.empty(self.slot * nseg, dtype=torch.uint8, device=self.cdev) for _ in range(world)] for _ in range(2)] if (dist and rank == 0) else [None, None]
+        self.send_host = [torch.zeros(self.slot * nseg, dtype=torch.uint8).pin_memory() for _ in range(2)] if self.host_staged else None
         self.pending = [None, None]
         self.nstep = 0
         self.ngather = 0
@@ -275,7 +279,11 @@ class Job:
             ev = torch.cuda.Event(); ev.record()       # the next decode may overwrite the TS buffers only after these copies
             for p in self.pieces:
                 p["stream"].wait_event(ev)
-            self.pending[b] = multi.gather_pieces(self.send[b], self.recv[b], dst=0, async_op=True)
+            if self.host_staged:                       # gloo: the packed pieces leave through a pinned host buffer
+                self.send_host[b].copy_(self.send[b])    # (synchronous D2H on the current stream, behind the packing copies)
+                self.pending[b] = multi.gather_pieces(self.send_host[b], self.recv[b], dst=0, async_op=True)
+            else:
+                self.pending[b] = multi.gather_pieces(self.send[b], self.recv[b], dst=0, async_op=True)
             self.last_buf = b
             self.ngather += 1
 
@@ -470,10 +478,51 @@ def timed_run(job, steps, warmup):
     job.step_ms = {"min": round(float(iv.min()), 3), "median": round(float(np.median(iv)), 3), "max": round(float(iv.max()), 3),
                    "p95": round(float(np.percentile(iv, 95)), 3), "n": int(len(iv))} if len(iv) else None
     if dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{job.local}")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=job.cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     return dt
+
+
+def launch_ranks(a, argv):
+    """`python bench.py --gpus N` without a launcher around it (WORLD_SIZE unset): start the N ranks here, one process per GPU, each with RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in its environment (what `python -m torch.distributed.run --nproc-per-node N` sets), and wait for them.
+    Rank 0 inherits this process's stdout (its ONE JSON line is the bench line); the other ranks' stdout goes to stderr.  Refuses when fewer than N
+    devices are visible (unless --ranks-share-gpu, the one-GPU test box's mode)."""
+    import socket
+    import subprocess
+    import gr_dvbt_amd as g
+    ndev = g.device_count()
+    if ndev <= 0:
+        raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
+    if ndev < a.gpus and not a.ranks_share_gpu:
+        raise SystemExit(f"bench.py --gpus {a.gpus}: only {ndev} HIP device(s) visible; one process per GPU needs {a.gpus} "
+                         "(--ranks-share-gpu puts every rank on device 0: a functional test, not a measurement)")
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                try:
+                    p.wait(timeout=0.5)
+                except subprocess.TimeoutExpired:
+                    continue
+                pending.remove(p)
+                if p.returncode != 0:
+                    rc = rc or p.returncode
+                    for q in pending:                      # a dead rank leaves the others in a collective: stop exactly the processes started here
+                        q.terminate()
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    raise SystemExit(rc)
 
 
 def main():
@@ -491,12 +540,24 @@ def main():
                     help="feed the 10 Msps file format: rational_resampler 64/70 + multiply_const run on the device in front of the chain "
                          "(SURVEY 8f row 2; samples are then counted at the 10 Msps input; single piece only)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) and run the gather path even with one rank")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="torch.distributed backend of the exchange step: nccl = RCCL over xGMI on device buffers (the design); gloo = the same gather staged "
+                         "through host tensors (functional tests where the ranks share one GPU, which RCCL refuses)")
+    ap.add_argument("--ranks-share-gpu", action="store_true", help="every rank decodes on device 0 (tests on a one-GPU box; needs --backend gloo when --gpus > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra workload lines (BASELINE configs 1, 2, 5) and the per-block ABI timing")
     ap.add_argument("--cpu-superframes", type=int, default=23)
     a = ap.parse_args()
     if a.from_file_rate and (a.gpus > 1 or a.segments > 1):
         raise SystemExit("--from-file-rate runs one piece on one GPU")
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        launch_ranks(a, sys.argv[1:])                        # does not return
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus} was launched with WORLD_SIZE={os.environ['WORLD_SIZE']}: the launcher's rank count and --gpus must agree")
+    if a.ranks_share_gpu and a.gpus > 1 and a.backend == "nccl":
+        raise SystemExit("--ranks-share-gpu with --gpus > 1 needs --backend gloo (RCCL refuses two ranks on one device)")
 
     # stdout carries exactly ONE line (the JSON of rank 0): libraries that print banners to the C-level stdout (RCCL does at the
     # first collective) are sent to stderr by swapping file descriptor 1; the JSON goes to the saved descriptor
@@ -509,15 +570,21 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if a.ranks_share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} HIP device(s) visible")
     torch.cuda.set_device(local)
     dist = None
     if world > 1 or a.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     job = Job(a, torch, g, dist, rank, world, local, a.workload, a.superframes, snr=a.snr, chunk=a.chunk, from_file_rate=a.from_file_rate)
     dt = timed_run(job, a.steps, a.warmup)
@@ -551,7 +618,10 @@ def main():
                                    + (", input at the 10 Msps file rate (resampler 64/70 + scale on the device)" if a.from_file_rate else ""),
                        "stream_superframes": job.nsf, "superframes_per_gpu": a.superframes, "pieces_per_gpu": nseg, "steps_in_flight": depth,
                        "stream_samples": n_stream, "samples_decoded_per_gpu_per_step": job.samples_decoded,
-                       "parallelism": f"one stream cut into {world * nseg} pieces at superframe boundaries, {nseg} per GPU" + (" + one RCCL gather of TS per step" if world > 1 else ""),
+                       "parallelism": f"one stream cut into {world * nseg} pieces at superframe boundaries, {nseg} per GPU"
+                                      + ((" + one RCCL gather of TS per step" if a.backend == "nccl" else " + one gloo gather of TS per step (host staged)") if dist else ""),
+                       "ranks": int(dist.get_world_size()) if dist else 1, "backend": (dist.get_backend() if dist else None),
+                       "devices": ("all ranks on device 0 (--ranks-share-gpu: functional run, not a measurement)" if a.ranks_share_gpu and world > 1 else "one process per GPU"),
                        "ts_bytes_per_step": n_ts, "status": [int(r.status) for r in reps], "rs_fail_words": [int(r.rs_fail_words) for r in reps],
                        **check},
             "roofline": {"bound": "valu", "kernel": "viterbi3_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -577,7 +647,7 @@ def main():
         out["stream_abi"] = stream_abi(g)
         out["per_block_abi"] = per_block_abi(g, a.workload)
     if rank == 0:
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:             # the contract: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_superframes)
             ref = reference_sse2_viterbi()
             if ref:

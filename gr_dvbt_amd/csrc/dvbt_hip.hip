@@ -342,7 +342,10 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   if (p->soft_decision) {
     RXHIP(hipMalloc((void **)&h->eq, sizeof(float2) * C * P)); RXHIP(hipMalloc((void **)&h->csi, sizeof(float) * C * P));
     RXHIP(hipMalloc((void **)&h->soft_a, C * P * d.m + 64)); RXHIP(hipMalloc((void **)&h->soft_tab, sizeof(uint16_t) * 2 * P * d.m));
-    RXHIP(hipMalloc((void **)&h->soft_scratch, sizeof(unsigned) * S4_SCRATCH_WORDS));
+    // decision slots: one per resident wavefront of the largest launch this handle can make (max_samples), not of the largest launch there is
+    // (2048 workgroups = 704 MB: what a 17-superframe segment of 8k QAM64 7/8 uses; a 2-superframe handle of the streaming entry needs 1/8 of that)
+    const long long max_vit_soft = (long long)C * P * d.m * d.k / (8 * d.n) + 1;
+    RXHIP(hipMalloc((void **)&h->soft_scratch, sizeof(unsigned) * (size_t)s4_grid(max_vit_soft, d.ntb) * S4_WAVES * S4_SLOT_WORDS));
     hipLaunchKernelGGL(soft_tab_kernel, dim3(64), dim3(256), 0, h->own_stream, h->T.inner_params(d.payload), (const uint16_t *)h->T.H, (const uint16_t *)h->T.Hinv, h->soft_tab);
     RXHIP(hipStreamSynchronize(h->own_stream));
   }
@@ -394,8 +397,9 @@ extern "C" int dvbt_rx_enable_taps(dvbt_rx *h, int enable)
 {
   if (!h) return DVBT_ERR_INVALID;
   if (enable) return ensure_taps(h);
-  void **all[] = {(void **)&h->acq_tap, (void **)&h->fft_out, (void **)&h->eq, (void **)&h->symdeint_tap, (void **)&h->deint_tap};
-  for (void **q : all) if (*q) { (void)hipFree(*q); *q = nullptr; }
+  // in soft-decision mode eq is not a debug tap but the soft demapper's input (allocated at create; it also selects the symbol kernel's instantiation that writes eq and csi)
+  void **all[] = {(void **)&h->acq_tap, (void **)&h->fft_out, h->prm.soft_decision ? (void **)nullptr : (void **)&h->eq, (void **)&h->symdeint_tap, (void **)&h->deint_tap};
+  for (void **q : all) if (q && *q) { (void)hipFree(*q); *q = nullptr; }
   return DVBT_OK;
 }
 
@@ -564,8 +568,7 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
     if (tm) HIPCHK(hipEventRecord(h->ev[ST_VIT], s));
     // the decoder: four chunks per wavefront, chunk size for whole rounds of the wavefront slots
     const S4Plan sp = s4_plan(max_vit, d.ntb);
-    const long long tasks = (max_vit + 4ll * sp.B - 1) / (4ll * sp.B);
-    const unsigned grid = (unsigned)std::min<long long>(S4_GRID, (tasks + S4_WAVES - 1) / S4_WAVES);
+    const unsigned grid = s4_grid(max_vit, d.ntb);             // <= the grid the scratch was sized for at create (C <= max_calls)
     hipLaunchKernelGGL(viterbi_soft4_kernel, dim3(grid), dim3(64 * S4_WAVES), 0, s, (const int8_t *)h->soft_a, h->vit + o.vit_off, (const RxState *)h->st, h->vp,
                        h->soft_scratch, sp.B, sp.nsteps);
   } else {

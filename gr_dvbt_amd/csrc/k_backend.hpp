@@ -573,10 +573,10 @@ __global__ __launch_bounds__(64) void rs_fix_kernel(const RsDefer *__restrict__ 
     if (tid < 16) s_syn[tid * RS_SYN_STRIDE] = d->syn[tid];
     __syncthreads();
     const int r = rs_decode_word_wave(s_cw, s_syn, s_exp, s_log, compat, s_scr, tid);
-    if (r < 0) nf++; else {
-      nc += r;
-      if (tid < 47) reinterpret_cast<unsigned *>(out + (size_t)d->word * 188)[tid] = reinterpret_cast<const unsigned *>(s_cw)[tid];
-    }
+    if (r < 0) nf++; else nc += r;
+    // reed_solomon_dec_impl.cc:100-102: the payload leaves regardless of success, with the patches applied before a zero Forney denominator aborted
+    // (reed_solomon.cc:470-486) -- as the first pass's wave and lane paths deliver it
+    if (tid < 47) reinterpret_cast<unsigned *>(out + (size_t)d->word * 188)[tid] = reinterpret_cast<const unsigned *>(s_cw)[tid];
   }
   if (tid == 0) { if (nf) atomicAdd(fail_cnt, nf); if (nc) atomicAdd(corr_cnt, nc); }
 }

@@ -55,6 +55,15 @@ inline S4Plan s4_plan(long long total_out, int ntb)
   return p;
 }
 
+// workgroups of the launch for a stream of total_out bytes (monotone in total_out: the decision scratch of a handle is sized for its largest segment)
+inline unsigned s4_grid(long long total_out, int ntb)
+{
+  const S4Plan sp = s4_plan(total_out, ntb);
+  const long long tasks = (total_out + 4ll * sp.B - 1) / (4ll * sp.B);
+  const long long g = (tasks + S4_WAVES - 1) / S4_WAVES;
+  return (unsigned)(g < 1 ? 1 : (g > S4_GRID ? S4_GRID : g));
+}
+
 struct S4Lane { unsigned sel[6][2]; };     // v_perm selectors: the 16-bit class delta of the lo / hi cell of VGPR r at phase P out of [A, B, -A, -B]
 __device__ inline void s4_init_lane(int pl, S4Lane &L)
 {

@@ -131,28 +131,37 @@ DVBT_AMD_BLOCK(resampler, dvbt_resampler_params, (int interpolation, int decimat
 #undef DVBT_AMD_BLOCK
 
 // gr::dvbt::rx_hip (gr_dvbt_amd/host/gr/include/dvbt/rx_hip.h): the ten receive blocks of apps/dvbt_rx_demo*.grc behind one block, over the
-// streaming entry of the C ABI (dvbt_rx_stream_*).  general_work(): samples in (any number), TS bytes out (what is ready); stop(): end of stream.
+// streaming entry of the C ABI (dvbt_rx_stream_*).  The same forecast / general_work logic as gr_dvbt_amd/host/gr/rx_hip_impl.cc, with the one thing the
+// shell asks the GNU Radio runtime (detail()->input(0)->done() && items_available() == 0) supplied by the host loop through input_ended():
+//   forecast: 1 item while the input lives, 0 once it has ended (so that the scheduler keeps calling general_work with nothing to read);
+//   general_work: pushes the input unless more than MAX_BACKLOG decoded bytes wait for the sink, hands out the TS bytes that are ready; at the end of the
+//   input it decodes the stream's tail (dvbt_rx_stream_finish), keeps delivering, and returns WORK_DONE when everything is out.
 class rx_hip {
  public:
   typedef std::shared_ptr<rx_hip> sptr;
+  enum { WORK_DONE = -1, MAX_BACKLOG = 8 << 20 };
   static sptr make(dvbt_constellation_t constellation, dvbt_hierarchy_t hierarchy, dvbt_code_rate_t code_rate, dvbt_guard_interval_t guard_interval,
                    dvbt_transmission_mode_t transmission_mode, float snr = 30.0f, int bsize = 768, int segment_superframes = 0, bool soft_decision = false)
   { return sptr(new rx_hip(constellation, hierarchy, code_rate, guard_interval, transmission_mode, snr, bsize, segment_superframes, soft_decision)); }
   ~rx_hip() { if (d_s) dvbt_rx_stream_destroy(d_s); }
   rx_hip(const rx_hip &) = delete;
-  void forecast(int, std::vector<int> &ninput_items_required) { for (auto &x : ninput_items_required) x = 1; }
-  // in: ninput_items complex64 samples; out: room for noutput_items bytes.  Consumes all of the input; returns the TS bytes produced
+  void input_ended(bool ended) { d_input_ended = ended; }     // the runtime's "upstream done and its buffer empty"
+  void forecast(int, std::vector<int> &ninput_items_required) { for (auto &x : ninput_items_required) x = d_input_ended ? 0 : 1; }
+  // in: ninput_items complex64 samples; out: room for noutput_items bytes.  n_consumed: all of the input, or 0 under back-pressure.
+  // Returns the TS bytes produced, or WORK_DONE
   int general_work(int noutput_items, int ninput_items, const void *in, void *out, int &n_consumed)
   {
-    check(dvbt_rx_stream_push(d_s, in, (size_t)ninput_items));
-    n_consumed = ninput_items;
+    n_consumed = 0;
+    const dvbt_rx_stream_info inf = info();
+    if (ninput_items == 0 && d_input_ended && !d_finished) { check(dvbt_rx_stream_finish(d_s)); d_finished = true; }
+    else if (ninput_items > 0 && !d_finished && inf.ts_bytes_ready < MAX_BACKLOG) { check(dvbt_rx_stream_push(d_s, in, (size_t)ninput_items)); n_consumed = ninput_items; }
     const long long n = dvbt_rx_stream_pull(d_s, out, (size_t)noutput_items);
     check((int)(n < 0 ? n : 0));
+    if (n == 0 && d_finished) return WORK_DONE;
     return (int)n;
   }
-  bool stop() { check(dvbt_rx_stream_finish(d_s)); return true; }
-  // bytes decoded at stop() that no work() call will fetch any more
-  long long drain(void *out, size_t cap) { const long long n = dvbt_rx_stream_pull(d_s, out, cap); check((int)(n < 0 ? n : 0)); return n; }
+  // a flowgraph stopped from outside: what was pushed is decoded, nothing more is delivered (no work() call follows stop())
+  bool stop() { if (!d_finished) { check(dvbt_rx_stream_finish(d_s)); d_finished = true; } return true; }
   dvbt_rx_stream_info info() const { dvbt_rx_stream_info i; check(dvbt_rx_stream_status(d_s, &i)); return i; }
  private:
   rx_hip(dvbt_constellation_t c, dvbt_hierarchy_t h, dvbt_code_rate_t r, dvbt_guard_interval_t g, dvbt_transmission_mode_t m, float snr, int bsize, int seg, bool soft)
@@ -162,7 +171,7 @@ class rx_hip {
     p.rx.snr_db = snr; p.rx.viterbi_bsize = bsize; p.rx.descramble = 1; p.rx.soft_decision = soft ? 1 : 0; p.segment_superframes = seg;
     check(dvbt_rx_stream_create(&p, &d_s));
   }
-  dvbt_rx_stream *d_s = nullptr;
+  dvbt_rx_stream *d_s = nullptr; bool d_input_ended = false, d_finished = false;
 };
 
 }}  // namespace gr::dvbt_amd

@@ -7,6 +7,7 @@
 #include <stdint.h>
 #include <gnuradio/io_signature.h>
 #include <pmt/pmt.h>
+#include <gnuradio/buffer.h>
 typedef std::complex<float> gr_complex;
 typedef std::vector<int> gr_vector_int;
 typedef std::vector<const void *> gr_vector_const_void_star;
@@ -24,6 +25,7 @@ namespace gr {
     virtual int general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &output_items);
     virtual bool stop();
     void consume_each(int how_many_items);
+    block_detail_sptr detail() const;
     void set_output_multiple(int multiple);
     void set_relative_rate(double relative_rate);
     uint64_t nitems_read(unsigned int which_input);
