@@ -234,11 +234,11 @@ class Job:
         # the single exchange step: packets + their counts -> rank 0 over xGMI, ONE gather per step.  Double
         # buffered and asynchronous: the gather of step k travels while step k+1 decodes; every gather is complete before
         # the closing barrier of the timed region.
-        self.slot = multi.HEADER_BYTES + max(p["cap"] for p in self.pieces)
+        self.slot = (multi.HEADER_BYTES + max(p["cap"] for p in self.pieces) + 63) // 64 * 64
         if dist:
             mx = torch.tensor([self.slot], dtype=torch.int64, device=self.cdev)
             dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-            self.slot = int(mx.item())
+            self.slot = (int(mx.item()) + 63) // 64 * 64
         self.send = [torch.zeros(self.slot * nseg, dtype=torch.uint8, device=f"cuda:{local}") for _ in range(2)] if dist else None
         self.recv = [[torch.empty(self.slot * nseg, dtype=torch.uint8, device=self.cdev) for _ in range(world)] for _ in range(2)] if (dist and rank == 0) else [None, None]
         self.send_host = [torch.zeros(self.slot * nseg, dtype=torch.uint8).pin_memory() for _ in range(2)] if self.host_staged else None

@@ -471,15 +471,13 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
   } else {
   const AcqState *carry = o.use_carry ? h->acq_carry : nullptr;
   int tries = C < o.init_tries ? C : o.init_tries;
-  // initial search: the first window normally holds a peak; windows 1..3 are computed and examined only if it did not
-  hipLaunchKernelGGL(acq_metric_kernel, dim3((N + 255) / 256, 1), dim3(256), 0, s, iq, fp, (const RxState *)h->st, 0, h->g_init, h->l_init, 0);
-  // (the first launch also clears the trackers' flag words, the symbol kernel's ticket and, for a period that starts the pilot engine afresh, its state)
+  // initial search: the metric of all `tries` windows in one launch (32 workgroups per window: four windows cost the latency of one), then ONE launch of the
+  // state machine, which examines them in order and stops at the first peak -- window 0 on a stream that is there, so the later windows' metric is rarely
+  // looked at; computing it unasked costs nothing on an otherwise idle device and saves two launches per lock period
+  // (the FSM launch also clears the trackers' flag words, the symbol kernel's ticket and, for a period that starts the pilot engine afresh, its state)
+  hipLaunchKernelGGL(acq_metric_kernel, dim3((N + 255) / 256, tries), dim3(256), 0, s, iq, fp, (const RxState *)h->st, 0, h->g_init, h->l_init, 0);
   const AcqReset rz = {h->trk_flags, h->sym_ticket, (o.acq_only || o.continuation) ? nullptr : reinterpret_cast<int *>(h->tps_state), (int)(sizeof(TpsState) / 4)};
-  hipLaunchKernelGGL(acq_init_fsm_kernel, dim3(1), dim3(256), (size_t)N * 5, s, fp, h->st, (const float2 *)h->g_init, (const float *)h->l_init, carry, 0, 1, rz);
-  if (tries > 1) {
-    hipLaunchKernelGGL(acq_metric_kernel, dim3((N + 255) / 256, tries - 1), dim3(256), 0, s, iq, fp, (const RxState *)h->st, 0, h->g_init, h->l_init, 1);
-    hipLaunchKernelGGL(acq_init_fsm_kernel, dim3(1), dim3(256), (size_t)N * 5, s, fp, h->st, (const float2 *)h->g_init, (const float *)h->l_init, carry, 1, tries);
-  }
+  hipLaunchKernelGGL(acq_init_fsm_kernel, dim3(1), dim3(1024), (size_t)N * 5, s, fp, h->st, (const float2 *)h->g_init, (const float *)h->l_init, carry, 0, tries, rz);
   {   // where the tracking metric is computed: CP position predicted per call from coarse estimates every ACQ_ANCHOR calls (sample-clock drift)
     const int n_anchors = (C - 1) / ACQ_ANCHOR;
     if (n_anchors > 0) hipLaunchKernelGGL(acq_anchor_kernel, dim3(n_anchors), dim3(1024), acq_anchor_lds_bytes(N, d.cp), s, iq, fp, (const RxState *)h->st, h->anchor_pos);
@@ -491,8 +489,12 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
                      (const float *)h->l_trk, h->trk_cp_a, h->trk_eps, h->trk_flags, (const int *)h->centre);
   hipLaunchKernelGGL(acq_finalize_kernel, dim3(1), dim3(1024), 0, s, fp, h->st, (const int *)h->trk_cp_a, (const float *)h->trk_eps,
                      (const int *)h->trk_flags, kIters - 1, h->meta, h->trk_flags + kIters);
+  // not settled: the sequential walk, positions and epsilon only (flags[kIters] = need_seq); flags[kIters + 1] = need_heavy, which it raises for a period
+  // outside the closed form of the phase -- that one goes through the float-faithful tracker of the block API
+  hipLaunchKernelGGL(acq_track_light_kernel, dim3(1), dim3(64), 0, s, fp, h->st, (const float2 *)h->g_trk, (const float *)h->l_trk, h->meta,
+                     (const int *)(h->trk_flags + kIters), h->trk_flags + kIters + 1, (const int *)h->centre, iq);
   hipLaunchKernelGGL(acq_track_kernel, dim3(1), dim3(64), 0, s, fp, h->st, (const float2 *)h->g_trk, (const float *)h->l_trk, h->meta,
-                     (const int *)(h->trk_flags + kIters), (AcqState *)nullptr, (const int *)h->centre, iq);
+                     (const int *)(h->trk_flags + kIters + 1), (AcqState *)nullptr, (const int *)h->centre, iq);
   hipLaunchKernelGGL(acq_lost_avg_kernel, dim3(1), dim3(64), 0, s, fp, h->st, (const int *)h->trk_cp_a, (const float *)h->l_trk, (const int *)h->centre,
                      (const int *)(h->trk_flags + kIters));
   if (o.acq_only) {
@@ -522,18 +524,20 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
                  h->T.inner_params(d.payload), (const float2 *)h->T.points, (const unsigned char *)h->T.label_tab, h->labels, h->sym_ticket, (const float *)h->drift.delta, (const int *)h->drift.flags, h->csi
   // 8k: persistent workgroups, two per CU (k_symbol8k.hpp); 2k: the same design, four symbols per workgroup (k_symbol2k.hpp).  The plain and the DRIFT
   // instantiation are both launched: the one that drift.flags[1] does not select returns before it takes a symbol
+  // (the persistent workgroups take symbols off a ticket: a short lock period launches no more of them than it has symbols)
+  const int g8 = std::min(h->sym_grid, C), g2 = std::min(h->sym_grid, (C + S2_Q - 1) / S2_Q);
   if (N == S8_N && !taps) {
-    hipLaunchKernelGGL((symbol8k_kernel<false, false>), dim3(h->sym_grid), dim3(S8_T), S8_LDS_BYTES, s, SYM_ARGS);
-    hipLaunchKernelGGL((symbol8k_kernel<false, true>), dim3(h->sym_grid), dim3(S8_T), S8_LDS_BYTES, s, SYM_ARGS);
+    hipLaunchKernelGGL((symbol8k_kernel<false, false>), dim3(g8), dim3(S8_T), S8_LDS_BYTES, s, SYM_ARGS);
+    hipLaunchKernelGGL((symbol8k_kernel<false, true>), dim3(g8), dim3(S8_T), S8_LDS_BYTES, s, SYM_ARGS);
   } else if (N == S8_N) {
-    hipLaunchKernelGGL((symbol8k_kernel<true, false>), dim3(h->sym_grid), dim3(S8_T), S8_LDS_BYTES, s, SYM_ARGS);
-    hipLaunchKernelGGL((symbol8k_kernel<true, true>), dim3(h->sym_grid), dim3(S8_T), S8_LDS_BYTES, s, SYM_ARGS);
+    hipLaunchKernelGGL((symbol8k_kernel<true, false>), dim3(g8), dim3(S8_T), S8_LDS_BYTES, s, SYM_ARGS);
+    hipLaunchKernelGGL((symbol8k_kernel<true, true>), dim3(g8), dim3(S8_T), S8_LDS_BYTES, s, SYM_ARGS);
   } else if (N == S2_N && !taps) {
-    hipLaunchKernelGGL((symbol2k_kernel<false, false>), dim3(h->sym_grid), dim3(S2_T * S2_Q), S2_LDS_BYTES, s, SYM_ARGS);
-    hipLaunchKernelGGL((symbol2k_kernel<false, true>), dim3(h->sym_grid), dim3(S2_T * S2_Q), S2_LDS_BYTES, s, SYM_ARGS);
+    hipLaunchKernelGGL((symbol2k_kernel<false, false>), dim3(g2), dim3(S2_T * S2_Q), S2_LDS_BYTES, s, SYM_ARGS);
+    hipLaunchKernelGGL((symbol2k_kernel<false, true>), dim3(g2), dim3(S2_T * S2_Q), S2_LDS_BYTES, s, SYM_ARGS);
   } else if (N == S2_N) {
-    hipLaunchKernelGGL((symbol2k_kernel<true, false>), dim3(h->sym_grid), dim3(S2_T * S2_Q), S2_LDS_BYTES, s, SYM_ARGS);
-    hipLaunchKernelGGL((symbol2k_kernel<true, true>), dim3(h->sym_grid), dim3(S2_T * S2_Q), S2_LDS_BYTES, s, SYM_ARGS);
+    hipLaunchKernelGGL((symbol2k_kernel<true, false>), dim3(g2), dim3(S2_T * S2_Q), S2_LDS_BYTES, s, SYM_ARGS);
+    hipLaunchKernelGGL((symbol2k_kernel<true, true>), dim3(g2), dim3(S2_T * S2_Q), S2_LDS_BYTES, s, SYM_ARGS);
   }
 #undef SYM_ARGS
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_DEMOD], s));

@@ -66,26 +66,42 @@ __device__ __forceinline__ float2 cdiv(float2 a, float2 b)
 // ---------------------------------------------------------------- A1: CP correlation metric
 // ml_sync (ofdm_sym_acquisition_impl.cc:148-250): gamma(i) = sum_{j<cp} x[i-j] conj(x[i-j-N]),
 // phi(i) = sum |x[i-j]|^2 + |x[i-j-N]|^2, lambda = |gamma| - rho/2 * phi.
-// One thread per lag: the initial search, lags N+cp-1 .. 2N+cp-2 of window `try`.
+// One thread per lag: the initial search, lags N+cp-1 .. 2N+cp-2 of window `try`.  A workgroup owns 256 consecutive lags: the cp + 255 products
+// x[i] conj(x[i-N]) and energy pairs they share are formed once (coalesced loads) and kept in LDS; a thread then sums its lag's cp terms in the
+// reference's order (j ascending, i.e. sample index descending) -- the same float expressions as summing from global memory, ~5 us per launch instead of
+// ~21 (a lock period's initial search was a quarter of config 5's time at 8 dB).
 __global__ __launch_bounds__(256) void acq_metric_kernel(const float2 *__restrict__ iq, FrontParams p, const RxState *st,
                                                         int mode, float2 *__restrict__ gamma, float *__restrict__ lambda, int t_begin)
 {
-  const int N = p.N, cp = p.cp;
+  __shared__ __attribute__((aligned(16))) float2 s_c[ACQ_CP_MAX + 256];
+  __shared__ __attribute__((aligned(16))) float s_e[ACQ_CP_MAX + 256];
+  const int N = p.N, cp = p.cp, tid = threadIdx.x;
   (void)mode;
   const int t = blockIdx.y + t_begin;
   if (t >= p.ncalls) return;
   if (t_begin > 0 && !(st->status & 1)) return;                 // later windows are searched only if the first one had no peak
-  const int q = blockIdx.x * 256 + threadIdx.x;
-  if (q >= N) return;
-  const long long wbase = (long long)t * (N + cp);
-  const int lag = N + cp - 1 + q, oidx = t * N + q;
-  const float2 *x = iq + wbase + lag;
-  float gr = 0.f, gi = 0.f, phi = 0.f;
-  for (int j = 0; j < cp; j++) {
-    float2 a = x[-j], b = x[-j - N];
-    gr += a.x * b.x + a.y * b.y; gi += a.y * b.x - a.x * b.y;
-    phi += (a.x * a.x + a.y * a.y) + (b.x * b.x + b.y * b.y);
+  const int q0 = blockIdx.x * 256, q = q0 + tid;
+  const float2 *w = iq + (long long)t * (N + cp) + q0;          // the workgroup's lags read samples N + q0 .. N + q0 + cp + 254 of the window and the same N earlier
+  const int span = cp + 255 < N + cp - 1 - q0 ? cp + 255 : N + cp - 1 - q0;   // (the window's last lag is 2N+cp-2)
+  for (int i = tid; i < span; i += 256) {
+    const float2 a = w[N + i], b = w[i];
+    s_c[i] = make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+    s_e[i] = (a.x * a.x + a.y * a.y) + (b.x * b.x + b.y * b.y);
   }
+  __syncthreads();
+  if (q >= N) return;
+  const int oidx = t * N + q;
+  const float2 *c = s_c + tid + cp - 1; const float *e = s_e + tid + cp - 1;   // the lag's own sample; tap j sits j below
+  float gr = 0.f, gi = 0.f, phi = 0.f;
+  int j = 0;
+  for (; j + 8 <= cp; j += 8) {
+    float2 cv[8]; float ev[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { cv[k] = c[-(j + k)]; ev[k] = e[-(j + k)]; }
+#pragma unroll
+    for (int k = 0; k < 8; k++) { gr += cv[k].x; gi += cv[k].y; phi += ev[k]; }
+  }
+  for (; j < cp; j++) { gr += c[-j].x; gi += c[-j].y; phi += e[-j]; }
   gamma[oidx] = make_float2(gr, gi);
   lambda[oidx] = sqrtf(gr * gr + gi * gi) - phi * p.half_rho;
 }
@@ -301,20 +317,20 @@ __device__ __forceinline__ float wrap_pi(double ph)
 // reset (segment path, first launch of a lock period): the flag words of the trackers (trk_flags[0..15]; [8], [9] = first superframe-start candidate, need_seq of the
 // TPS bookkeeping), the symbol kernel's ticket and -- for a period that starts the pilot engine afresh -- its state: three memset / copy launches less
 struct AcqReset { int *trk_flags; int *ticket; int *tps_state; int tps_state_words; };
-__global__ __launch_bounds__(256) void acq_init_fsm_kernel(FrontParams p, RxState *st, const float2 *gamma, const float *lambda, const AcqState *as,
+__global__ __launch_bounds__(1024) void acq_init_fsm_kernel(FrontParams p, RxState *st, const float2 *gamma, const float *lambda, const AcqState *as,
                                                           int t_begin, int t_end, AcqReset rz = AcqReset{nullptr, nullptr, nullptr, 0})
 {
   if (t_begin == 0) {
     if (rz.trk_flags && threadIdx.x < 16) rz.trk_flags[threadIdx.x] = threadIdx.x == 8 ? 0x7fffffff : 0;
     if (rz.ticket && threadIdx.x == 16) rz.ticket[0] = 0;
-    if (rz.tps_state) for (int i = threadIdx.x; i < rz.tps_state_words; i += 256) rz.tps_state[i] = 0;
+    if (rz.tps_state) for (int i = threadIdx.x; i < rz.tps_state_words; i += blockDim.x) rz.tps_state[i] = 0;
   }
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float *lam = reinterpret_cast<float *>(smem_raw);
   unsigned char *flg = smem_raw + (size_t)p.N * 4;
   __shared__ int s_done;
   __shared__ float s_avg;
-  const int tid = threadIdx.x, N = p.N;
+  const int tid = threadIdx.x, N = p.N, nthr = blockDim.x;     // 256 (block API) or 1024 threads (segment path: the averages are 32-deep chains, 8 instead of 32 per thread)
   int tries = p.ncalls < t_end ? p.ncalls : t_end;
   if (tid == 0 && t_begin > 0) { s_done = (st->status & 1) ? 0 : 2; s_avg = st->avg; }   // continuation: only if the earlier windows had no peak
   if (tid == 0 && t_begin == 0) {
@@ -331,10 +347,10 @@ __global__ __launch_bounds__(256) void acq_init_fsm_kernel(FrontParams p, RxStat
   const float rise = 0.8f, fall = 0.9f, alpha = 0.9f;
   constexpr int HIST = 32;
   for (int t = t_begin; t < tries; t++) {
-    for (int i = tid; i < N; i += 256) lam[i] = lambda[(size_t)t * N + i];
+    for (int i = tid; i < N; i += nthr) lam[i] = lambda[(size_t)t * N + i];
     __syncthreads();
     const float avg0 = s_avg;
-    for (int i = tid; i <= N; i += 256) {                          // avg before sample i (i == N: the carried value)
+    for (int i = tid; i <= N; i += nthr) {                         // avg before sample i (i == N: the carried value)
       float avg;
       if (i > HIST) {                                              // fixed-length history: its LDS reads are issued together
         float hbuf[HIST];
@@ -532,6 +548,83 @@ __global__ __launch_bounds__(64) void acq_track_kernel(FrontParams p, RxState *s
     as->acquired = lost ? 0 : 1; as->lost = lost ? 1 : 0; as->cp_start = cur; as->avg = avg; as->phase = phase;
     as->phaseinc = phaseinc; as->nextphaseinc = nextphaseinc; as->nextpos = nextpos;
   }
+}
+
+// The sequential tracker of the SEGMENT path (lock periods on which the Jacobi placement below does not settle: a lock that is being lost, noise that moves the
+// peak by several samples from call to call).  One wavefront in lockstep like acq_track_kernel, but it walks POSITIONS AND EPSILON ONLY: peak detector and atan2
+// per call, the derotation phase as the exact line in double (sw * incA + (L - sw) * incB per call: acq_finalize_kernel's closed form, accumulated on the way).
+// The float accumulator's wander on top of that line is the drift kernels' business (k_drift.hpp), which treat the period exactly as they treat one that the
+// parallel placement has settled -- no table of 15 regions per call, no double-precision division in the chain: ~0.5 us per call instead of ~4 (config 5 at
+// 8 dB: 18 of 59 ms were this chain).  A phase-increment switch outside its call (never for a tracked peak, see acq_finalize_kernel) hands the period to
+// acq_track_kernel through *need_heavy.
+__global__ __launch_bounds__(64) void acq_track_light_kernel(FrontParams p, RxState *st, const float2 *gamma, const float *lambda, SymMeta *meta, const int *need_seq,
+                                                             int *need_heavy, const int *__restrict__ centre, const float2 *__restrict__ iq)
+{
+  __shared__ __attribute__((aligned(16))) float s_lam[16]; __shared__ __attribute__((aligned(16))) float2 s_gam[16];
+  __shared__ __attribute__((aligned(16))) float2 s_xa[ACQ_CP_MAX + 16], s_xb[ACQ_CP_MAX + 16];
+  __shared__ __attribute__((aligned(16))) float s_rl[2][2 * ACQ_R]; __shared__ __attribute__((aligned(16))) float2 s_rg[2][2 * ACQ_R];
+  const int lane = threadIdx.x;
+  if (blockIdx.x != 0 || (st->status & 1) || *need_seq == 0) return;
+  const int N = p.N, cp = p.cp, R = p.R, L = N + cp, c0 = st->cp_start0, call0 = st->call0;
+  float avg = st->avg;
+  double incA = 0.0, incB = (-1.0 / (double)N) * (double)st->eps_init, base = 0.0;
+  int sw = c0 - L, cur = c0, s = 0;
+  bool lost = false, viol = false;
+  float nl = 0.f; float2 ng = make_float2(0.f, 0.f); int ncen = 0;
+  auto fetch_row = [&](int call) {
+    if (call < p.ncalls) { ncen = centre[call]; if (lane < 2 * R) { nl = lambda[(size_t)call * 2 * R + lane]; ng = gamma[(size_t)call * 2 * R + lane]; } }
+  };
+  fetch_row(call0);
+  for (int call = call0; call < p.ncalls; call++, s++) {
+    const int buf = (call - call0) & 1, cen = ncen;
+    __syncthreads();
+    if (lane < 2 * R) { s_rl[buf][lane] = nl; s_rg[buf][lane] = ng; }
+    __syncthreads();
+    fetch_row(call + 1);
+    int rel0 = (cur - 8) - (cen - R);
+    const bool direct = rel0 < 0 || rel0 + 16 > 2 * R;            // the window left the precomputed lags: this call's metric on the spot, a lag per lane
+    if (direct) {
+      const long long lo = (long long)call * L + cur - 8 - (cp - 1);
+      __syncthreads();
+      for (int t = lane; t < cp + 15; t += 64) {
+        s_xa[t] = lo + t >= -p.hist ? iq[lo + t] : make_float2(0.f, 0.f);
+        s_xb[t] = lo - N + t >= -p.hist ? iq[lo - N + t] : make_float2(0.f, 0.f);
+      }
+      __syncthreads();
+      if (lane < 16) {
+        const int lag = cur - 8 + lane;
+        float gr = 0.f, gi = 0.f, phi = 0.f;
+        if ((long long)call * L + lag - cp + 1 - N < -p.hist) { s_lam[lane] = -3.0e38f; s_gam[lane] = make_float2(0.f, 0.f); }
+        else {
+          const float2 *xa = s_xa + (cp - 1) + lane, *xb = s_xb + (cp - 1) + lane;
+          for (int j = 0; j < cp; j++) {                            // the expressions and the order of acq_track_metric_kernel
+            const float2 a = xa[-j], b = xb[-j];
+            gr += a.x * b.x + a.y * b.y; gi += a.y * b.x - a.x * b.y; phi += (a.x * a.x + a.y * a.y) + (b.x * b.x + b.y * b.y);
+          }
+          s_gam[lane] = make_float2(gr, gi); s_lam[lane] = sqrtf(gr * gr + gi * gi) - phi * p.half_rho;
+        }
+      }
+      __syncthreads();
+      rel0 = 0;
+    }
+    const float *lam = direct ? s_lam : &s_rl[buf][rel0];
+    int pos = 0;
+    const int npk = peak_detect(lam, 16, avg, pos);
+    if (!npk) { lost = true; break; }                               // the reference drops lock and re-acquires (:545-559)
+    if (sw < 0 || sw >= L) { viol = true; break; }                  // outside the closed form: the float-faithful tracker takes the period
+    const float2 g = direct ? s_gam[pos] : s_rg[buf][rel0 + pos];
+    const float eps = atan2f(g.y, g.x);
+    const int peak = pos + cur - 8;
+    if (lane == 0) { SymMeta m; m.cp_start = peak; m.eps = eps; m.ph_base = wrap_pi(base); m.incA = incA; m.incB = incB; m.sw = sw; meta[s] = m; }
+    base += sw * incA + (L - sw) * incB;
+    incA = incB; incB = (-1.0 / (double)N) * (double)eps;
+    sw = peak - L; cur = peak;
+  }
+  if (lane != 0) return;
+  if (viol) { *need_heavy = 1; return; }
+  if (lost) st->status |= 2;
+  st->n_symbols = s;
+  st->avg_lost = lost ? avg : st->avg;                            // d_avg after the call that lost the lock
 }
 
 // ---- parallel tracking.  Two facts make the per-call FSM independent of its predecessors:

@@ -158,7 +158,7 @@ def pack_piece(buf, meta, ts):
 
 def unpack_piece(buf):
     import torch
-    hdr = buf[:HEADER_BYTES].cpu().view(torch.int64)
+    hdr = buf[:HEADER_BYTES].cpu().clone().view(torch.int64)      # (clone: a slice of a host buffer keeps its storage offset, which need not be 8-aligned)
     meta = {k: int(hdr[i]) for i, k in enumerate(META_FIELDS)}
     return meta, buf[HEADER_BYTES:HEADER_BYTES + meta["n_ts_bytes"]]
 
