@@ -362,6 +362,7 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   { int ncu = 256; (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->prm.device); h->sym_grid = s8_grid(ncu); }
   RXCHK(set_lds((const void *)inner_kernel<6>, inner_lds_bytes(P)));
   RXCHK(set_lds((const void *)acq_anchor_kernel, acq_anchor_lds_bytes((int)N, d.cp)));
+  RXCHK(set_lds((const void *)acq_small_kernel, (size_t)acq_small_cpc(d.cp) * 2 * (d.cp + 2 * ACQ_R) * sizeof(float2)));
   *out = h;
   return DVBT_OK;
 }
@@ -416,6 +417,7 @@ struct EnqOpt {
   bool keep_last = false;     // a later period delivers items: the last item of this one leaves the demodulator too
   size_t vit_off = 0;         // where this period's decoded bytes go in the Viterbi stream of the segment
   bool tail = true;           // byte de-interleaver + RS + descrambler right behind (single period)
+  bool no_small = false;      // acq_only: not through acq_small_kernel (it has handed the period back: RxState.small_viol)
 };
 
 // samples at the OFDM elementary rate: the segment itself, or its resampled image (next row 2)
@@ -478,6 +480,11 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
   hipLaunchKernelGGL(acq_metric_kernel, dim3((N + 255) / 256, tries), dim3(256), 0, s, iq, fp, (const RxState *)h->st, 0, h->g_init, h->l_init, 0);
   const AcqReset rz = {h->trk_flags, h->sym_ticket, (o.acq_only || o.continuation) ? nullptr : reinterpret_cast<int *>(h->tps_state), (int)(sizeof(TpsState) / 4)};
   hipLaunchKernelGGL(acq_init_fsm_kernel, dim3(1), dim3(1024), (size_t)N * 5, s, fp, h->st, (const float2 *)h->g_init, (const float *)h->l_init, carry, 0, tries, rz);
+  if (o.acq_only && !o.no_small && C <= ACQ_SMALL_MAX_CALLS) {
+    // the lock-period walk's short look-ahead windows: everything behind the initial search in one launch, work in proportion to the symbols the lock holds
+    const int cpc = acq_small_cpc(d.cp);
+    hipLaunchKernelGGL(acq_small_kernel, dim3(1), dim3(64 * (1 + cpc / 2)), (size_t)cpc * 2 * (d.cp + 2 * ACQ_R) * sizeof(float2), s, iq, fp, h->st, h->meta, cpc);
+  } else {
   {   // where the tracking metric is computed: CP position predicted per call from coarse estimates every ACQ_ANCHOR calls (sample-clock drift)
     const int n_anchors = (C - 1) / ACQ_ANCHOR;
     if (n_anchors > 0) hipLaunchKernelGGL(acq_anchor_kernel, dim3(n_anchors), dim3(1024), acq_anchor_lds_bytes(N, d.cp), s, iq, fp, (const RxState *)h->st, h->anchor_pos);
@@ -497,6 +504,7 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
                      (const int *)(h->trk_flags + kIters + 1), (AcqState *)nullptr, (const int *)h->centre, iq);
   hipLaunchKernelGGL(acq_lost_avg_kernel, dim3(1), dim3(64), 0, s, fp, h->st, (const int *)h->trk_cp_a, (const float *)h->l_trk, (const int *)h->centre,
                      (const int *)(h->trk_flags + kIters));
+  }
   if (o.acq_only) {
     HIPCHK(hipMemcpyAsync(h->st_host, h->st, sizeof(RxState), hipMemcpyDeviceToHost, s));
     HIPCHK(hipGetLastError());
@@ -746,6 +754,7 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
       for (;;) {
         int r = enqueue(h, chain + off, look, s, o); if (r) return r;
         HIPCHK(hipStreamSynchronize(s));
+        if (!(h->st_host->status & 1) && h->st_host->small_viol && !o.no_small) { o.no_small = true; continue; }   // outside acq_small_kernel's closed form: the general kernels
         if ((h->st_host->status & 3) || look >= chain_n - off) break;
         look = std::min(chain_n - off, win + 4 * (look - win) + 3 * L);
       }
@@ -958,6 +967,21 @@ extern "C" double dvbt_rx_stage_ms(dvbt_rx *h, const char *stage)
 }
 
 extern "C" void dvbt_rx_destroy(dvbt_rx *h) { if (h) rx_free(h); }
+
+// test hook: the trackers' two peak detectors (peak_detect, the reference's state machine sample by sample; peak_detect16_wave, the wavefront-wide form the
+// sequential trackers use) on n cases of 16 metric values and a carried average each.  out[4k..]: npk, pos of the first, npk, pos of the second; avg_out[2k..]: d_avg after
+extern "C" int dvbt_debug_peak_detect(const float *lam_host, const float *avg_host, int n, int32_t *out_host, float *avg_out_host)
+{
+  if (!lam_host || !avg_host || !out_host || !avg_out_host || n <= 0) return fail(DVBT_ERR_INVALID, "null argument");
+  int r = need_device(); if (r) return r;
+  float *dl = nullptr, *da = nullptr, *dao = nullptr; int *dout = nullptr;
+  HIPCHK(hipMalloc((void **)&dl, sizeof(float) * 16 * n)); HIPCHK(hipMalloc((void **)&da, sizeof(float) * n)); HIPCHK(hipMalloc((void **)&dao, sizeof(float) * 2 * n)); HIPCHK(hipMalloc((void **)&dout, sizeof(int) * 4 * n));
+  HIPCHK(hipMemcpy(dl, lam_host, sizeof(float) * 16 * n, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(da, avg_host, sizeof(float) * n, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(peak_selftest_kernel, dim3(n), dim3(64), 0, nullptr, (const float *)dl, (const float *)da, n, dout, dao);
+  HIPCHK(hipMemcpy(out_host, dout, sizeof(int) * 4 * n, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(avg_out_host, dao, sizeof(float) * 2 * n, hipMemcpyDeviceToHost));
+  (void)hipFree(dl); (void)hipFree(da); (void)hipFree(dao); (void)hipFree(dout);
+  return DVBT_OK;
+}
 
 #include "dvbt_stream.inc"
 #include "dvbt_blocks.inc"

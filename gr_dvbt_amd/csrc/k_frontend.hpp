@@ -33,6 +33,8 @@ struct RxState {
   long long ts_first_packet; // RS word index (of this segment) of the first packet of the TS tap
   unsigned long long tps_bits; // TPS word of a BCH-valid frame, bit i = s_i, with the fields that change from frame to frame (sync word s1-s16,
                                // frame number s23-s24, parity s54-s67) cleared: identical for every frame of a stream; 0 = none seen
+  int small_viol;              // acq_small_kernel met a phase-increment switch outside its call: the period goes through the general kernels
+  int pad_;
 };
 // fields of a TPS word that are the same in every frame (reference_signals_impl.cc:883-916): s17-s22 length, s25-s53 parameters
 constexpr unsigned long long TPS_STATIC_MASK = ((1ull << 54) - 1) & ~((1ull << 17) - 1) & ~(3ull << 23);
@@ -300,6 +302,62 @@ __device__ inline int peak_detect(const float *d, int n, float &avg, int &best_p
   return npk;
 }
 
+// peak_detect over the 16 lags of a tracking window by a whole wavefront (all lanes in lockstep; lane i < 16 holds lambda[i]).  peak_step walks a state machine
+// sample by sample: ~45 instructions each, dependent, ~1.8 us per call for a lone wavefront -- the sequential trackers' whole budget.  Here only what IS a
+// recurrence stays one: the IIR average (16 x multiply-add, the reference's expression, lane i keeps the value sample i sees).  The two threshold tests of
+// every sample are then one compare per lane and two ballots; the state machine runs on those 16-bit masks: state 0 skips to the next rise bit; state 1 from
+// rise sample r ends at the first sample that neither exceeds the running maximum max(v_r .. v_{i-1}) (a prefix maximum over the row: four DPP shifts) nor
+// passes the keep test; the completed peak's value and first position come from one more ballot; the sample that completed it is re-examined in state 0
+// (its rise bit).  A peak still open at the end of the window is not counted (peak_detect_process records completed peaks only).  Same results as
+// peak_detect, bit for bit (tests/test_gpu_blocks.py::test_wave_peak_detector drives both through dvbt_debug_peak_detect).
+template <int SH> __device__ __forceinline__ float row_shr_fill(float x, float fill)
+{ return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, x), 0x110 | SH, 0xf, 0xf, false)); }
+__device__ inline int peak_detect16_wave(float v, int lane, float &avg, int &best_pos)
+{
+  const float rise = 0.8f, fall = 0.9f, alpha = 0.9f;
+  const float tv = alpha * v;
+  float a = avg, mine = avg;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    mine = lane == i ? a : mine;                                   // d_avg as sample i sees it
+    const float ti = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tv), i));
+    a = ti + (1 - alpha) * a;
+  }
+  avg = a;
+  const bool ok = lane < 16;
+  const unsigned R = (unsigned)__ballot(ok && v > mine * rise), K = (unsigned)__ballot(ok && v > mine * fall);
+  const float NINF = -INFINITY;
+  int npk = 0, pos = 0; float best_val = 0.f;
+  for (;;) {
+    const unsigned m = pos < 16 ? (R & (0xffffu << pos)) : 0u;
+    if (!m) break;
+    const int r = __ffs((int)m) - 1;
+    float x = (ok && lane >= r) ? v : NINF;
+    x = fmaxf(x, row_shr_fill<1>(x, NINF)); x = fmaxf(x, row_shr_fill<2>(x, NINF)); x = fmaxf(x, row_shr_fill<4>(x, NINF)); x = fmaxf(x, row_shr_fill<8>(x, NINF));
+    const float ex = row_shr_fill<1>(x, NINF);                      // max(v_r .. v_{i-1})
+    const unsigned D = (unsigned)__ballot(ok && lane > r && !(v > ex) && !((K >> lane) & 1u));
+    if (!D) break;
+    const int c = __ffs((int)D) - 1;
+    const float pv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), c - 1));
+    const unsigned E = (unsigned)__ballot(ok && lane >= r && lane < c && v == pv);
+    const int pi = __ffs((int)E) - 1;
+    if (npk == 0 || pv > best_val) { best_val = pv; best_pos = pi; }
+    npk++; pos = c;
+  }
+  return npk;
+}
+
+// test hook (dvbt_debug_peak_detect): a wavefront per case runs both detectors on the same 16 values and the same carried average
+__global__ __launch_bounds__(64) void peak_selftest_kernel(const float *__restrict__ lam, const float *__restrict__ avg_in, int n, int *__restrict__ out, float *__restrict__ avg_out)
+{
+  const int k = blockIdx.x, lane = threadIdx.x;
+  if (k >= n) return;
+  float a0 = avg_in[k], a1 = a0; int p0 = 0, p1 = 0;
+  const int n0 = peak_detect(lam + (size_t)k * 16, 16, a0, p0);
+  const int n1 = peak_detect16_wave(lane < 16 ? lam[(size_t)k * 16 + lane] : 0.f, lane, a1, p1);
+  if (lane == 0) { out[4 * k] = n0; out[4 * k + 1] = n0 ? p0 : -1; out[4 * k + 2] = n1; out[4 * k + 3] = n1 ? p1 : -1; avg_out[2 * k] = a0; avg_out[2 * k + 1] = a1; }
+}
+
 __device__ __forceinline__ float wrap_pi(double ph)
 {
   const double twopi = 6.283185307179586;
@@ -328,8 +386,9 @@ __global__ __launch_bounds__(1024) void acq_init_fsm_kernel(FrontParams p, RxSta
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float *lam = reinterpret_cast<float *>(smem_raw);
   unsigned char *flg = smem_raw + (size_t)p.N * 4;
-  __shared__ int s_done;
+  __shared__ int s_done, s_pos;
   __shared__ float s_avg;
+  __shared__ unsigned long long s_rise[8192 / 64];                  // rise flags of the window, a bit per sample (the walk skips from peak to peak)
   const int tid = threadIdx.x, N = p.N, nthr = blockDim.x;     // 256 (block API) or 1024 threads (segment path: the averages are 32-deep chains, 8 instead of 32 per thread)
   int tries = p.ncalls < t_end ? p.ncalls : t_end;
   if (tid == 0 && t_begin > 0) { s_done = (st->status & 1) ? 0 : 2; s_avg = st->avg; }   // continuation: only if the earlier windows had no peak
@@ -363,8 +422,11 @@ __global__ __launch_bounds__(1024) void acq_init_fsm_kernel(FrontParams p, RxSta
         avg = avg0;
         for (int j = 0; j < i; j++) avg = alpha * lam[j] + (1 - alpha) * avg;
       }
-      if (i < N) { const float v = lam[i]; flg[i] = (unsigned char)((v > avg * rise ? 1 : 0) | (v > avg * fall ? 2 : 0)); }
+      unsigned f = 0;
+      if (i < N) { const float v = lam[i]; f = (v > avg * rise ? 1u : 0u) | (v > avg * fall ? 2u : 0u); flg[i] = (unsigned char)f; }
       else s_avg = avg;
+      const unsigned long long rb = __ballot(i < N && (f & 1u));    // the wavefront's 64 samples are consecutive and 64-aligned
+      if ((tid & 63) == 0 && i < N) s_rise[i >> 6] = rb;
     }
     __syncthreads();
     if (tid < 64) {
@@ -380,9 +442,24 @@ __global__ __launch_bounds__(1024) void acq_init_fsm_kernel(FrontParams p, RxSta
         const float v = in ? lam[i] : -INFINITY;
         const unsigned f = in ? flg[i] : 2u;
         if (state == 0) {
-          const unsigned long long m = __ballot(in && (f & 1u));
-          if (m) { const int l = __ffsll((long long)m) - 1; state = 1; peak_index = pos + l; peak_val = lam[peak_index]; pos = peak_index + 1; }
-          else pos += 64;
+          // the next sample at or behind pos with the rise flag: straight from the bit words (a window has a handful of peaks; walking its 128 chunks of
+          // silence one ballot at a time was most of this kernel's time)
+          int cand = 0x7fffffff;
+          for (int w0 = 0; w0 < (N >> 6); w0 += 64) {
+            const int w = w0 + tid;
+            unsigned long long m = w < (N >> 6) ? s_rise[w] : 0ull;
+            if ((w << 6) + 63 < pos) m = 0ull; else if ((w << 6) < pos) m &= ~0ull << (pos - (w << 6));
+            const unsigned long long any = __ballot(m != 0ull);
+            if (any) {
+              const int l = __ffsll((long long)any) - 1;
+              if (tid == l) s_pos = (w << 6) + __ffsll((long long)m) - 1;
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+              cand = s_pos;
+              break;
+            }
+          }
+          if (cand < N) { state = 1; peak_index = cand; peak_val = lam[peak_index]; pos = peak_index + 1; }
+          else pos = N;
         } else {
           float pm = v;                                            // inclusive prefix maximum over the lanes
           for (int o = 1; o < 64; o <<= 1) { const float u = __shfl_up(pm, o); if (tid >= o) pm = fmaxf(pm, u); }
@@ -609,7 +686,7 @@ __global__ __launch_bounds__(64) void acq_track_light_kernel(FrontParams p, RxSt
     }
     const float *lam = direct ? s_lam : &s_rl[buf][rel0];
     int pos = 0;
-    const int npk = peak_detect(lam, 16, avg, pos);
+    const int npk = peak_detect16_wave(lane < 16 ? lam[lane] : 0.f, lane, avg, pos);
     if (!npk) { lost = true; break; }                               // the reference drops lock and re-acquires (:545-559)
     if (sw < 0 || sw >= L) { viol = true; break; }                  // outside the closed form: the float-faithful tracker takes the period
     const float2 g = direct ? s_gam[pos] : s_rg[buf][rel0 + pos];
@@ -625,6 +702,142 @@ __global__ __launch_bounds__(64) void acq_track_light_kernel(FrontParams p, RxSt
   if (lost) st->status |= 2;
   st->n_symbols = s;
   st->avg_lost = lost ? avg : st->avg;                            // d_avg after the call that lost the lock
+}
+
+// ---- the tracker of a SHORT lock period in one launch (the lock-period walk of the synchronous entries: a stream on which the reference's detector drops the
+// lock every few dozen symbols, BASELINE config 5 at 8-9 dB).  Everything behind the initial search that the general path spreads over eight launches sized
+// for tens of thousands of calls (anchors, centres, the tracking metric of the whole look-ahead window, the Jacobi placement, its bookkeeping, the sequential walk,
+// the lost-lock average): ONE workgroup, work proportional to the symbols the lock actually holds.
+//   * waves 1 .. cpc/2 compute the tracking metric of the next chunk of `cpc` calls, two calls per wave (half a wave = the 2R lags of a call, a lag per
+//     lane): the cp + 2R - 1 samples the lags share and the same N earlier through LDS, the sums in acq_track_metric_kernel's expressions and order
+//     (bit-identical lambda / gamma).  The chunk's lags are centred on the peak the walk had reached when the chunk was started: a drifting CP position is
+//     followed chunk by chunk, no anchors;
+//   * wave 0 walks the chunk computed before (acq_track_light_kernel's walk: peak detector, atan2, the phase as the exact line), the two overlap;
+//   * a window that has left its chunk's lags is computed on the spot by wave 0 (a lag per lane, from global memory).
+// Writes what the general path writes: meta[], st->n_symbols / status bit 1 / avg_lost.  st->small_viol = 1: a switch position outside its call -- the host
+// runs the general path on the period instead.
+constexpr int ACQ_SMALL_MAX_CALLS = 768;
+constexpr size_t ACQ_SMALL_LDS = 96 * 1024;
+inline int acq_small_cpc(int cp) { int c = (int)(ACQ_SMALL_LDS / ((size_t)(cp + 2 * ACQ_R) * 16)); c &= ~1; return c > 16 ? 16 : (c < 2 ? 2 : c); }
+__global__ __launch_bounds__(576) void acq_small_kernel(const float2 *__restrict__ iq, FrontParams p, RxState *st, SymMeta *__restrict__ meta, int cpc)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __shared__ __attribute__((aligned(16))) float s_lam[2][16][2 * ACQ_R]; __shared__ __attribute__((aligned(16))) float2 s_gam[2][16][2 * ACQ_R];
+  __shared__ __attribute__((aligned(16))) float s_dl[16]; __shared__ __attribute__((aligned(16))) float2 s_dg[16];
+  __shared__ int s_cen[2], s_next_cen, s_stop;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (st->status & 1) return;
+  const int N = p.N, cp = p.cp, R = p.R, L = N + cp, c0 = st->cp_start0, call0 = st->call0;
+  const int span = cp + 2 * R - 1, stride = cp + 2 * R;             // samples a call's lags share
+  float2 *stage = reinterpret_cast<float2 *>(smem_raw);             // [cpc][2][stride]
+  if (tid == 0) { s_next_cen = c0; s_stop = 0; st->small_viol = 0; }
+  __syncthreads();
+  // metric of chunk k (calls call0 + k cpc ...) into buffer k & 1, lags cen - R .. cen + R - 1 of every call.  The products x[i] conj(x[i-N]) and the energy pairs
+  // of the cp + 2R - 1 samples a call's lags share are formed ONCE while staging (the same float expressions acq_track_metric_kernel evaluates per tap: the
+  // sums below add the same values in the same order); a lane then adds its lag's cp terms.  (Forming them per lag and tap made this the kernel's
+  // critical path: 14 operations per tap and lane instead of 3.)
+  auto metric_chunk = [&](int k, int cen) {
+    const int slot = 2 * (wave - 1) + (lane >> 5), q = lane & 31, call = call0 + k * cpc + slot;
+    if (wave < 1 || slot >= cpc || call >= p.ncalls) return;
+    float2 *sc = stage + (size_t)slot * 2 * stride; float *se = reinterpret_cast<float *>(sc + stride);
+    const long long lo = (long long)call * L + cen - R - (cp - 1);  // sample of sc[0]
+    for (int t0 = q; t0 < span; t0 += 32 * 5) {                     // ten loads per lane in flight (cp = 256: two trips)
+      float2 ra[5], rb[5];
+#pragma unroll
+      for (int u = 0; u < 5; u++) {
+        const int t = t0 + 32 * u; const bool in = t < span;
+        ra[u] = in && lo + t >= -p.hist ? iq[lo + t] : make_float2(0.f, 0.f);
+        rb[u] = in && lo - N + t >= -p.hist ? iq[lo - N + t] : make_float2(0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 5; u++) {
+        const int t = t0 + 32 * u;
+        if (t < span) {
+          const float2 a = ra[u], b = rb[u];
+          sc[t] = make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+          se[t] = (a.x * a.x + a.y * a.y) + (b.x * b.x + b.y * b.y);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // the half wave's own staging only
+    float gr = 0.f, gi = 0.f, phi = 0.f;
+    const float2 *xc = sc + (cp - 1) + q; const float *xe = se + (cp - 1) + q;
+    int j = 0;
+    for (; j + 8 <= cp; j += 8) {
+      float2 cv[8]; float ev[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { cv[u] = xc[-(j + u)]; ev[u] = xe[-(j + u)]; }
+#pragma unroll
+      for (int u = 0; u < 8; u++) { gr += cv[u].x; gi += cv[u].y; phi += ev[u]; }
+    }
+    for (; j < cp; j++) { gr += xc[-j].x; gi += xc[-j].y; phi += xe[-j]; }
+    const bool before = (long long)call * L + (cen - R + q) - cp + 1 - N < -p.hist;   // the lag reaches in front of the stream's first sample
+    s_lam[k & 1][slot][q] = before ? -3.0e38f : sqrtf(gr * gr + gi * gi) - phi * p.half_rho;
+    s_gam[k & 1][slot][q] = before ? make_float2(0.f, 0.f) : make_float2(gr, gi);
+  };
+  if (tid == 0) s_cen[0] = c0;
+  metric_chunk(0, c0);
+  __syncthreads();
+  // walk state (wave 0, all lanes alike)
+  float avg = st->avg;
+  double incA = 0.0, incB = (-1.0 / (double)N) * (double)st->eps_init, base = 0.0;
+  int sw = c0 - L, cur = c0, s = 0;
+  bool lost = false, viol = false;
+  for (int k = 0;; k++) {
+    const int cb = call0 + k * cpc;
+    if (cb >= p.ncalls) break;
+    if (wave == 0) {
+      if (lane == 0) { s_next_cen = cur; s_cen[(k + 1) & 1] = cur; }                // the next chunk's lags: around the peak reached so far
+    }
+    __syncthreads();
+    if (wave > 0) metric_chunk(k + 1, s_next_cen);
+    else {
+      const int cen = s_cen[k & 1];
+      for (int c = 0; c < cpc && cb + c < p.ncalls; c++, s++) {
+        const int call = cb + c;
+        int rel0 = (cur - 8) - (cen - R);
+        const bool direct = rel0 < 0 || rel0 + 16 > 2 * R;
+        if (direct) {
+          if (lane < 16) {
+            const int lag = cur - 8 + lane;
+            const long long at = (long long)call * L + lag;
+            float gr = 0.f, gi = 0.f, phi = 0.f;
+            if (at - cp + 1 - N < -p.hist) { s_dl[lane] = -3.0e38f; s_dg[lane] = make_float2(0.f, 0.f); }
+            else {
+              for (int j = 0; j < cp; j++) {
+                const float2 a = iq[at - j], b = iq[at - j - N];
+                gr += a.x * b.x + a.y * b.y; gi += a.y * b.x - a.x * b.y; phi += (a.x * a.x + a.y * a.y) + (b.x * b.x + b.y * b.y);
+              }
+              s_dg[lane] = make_float2(gr, gi); s_dl[lane] = sqrtf(gr * gr + gi * gi) - phi * p.half_rho;
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          rel0 = 0;
+        }
+        const float *lam = direct ? s_dl : &s_lam[k & 1][c][rel0];
+        int pos = 0;
+        const int npk = peak_detect16_wave(lane < 16 ? lam[lane] : 0.f, lane, avg, pos);
+        if (!npk) { lost = true; break; }
+        if (sw < 0 || sw >= L) { viol = true; break; }
+        const float2 g = direct ? s_dg[pos] : s_gam[k & 1][c][rel0 + pos];
+        const float eps = atan2f(g.y, g.x);
+        const int peak = pos + cur - 8;
+        if (lane == 0) { SymMeta m; m.cp_start = peak; m.eps = eps; m.ph_base = wrap_pi(base); m.incA = incA; m.incB = incB; m.sw = sw; meta[s] = m; }
+        base += sw * incA + (L - sw) * incB;
+        incA = incB; incB = (-1.0 / (double)N) * (double)eps;
+        sw = peak - L; cur = peak;
+        if (direct) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }   // s_dl / s_dg are rewritten by the next direct call
+      }
+      if ((lost || viol) && lane == 0) s_stop = 1;
+    }
+    __syncthreads();
+    if (s_stop) break;
+  }
+  if (tid != 0) return;
+  if (viol) { st->small_viol = 1; return; }
+  if (lost) st->status |= 2;
+  st->n_symbols = s;
+  st->avg_lost = lost ? avg : st->avg;
 }
 
 // ---- parallel tracking.  Two facts make the per-call FSM independent of its predecessors:

@@ -439,6 +439,12 @@ int  dvbt_rx_stream_finish(dvbt_rx_stream *s);
 int  dvbt_rx_stream_status(const dvbt_rx_stream *s, dvbt_rx_stream_info *info);
 void dvbt_rx_stream_destroy(dvbt_rx_stream *s);
 
+/* ------------------------------------------------------------------ test hooks (used by tests/ only)
+ * the two peak detectors of the acquisition's trackers (lib/ofdm_sym_acquisition_impl.cc:72-146 restated sample by sample, and the wavefront-wide form the
+ * sequential trackers run) on n cases of 16 metric values + a carried d_avg each: out[4k] npk, out[4k+1] position (-1: none) of the first, out[4k+2..3]
+ * of the second; avg_out[2k], avg_out[2k+1]: d_avg after the window */
+int dvbt_debug_peak_detect(const float *lambda_host, const float *avg_host, int n, int32_t *out_host, float *avg_out_host);
+
 #ifdef __cplusplus
 }
 #endif

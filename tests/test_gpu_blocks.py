@@ -334,3 +334,44 @@ def test_cpp_host_mirror_example(po, g, tmp_path):
     n = min(len(got), len(o["ts"]))
     assert n > 100000 and abs(len(got) - len(o["ts"])) <= 4 * 1504
     assert (got[:n] == o["ts"][:n]).all()
+
+
+def test_wave_peak_detector(g):
+    """the sequential trackers' wavefront-wide peak detector (k_frontend.hpp::peak_detect16_wave: IIR average as the one recurrence, threshold tests as ballots,
+    the state machine on 16-bit masks with DPP prefix maxima) against the sample-by-sample restatement of peak_detect_process
+    (lib/ofdm_sym_acquisition_impl.cc:72-146) on 60,000 windows: noise around a carried average of either sign, triangles like a CP peak, plateaus and
+    exact ties (quantised values), windows that end inside an open peak, several peaks per window, the -3e38 sentinel of lags in front of the stream."""
+    rng = np.random.RandomState(11)
+    n = 60000
+    lam = np.empty((n, 16), np.float32)
+    avg = np.empty(n, np.float32)
+    kind = rng.randint(0, 6, n)
+    for k in range(n):
+        t = kind[k]
+        base = rng.uniform(-300, 50)
+        if t == 0:
+            x = base + rng.randn(16) * rng.choice([0.1, 3, 30])
+        elif t == 1:                                                     # a triangle (the CP peak) on a noisy floor
+            c = rng.uniform(-4, 20); h = rng.uniform(10, 400)
+            x = base + np.maximum(0, h * (1 - np.abs(np.arange(16) - c) / rng.uniform(2, 12))) + rng.randn(16) * rng.choice([0.5, 5, 20])
+        elif t == 2:                                                     # quantised: plateaus and exact ties
+            x = np.round((base + rng.randn(16) * 20) / 16) * 16
+        elif t == 3:                                                     # positive values, several peaks
+            x = np.abs(rng.randn(16)) * rng.choice([1, 50]) * (rng.rand(16) > 0.4)
+        elif t == 4:                                                     # lags in front of the stream's first sample
+            x = base + rng.randn(16) * 10; x[:rng.randint(1, 16)] = -3.0e38
+        else:                                                            # ramps: a window that ends inside an open peak
+            x = base + np.arange(16) * rng.uniform(-30, 30) + rng.randn(16) * 3
+        lam[k] = x.astype(np.float32)
+        avg[k] = np.float32(rng.choice([0.0, base, base * 0.5, -base, x[0]]) + rng.randn() * 5)
+    out = np.zeros((n, 4), np.int32)
+    avg_out = np.zeros((n, 2), np.float32)
+    L = g.lib()
+    L.dvbt_debug_peak_detect.restype = C.c_int
+    L.dvbt_debug_peak_detect.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    assert L.dvbt_debug_peak_detect(lam.ctypes.data, avg.ctypes.data, n, out.ctypes.data, avg_out.ctypes.data) == 0
+    assert (out[:, 0] == out[:, 2]).all(), np.flatnonzero(out[:, 0] != out[:, 2])[:5]
+    assert (out[:, 1] == out[:, 3]).all(), np.flatnonzero(out[:, 1] != out[:, 3])[:5]
+    assert (avg_out[:, 0].view(np.uint32) == avg_out[:, 1].view(np.uint32)).all()
+    # the cases are not degenerate: windows without a peak, with one, with several
+    assert (out[:, 0] == 0).sum() > 1000 and (out[:, 0] == 1).sum() > 1000 and (out[:, 0] >= 2).sum() > 1000
