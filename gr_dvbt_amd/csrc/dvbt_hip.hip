@@ -410,7 +410,8 @@ struct EnqOpt {
   bool acq_only = false;      // ofdm_sym_acquisition alone (where does the lock start, how long does it hold)
   int init_tries = ACQ_INIT_TRIES;   // windows the initial search examines before it gives up (the reference consumes them one by one)
   bool skip_acq = false;      // the acquisition results of the acq_only run just before (same iq, same hist, same carry) are still in the handle: go on from there
-  bool use_carry = false;     // the peak detector's average is carried in from the call that lost the previous lock (h->acq_carry)
+  bool use_carry = false;     // the peak detector's average is carried in from the call that lost the previous lock ...
+  float carry_avg = 0.f;      // ... this value
   long long hist = 0;         // samples of the stream in memory in front of iq[0]
   bool continuation = false;  // not the first period that reaches demod_reference_signals: its TPS state and the previous symbol's TPS carriers are
                               // carried over, the first item bears the sync_start tag (demod_reference_signals_impl.cc:115-116)
@@ -471,19 +472,20 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
     // what acq_init_fsm_kernel's reset would have done on top of the acq_only run's (tracker flags and the symbol ticket are still clear)
     if (!o.continuation) HIPCHK(hipMemsetAsync(h->tps_state, 0, sizeof(TpsState), s));
   } else {
-  const AcqState *carry = o.use_carry ? h->acq_carry : nullptr;
+  const AcqState *carry = nullptr;
   int tries = C < o.init_tries ? C : o.init_tries;
   // initial search: the metric of all `tries` windows in one launch (32 workgroups per window: four windows cost the latency of one), then ONE launch of the
   // state machine, which examines them in order and stops at the first peak -- window 0 on a stream that is there, so the later windows' metric is rarely
   // looked at; computing it unasked costs nothing on an otherwise idle device and saves two launches per lock period
   // (the FSM launch also clears the trackers' flag words, the symbol kernel's ticket and, for a period that starts the pilot engine afresh, its state)
   hipLaunchKernelGGL(acq_metric_kernel, dim3((N + 255) / 256, tries), dim3(256), 0, s, iq, fp, (const RxState *)h->st, 0, h->g_init, h->l_init, 0);
-  const AcqReset rz = {h->trk_flags, h->sym_ticket, (o.acq_only || o.continuation) ? nullptr : reinterpret_cast<int *>(h->tps_state), (int)(sizeof(TpsState) / 4)};
+  const AcqReset rz = {h->trk_flags, h->sym_ticket, (o.acq_only || o.continuation) ? nullptr : reinterpret_cast<int *>(h->tps_state), (int)(sizeof(TpsState) / 4),
+                       o.carry_avg, o.use_carry ? 1 : 0};
   hipLaunchKernelGGL(acq_init_fsm_kernel, dim3(1), dim3(1024), (size_t)N * 5, s, fp, h->st, (const float2 *)h->g_init, (const float *)h->l_init, carry, 0, tries, rz);
   if (o.acq_only && !o.no_small && C <= ACQ_SMALL_MAX_CALLS) {
     // the lock-period walk's short look-ahead windows: everything behind the initial search in one launch, work in proportion to the symbols the lock holds
     const int cpc = acq_small_cpc(d.cp);
-    hipLaunchKernelGGL(acq_small_kernel, dim3(1), dim3(64 * (1 + cpc / 2)), (size_t)cpc * 2 * (d.cp + 2 * ACQ_R) * sizeof(float2), s, iq, fp, h->st, h->meta, cpc);
+    hipLaunchKernelGGL(acq_small_kernel, dim3(1), dim3(64 * (1 + cpc / 2)), (size_t)cpc * 2 * (d.cp + 2 * ACQ_R) * sizeof(float2), s, iq, fp, h->st, h->meta, cpc, h->drift.flags);
   } else {
   {   // where the tracking metric is computed: CP position predicted per call from coarse estimates every ACQ_ANCHOR calls (sample-clock drift)
     const int n_anchors = (C - 1) / ACQ_ANCHOR;
@@ -513,7 +515,9 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
   }
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_FFT], s));
   // A1 tail + A2 + A3 in one kernel: the FFT item of a symbol never leaves LDS (acq/fft taps are written only when enabled)
-  {
+  // a period found by acq_small_kernel whose state block the host has just read back: the drift model's verdict is known (and flags[1] cleared on the device)
+  const bool drift_off = o.skip_acq && h->st_host->drift_known_off;
+  if (!drift_off) {
     // the wander of the reference's float phase accumulator (k_drift.hpp): tables per call, the fixed point (one workgroup), the deviations per 32-sample block;
     // every kernel returns at once when the lock period has no usable carrier offset (drift.flags, device side: no host round trip)
     const DriftBufs &D = h->drift;
@@ -536,16 +540,16 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
   const int g8 = std::min(h->sym_grid, C), g2 = std::min(h->sym_grid, (C + S2_Q - 1) / S2_Q);
   if (N == S8_N && !taps) {
     hipLaunchKernelGGL((symbol8k_kernel<false, false>), dim3(g8), dim3(S8_T), S8_LDS_BYTES, s, SYM_ARGS);
-    hipLaunchKernelGGL((symbol8k_kernel<false, true>), dim3(g8), dim3(S8_T), S8_LDS_BYTES, s, SYM_ARGS);
+    if (!drift_off) hipLaunchKernelGGL((symbol8k_kernel<false, true>), dim3(g8), dim3(S8_T), S8_LDS_BYTES, s, SYM_ARGS);
   } else if (N == S8_N) {
     hipLaunchKernelGGL((symbol8k_kernel<true, false>), dim3(g8), dim3(S8_T), S8_LDS_BYTES, s, SYM_ARGS);
-    hipLaunchKernelGGL((symbol8k_kernel<true, true>), dim3(g8), dim3(S8_T), S8_LDS_BYTES, s, SYM_ARGS);
+    if (!drift_off) hipLaunchKernelGGL((symbol8k_kernel<true, true>), dim3(g8), dim3(S8_T), S8_LDS_BYTES, s, SYM_ARGS);
   } else if (N == S2_N && !taps) {
     hipLaunchKernelGGL((symbol2k_kernel<false, false>), dim3(g2), dim3(S2_T * S2_Q), S2_LDS_BYTES, s, SYM_ARGS);
-    hipLaunchKernelGGL((symbol2k_kernel<false, true>), dim3(g2), dim3(S2_T * S2_Q), S2_LDS_BYTES, s, SYM_ARGS);
+    if (!drift_off) hipLaunchKernelGGL((symbol2k_kernel<false, true>), dim3(g2), dim3(S2_T * S2_Q), S2_LDS_BYTES, s, SYM_ARGS);
   } else if (N == S2_N) {
     hipLaunchKernelGGL((symbol2k_kernel<true, false>), dim3(g2), dim3(S2_T * S2_Q), S2_LDS_BYTES, s, SYM_ARGS);
-    hipLaunchKernelGGL((symbol2k_kernel<true, true>), dim3(g2), dim3(S2_T * S2_Q), S2_LDS_BYTES, s, SYM_ARGS);
+    if (!drift_off) hipLaunchKernelGGL((symbol2k_kernel<true, true>), dim3(g2), dim3(S2_T * S2_Q), S2_LDS_BYTES, s, SYM_ARGS);
   }
 #undef SYM_ARGS
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_DEMOD], s));
@@ -561,11 +565,10 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
   } else {
     // the pilot engine's members live on (FIFO, symbol and frame counters: reference_signals_impl.h); the sync_start tag on the period's first
     // item clears d_init (the superframe hunt starts over); DBPSK against the last symbol in front of the gap.  Sequential bookkeeping.
-    HIPCHK(hipMemsetAsync(&h->tps_state->d_init, 0, sizeof(int), s));
     hipLaunchKernelGGL(tps_vote_kernel, dim3((C + 63) / 64), dim3(256), 0, s, (const float2 *)h->tpsval, d.n_tps, (const RxState *)h->st, 0,
                        (const float2 *)h->tps_prev, h->maj, fp.keep_last);
     hipLaunchKernelGGL(tps_fsm_kernel, dim3(1), dim3(256), 0, s, fp, h->st, 0, (const SymInfo *)h->info, (const int *)h->maj, h->tps_state,
-                       h->sym_index, (int *)nullptr, (const unsigned char *)nullptr, (const int *)nullptr);
+                       h->sym_index, (int *)nullptr, (const unsigned char *)nullptr, (const int *)nullptr, 1);
   }
   hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(64), 0, s, h->st, h->vp, h->prm.descramble, (long long)h->cut.stream_symbol_offset);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_INNER], s));
@@ -710,8 +713,7 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
     bk.total_symbols += per[p].n_symbols;
     if (usable < 1) return DVBT_OK;
     if (!reuse) { int r = acq_ctx(); if (r) return r; }
-    if (!reuse && per[p].carry) { AcqState as; memset(&as, 0, sizeof as); as.avg = per[p].avg_in; HIPCHK(hipMemcpyAsync(h->acq_carry, &as, sizeof as, hipMemcpyHostToDevice, s)); }
-    EnqOpt o; o.use_carry = per[p].carry; o.hist = (long long)per[p].off; o.continuation = bk.processed > 0; o.keep_last = later; o.tail = false; o.skip_acq = reuse;
+    EnqOpt o; o.use_carry = per[p].carry; o.carry_avg = per[p].avg_in; o.hist = (long long)per[p].off; o.continuation = bk.processed > 0; o.keep_last = later; o.tail = false; o.skip_acq = reuse;
     o.vit_off = bk.delivering > 0 ? (bk.acc / 3264) * 3264 : 0;   // convolutional_deinterleaver_impl.cc:109-120: the tag realigns the input
     o.init_tries = std::min(ACQ_INIT_TRIES_MAX, std::max(ACQ_INIT_TRIES, per[p].call0 + 1));   // (a second acquisition must reach the window the wide search found the peak in)
     // a period that ends in a lost lock is decoded over its own calls and the one that lost the lock, not over the whole rest of the segment
@@ -737,8 +739,7 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
     for (int guard = 0; off + win <= chain_n; guard++) {
       if (guard >= 4096) { capped = true; break; }
       { int r = acq_ctx(); if (r) return r; }
-      if (carry) { AcqState as; memset(&as, 0, sizeof as); as.avg = avg; HIPCHK(hipMemcpyAsync(h->acq_carry, &as, sizeof as, hipMemcpyHostToDevice, s)); }
-      EnqOpt o; o.acq_only = true; o.use_carry = carry; o.hist = (long long)off;
+      EnqOpt o; o.acq_only = true; o.use_carry = carry; o.carry_avg = avg; o.hist = (long long)off;
       // searches that found nothing are followed by wider ones (4, 8, ... 64 windows per launch): dead air costs a launch sequence per 64 windows, not per 4
       o.init_tries = std::min(ACQ_INIT_TRIES_MAX, ACQ_INIT_TRIES << std::min(fails, 4));
       // the search and the tracker look at a window of the rest of the segment that grows while the lock holds to its end: a segment with many lock

@@ -34,7 +34,8 @@ struct RxState {
   unsigned long long tps_bits; // TPS word of a BCH-valid frame, bit i = s_i, with the fields that change from frame to frame (sync word s1-s16,
                                // frame number s23-s24, parity s54-s67) cleared: identical for every frame of a stream; 0 = none seen
   int small_viol;              // acq_small_kernel met a phase-increment switch outside its call: the period goes through the general kernels
-  int pad_;
+  int drift_known_off;         // acq_small_kernel has established that the float-accumulator model (k_drift.hpp) does not apply to this period (increments of both
+                               // signs / too small): the host, which reads this block back before it decodes the period, launches none of the drift kernels
 };
 // fields of a TPS word that are the same in every frame (reference_signals_impl.cc:883-916): s17-s22 length, s25-s53 parameters
 constexpr unsigned long long TPS_STATIC_MASK = ((1ull << 54) - 1) & ~((1ull << 17) - 1) & ~(3ull << 23);
@@ -374,9 +375,9 @@ __device__ __forceinline__ float wrap_pi(double ph)
 //      maximum of the open peak, so a step costs a few cycles instead of a dependent float chain.
 // reset (segment path, first launch of a lock period): the flag words of the trackers (trk_flags[0..15]; [8], [9] = first superframe-start candidate, need_seq of the
 // TPS bookkeeping), the symbol kernel's ticket and -- for a period that starts the pilot engine afresh -- its state: three memset / copy launches less
-struct AcqReset { int *trk_flags; int *ticket; int *tps_state; int tps_state_words; };
+struct AcqReset { int *trk_flags; int *ticket; int *tps_state; int tps_state_words; float carry_avg; int has_carry; };   // carry_avg: d_avg carried in from the call that lost the previous lock
 __global__ __launch_bounds__(1024) void acq_init_fsm_kernel(FrontParams p, RxState *st, const float2 *gamma, const float *lambda, const AcqState *as,
-                                                          int t_begin, int t_end, AcqReset rz = AcqReset{nullptr, nullptr, nullptr, 0})
+                                                          int t_begin, int t_end, AcqReset rz = AcqReset{nullptr, nullptr, nullptr, 0, 0.f, 0})
 {
   if (t_begin == 0) {
     if (rz.trk_flags && threadIdx.x < 16) rz.trk_flags[threadIdx.x] = threadIdx.x == 8 ? 0x7fffffff : 0;
@@ -395,8 +396,8 @@ __global__ __launch_bounds__(1024) void acq_init_fsm_kernel(FrontParams p, RxSta
   if (tid == 0 && t_begin == 0) {
     st->status = 1; st->call0 = 0; st->cp_start0 = 0; st->n_symbols = 0; st->first_out = -1; st->n_out_symbols = 0;
     st->n_vit_in = st->n_vit_steps = st->n_vit_bytes = st->n_rs_items = st->n_ts_bytes = 0; st->rs_fail = st->rs_corr = 0; st->rs_list_n = 0;
-    st->n_rs_words = st->stream_rs_items = st->ts_first_packet = 0; st->tps_bits = 0;
-    s_done = 0; s_avg = as ? as->avg : 0.f;
+    st->n_rs_words = st->stream_rs_items = st->ts_first_packet = 0; st->tps_bits = 0; st->small_viol = 0; st->drift_known_off = 0;
+    s_done = 0; s_avg = as ? as->avg : (rz.has_carry ? rz.carry_avg : 0.f);
     if (as && as->acquired) {          // block API: still locked from the previous work() call, nothing to search
       st->status = 0; st->cp_start0 = as->cp_start; st->eps_init = 0.f; s_done = 2;
     }
@@ -719,7 +720,7 @@ __global__ __launch_bounds__(64) void acq_track_light_kernel(FrontParams p, RxSt
 constexpr int ACQ_SMALL_MAX_CALLS = 768;
 constexpr size_t ACQ_SMALL_LDS = 96 * 1024;
 inline int acq_small_cpc(int cp) { int c = (int)(ACQ_SMALL_LDS / ((size_t)(cp + 2 * ACQ_R) * 16)); c &= ~1; return c > 16 ? 16 : (c < 2 ? 2 : c); }
-__global__ __launch_bounds__(576) void acq_small_kernel(const float2 *__restrict__ iq, FrontParams p, RxState *st, SymMeta *__restrict__ meta, int cpc)
+__global__ __launch_bounds__(576) void acq_small_kernel(const float2 *__restrict__ iq, FrontParams p, RxState *st, SymMeta *__restrict__ meta, int cpc, int *drift_flags)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ __attribute__((aligned(16))) float s_lam[2][16][2 * ACQ_R]; __shared__ __attribute__((aligned(16))) float2 s_gam[2][16][2 * ACQ_R];
@@ -781,7 +782,7 @@ __global__ __launch_bounds__(576) void acq_small_kernel(const float2 *__restrict
   // walk state (wave 0, all lanes alike)
   float avg = st->avg;
   double incA = 0.0, incB = (-1.0 / (double)N) * (double)st->eps_init, base = 0.0;
-  int sw = c0 - L, cur = c0, s = 0;
+  int sw = c0 - L, cur = c0, s = 0, dfl = 0;                        // dfl: drift_prep_kernel's eligibility bits over the period's increments
   bool lost = false, viol = false;
   for (int k = 0;; k++) {
     const int cb = call0 + k * cpc;
@@ -823,6 +824,7 @@ __global__ __launch_bounds__(576) void acq_small_kernel(const float2 *__restrict
         const float eps = atan2f(g.y, g.x);
         const int peak = pos + cur - 8;
         if (lane == 0) { SymMeta m; m.cp_start = peak; m.eps = eps; m.ph_base = wrap_pi(base); m.incA = incA; m.incB = incB; m.sw = sw; meta[s] = m; }
+        dfl |= (incB > 0 ? 1 : (incB < 0 ? 2 : 4)) | (fabs(incB) < DRIFT_MIN_INC ? 4 : 0);
         base += sw * incA + (L - sw) * incB;
         incA = incB; incB = (-1.0 / (double)N) * (double)eps;
         sw = peak - L; cur = peak;
@@ -838,6 +840,8 @@ __global__ __launch_bounds__(576) void acq_small_kernel(const float2 *__restrict
   if (lost) st->status |= 2;
   st->n_symbols = s;
   st->avg_lost = lost ? avg : st->avg;
+  // drift_exact_kernel's decision, taken here for the host: `on` needs >= 2 symbols and increments of one sign, none below the model's floor
+  if (!(s >= 2 && (dfl == 1 || dfl == 2))) { st->drift_known_off = 1; drift_flags[1] = 0; }
 }
 
 // ---- parallel tracking.  Two facts make the per-call FSM independent of its predecessors:
@@ -1433,7 +1437,7 @@ __device__ inline int bch_check(unsigned long long lo, unsigned hi)
 // whole workgroup so the walking lane never waits on HBM.
 constexpr int TPS_TILE = 2048;
 __global__ __launch_bounds__(256) void tps_fsm_kernel(FrontParams p, RxState *st, int nitems_fixed, const SymInfo *info, const int *maj,
-                               TpsState *ts, int *sym_index, int *superframe_flag, const unsigned char *sync_flags, const int *need_seq)
+                               TpsState *ts, int *sym_index, int *superframe_flag, const unsigned char *sync_flags, const int *need_seq, int clear_d_init = 0)
 {
   if (need_seq && *need_seq == 0) return;
   __shared__ signed char s_mod[TPS_TILE];
@@ -1444,7 +1448,7 @@ __global__ __launch_bounds__(256) void tps_fsm_kernel(FrontParams p, RxState *st
   const int tid = threadIdx.x;
   const int nsym = st ? st->n_symbols : nitems_fixed;
   const int ntot = p.keep_last ? nsym : (nsym > 0 ? nsym - 1 : 0);
-  if (tid == 0) { s_t = *ts; s_first_out = -1; }
+  if (tid == 0) { s_t = *ts; s_first_out = -1; if (clear_d_init) s_t.d_init = 0; }   // clear_d_init: the period's first item bears the sync_start tag
   // sync words s1..s15 as fifo bits 1..15 (only 15 of the 16 are compared: B-11)
   unsigned mask_even = 0, mask_odd = 0;
   {
