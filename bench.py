@@ -418,6 +418,38 @@ def stream_abi(g):
     return [stream_bench.run(po, g, symbols=sym, device=dev) for sym, dev in ((4, False), (64, False), (64, True))]
 
 
+def host_pointer_ceiling(g, c):
+    """Why the ten blocks behind HOST pointers cannot reach the segment API's rate whatever the kernels do: gr::block's contract puts every intermediate item
+    through host memory, i.e. across PCIe twice per block.  Bytes per OFDM symbol in and out of the ten blocks (item sizes of the flowgraph), the pageable
+    copy rates of this box measured with the library's own hipMemcpy path at a 64-symbol call's size, and the rate at which copies alone would run
+    (no kernel, no launch, no Python: an upper bound for dvbt_<blk>_work driven by one thread, as here; GNU Radio runs a thread per block)."""
+    import ctypes as C
+    N, cp, P = c.N, c.cp, c.payload
+    vit = P * c.m * c.k // (8 * c.n)
+    words = vit // 204
+    h2d = (N + cp) * 8 + N * 8 + N * 8 + P * 8 + P + P + P + vit + words * 204 + words * 188       # acq, fft, demod, demap, symdeint, bitdeint, viterbi, deint, rs, descramble
+    d2h = N * 8 + N * 8 + P * 8 + P + P + P + vit + words * 204 + words * 188 + words * 188
+    L = g.lib()
+    L.dvbt_device_malloc.restype = C.c_void_p; L.dvbt_device_malloc.argtypes = [C.c_size_t]
+    L.dvbt_device_free.argtypes = [C.c_void_p]
+    L.dvbt_copy_to_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]; L.dvbt_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    nb = 64 * N * 8
+    host = np.ones(nb, np.uint8)
+    dev = L.dvbt_device_malloc(nb)
+    rates = []
+    for fn, a, b in ((L.dvbt_copy_to_device, dev, host.ctypes.data), (L.dvbt_copy_to_host, host.ctypes.data, dev)):
+        fn(a, b, nb)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            fn(a, b, nb)
+        rates.append(20 * nb / (time.perf_counter() - t0) / 1e9)
+    L.dvbt_device_free(dev)
+    per_sym_s = h2d / (rates[0] * 1e9) + d2h / (rates[1] * 1e9)
+    return {"bytes_per_symbol_host_to_device": int(h2d), "bytes_per_symbol_device_to_host": int(d2h), "bytes_per_sample_over_pcie": round((h2d + d2h) / (N + cp), 1),
+            "pageable_copy_gbs": {"host_to_device": round(rates[0], 1), "device_to_host": round(rates[1], 1), "bytes_per_copy": nb},
+            "copies_alone_msamples_per_s": round((N + cp) / per_sym_s / 1e6, 1)}
+
+
 def per_block_abi(g, workload, nsf=4):
     """The drop-in path timed: config `workload` pushed through the ten per-block ABI calls (gr_dvbt_amd/flowgraph.py) at GNU Radio-like
     call sizes, host-pointer entry (dvbt_<blk>_work: H2D + kernels + D2H + synchronise per block, what a gr::block shell does) and
@@ -432,6 +464,7 @@ def per_block_abi(g, workload, nsf=4):
     want = seg.tap(g.TAP_TS)
     seg.close()
     out = {"sample": f"{nsf + 1} superframes of {workload} ({len(iq)} samples)", "unit": "Msamples/s", "variants": {}}
+    out["host_pointer_ceiling"] = host_pointer_ceiling(g, c)
     for mode_name, cs in (("host", 4), ("host", 64), ("device", 4), ("device", 64)):
         best = None
         for rep in range(2):

@@ -985,4 +985,5 @@ extern "C" int dvbt_debug_peak_detect(const float *lam_host, const float *avg_ho
 }
 
 #include "dvbt_stream.inc"
+#include "dvbt_rccl.inc"
 #include "dvbt_blocks.inc"

@@ -439,6 +439,25 @@ int  dvbt_rx_stream_finish(dvbt_rx_stream *s);
 int  dvbt_rx_stream_status(const dvbt_rx_stream *s, dvbt_rx_stream_info *info);
 void dvbt_rx_stream_destroy(dvbt_rx_stream *s);
 
+/* ------------------------------------------------------------------ the exchange step of a sharded stream
+ * north_star: "C++ host code ... a single RCCL gather of decoded TS packets over xGMI".  One process per GPU; every process creates a dvbt_rx_stream with its
+ * rank / world, is pushed the same stream and decodes its own pieces (no data-path collective).  Per step, dvbt_rx_stream_gather moves every rank's next run
+ * of finished packets to `root` in ONE group of ncclSend / ncclRecv on device buffers (a gather of fixed-stride slots: 64-byte header {first packet index,
+ * byte count, drained flag} + packets, the layout of gr_dvbt_amd/multi.py) and hands root the runs with their packet indices; ordered by that index they are
+ * the single chain's TS.  librccl.so is opened with dlopen at first use (no link-time dependency).  The communicator can come from here
+ * (dvbt_rccl_unique_id on one rank, its 128 bytes carried to the others by the host -- a file, a socket, MPI --, then dvbt_rccl_comm_create everywhere:
+ * ncclGetUniqueId / ncclCommInitRank), so a host needs no RCCL headers.  gr_dvbt_amd/host/rx_multi_example.cpp is such a host. */
+typedef struct dvbt_rccl_comm dvbt_rccl_comm;
+int  dvbt_rccl_unique_id(void *id128_out);                                    /* 128 bytes */
+int  dvbt_rccl_comm_create(const void *id128, int rank, int world, int device, dvbt_rccl_comm **out);   /* collective over the `world` processes */
+void dvbt_rccl_comm_destroy(dvbt_rccl_comm *c);
+typedef struct { int64_t first_packet; int64_t nbytes; int64_t offset; } dvbt_gather_chunk;   /* rank r's run: packet index in the stream's TS, bytes, where they sit in ts_host */
+/* collective: every rank calls it with the same root and slot_packets (the stride of the exchange in 188-byte packets; a rank gives at most that much per step).
+ * root: ts_host (cap bytes) receives the runs in rank order, chunks[world] describes them; returns the bytes written.  Others: ts_host / chunks may be NULL;
+ * returns 0.  *all_done (every rank) = 1 once every rank's stream is finished and drained -- root reads that from the headers and returns it to the others in
+ * the same call.  Negative: dvbt_status. */
+int64_t dvbt_rx_stream_gather(dvbt_rx_stream *s, dvbt_rccl_comm *c, int root, int slot_packets, void *ts_host, size_t cap, dvbt_gather_chunk *chunks, int *all_done);
+
 /* ------------------------------------------------------------------ test hooks (used by tests/ only)
  * the two peak detectors of the acquisition's trackers (lib/ofdm_sym_acquisition_impl.cc:72-146 restated sample by sample, and the wavefront-wide form the
  * sequential trackers run) on n cases of 16 metric values + a carried d_avg each: out[4k] npk, out[4k+1] position (-1: none) of the first, out[4k+2..3]

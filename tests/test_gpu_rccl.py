@@ -81,3 +81,29 @@ def test_bench_refuses_more_ranks_than_devices():
     n = g.device_count()
     r = _run(["--gpus", str(n + 1), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras"], timeout=120)
     assert r.returncode != 0 and "HIP device(s) visible" in r.stderr and not r.stdout.strip()
+
+
+def test_cpp_host_gathers_over_rccl(tmp_path):
+    """gr_dvbt_amd/host/rx_multi_example: BASELINE config 4's host in C++ -- a sharded dvbt_rx_stream per process, the communicator from the library
+    (dvbt_rccl_unique_id / dvbt_rccl_comm_create = ncclGetUniqueId / ncclCommInitRank through dlopen'd librccl), the packets brought to rank 0 by
+    dvbt_rx_stream_gather (ONE group of ncclSend / ncclRecv on device buffers per step + the step's control word), ordered by packet index and written out.
+    One rank here (one GPU per test box); the TS file must be the oracle's chain over the whole stream."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from oracle import pyoracle as po
+    import gr_dvbt_amd as g
+    host = os.path.join(ROOT, "gr_dvbt_amd", "host")
+    exe = os.path.join(host, "rx_multi_example")
+    if not os.path.exists(exe):
+        subprocess.check_call(["bash", os.path.join(host, "build.sh")], stdout=subprocess.DEVNULL)
+    c = po.cfg(g.QAM64, g.C7_8, g.T8k)
+    iq = po.stream_slice(c, 9, 6)
+    want = po.rx(c, iq, want=("ts",))["ts"]
+    fin, fout, idf = tmp_path / "bb.cf32", tmp_path / "out.ts", tmp_path / "nccl.id"
+    iq.tofile(fin)
+    r = subprocess.run([exe, "0", "1", str(idf), "8k", "qam64", "7/8", str(fin), str(fout), "2"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+    assert "0 gaps (status 0)" in r.stdout and "exchange steps" in r.stdout, r.stdout
+    got = np.fromfile(fout, np.uint8)
+    assert len(got) == len(want) > 0 and (got == want).all()
