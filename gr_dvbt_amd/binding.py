@@ -14,7 +14,8 @@ C1_2, C2_3, C3_4, C5_6, C7_8 = 0, 1, 2, 3, 4
 T2k, T8k = 0, 1
 G1_32, G1_16, G1_8, G1_4 = 0, 1, 2, 3
 (TAP_ACQ, TAP_FFT, TAP_EQ, TAP_DEMAP, TAP_SYMDEINT, TAP_BITDEINT, TAP_VITERBI, TAP_DEINT, TAP_RS,
- TAP_TS, TAP_CP_START, TAP_SYMBOL_INDEX, TAP_FREQ_OFFSET) = range(13)
+ TAP_TS, TAP_CP_START, TAP_SYMBOL_INDEX, TAP_FREQ_OFFSET, TAP_BITDEINT_LP) = range(14)
+ALPHA1, ALPHA2, ALPHA4 = 1, 2, 3
 
 
 class DvbtError(RuntimeError):
@@ -47,7 +48,7 @@ class RxParams(C.Structure):
                 ("cell_id", C.c_int), ("snr_db", C.c_float), ("viterbi_bsize", C.c_int),
                 ("rs_oracle_compat", C.c_int), ("descramble", C.c_int), ("max_samples", C.c_size_t),
                 ("device", C.c_int), ("viterbi_chunk_bytes", C.c_int), ("resample_interp", C.c_int), ("resample_decim", C.c_int),
-                ("front_scale", C.c_float), ("soft_decision", C.c_int)]
+                ("front_scale", C.c_float), ("soft_decision", C.c_int), ("hier_stream", C.c_int)]
 
 
 class RxReport(C.Structure):
@@ -139,10 +140,10 @@ class Rx:
 
     def __init__(self, constellation, code_rate, mode, max_samples, guard=G1_32, hierarchy=NH, snr_db=30.0,
                  viterbi_bsize=768, rs_oracle_compat=0, descramble=1, device=0, viterbi_chunk_bytes=0, taps=False,
-                 resample=(0, 0), front_scale=0.0, soft_decision=0):
+                 resample=(0, 0), front_scale=0.0, soft_decision=0, hier_stream=0):
         self.L = lib()
         self.p = RxParams(constellation, hierarchy, code_rate, guard, mode, 0, 0, snr_db, viterbi_bsize,
-                          rs_oracle_compat, descramble, max_samples, device, viterbi_chunk_bytes, resample[0], resample[1], front_scale, soft_decision)
+                          rs_oracle_compat, descramble, max_samples, device, viterbi_chunk_bytes, resample[0], resample[1], front_scale, soft_decision, hier_stream)
         self.h = C.c_void_p()
         _chk(self.L.dvbt_rx_create(C.byref(self.p), C.byref(self.h)))
         self.dims = get_dims(constellation, code_rate, mode, guard, hierarchy)
@@ -187,7 +188,7 @@ class Rx:
                  TAP_SYMDEINT: r.n_out_symbols * d.payload_length, TAP_BITDEINT: r.n_out_symbols * d.payload_length,
                  TAP_VITERBI: r.n_viterbi_bytes, TAP_DEINT: r.n_rs_bytes // 188 * 204, TAP_RS: r.n_rs_bytes,
                  TAP_TS: r.n_ts_bytes, TAP_CP_START: r.n_symbols * 4, TAP_SYMBOL_INDEX: max(r.n_symbols - 1, 0) * 4,
-                 TAP_FREQ_OFFSET: max(r.n_symbols - 1, 0) * 4}
+                 TAP_FREQ_OFFSET: max(r.n_symbols - 1, 0) * 4, TAP_BITDEINT_LP: r.n_out_symbols * d.payload_length}
         nbytes = max(int(sizes[tap]), 0)
         buf = np.zeros(nbytes, np.uint8)
         if nbytes:
@@ -196,7 +197,7 @@ class Rx:
         out = buf.view(self._TAP_DTYPE.get(tap, np.uint8))
         if tap in (TAP_ACQ, TAP_FFT):
             out = out.reshape(-1, d.fft_length)
-        elif tap in (TAP_EQ, TAP_DEMAP, TAP_SYMDEINT, TAP_BITDEINT):
+        elif tap in (TAP_EQ, TAP_DEMAP, TAP_SYMDEINT, TAP_BITDEINT, TAP_BITDEINT_LP):
             out = out.reshape(-1, d.payload_length)
         return out
 

@@ -87,7 +87,7 @@ struct Tables {          // device lookup tables for one configuration
   uint16_t *pay_c = nullptr, *pay_L = nullptr, *pay_R = nullptr, *tps_L = nullptr, *tps_R = nullptr;
   uint16_t *pil_k = nullptr, *pay_Li = nullptr, *pay_Ri = nullptr, *tps_Li = nullptr, *tps_Ri = nullptr; uint8_t *pay_d = nullptr, *tps_d = nullptr; int np[4] = {0, 0, 0, 0};
   uint32_t *pay_pack = nullptr;              // [4][payload]: carrier | rank of the left estimation carrier << 13 | distance to it << 23 (one word per payload carrier)
-  uint16_t *H = nullptr, *Hinv = nullptr; float2 *points = nullptr; uint8_t *label_tab = nullptr; int nlev = 0; float inv_step = 0.f, guard = 0.f;
+  uint16_t *H = nullptr, *Hinv = nullptr; float2 *points = nullptr; uint8_t *label_tab = nullptr; int nlev = 0; float inv_step = 0.f, guard = 0.f, hshift = 0.f;
   uint8_t *mul_alpha = nullptr, *gexp = nullptr, *glog = nullptr, *prbs = nullptr;
   bool front = false, inner = false, rs = false;
 
@@ -142,20 +142,23 @@ struct Tables {          // device lookup tables for one configuration
     std::vector<float> p = constellation_points(d, gain);
     std::vector<float2> p2(64, make_float2(0.f, 0.f));
     for (int i = 0; i < d.csize; i++) p2[i] = make_float2(p[2 * i], p[2 * i + 1]);
-    // level grid for the candidate search (uniform only when alpha == 1): label_of[i_re * 8 + i_im]
+    // level grid for the candidate search: label_of[i_re * 8 + i_im].  alpha = 2, 4 (hierarchical): the same grid once the centre gap of 2 alpha
+    // units is closed to 2 (every level moved (alpha - 1) units towards the centre: hshift)
     std::vector<uint8_t> lab(64, 0);
-    nlev = 0;
-    if (d.alpha == 1 && gain > 0.f) {
+    nlev = 0; hshift = 0.f;
+    if (gain > 0.f) {
       int n = 1 << (d.m / 2);
       float step = 2.0f * gain * d.norm;                       // spacing between adjacent levels
+      const float sh = (float)(d.alpha - 1) * gain * d.norm;
       bool ok = true;
       for (int i = 0; i < d.csize && ok; i++) {
-        float fi = p2[i].x / step + 0.5f * (n - 1), fq = p2[i].y / step + 0.5f * (n - 1);
+        const float ux = p2[i].x - (p2[i].x > 0 ? sh : -sh), uy = p2[i].y - (p2[i].y > 0 ? sh : -sh);
+        float fi = ux / step + 0.5f * (n - 1), fq = uy / step + 0.5f * (n - 1);
         int ii = (int)std::lround(fi), qq = (int)std::lround(fq);
         if (ii < 0 || ii >= n || qq < 0 || qq >= n || std::fabs(fi - ii) > 1e-3f || std::fabs(fq - qq) > 1e-3f) ok = false;
         else lab[ii * 8 + qq] = (uint8_t)i;
       }
-      if (ok) { nlev = n; inv_step = 1.0f / step; guard = 1.0e4f * step; }
+      if (ok) { nlev = n; inv_step = 1.0f / step; guard = 1.0e4f * step; hshift = sh; }
     }
     if (points) { (void)hipFree(points); points = nullptr; }
     if (label_tab) { (void)hipFree(label_tab); label_tab = nullptr; }
@@ -163,7 +166,8 @@ struct Tables {          // device lookup tables for one configuration
     inner = true;
     return DVBT_OK;
   }
-  InnerParams inner_params(int payload) const { InnerParams ip; ip.payload = payload; ip.m = d.m; ip.csize = d.csize; ip.nlev = nlev; ip.inv_step = inv_step; ip.guard = guard; return ip; }
+  InnerParams inner_params(int payload) const { InnerParams ip; ip.payload = payload; ip.m = d.m; ip.csize = d.csize; ip.nlev = nlev; ip.inv_step = inv_step; ip.guard = guard;
+                                                  ip.hshift = hshift; ip.hier = d.hierarchy != 0 ? 1 : 0; return ip; }
   int build_rs()
   {
     std::vector<uint8_t> ex(512), lg(256), mul = rs_division_table();
@@ -260,6 +264,7 @@ struct dvbt_rx {
   int *centre = nullptr, *anchor_pos = nullptr;   // predicted CP position per call / coarse estimates every ACQ_ANCHOR calls
   float2 *acq_tap = nullptr, *fft_out = nullptr, *eq = nullptr, *tpsval = nullptr; SymInfo *info = nullptr; int *maj = nullptr, *sym_index = nullptr;
   uint8_t *labels = nullptr, *symdeint_tap = nullptr, *bitdeint = nullptr, *vit = nullptr, *deint_tap = nullptr, *rs_out = nullptr, *ts_out = nullptr;
+  uint8_t *bitdeint_lp = nullptr;           // hierarchical modes: the bit de-interleaver's second output
   size_t vit_cap = 0; RsDefer *rs_defer = nullptr; int rs_defer_cap = 0;
   float *csi = nullptr; int8_t *soft_a = nullptr; uint16_t *soft_tab = nullptr; unsigned *soft_scratch = nullptr;   // soft-decision mode (k_soft.hpp): channel state per carrier, soft values, A5 + A6 gather table, decision slots
   bool timing = false, pending = false;
@@ -276,7 +281,7 @@ struct dvbt_rx {
 
 static void rx_free(dvbt_rx *h)
 {
-  void *all[] = {h->st_ctx[0], h->st_ctx[1], h->meta_ctx[0], h->meta_ctx[1], h->tps_prev_snap[0], h->tps_prev_snap[1], h->tps_snap[0], h->tps_snap[1], h->csi, h->soft_a, h->soft_tab, h->soft_scratch, h->rs_defer, h->drift_mem, h->drift.delta, h->drift.flags, h->tps_prev, h->descr_runs, h->descr_nruns, h->centre, h->anchor_pos, h->sym_ticket, h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags, h->trk_eps, h->d_iq, h->rs_iq, h->acq_carry, h->g_init, h->l_init, h->g_trk, h->l_trk, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
+  void *all[] = {h->bitdeint_lp, h->st_ctx[0], h->st_ctx[1], h->meta_ctx[0], h->meta_ctx[1], h->tps_prev_snap[0], h->tps_prev_snap[1], h->tps_snap[0], h->tps_snap[1], h->csi, h->soft_a, h->soft_tab, h->soft_scratch, h->rs_defer, h->drift_mem, h->drift.delta, h->drift.flags, h->tps_prev, h->descr_runs, h->descr_nruns, h->centre, h->anchor_pos, h->sym_ticket, h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags, h->trk_eps, h->d_iq, h->rs_iq, h->acq_carry, h->g_init, h->l_init, h->g_trk, h->l_trk, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
                  h->info, h->maj, h->sym_index, h->labels, h->symdeint_tap, h->bitdeint, h->vit, h->deint_tap, h->rs_out, h->ts_out};
   for (void *q : all) if (q) (void)hipFree(q);
   if (h->st_host) (void)hipHostFree(h->st_host);
@@ -293,6 +298,9 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   if (!d.valid) return fail(DVBT_ERR_INVALID, "bad DVB-T parameters");
   if (p->viterbi_bsize <= 0 || (2 * d.k * p->viterbi_bsize) % 16 != 0 || (p->viterbi_bsize * d.n) % d.m != 0)
     return fail(DVBT_ERR_INVALID, "viterbi_bsize must make bsize*n/m integral and 2*k*bsize a multiple of 16");
+  if (d.hierarchy != 0 && d.m == 2) return fail(DVBT_ERR_INVALID, "hierarchical QPSK does not exist (the reference's bit_inner_deinterleaver divides by d_v - 2 = 0 in its constructor)");
+  if (d.hierarchy != 0 && p->soft_decision) return fail(DVBT_ERR_INVALID, "soft decisions are built for the non-hierarchical modes");
+  if (p->hier_stream < 0 || p->hier_stream > 1) return fail(DVBT_ERR_INVALID, "hier_stream must be 0 (HP) or 1 (LP)");
   HIPCHK(hipSetDevice(p->device));
   dvbt_rx *h = new dvbt_rx();
   h->prm = *p; h->d = d; h->T.d = d;
@@ -331,6 +339,7 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   RXHIP(hipMalloc((void **)&h->tpsval, sizeof(float2) * C * d.n_tps)); RXHIP(hipMalloc((void **)&h->info, sizeof(SymInfo) * C));
   RXHIP(hipMalloc((void **)&h->maj, sizeof(int) * C)); RXHIP(hipMalloc((void **)&h->sym_index, sizeof(int) * C));
   RXHIP(hipMalloc((void **)&h->bitdeint, C * P + 64));
+  if (d.hierarchy != 0) RXHIP(hipMalloc((void **)&h->bitdeint_lp, C * P + 64));
   h->vit_cap = C * P * d.m * d.k / (8 * d.n) + 4096;
   h->rs_defer_cap = (int)((h->vit_cap / 204 / 64 + 2) * (RS_LANE_MIN - 1));
   RXHIP(hipMalloc((void **)&h->rs_defer, sizeof(RsDefer) * (size_t)h->rs_defer_cap));
@@ -590,7 +599,7 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
   // A5 + A6 on the label bytes of the symbols from first_out on (A4 ran inside the symbol kernel)
   hipLaunchKernelGGL(inner_kernel<6>, dim3(C), dim3(INNER_THREADS), inner_lds_bytes((size_t)d.payload), s, (const float2 *)nullptr, (const uint8_t *)h->labels, ip,
                      (const RxState *)h->st, 0, (const int *)h->sym_index, (const float2 *)nullptr, (const unsigned char *)nullptr,
-                     (const uint16_t *)h->T.H, (const uint16_t *)h->T.Hinv, (uint8_t *)nullptr, h->symdeint_tap, h->bitdeint);
+                     (const uint16_t *)h->T.H, (const uint16_t *)h->T.Hinv, (uint8_t *)nullptr, h->symdeint_tap, h->bitdeint, h->bitdeint_lp);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_VIT], s));
   VitParams vp = h->vp;
   if (h->prm.viterbi_chunk_bytes <= 0) {
@@ -609,7 +618,14 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
     if (B < 256) B = 256;
     vp.chunk_bytes = (int)B;
   }
-  launch_viterbi(s, (const uint8_t *)h->bitdeint, h->vit + o.vit_off, (const RxState *)h->st, 0ll, vp, 0ll, 0ll, max_vit);
+  // hierarchical modes: the decoder is handed bytes of which only two (HP) or m - 2 (LP) bits carry anything, unpacked as m coded bits each
+  // (viterbi_decoder_impl.cc:236-243): a highly degenerate input -- two thirds of the "received" bits are constant zeros -- whose survivors need not merge
+  // inside a chunk's warm-up.  The chunked decoder equals the streaming one only where they do, so here ONE decoder runs from the stream's
+  // start, as the reference's does: exact whatever the input, and slow (one wavefront) -- these modes are on no throughput path.
+  if (d.hierarchy != 0) vp.chunk_bytes = (int)std::min<long long>(max_vit + 64, 1ll << 30);
+  // hierarchical modes: the decoder reads the bit de-interleaver's output 0 (HP: what the flowgraphs connect), or its output 1 on request; it unpacks d_m
+  // bits of every byte either way (viterbi_decoder_impl.cc:93,236-243: the reference's decoder knows no priority streams)
+  launch_viterbi(s, (const uint8_t *)((h->prm.hier_stream && h->bitdeint_lp) ? h->bitdeint_lp : h->bitdeint), h->vit + o.vit_off, (const RxState *)h->st, 0ll, vp, 0ll, 0ll, max_vit);
   }
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_RS], s));
   if (o.tail) { int r = enqueue_tail(h, s, max_vit / 204 + 1, -1); if (r) return r; }
@@ -909,6 +925,7 @@ static int tap_info(dvbt_rx *h, int tap, void **ptr, size_t *bytes)
     case DVBT_TAP_RS: *ptr = h->rs_out; *bytes = (size_t)r.n_rs_bytes; break;
     case DVBT_TAP_TS: *ptr = h->ts_out; *bytes = (size_t)r.n_ts_bytes; break;
     case DVBT_TAP_SYMBOL_INDEX: *ptr = h->sym_index; *bytes = (ns > 0 ? ns - 1 : 0) * 4; break;
+    case DVBT_TAP_BITDEINT_LP: *ptr = h->bitdeint_lp; *bytes = no * d.payload; break;
     default: return fail(DVBT_ERR_INVALID, "unknown tap");
   }
   return DVBT_OK;

@@ -12,9 +12,12 @@ namespace dvbt {
 //   A4 dvbt_demap_impl.cc:167-203  : first strict minimum of (dr*dr + di*di) over the label table
 //   A5 symbol_inner_interleaver_impl.cc:202-208 : even symbol out[q]=in[H(q)], odd out[H(q)]=in[q]
 //   A6 bit_inner_deinterleaver_impl.cc:138-157 : out[i] bit k = bit (v-1-e) of in[(i-off_e) mod 126], e = perm(k)
-struct InnerParams { int payload, m, csize; int nlev; float inv_step, guard; };
-// nlev: levels per axis when the constellation is a uniform square grid (non-hierarchical), else 0;
-// inv_step = 1/(level spacing); guard: |component| above which the exhaustive search is used
+struct InnerParams { int payload, m, csize; int nlev; float inv_step, guard; float hshift; int hier; };
+// nlev: levels per axis of the constellation's grid (0: no grid, exhaustive search); inv_step = 1/(level spacing); guard: |component| above which the
+// exhaustive search is used.  hshift: hierarchical constellations (alpha = 2, 4: dvbt_config.cc:213-225, dvbt_demap_impl.cc:141-142) are the uniform grid
+// with the two halves of each axis pushed (alpha - 1) units apart; the grid CELL of a carrier is found on |x| - hshift (clamped at 0), the distances are
+// always taken to the true points.  hier: the bit de-interleaver's hierarchical form (two outputs, bit_inner_deinterleaver_impl.cc:148-184)
+__device__ __forceinline__ float hier_unshift(float x, float hshift) { return copysignf(fmaxf(fabsf(x) - hshift, 0.f), x); }
 
 // exhaustive search: literally dvbt_demap_impl.cc:167-203
 __device__ __forceinline__ int demap_all(float2 v, const float2 *pts, int csize)
@@ -41,7 +44,10 @@ __device__ __forceinline__ int demap_fast(float2 v, const float2 *pts, const uns
 {
   const bool in_range = p.nlev != 0 && fabsf(v.x) < p.guard && fabsf(v.y) < p.guard;
   const int n = p.nlev;
-  int ji = (int)floorf(v.x * p.inv_step + 0.5f * (float)n), jq = (int)floorf(v.y * p.inv_step + 0.5f * (float)n);
+  // the carrier's cell (hierarchical: on the coordinate with the centre gap closed; a carrier inside the gap lands on the cell boundary at the centre, and the
+  // second candidate below -- chosen against the TRUE point -- is then the inner level of the other side: both are evaluated exactly)
+  const float gx = p.hshift != 0.f ? hier_unshift(v.x, p.hshift) : v.x, gy = p.hshift != 0.f ? hier_unshift(v.y, p.hshift) : v.y;
+  int ji = (int)floorf(gx * p.inv_step + 0.5f * (float)n), jq = (int)floorf(gy * p.inv_step + 0.5f * (float)n);
   ji = ji < 0 ? 0 : ji > n - 1 ? n - 1 : ji; jq = jq < 0 ? 0 : jq > n - 1 ? n - 1 : jq;
   const int L00 = label_of[ji * 8 + jq];
   const float px0 = pts[L00].x, py0 = pts[L00].y;
@@ -103,6 +109,30 @@ template <int VB> __device__ __forceinline__ void bit_deint_words(const uint8_t 
   }
 }
 
+// A6, hierarchical modes (bit_inner_deinterleaver_impl.cc:91-99,148-184): two output streams.  The reference indexes its bit matrix d_b[v][126] with second
+// indices beyond 125; the matrix is contiguous, so d_b[e][j] is flat element f = e * 126 + j = bit (v - 1 - f / 126) of input byte (f % 126 - off) mod 126.
+// HP byte i: bits f_k = ((v i + k) % 2) * 126 + (v i + k) / 2, k = 0, 1.  LP byte i: k = 2 .. v - 3 (none for 16-QAM: 0; two bits for 64-QAM) with
+// f_k = d_perm[v i + k] * 126 + (v i + k) / (v - 2); an f behind the matrix (row 5, i >= 84) is undefined behaviour in the reference (it reads its stack): 0 here,
+// as in oracle/o_inner.c::o_bit_deinterleave_hier.  Byte-wise: the hierarchical modes are on no throughput path.
+__device__ __forceinline__ void bit_deint_hier(const uint8_t *v, uint8_t *o_hp, uint8_t *o_lp, int payload, int m, int tid)
+{
+  constexpr int offs[6] = {0, 63, 105, 42, 21, 84};
+  for (int idx = tid; idx < payload; idx += DVBT_INNER_THREADS) {
+    const int blk = idx / 126, i = idx - blk * 126;
+    const uint8_t *bb = v + blk * 132;
+    auto bit = [&](int f) -> int { const int e = f / 126, j = f - e * 126; int w = j - offs[e]; if (w < 0) w += 126; return (bb[w] >> (m - 1 - e)) & 1; };
+    const int t0 = m * i;
+    const int hp = (bit((t0 & 1) * 126 + t0 / 2) << 1) | bit(((t0 + 1) & 1) * 126 + (t0 + 1) / 2);
+    int lp = 0;
+    for (int k = 2; k < m - 2; k++) {
+      const int t = t0 + k, e = (t % (m - 2)) / ((m - 2) / 2) + 2 * (t % ((m - 2) / 2)) + 2, f = e * 126 + t / (m - 2);
+      lp = (lp << 1) | (f < m * 126 ? bit(f) : 0);
+    }
+    o_hp[idx] = (uint8_t)hp;
+    if (o_lp) o_lp[idx] = (uint8_t)lp;
+  }
+}
+
 constexpr int INNER_NB = 12;                         // carriers per thread and batch
 constexpr int INNER_THREADS = DVBT_INNER_THREADS;   // workgroup size of inner_kernel: a symbol's 6048 carriers are few serial steps per thread
 template <int MODE> __global__ __launch_bounds__(INNER_THREADS) void inner_kernel(const float2 *__restrict__ eq, const uint8_t *__restrict__ in_bytes, InnerParams p,
@@ -110,7 +140,7 @@ template <int MODE> __global__ __launch_bounds__(INNER_THREADS) void inner_kerne
                                                    const float2 *__restrict__ points, const unsigned char *__restrict__ label_tab,
                                                    const uint16_t *__restrict__ H, const uint16_t *__restrict__ Hinv,
                                                    uint8_t *__restrict__ tap_demap, uint8_t *__restrict__ tap_symdeint,
-                                                   uint8_t *__restrict__ out)
+                                                   uint8_t *__restrict__ out, uint8_t *__restrict__ out_lp = nullptr)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint8_t *v = smem_raw;                                       // labels, padded block layout
@@ -161,7 +191,8 @@ template <int MODE> __global__ __launch_bounds__(INNER_THREADS) void inner_kerne
   // A6: output byte i of a block, bit k (MSB first) = bit (m-1-e) of input byte (i - off_e) mod 126, e = perm(k).
   // One item = 4 consecutive output bytes: per bit plane one (unaligned) word of the rotated block, masked and
   // shifted into place.
-  if (p.m == 2) bit_deint_words<2>(v, o, p.payload, tid);
+  if (p.hier) bit_deint_hier(v, o, out_lp ? out_lp + (size_t)u * p.payload : nullptr, p.payload, p.m, tid);
+  else if (p.m == 2) bit_deint_words<2>(v, o, p.payload, tid);
   else if (p.m == 4) bit_deint_words<4>(v, o, p.payload, tid);
   else bit_deint_words<6>(v, o, p.payload, tid);
 }

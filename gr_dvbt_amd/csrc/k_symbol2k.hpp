@@ -281,7 +281,7 @@ template <bool TAPS, bool DRIFT> __global__ __launch_bounds__(S2_T * S2_Q, 4) vo
     };
     {
       uint8_t *lab = labels + (size_t)s * S2_PAY;
-      bool slow = false;
+      bool slow = ip.hshift != 0.f;                              // hierarchical constellations: every carrier through the candidate search on the shifted grid
 #pragma unroll
       for (int it = 0; it < S2_IT; it++) {
         const int i = t + it * S2_T;

@@ -479,7 +479,7 @@ template <bool TAPS, bool DRIFT> __global__ __launch_bounds__(S8_T, 4) void symb
     };
     {
       uint8_t *lab = labels + (size_t)s * S8_PAY;
-      bool slow = false;
+      bool slow = ip.hshift != 0.f;                              // hierarchical constellations: every carrier through the candidate search on the shifted grid
 #pragma unroll
       for (int it = 0; it < S8_IT; it++) {
         const int i = tid + it * S8_T;

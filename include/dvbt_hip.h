@@ -157,8 +157,12 @@ void dvbt_symbol_inner_interleaver_destroy(dvbt_symbol_inner_interleaver *h);
 
 /* ------------------------------------------------------------------ A6 bit_inner_deinterleaver
  * replaces bit_inner_deinterleaver::make(nsize, constellation, hierarchy, transmission)
- * (include/dvbt/bit_inner_deinterleaver.h:50-51); general_work lib/bit_inner_deinterleaver_impl.cc:120-184
- * (non-hierarchical: one output stream). */
+ * (include/dvbt/bit_inner_deinterleaver.h:50-51); general_work lib/bit_inner_deinterleaver_impl.cc:120-184.
+ * Non-hierarchical: one output stream (work / work_device).  Hierarchical (ALPHA1 / 2 / 4; io_signature (1, 2)): two output streams, the high-priority
+ * bytes (2 bits each) and the low-priority ones (:148-184): work_hier / work_hier_device; work / work_device then deliver output 0 alone, as a flowgraph
+ * that connects only the first port gets it.  Two things of the reference's hierarchical branch are not reproducible and are defined here: the bits it
+ * reads from behind its bit matrix (64-QAM, low-priority bytes i >= 84 of a block, row 5: undefined behaviour there) are 0; hierarchical QPSK is rejected
+ * (the reference's constructor divides by d_v - 2 = 0). */
 typedef struct { int nsize, constellation, hierarchy, transmission_mode; } dvbt_bit_inner_deinterleaver_params;
 typedef struct dvbt_bit_inner_deinterleaver dvbt_bit_inner_deinterleaver;
 int  dvbt_bit_inner_deinterleaver_create(const dvbt_bit_inner_deinterleaver_params *p, dvbt_bit_inner_deinterleaver **out);
@@ -167,6 +171,10 @@ int  dvbt_bit_inner_deinterleaver_work(dvbt_bit_inner_deinterleaver *h, int nout
                                        const void *in, void *out, dvbt_sideband *sb);
 int  dvbt_bit_inner_deinterleaver_work_device(dvbt_bit_inner_deinterleaver *h, int noutput_items, int ninput_items, const void *in_device, void *out_device,
                                                dvbt_sideband *sb, void *stream);
+int  dvbt_bit_inner_deinterleaver_work_hier(dvbt_bit_inner_deinterleaver *h, int noutput_items, int ninput_items,
+                                            const void *in, void *out_hp, void *out_lp, dvbt_sideband *sb);
+int  dvbt_bit_inner_deinterleaver_work_hier_device(dvbt_bit_inner_deinterleaver *h, int noutput_items, int ninput_items, const void *in_device,
+                                                   void *out_hp_device, void *out_lp_device, dvbt_sideband *sb, void *stream);
 void dvbt_bit_inner_deinterleaver_destroy(dvbt_bit_inner_deinterleaver *h);
 
 /* ------------------------------------------------------------------ A7 viterbi_decoder
@@ -272,6 +280,11 @@ typedef struct {
                               values, decoded by a soft-input Viterbi decoder; everything behind the decoder unchanged.  No reference exists for it: identical
                               TS on a clean loopback, 2-3 dB of gain at the waterfall (tests/test_gpu_soft.py); the chain takes about 1.6x the hard chain's time.
                               The DEMAP / SYMDEINT / BITDEINT taps are not filled in this mode. */
+  int hier_stream;         /* hierarchical modes (hierarchy = ALPHA1 / 2 / 4): which output of bit_inner_deinterleaver feeds the Viterbi decoder: 0 = port 0, the
+                              high-priority stream (what a flowgraph that connects the block's first output gets), 1 = port 1, the low-priority stream.
+                              The decoder behind it is the reference's: it unpacks d_m bits of every byte whatever the stream carries
+                              (lib/viterbi_decoder_impl.cc:93,236-243), so -- as with gr-dvbt itself -- no transport stream comes out of a hierarchical
+                              transmission; what is reproduced is every block's output */
 } dvbt_rx_params;
 
 typedef struct {
@@ -330,7 +343,8 @@ typedef enum {
   DVBT_TAP_TS = 9,         /* u8[n_ts_bytes] */
   DVBT_TAP_CP_START = 10,  /* i32[n_symbols] */
   DVBT_TAP_SYMBOL_INDEX = 11, /* i32[n_symbols - 1] */
-  DVBT_TAP_FREQ_OFFSET = 12  /* i32[n_symbols - 1]  integer carrier offset found for each demodulated symbol (reference_signals_impl.cc:715-744) */
+  DVBT_TAP_FREQ_OFFSET = 12, /* i32[n_symbols - 1]  integer carrier offset found for each demodulated symbol (reference_signals_impl.cc:715-744) */
+  DVBT_TAP_BITDEINT_LP = 13  /* u8[n_out_symbols][payload]  hierarchical modes: the bit de-interleaver's second output (BITDEINT holds the first) */
 } dvbt_tap;
 
 typedef struct dvbt_rx dvbt_rx;

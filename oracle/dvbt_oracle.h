@@ -73,6 +73,8 @@ void o_sym_interleave(const o_cfg *c, const int *h, const unsigned char *in,
 /* ---- bit (de)interleaver ---- */
 void o_bit_interleave(const o_cfg *c, const unsigned char *in, unsigned char *out, size_t n);
 void o_bit_deinterleave(const o_cfg *c, const unsigned char *in, unsigned char *out, size_t n);
+/* hierarchical modes: the block's two output streams (lib/bit_inner_deinterleaver_impl.cc:148-184); bits the reference reads from behind its matrix are 0 */
+void o_bit_deinterleave_hier(const o_cfg *c, const unsigned char *in, unsigned char *outh, unsigned char *outl, size_t n);
 
 /* ---- constellation (lib/dvbt_demap_impl.cc:117-203) ---- */
 void o_constellation(const o_cfg *c, float gain, ocf *points /* csize */);
@@ -177,6 +179,7 @@ typedef struct {
   int *freq_offset;           /* optional, meta_cap entries: d_freq_offset of every demodulator call (reference_signals_impl.cc:715-744) */
   long long *call_pos;        /* optional, meta_cap entries: sample at which the general_work call that delivered acquired symbol i began */
   unsigned char *sync_flag;   /* optional, meta_cap entries: 1 = the item carries the sync_start tag (first item of a lock period) */
+  unsigned char *bitdeint_lp_out; /* optional, sym_cap symbols: the bit de-interleaver's second output (hierarchical modes; port 0 = bitdeint_out feeds the decoder) */
 } o_rx_taps;
 
 int o_rx_run(const o_cfg *c, const ocf *iq, size_t nsamples, float snr_db, int bsize,

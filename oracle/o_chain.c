@@ -114,6 +114,14 @@ int o_rx_run_cut(const o_cfg *c, const ocf *iq, size_t nsamples, float snr_db, i
     t->t_stage[3] = now() - t0; t0 = now();
     for (size_t s = 0; s < nout; s++) o_sym_interleave(c, H, b0 + s * P, b1 + s * P, symidx[s], 0);
     t->t_stage[4] = now() - t0; t0 = now();
+    /* hierarchical modes: two outputs; port 0 (HP) is what the flowgraphs connect to the Viterbi decoder, which unpacks d_m bits of every byte whatever
+     * the stream carries (viterbi_decoder_impl.cc:93,236-243: its config knows no priority streams) */
+    if (c->hierarchy != O_NH) {
+      unsigned char *lp = malloc((size_t)P * (nout + 1));
+      o_bit_deinterleave_hier(c, b1, b2, lp, (size_t)P * nout);
+      if (t->bitdeint_lp_out) { size_t n = nout < t->sym_cap ? nout : t->sym_cap; memcpy(t->bitdeint_lp_out, lp, (size_t)P * n); }
+      free(lp);
+    } else
     o_bit_deinterleave(c, b1, b2, (size_t)P * nout);
     t->t_stage[5] = now() - t0;
     free(points); free(H);

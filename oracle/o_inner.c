@@ -133,3 +133,34 @@ void o_bit_deinterleave(const o_cfg *c, const unsigned char *in, unsigned char *
     }
   }
 }
+
+/* ---------------- bit de-interleaver, hierarchical: lib/bit_inner_deinterleaver_impl.cc:91-99,148-184, two output streams.
+ * The reference addresses its bit matrix d_b[v][126] with second indices far beyond 125 (:169 `(d_v * i + k) / 2`, :176 `(d_v * i + k) / (d_v - 2)`): C lays
+ * the matrix out row after row, so d_b[e][j] IS flat element e * 126 + j -- inside the matrix for every HP bit and for the LP bits of rows 2..4.
+ * Row 5 (64-QAM) with j >= 126 (i >= 84) lies BEHIND the matrix: the reference reads whatever the stack holds there (undefined behaviour, not
+ * reproducible); this restatement -- and the product -- take 0 for those bits and say so.  The LP loop runs k = 2 .. d_v - 3 (:175), i.e. not at all for
+ * 16-QAM (outl = 0) and over two bits for 64-QAM, with d_perm of :91-99's hierarchical branch. */
+static int perm_h(int v, int i) { return (i % (v - 2)) / ((v - 2) / 2) + 2 * (i % ((v - 2) / 2)) + 2; }
+
+void o_bit_deinterleave_hier(const o_cfg *c, const unsigned char *in, unsigned char *outh, unsigned char *outl, size_t n)
+{
+  int v = c->m;
+  unsigned char b[6 * 126];
+  for (size_t blk = 0; blk < n / 126; blk++) {
+    for (int w = 0; w < 126; w++) {
+      int ch = in[blk * 126 + w];
+      for (int e = 0; e < v; e++) b[e * 126 + Hbit(e, w)] = (ch >> (v - e - 1)) & 1;
+    }
+    for (int i = 0; i < 126; i++) {
+      int val = 0;
+      for (int k = 0; k < 2; k++) val = (val << 1) | b[((v * i + k) % 2) * 126 + (v * i + k) / 2];
+      outh[blk * 126 + i] = (unsigned char)val;
+      val = 0;
+      for (int k = 2; k < v - 2; k++) {
+        int f = perm_h(v, v * i + k) * 126 + (v * i + k) / (v - 2);
+        val = (val << 1) | (f < v * 126 ? b[f] : 0);              /* behind the matrix: undefined in the reference, 0 here */
+      }
+      outl[blk * 126 + i] = (unsigned char)val;
+    }
+  }
+}

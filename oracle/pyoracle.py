@@ -63,7 +63,7 @@ class Taps(C.Structure):
         ("first_out_symbol", C.c_int), ("n_acquired", C.c_int),
         ("rs_fail", C.c_int), ("rs_corr", C.c_int),
         ("t_stage", C.c_double * 10), ("ts_first_packet", C.c_longlong), ("stream_rs_items", C.c_longlong),
-        ("freq_offset", C.c_void_p), ("call_pos", C.c_void_p), ("sync_flag", C.c_void_p)]
+        ("freq_offset", C.c_void_p), ("call_pos", C.c_void_p), ("sync_flag", C.c_void_p), ("bitdeint_lp_out", C.c_void_p)]
 
 
 _lib = None
@@ -329,6 +329,8 @@ def rx(c, iq, snr_db=30.0, bsize=768, rs_compat=0, want=("rs",), max_sym_taps=No
         t.symdeint_out = alloc("symdeint", (ns, c.payload), np.uint8)
     if "bitdeint" in want:
         t.bitdeint_out = alloc("bitdeint", (ns, c.payload), np.uint8)
+    if "bitdeint_lp" in want:
+        t.bitdeint_lp_out = alloc("bitdeint_lp", (ns, c.payload), np.uint8)
     t.sym_cap = ns
     vitcap = nsym * c.payload * c.m * c.k // (8 * c.n) + 64
     if "vit" in want:
@@ -351,7 +353,7 @@ def rx(c, iq, snr_db=30.0, bsize=768, rs_compat=0, want=("rs",), max_sym_taps=No
            "rs_fail": t.rs_fail, "rs_corr": t.rs_corr, "t_stage": list(t.t_stage),
            "ts_first_packet": t.ts_first_packet, "stream_rs_items": t.stream_rs_items, "stream_symbol_offset": sym_off}
     for k, n in (("acq", t.acq_n), ("fft", t.fft_n), ("eq", t.eq_n), ("demap", t.sym_n),
-                 ("symdeint", t.sym_n), ("bitdeint", t.sym_n), ("vit", t.vit_n), ("deint", t.deint_n),
+                 ("symdeint", t.sym_n), ("bitdeint", t.sym_n), ("bitdeint_lp", t.sym_n), ("vit", t.vit_n), ("deint", t.deint_n),
                  ("rs", t.rs_n), ("ts", t.ts_n)):
         if k in bufs:
             out[k] = bufs[k][:n]

@@ -375,3 +375,59 @@ def test_wave_peak_detector(g):
     assert (avg_out[:, 0].view(np.uint32) == avg_out[:, 1].view(np.uint32)).all()
     # the cases are not degenerate: windows without a peak, with one, with several
     assert (out[:, 0] == 0).sum() > 1000 and (out[:, 0] == 1).sum() > 1000 and (out[:, 0] >= 2).sum() > 1000
+
+
+# ---------------------------------------------------------------- hierarchical modes (rows A0 / A4 / A6: dvbt_config.cc:213-225, dvbt_demap_impl.cc:117-165,
+# bit_inner_deinterleaver_impl.cc:148-184)
+@pytest.mark.parametrize("const,hier,mode", [(1, 2, 0), (1, 3, 1), (2, 2, 1), (2, 3, 0), (2, 1, 0)])
+def test_demap_block_hierarchical_constellations(po, g, const, hier, mode):
+    """alpha = 2 / 4: the constellation's two halves per axis lie (alpha - 1) units further apart.  Random carriers, exact points, exact midpoints (the first
+    strict minimum decides), carriers inside the centre gap, far outside the grid, and a dense sweep across every decision boundary of one axis."""
+    c = po.cfg(const, po.C1_2, mode, hierarchy=hier)
+    pts = np.zeros(c.csize, np.complex64)
+    po.lib().o_constellation(C.byref(c), C.c_float(1.0), _p(pts))
+    rng = np.random.RandomState(12)
+    n = 4
+    lab = rng.randint(0, c.csize, (n, c.payload))
+    x = (pts[lab] + 0.45 * c.norm * (rng.randn(n, c.payload) + 1j * rng.randn(n, c.payload))).astype(np.complex64)
+    x[0, :c.csize] = pts
+    x[0, c.csize:2 * c.csize] = (pts + np.roll(pts, 1)) / 2
+    x[0, 2 * c.csize:3 * c.csize] = (pts + np.roll(pts, 3)) / 2
+    x[1, :400] = ((rng.rand(400) - 0.5) + 1j * (rng.rand(400) - 0.5)).astype(np.complex64) * 2 * c.alpha * c.norm      # inside the centre gap
+    x[1, 400:800] = ((rng.randn(400) + 1j * rng.randn(400)) * 40).astype(np.complex64)                                 # far outside
+    sweep = np.linspace(-12 * c.norm, 12 * c.norm, 600).astype(np.float32)
+    x[2, :600] = sweep + 1j * np.float32(0.3 * c.norm)
+    x[2, 600:1200] = np.float32(-1.7 * c.norm) + 1j * sweep
+    ref = np.zeros((n, c.payload), np.uint8)
+    po.lib().o_demap(C.byref(c), _p(pts), _p(x), _p(ref), C.c_size_t(n * c.payload))
+    b = g.Block("demap", c.payload, const, hier, mode, 1.0)
+    out = np.zeros_like(ref)
+    assert b.work(n, n, x, out)[0] == n
+    assert (out == ref).all(), np.argwhere(out != ref)[:5]
+    b.close()
+
+
+@pytest.mark.parametrize("const,hier", [(1, 1), (1, 2), (2, 2), (2, 3)])
+def test_bit_deinterleaver_block_hierarchical_two_outputs(po, g, const, hier):
+    c = po.cfg(const, po.C1_2, po.T2k, hierarchy=hier)
+    rng = np.random.RandomState(13)
+    x = rng.randint(0, c.csize, (5, c.payload)).astype(np.uint8)
+    rh, rl = np.zeros_like(x), np.zeros_like(x)
+    po.lib().o_bit_deinterleave_hier(C.byref(c), _p(x), _p(rh), _p(rl), C.c_size_t(x.size))
+    b = g.Block("bit_inner_deinterleaver", c.payload, const, hier, po.T2k)
+    L = g.lib()
+    L.dvbt_bit_inner_deinterleaver_work_hier.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    oh, ol = np.zeros_like(x), np.full_like(x, 0xee)
+    assert L.dvbt_bit_inner_deinterleaver_work_hier(b.h, 5, 5, _p(x), _p(oh), _p(ol), None) == 5
+    assert (oh == rh).all() and (ol == rl).all()
+    assert oh.max() == 3 and (ol.max() == 3 if const == 2 else ol.max() == 0)
+    # the one-output entry delivers port 0, as a flowgraph that connects only the first output gets it
+    o0 = np.zeros_like(x)
+    assert b.work(5, 5, x, o0)[0] == 5 and (o0 == rh).all()
+    b.close()
+    # a non-hierarchical block has one output; hierarchical QPSK does not exist (the reference divides by zero)
+    nh = g.Block("bit_inner_deinterleaver", c.payload, const, 0, po.T2k)
+    assert L.dvbt_bit_inner_deinterleaver_work_hier(nh.h, 5, 5, _p(x), _p(oh), _p(ol), None) < 0
+    nh.close()
+    with pytest.raises(g.DvbtError):
+        g.Block("bit_inner_deinterleaver", c.payload, 0, hier, po.T2k)

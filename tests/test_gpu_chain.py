@@ -260,3 +260,45 @@ def test_long_silence_before_the_signal(po, g, const, cr, mode, guard, lead):
         a, b = rx.tap(tap).reshape(-1), o[name].reshape(-1)
         assert a.size == b.size and (a == b).all(), name
     rx.close()
+
+
+@pytest.mark.parametrize("const,hier,mode,cr", [(1, 2, 0, 0), (2, 3, 0, 2), (2, 2, 1, 4), (1, 3, 1, 1)], ids=["2k QAM16 alpha 2", "2k QAM64 alpha 4", "8k QAM64 alpha 2", "8k QAM16 alpha 4"])
+def test_hierarchical_modes_every_tap(po, g, const, hier, mode, cr):
+    """A loopback on the alpha = 2 / 4 constellations through the chain configured as the reference's flowgraph would be (hierarchy on demod_reference_signals,
+    dvbt_demap, bit_inner_deinterleaver, viterbi_decoder): the TPS word signals the hierarchy, the demapper decides on the non-uniform grid, the bit
+    de-interleaver delivers its two outputs, output 0 feeds the decoder (which -- the reference's -- unpacks d_m bits of every byte whatever the stream carries:
+    no transport stream comes out, as with gr-dvbt itself).  Every block's output equals the oracle's, byte for byte; with hier_stream = 1 the decoder reads
+    output 1."""
+    c = po.cfg(const, cr, mode, hierarchy=hier)
+    ibits = c.payload * c.m * c.k // c.n
+    ts = po.make_ts((272 * ibits * 2) // (204 * 8), 14)
+    iq = po.tx(c, ts, lead_in=700, tail=3 * c.N)
+    want = ("eq", "demap", "symdeint", "bitdeint", "bitdeint_lp", "vit", "rs")
+    o = po.rx(c, iq, want=want)
+    rx = g.Rx(const, cr, mode, max_samples=len(iq), hierarchy=hier, taps=True)
+    rep = rx.run(iq)
+    assert rep.n_symbols == o["n_acquired"] and rep.first_out_symbol == o["first_out_symbol"] >= 0
+    assert rep.tps_valid and rep.tps_hierarchy == hier and rep.tps_mismatch == 0
+    eq = rx.tap(g.TAP_EQ)
+    d = eq - o["eq"]
+    assert max(np.abs(d.real).max(), np.abs(d.imag).max()) <= 1e-3 * 2 * c.norm
+    for name, tap in (("demap", g.TAP_DEMAP), ("symdeint", g.TAP_SYMDEINT), ("bitdeint", g.TAP_BITDEINT), ("bitdeint_lp", g.TAP_BITDEINT_LP),
+                      ("vit", g.TAP_VITERBI), ("rs", g.TAP_RS)):
+        a, b = rx.tap(tap), o[name]
+        assert a.size == b.size > 0, name
+        assert (a.reshape(-1) == b.reshape(-1)).all(), name
+    hp = rx.tap(g.TAP_BITDEINT).copy()
+    assert hp.max() == 3                                                  # two bits per carrier on the high-priority stream
+    rx.close()
+    # the low-priority output into the decoder: same front end, the decoder's input is output 1
+    rx = g.Rx(const, cr, mode, max_samples=len(iq), hierarchy=hier, taps=True, hier_stream=1)
+    rx.run(iq)
+    assert (rx.tap(g.TAP_BITDEINT_LP).reshape(-1) == o["bitdeint_lp"].reshape(-1)).all() and (rx.tap(g.TAP_BITDEINT) == hp).all()
+    lp = o["bitdeint_lp"].reshape(-1)
+    ref = np.zeros(len(lp) * c.m * c.k // (8 * c.n) + 64, np.uint8)
+    import ctypes as C
+    po.lib().o_viterbi_decode.restype = C.c_size_t
+    n = po.lib().o_viterbi_decode(C.byref(c), 768, lp.ctypes.data_as(C.c_void_p), C.c_size_t(len(lp)), ref.ctypes.data_as(C.c_void_p))
+    v = rx.tap(g.TAP_VITERBI)
+    assert len(v) == n and (v == ref[:n]).all()
+    rx.close()
