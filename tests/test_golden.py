@@ -83,3 +83,20 @@ def test_oracle_rs_words(po):
     # correction at the lowest error location
     ok = s["rs_nerr"] <= 8
     assert (s["rs_out_compat0"][ok] != s["rs_out_compat1"][ok]).any()
+
+
+HIER = json.load(open(os.path.join(G, "hier_taps.json")))
+HIER_CASES = {c[0]: c for c in mg.HIER_CASES}
+
+
+@pytest.mark.parametrize("name", sorted(HIER_CASES))
+def test_oracle_hierarchical_taps(po, name):
+    """round 4: alpha = 1 / 2 / 4 constellations, the bit de-interleaver's two outputs, the decoder on output 0 (tests/golden/hier_taps.json)"""
+    _, const, hier, cr, mode, nsf, seed, lead = HIER_CASES[name]
+    e = HIER[name]
+    c, iq = mg.make_hier_case(const, hier, cr, mode, nsf, seed, lead)
+    assert len(iq) == e["n_samples"] and mg.sha(iq) == e["iq_sha256"], "seeded generator drifted"
+    o = po.rx(c, iq, want=mg.HIER_TAPS)
+    assert o["n_acquired"] == e["n_acquired"] and o["first_out_symbol"] == e["first_out_symbol"]
+    for t in mg.HIER_TAPS:
+        assert o[t].size == e["taps"][t]["n"] and mg.sha(o[t]) == e["taps"][t]["sha256"], t

@@ -120,3 +120,25 @@ def test_rs_words_equal_golden(g, compat):
     assert r == 2 and cons == 2
     assert (out == s["rs_out_compat%d" % compat]).all()
     b.close()
+
+
+HIER = json.load(open(os.path.join(G, "hier_taps.json")))
+HIER_CASES = {c[0]: c for c in mg.HIER_CASES}
+
+
+@pytest.mark.parametrize("name", sorted(HIER_CASES))
+def test_hierarchical_taps_equal_golden(po, g, name):
+    """the chain in a hierarchical mode against the committed hashes: demapper decisions on the alpha grid, symbol de-interleaver, both outputs of the bit
+    de-interleaver, the decoder's bytes on output 0"""
+    _, const, hier, cr, mode, nsf, seed, lead = HIER_CASES[name]
+    e = HIER[name]
+    c, iq = mg.make_hier_case(const, hier, cr, mode, nsf, seed, lead)
+    assert mg.sha(iq) == e["iq_sha256"]
+    rx = g.Rx(const, cr, mode, max_samples=len(iq), hierarchy=hier, taps=True)
+    rep = rx.run(iq)
+    assert rep.n_symbols == e["n_acquired"] and rep.first_out_symbol == e["first_out_symbol"]
+    tapid = {"demap": g.TAP_DEMAP, "symdeint": g.TAP_SYMDEINT, "bitdeint": g.TAP_BITDEINT, "bitdeint_lp": g.TAP_BITDEINT_LP, "vit": g.TAP_VITERBI}
+    for t in mg.HIER_TAPS:
+        a = rx.tap(tapid[t]).reshape(-1)
+        assert a.size == e["taps"][t]["n"] and mg.sha(a) == e["taps"][t]["sha256"], t
+    rx.close()
