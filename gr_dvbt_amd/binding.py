@@ -9,6 +9,7 @@ _SO = os.path.join(_HERE, "lib", "libdvbt_hip.so")
 _SRC = os.path.join(_HERE, "csrc", "dvbt_hip.hip")
 
 QPSK, QAM16, QAM64 = 0, 1, 2
+AUTO = -1          # RxStream: constellation / hierarchy / code_rate from the stream's TPS word
 NH = 0
 C1_2, C2_3, C3_4, C5_6, C7_8 = 0, 1, 2, 3, 4
 T2k, T8k = 0, 1
@@ -236,7 +237,8 @@ class StreamParams(C.Structure):
 class StreamInfo(C.Structure):
     _fields_ = [("status", C.c_int32), ("pieces_in_flight", C.c_int32), ("finished", C.c_int32),
                 ("samples_pushed", C.c_int64), ("ts_bytes_decoded", C.c_int64), ("ts_bytes_ready", C.c_int64), ("ts_bytes_pulled", C.c_int64),
-                ("first_superframe_call", C.c_int64), ("first_ts_packet", C.c_int64)]
+                ("first_superframe_call", C.c_int64), ("first_ts_packet", C.c_int64),
+                ("constellation", C.c_int32), ("hierarchy", C.c_int32), ("code_rate", C.c_int32), ("auto_configured", C.c_int32)]
 
 
 class RxStream:

@@ -44,6 +44,7 @@ typedef enum { DVBT_C1_2 = 0, DVBT_C2_3, DVBT_C3_4, DVBT_C5_6, DVBT_C7_8 } dvbt_
 typedef enum { DVBT_T2k = 0, DVBT_T8k = 1 } dvbt_transmission_mode_t;
 typedef enum { DVBT_G1_32 = 0, DVBT_G1_16, DVBT_G1_8, DVBT_G1_4 } dvbt_guard_interval_t;
 #endif
+#define DVBT_AUTO (-1)   /* dvbt_rx_stream_params.rx.constellation / hierarchy / code_rate: take it from the stream's TPS word */
 
 /* sideband: replaces the stream tags of SURVEY Appendix D */
 typedef enum { DVBT_TAG_SYNC_START = 1, DVBT_TAG_SUPERFRAME_START = 2, DVBT_TAG_SYMBOL_INDEX = 3 } dvbt_tag_key;
@@ -419,6 +420,11 @@ void dvbt_rx_destroy(dvbt_rx *h);
  * are missing) and the piece goes on from the next superframe start it can reach from the sample where the reference's search resumes -- one or two
  * superframes are not delivered (the reference itself loses the acquisition, a TPS frame and the wait for a superframe start there).
  * Threading: like every handle, one thread at a time. */
+/* TPS auto-configuration (gr-dvbt's TODO.txt:28 "Autodetect transmission params"): rx.constellation, rx.hierarchy and / or rx.code_rate = DVBT_AUTO.  The
+ * transmission mode and the guard interval must be given (the front end is built from them); everything else the stream says itself: the head of the stream
+ * (two TPS frames and a margin: 160 symbols + one window) is held back, a probe chain reads a BCH-valid TPS word out of it (lib/reference_signals_impl.cc:385-425,
+ * field layout :883-916), the chains are built for what it names and the head is replayed into them -- the TS is that of a stream created with those
+ * parameters (tests/test_gpu_tps.py).  While no valid word has been seen the look-ahead doubles (up to four attempts); then push fails with DVBT_ERR_STATE. */
 typedef struct {
   dvbt_rx_params rx; int segment_superframes;
   /* sharding over the GPUs of a node, one stream object per process / GPU: every rank is pushed the SAME stream; piece k >= 1 belongs to rank
@@ -435,6 +441,8 @@ typedef struct {
   int64_t samples_pushed, ts_bytes_decoded, ts_bytes_ready, ts_bytes_pulled;
   int64_t first_superframe_call;   /* call (window of N+cp samples) of the stream's first superframe start, -1 before it is known */
   int64_t first_ts_packet;         /* RS word (counted from that superframe start) of the first TS packet, -1 before it is known */
+  int32_t constellation, hierarchy, code_rate;   /* the parameters the chains run with; -1 while they are being detected (DVBT_AUTO) */
+  int32_t auto_configured;         /* 1: they were taken from the stream's TPS word */
 } dvbt_rx_stream_info;
 typedef struct dvbt_rx_stream dvbt_rx_stream;
 int  dvbt_rx_stream_create(const dvbt_rx_stream_params *p, dvbt_rx_stream **out);

@@ -56,3 +56,84 @@ def test_no_signal_no_tps(po):
     rep = rx.run(iq)
     rx.close()
     assert rep.tps_valid == 0 and rep.tps_bits == 0 and rep.tps_mismatch == 0
+
+
+# ---------------------------------------------------------------- TPS auto-CONFIGURATION of the streaming entry (TODO.txt:28 "Autodetect transmission params")
+def _stream(po, const, cr, mode, iq, call, hierarchy=g.NH, **kw):
+    st = g.RxStream(const, cr, mode, segment_superframes=2, hierarchy=hierarchy, **kw)
+    out = []
+    for a in range(0, len(iq), call):
+        st.push(iq[a:a + call])
+        out.append(st.pull())
+    st.finish()
+    out.append(st.pull())
+    info = st.info()
+    st.close()
+    return np.concatenate(out), info
+
+
+@pytest.mark.parametrize("const,cr,mode", CONFIGS)
+def test_auto_configured_stream_equals_the_configured_one(po, const, cr, mode):
+    """constellation / hierarchy / code_rate = AUTO: the head of the stream is held back until a probe chain has read a BCH-valid TPS word, the chains are built for
+    what it names, the head is replayed.  The TS must be the oracle's chain with the true parameters (= the configured stream's), for each BASELINE config."""
+    c = po.cfg(const, cr, mode)
+    iq = po.stream_slice(c, 7, 21)
+    want = po.rx(c, iq, want=("ts",))["ts"]
+    L = c.N + c.cp
+    ts, info = _stream(po, g.AUTO, g.AUTO, mode, iq, 50 * L + 7, hierarchy=g.AUTO)
+    assert info.auto_configured == 1 and (info.constellation, info.hierarchy, info.code_rate) == (const, g.NH, cr)
+    assert info.status & ~2 == 0 and len(ts) == len(want) > 0 and (ts == want).all()
+    ref, info2 = _stream(po, const, cr, mode, iq, 50 * L + 7)
+    assert info2.auto_configured == 0 and (ref == ts).all()
+
+
+def test_auto_only_the_code_rate_and_device_pushes(po):
+    """one field AUTO, the others given; samples pushed from device memory; a head that arrives in 4-symbol calls"""
+    import torch
+    const, cr, mode = g.QAM64, g.C7_8, g.T8k
+    c = po.cfg(const, cr, mode)
+    iq = po.stream_slice(c, 5, 22)
+    want = po.rx(c, iq, want=("ts",))["ts"]
+    dev = torch.from_numpy(iq.view(np.float32)).cuda()
+    torch.cuda.synchronize()
+    st = g.RxStream(const, g.AUTO, mode, segment_superframes=1)
+    out, step = [], 4 * (c.N + c.cp)
+    for a in range(0, len(iq), step):
+        st.push_device(dev.data_ptr() + 8 * a, min(step, len(iq) - a))
+        out.append(st.pull())
+    st.finish(); out.append(st.pull())
+    info = st.info(); st.close()
+    ts = np.concatenate(out)
+    assert info.auto_configured == 1 and info.code_rate == cr and len(ts) == len(want) and (ts == want).all()
+
+
+def test_auto_detects_a_hierarchical_transmission(po):
+    c = po.cfg(g.QAM64, g.C2_3, g.T2k, hierarchy=g.ALPHA2)
+    ibits = c.payload * c.m * c.k // c.n
+    iq = po.tx(c, po.make_ts((272 * ibits * 3) // (204 * 8), 5), lead_in=500, tail=3 * c.N)
+    ts, info = _stream(po, g.AUTO, g.AUTO, g.T2k, iq, 30000, hierarchy=g.AUTO)
+    assert info.auto_configured == 1 and (info.constellation, info.hierarchy, info.code_rate) == (g.QAM64, g.ALPHA2, g.C2_3)
+
+
+def test_auto_short_stream_and_no_signal(po):
+    # a stream that ends before the look-ahead is full: finish() detects on what there is
+    const, cr, mode = g.QAM16, g.C1_2, g.T2k
+    c = po.cfg(const, cr, mode)
+    iq = po.stream_slice(c, 3, 23)
+    want = po.rx(c, iq, want=("ts",))["ts"]
+    st = g.RxStream(g.AUTO, g.AUTO, mode, segment_superframes=4)
+    st.push(iq[:100 * (c.N + c.cp)])                                  # less than the 160 symbols the detection waits for
+    assert st.info().constellation == -1 and len(st.pull()) == 0
+    st.push(iq[100 * (c.N + c.cp):])
+    st.finish()
+    ts = st.pull(); info = st.info(); st.close()
+    assert info.auto_configured == 1 and len(ts) == len(want) and (ts == want).all()
+    # noise: no TPS word, the look-ahead doubles three times, then the stream refuses
+    rng = np.random.RandomState(2)
+    noise = (1e-3 * (rng.randn(40 * 160 * 2112) + 1j * rng.randn(40 * 160 * 2112))).astype(np.complex64)
+    st = g.RxStream(g.AUTO, g.AUTO, mode)
+    with pytest.raises(g.DvbtError):
+        for a in range(0, len(noise), 200000):
+            st.push(noise[a:a + 200000])
+    assert st.info().status & 4
+    st.close()
