@@ -15,7 +15,7 @@ C1_2, C2_3, C3_4, C5_6, C7_8 = 0, 1, 2, 3, 4
 T2k, T8k = 0, 1
 G1_32, G1_16, G1_8, G1_4 = 0, 1, 2, 3
 (TAP_ACQ, TAP_FFT, TAP_EQ, TAP_DEMAP, TAP_SYMDEINT, TAP_BITDEINT, TAP_VITERBI, TAP_DEINT, TAP_RS,
- TAP_TS, TAP_CP_START, TAP_SYMBOL_INDEX, TAP_FREQ_OFFSET, TAP_BITDEINT_LP) = range(14)
+ TAP_TS, TAP_CP_START, TAP_SYMBOL_INDEX, TAP_FREQ_OFFSET, TAP_BITDEINT_LP, TAP_SOFT, TAP_CSI) = range(16)
 ALPHA1, ALPHA2, ALPHA4 = 1, 2, 3
 
 
@@ -137,7 +137,7 @@ class Rx:
     """Device-resident DVB-T receive chain (segment API of include/dvbt_hip.h)."""
 
     _TAP_DTYPE = {TAP_ACQ: np.complex64, TAP_FFT: np.complex64, TAP_EQ: np.complex64, TAP_CP_START: np.int32,
-                  TAP_SYMBOL_INDEX: np.int32, TAP_FREQ_OFFSET: np.int32}
+                  TAP_SYMBOL_INDEX: np.int32, TAP_FREQ_OFFSET: np.int32, TAP_SOFT: np.int8, TAP_CSI: np.float32}
 
     def __init__(self, constellation, code_rate, mode, max_samples, guard=G1_32, hierarchy=NH, snr_db=30.0,
                  viterbi_bsize=768, rs_oracle_compat=0, descramble=1, device=0, viterbi_chunk_bytes=0, taps=False,
@@ -189,7 +189,8 @@ class Rx:
                  TAP_SYMDEINT: r.n_out_symbols * d.payload_length, TAP_BITDEINT: r.n_out_symbols * d.payload_length,
                  TAP_VITERBI: r.n_viterbi_bytes, TAP_DEINT: r.n_rs_bytes // 188 * 204, TAP_RS: r.n_rs_bytes,
                  TAP_TS: r.n_ts_bytes, TAP_CP_START: r.n_symbols * 4, TAP_SYMBOL_INDEX: max(r.n_symbols - 1, 0) * 4,
-                 TAP_FREQ_OFFSET: max(r.n_symbols - 1, 0) * 4, TAP_BITDEINT_LP: r.n_out_symbols * d.payload_length}
+                 TAP_FREQ_OFFSET: max(r.n_symbols - 1, 0) * 4, TAP_BITDEINT_LP: r.n_out_symbols * d.payload_length,
+                 TAP_SOFT: r.n_out_symbols * d.payload_length * d.m, TAP_CSI: r.n_out_symbols * d.payload_length * 4}
         nbytes = max(int(sizes[tap]), 0)
         buf = np.zeros(nbytes, np.uint8)
         if nbytes:
@@ -198,8 +199,10 @@ class Rx:
         out = buf.view(self._TAP_DTYPE.get(tap, np.uint8))
         if tap in (TAP_ACQ, TAP_FFT):
             out = out.reshape(-1, d.fft_length)
-        elif tap in (TAP_EQ, TAP_DEMAP, TAP_SYMDEINT, TAP_BITDEINT, TAP_BITDEINT_LP):
+        elif tap in (TAP_EQ, TAP_DEMAP, TAP_SYMDEINT, TAP_BITDEINT, TAP_BITDEINT_LP, TAP_CSI):
             out = out.reshape(-1, d.payload_length)
+        elif tap == TAP_SOFT:
+            out = out.reshape(-1, d.payload_length * d.m)
         return out
 
     def lock_periods(self):

@@ -926,6 +926,8 @@ static int tap_info(dvbt_rx *h, int tap, void **ptr, size_t *bytes)
     case DVBT_TAP_TS: *ptr = h->ts_out; *bytes = (size_t)r.n_ts_bytes; break;
     case DVBT_TAP_SYMBOL_INDEX: *ptr = h->sym_index; *bytes = (ns > 0 ? ns - 1 : 0) * 4; break;
     case DVBT_TAP_BITDEINT_LP: *ptr = h->bitdeint_lp; *bytes = no * d.payload; break;
+    case DVBT_TAP_SOFT: *ptr = h->soft_a; *bytes = no * d.payload * d.m; break;
+    case DVBT_TAP_CSI: *ptr = h->csi ? (void *)(h->csi + fo * d.payload) : nullptr; *bytes = no * d.payload * 4; break;
     default: return fail(DVBT_ERR_INVALID, "unknown tap");
   }
   return DVBT_OK;

@@ -345,7 +345,10 @@ typedef enum {
   DVBT_TAP_CP_START = 10,  /* i32[n_symbols] */
   DVBT_TAP_SYMBOL_INDEX = 11, /* i32[n_symbols - 1] */
   DVBT_TAP_FREQ_OFFSET = 12, /* i32[n_symbols - 1]  integer carrier offset found for each demodulated symbol (reference_signals_impl.cc:715-744) */
-  DVBT_TAP_BITDEINT_LP = 13  /* u8[n_out_symbols][payload]  hierarchical modes: the bit de-interleaver's second output (BITDEINT holds the first) */
+  DVBT_TAP_BITDEINT_LP = 13, /* u8[n_out_symbols][payload]  hierarchical modes: the bit de-interleaver's second output (BITDEINT holds the first) */
+  DVBT_TAP_SOFT = 14,      /* i8[n_out_symbols][payload * m]  soft-decision mode: the log-likelihood ratio of every coded bit in the decoder's input order (behind both
+                              inner de-interleavers); > 0: the bit is more likely 0.  The EQ tap is its input (always filled in this mode) ... */
+  DVBT_TAP_CSI = 15        /* f32[n_out_symbols][payload]  ... together with the channel state of every carrier, 1 / |interpolated equaliser gain|^2 */
 } dvbt_tap;
 
 typedef struct dvbt_rx dvbt_rx;

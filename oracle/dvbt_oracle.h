@@ -155,6 +155,11 @@ size_t o_tx_generate(const o_cfg *c, const unsigned char *ts, size_t npackets, f
 size_t o_tx_generate_from(const o_cfg *c, const unsigned char *ts, size_t npackets, size_t packet0, float scale,
                           ocf *iq, size_t cap_samples, ocf *freq_taps);
 
+/* ---- MODEL (not a restatement of the reference, which has no soft path) of the product's soft-decision kernels: o_soft.c */
+void o_soft_demap(const o_cfg *c, const ocf *eq, const float *csi, const int *parity, size_t nsym, signed char *out);
+void o_soft_plan(long long total_out, int ntb, int *B_out, int *nsteps_out);
+long long o_soft_viterbi(const o_cfg *c, const signed char *soft, long long n_soft, long long total_steps, int B, int nsteps, unsigned char *out);
+
 /* ---- the reference's own SSE2 Viterbi kernels (oracle/_ref), timed natively: decoded Mbit/s, -1 when the library is missing */
 double o_ref_viterbi_mbps(const char *so_path, size_t nsym, int ntraceback);
 

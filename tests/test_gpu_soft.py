@@ -87,3 +87,77 @@ def test_soft_mode_through_the_streaming_entry(po, const, cr, mode, nsf, seg_sf,
     st.close()
     ts = np.concatenate(out)
     assert info.status & ~2 == 0 and len(ts) == len(ref) > 0 and (ts == ref).all()
+
+
+# ---------------------------------------------------------------- the soft path against an independent model (oracle/o_soft.c: a MODEL of the kernels' specification,
+# not of the reference, which has no soft path).  The GPU's own EQ / CSI taps go into the model's demapper, the GPU's soft values into the model's decoder:
+# soft values and decoded bytes must be IDENTICAL.  A wrong weight, tie rule, depuncturing phase or traceback start would cost tenths of a dB that no
+# packet-error threshold notices; here it is a differing byte.
+def _model_check(po, const, cr, mode, nsf, snr, echoes=(), seed=9, optional=False):
+    import ctypes as C
+    c = po.cfg(const, cr, mode)
+    clean = po.stream_slice(c, nsf, seed)
+    iq = po.channel(clean, c.N, echoes=echoes, snr_db=snr, seed=5)
+    import torch
+    dev = torch.from_numpy(iq.view(np.float32)).cuda()
+    torch.cuda.synchronize()
+    rx = g.Rx(const, cr, mode, max_samples=len(iq), snr_db=snr, soft_decision=1)
+    rx.enqueue_device(dev.data_ptr(), len(iq))                       # the asynchronous entry: the stream's first lock period, one launch of every kernel
+    rep = rx.finish()
+    if optional and not (rep.first_out_symbol >= 0 and rep.n_out_symbols >= 272):
+        rx.close()
+        return None
+    assert rep.first_out_symbol >= 0 and rep.n_out_symbols >= 272, "the point is meant to be one the reference's tracker holds for a superframe at least"
+    eq, csi, soft, vit = rx.tap(g.TAP_EQ), rx.tap(g.TAP_CSI), rx.tap(g.TAP_SOFT), rx.tap(g.TAP_VITERBI).copy()
+    sidx = rx.tap(g.TAP_SYMBOL_INDEX)
+    rx.close()
+    n_out, P, m = rep.n_out_symbols, c.payload, c.m
+    assert eq.shape == (n_out, P) and csi.shape == (n_out, P) and soft.shape == (n_out, P * m)
+    assert (csi > 0).all() and np.isfinite(csi).all()
+    parity = np.ascontiguousarray(sidx[rep.first_out_symbol:rep.first_out_symbol + n_out] & 1, dtype=np.int32)
+    L = po.lib()
+    # ---- the demapper
+    model_soft = np.zeros((n_out, P * m), np.int8)
+    L.o_soft_demap.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.o_soft_demap(C.byref(c), np.ascontiguousarray(eq).ctypes.data, np.ascontiguousarray(csi).ctypes.data, parity.ctypes.data, n_out, model_soft.ctypes.data)
+    diff = soft.astype(np.int32) - model_soft.astype(np.int32)
+    assert np.abs(diff).max() == 0, (int(np.abs(diff).max()), int((diff != 0).sum()))
+    hist = np.bincount(np.abs(soft.reshape(-1).astype(np.int32)), minlength=32)
+    assert hist[31] < 0.9 * soft.size and hist[:8].sum() > 0.01 * soft.size        # the values use their range: neither all clamped nor all confident
+    # ---- the decoder
+    ntb = {0: 5, 1: 9, 2: 10, 3: 15, 4: 24}[cr]
+    total_steps = (rep.n_viterbi_bytes + ntb) * 8
+    n_soft = total_steps * c.n // c.k
+    Lc = c.N + c.cp
+    ncalls = (len(iq) - (2 * c.N + c.cp + 16)) // Lc + 1
+    max_vit = ncalls * P * m * c.k // (8 * c.n) + 1
+    B, nsteps = C.c_int(), C.c_int()
+    L.o_soft_plan.argtypes = [C.c_longlong, C.c_int, C.c_void_p, C.c_void_p]
+    L.o_soft_plan(max_vit, ntb, C.byref(B), C.byref(nsteps))
+    out = np.zeros(rep.n_viterbi_bytes + 64, np.uint8)
+    L.o_soft_viterbi.restype = C.c_longlong
+    L.o_soft_viterbi.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_int, C.c_int, C.c_void_p]
+    flat = np.ascontiguousarray(soft.reshape(-1))
+    n = L.o_soft_viterbi(C.byref(c), flat.ctypes.data, n_soft, total_steps, B.value, nsteps.value, out.ctypes.data)
+    assert n == rep.n_viterbi_bytes == len(vit)
+    bad = np.flatnonzero(out[:n] != vit)
+    assert len(bad) == 0, (len(bad), bad[:8], B.value, nsteps.value)
+    return rep
+
+
+@pytest.mark.parametrize("const,cr,mode,nsf,snr", [(g.QAM16, g.C1_2, g.T2k, 4, 10.0), (g.QAM64, g.C7_8, g.T8k, 2, 20.0), (g.QPSK, g.C2_3, g.T8k, 2, 30.0), (g.QAM64, g.C2_3, g.T2k, 4, 17.0)],
+                         ids=["2k QAM16 1/2 at 10 dB (hard path dead)", "8k QAM64 7/8 at 20 dB (hard path dead)", "8k QPSK 2/3 clean", "2k QAM64 2/3 at 17 dB (hard path dead)"])
+def test_soft_values_and_decoded_bytes_equal_the_model(po, const, cr, mode, nsf, snr):
+    rep = _model_check(po, const, cr, mode, nsf, snr)
+    if snr < 25:
+        assert rep.rs_corrected_symbols > 0 or rep.rs_fail_words > 11          # the decoder had errors to make: the comparison is not of two clean streams
+
+
+def test_soft_values_and_decoded_bytes_equal_the_model_on_an_echo_channel(po):
+    """an echo of -10 dB: the channel-state weights vary by 10 dB across the carriers (the cap at 4 and the mean both matter).  The asynchronous entry decodes the
+    stream's FIRST lock period: the noise level is raised until the reference's tracker holds that one for a superframe"""
+    for snr in (16.0, 18.0, 20.0, 24.0):
+        rep = _model_check(po, g.QAM16, g.C3_4, g.T2k, 4, snr, echoes=((19, 0.3),), optional=True)
+        if rep is not None:
+            return
+    pytest.fail("no noise level at which the first lock period delivers a superframe")
