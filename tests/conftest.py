@@ -24,3 +24,15 @@ def po():
     from oracle import pyoracle
     pyoracle.build()
     return pyoracle
+
+
+def host_example(name):
+    """path of a C++ host example under gr_dvbt_amd/host, (re)built when it is missing or older than the header / sources it was compiled from (a stale
+    binary has the previous layout of the ABI's structs)"""
+    import subprocess
+    host = os.path.join(ROOT, "gr_dvbt_amd", "host")
+    exe = os.path.join(host, name)
+    deps = [os.path.join(ROOT, "include", "dvbt_hip.h"), os.path.join(host, "dvbt_blocks.hpp"), os.path.join(host, name + ".cpp")]
+    if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
+        subprocess.check_call(["bash", os.path.join(host, "build.sh")], stdout=subprocess.DEVNULL)
+    return exe

@@ -320,9 +320,8 @@ def test_cpp_host_mirror_example(po, g, tmp_path):
     gr::dvbt block classes (same make() calls and general_work contract), fed with the oracle's bit-de-interleaver output."""
     import os
     import subprocess
-    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gr_dvbt_amd", "host", "rx_flowgraph_example")
-    if not os.path.exists(exe):
-        subprocess.check_call(["bash", os.path.join(os.path.dirname(exe), "build.sh")], stdout=subprocess.DEVNULL)
+    from conftest import host_example
+    exe = host_example("rx_flowgraph_example")
     c = po.cfg(po.QAM16, po.C1_2, po.T2k)
     ts = po.make_ts(504 * 3, 9)
     iq = po.tx(c, ts, lead_in=500, tail=3 * c.N)

@@ -92,10 +92,8 @@ def test_cpp_host_gathers_over_rccl(tmp_path):
     sys.path.insert(0, ROOT)
     from oracle import pyoracle as po
     import gr_dvbt_amd as g
-    host = os.path.join(ROOT, "gr_dvbt_amd", "host")
-    exe = os.path.join(host, "rx_multi_example")
-    if not os.path.exists(exe):
-        subprocess.check_call(["bash", os.path.join(host, "build.sh")], stdout=subprocess.DEVNULL)
+    from conftest import host_example
+    exe = host_example("rx_multi_example")
     c = po.cfg(g.QAM64, g.C7_8, g.T8k)
     iq = po.stream_slice(c, 9, 6)
     want = po.rx(c, iq, want=("ts",))["ts"]

@@ -166,13 +166,8 @@ def test_sharded_stream_equals_one_chain(po, const, cr, mode, nsf, seg_sf, world
 
 
 def _example():
-    import os
-    import subprocess
-    host = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gr_dvbt_amd", "host")
-    exe = os.path.join(host, "rx_stream_example")
-    if not os.path.exists(exe):
-        subprocess.check_call(["bash", os.path.join(host, "build.sh")], stdout=subprocess.DEVNULL)
-    return exe
+    from conftest import host_example
+    return host_example("rx_stream_example")
 
 
 @pytest.mark.parametrize("nsf,symbols,out_bytes,seg_sf", [(11, 64, 1 << 22, 4), (11, 4, 188 * 16, 2), (2, 64, 1 << 22, 16), (7, 33, 188 * 700, 1)],
