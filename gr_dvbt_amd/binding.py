@@ -24,10 +24,8 @@ class DvbtError(RuntimeError):
 
 
 def hipcc():
-    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
-        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
-            return c
-    return "hipcc"
+    """the ROCm compiler driver (no environment variable is consulted: the package reads none)"""
+    return "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"
 
 
 def build(force=False):
