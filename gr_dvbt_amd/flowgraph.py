@@ -81,71 +81,147 @@ class RxFlowgraph:
             return st.blk.work_device(nout, nin, in_buf.data_ptr() + in_off_bytes, st.out.data_ptr() + out_off, tags_rel, self.stream.cuda_stream)
         return st.blk.work(nout, nin, in_buf[in_off_bytes:], st.out[out_off:], tags_rel)
 
-    def run(self, iq):
-        """iq: complex64 samples (numpy).  Returns the TS bytes (numpy uint8)."""
+    def _setup(self, iq):
         d = self.dims
         N, cp, P, cs = d.fft_length, d.cp_length, d.payload_length, self.call_symbols
         if self.mode == "device":
-            src = self.torch.from_numpy(np.ascontiguousarray(iq).view(np.uint8)).cuda()
+            self.src = self.torch.from_numpy(np.ascontiguousarray(iq).view(np.uint8)).cuda()
         else:
-            src = np.ascontiguousarray(iq).view(np.uint8)
-        S = self.stages
-        S[0].w = len(iq)
+            self.src = np.ascontiguousarray(iq).view(np.uint8)
+        self.stages[0].w = len(iq)
         # items per call, per stage (output side): `cs` OFDM symbols' worth
         vit_blocks = max(1, cs * P // self.vit_in_block)
-        per_call = [cs, cs, cs, cs, cs, cs, vit_blocks * self.vit_out_mult, max(2, (cs * d.info_bits_per_symbol // 8 // 1632) & ~1),
-                    max(2, cs * d.info_bits_per_symbol // 8 // 1632), max(1, cs * d.info_bits_per_symbol // 8 // (4 * 1504)) * 4 * 1504]
-        progress = True
-        while progress:
-            progress = False
-            for k, st in enumerate(S):
-                in_buf = src if k == 0 else S[k - 1].out
-                while True:
-                    avail = st.w - st.r
-                    nout = min(per_call[k], st.out_cap - st.produced)
-                    if nout <= 0 or avail <= 0:
-                        break
-                    need = st.blk.forecast(nout)
-                    # a scheduler offers what it has when the forecast cannot be met at the stream's end; the block decides
-                    nin = avail if k != 0 else min(avail, need + 0)
-                    if k == 0 and avail < 2 * N + cp + 16:
-                        break
-                    if k == 0:
-                        nin = min(avail, (nout - 1) * (N + cp) + 2 * N + cp + 16)
-                    elif k == 6:
-                        nin = min(avail, need)
-                        if nin < self.vit_in_block:
-                            break
-                    elif k == 7:
-                        nin = min(avail, need)
-                        if nin < 2 * 1632:
-                            break
-                    else:
-                        nin = min(avail, need)
-                    tags_rel = [(o - st.r, key, v) for (o, key, v) in st.tags if st.r <= o < st.r + nin]
-                    produced, consumed, tout = self._call(k, nout, nin, in_buf, st.r * st.in_item, tags_rel)
-                    st.calls += 1
-                    if consumed == 0 and produced == 0:
-                        break
-                    # tags travel to the next stage at absolute offsets (x payload through vector_to_stream).  Blocks with one
-                    # output item per input item pass the tags of their input on, as GNU Radio's default propagation policy does
-                    if k + 1 < len(S):
-                        scale = P if k == 5 else 1
-                        if k in (1, 3, 4, 5, 8):
-                            tout = tout + [t for t in tags_rel if t[0] < consumed]
-                        for (o, key, v) in sorted(tout):
-                            S[k + 1].tags.append(((st.produced + o) * scale, key, v))
-                    st.r += consumed
-                    st.tags = [t for t in st.tags if t[0] >= st.r]
-                    st.produced += produced
-                    if k + 1 < len(S):
-                        S[k + 1].w = st.produced * (P if k == 5 else 1)
-                    progress = True
-        last = S[-1]
+        self.out_mult = [1, 1, 1, 1, 1, 1, self.vit_out_mult, 2, 1, 4 * 1504]          # set_output_multiple of the reference blocks
+        self.per_call = [cs, cs, cs, cs, cs, cs, vit_blocks * self.vit_out_mult, max(2, (cs * d.info_bits_per_symbol // 8 // 1632) & ~1),
+                         max(2, cs * d.info_bits_per_symbol // 8 // 1632), max(1, cs * d.info_bits_per_symbol // 8 // (4 * 1504)) * 4 * 1504]
+
+    def _step(self, k, lock=None):
+        """one general_work call of stage k if its input allows one; returns True when something was consumed or produced.  lock: a threading.Lock that
+        guards what neighbouring stages share (items available, the tag list) in the threaded driver."""
+        d = self.dims
+        N, cp, P = d.fft_length, d.cp_length, d.payload_length
+        S, st = self.stages, self.stages[k]
+        in_buf = self.src if k == 0 else S[k - 1].out
+        if lock:
+            lock.acquire()
+        avail = st.w - st.r
+        tags_all = list(st.tags)
+        if lock:
+            lock.release()
+        nout = min(self.per_call[k], st.out_cap - st.produced)
+        if nout <= 0 or avail <= 0:
+            return False
+        need = st.blk.forecast(nout)
+        # GNU Radio's executor halves the output request (down to the block's output multiple) while the forecast cannot be met
+        # (gnuradio-runtime/lib/block_executor.cc "try_again"); only then is the block blocked on input.  At the stream's end the block is offered what is
+        # there and decides itself
+        mult = self.out_mult[k]
+        while need > avail and nout // 2 >= mult:
+            nout = (nout // 2) // mult * mult
+            need = st.blk.forecast(nout)
+        if k == 0:
+            if avail < 2 * N + cp + 16:
+                return False
+            nin = min(avail, (nout - 1) * (N + cp) + 2 * N + cp + 16)
+        elif k == 6:
+            nin = min(avail, need)
+            if nin < self.vit_in_block:
+                return False
+        elif k == 7:
+            nin = min(avail, need)
+            if nin < 2 * 1632:
+                return False
+        else:
+            nin = min(avail, need)
+        tags_rel = [(o - st.r, key, v) for (o, key, v) in tags_all if st.r <= o < st.r + nin]
+        produced, consumed, tout = self._call(k, nout, nin, in_buf, st.r * st.in_item, tags_rel)
+        st.calls += 1
+        if consumed == 0 and produced == 0:
+            return False
+        # tags travel to the next stage at absolute offsets (x payload through vector_to_stream).  Blocks with one
+        # output item per input item pass the tags of their input on, as GNU Radio's default propagation policy does
+        if lock:
+            lock.acquire()
+        if k + 1 < len(S):
+            scale = P if k == 5 else 1
+            if k in (1, 3, 4, 5, 8):
+                tout = tout + [t for t in tags_rel if t[0] < consumed]
+            for (o, key, v) in sorted(tout):
+                S[k + 1].tags.append(((st.produced + o) * scale, key, v))
+        st.r += consumed
+        st.tags = [t for t in st.tags if t[0] >= st.r]
+        st.produced += produced
+        if k + 1 < len(S):
+            S[k + 1].w = st.produced * (P if k == 5 else 1)
+        if lock:
+            lock.release()
+        return True
+
+    def _result(self):
+        last = self.stages[-1]
         if self.mode == "device":
             self.stream.synchronize()
             return last.out[:last.produced].cpu().numpy()
         return last.out[:last.produced].copy()
+
+    def run(self, iq):
+        """iq: complex64 samples (numpy).  Returns the TS bytes (numpy uint8).  ONE thread calls the ten blocks in turn."""
+        self._setup(iq)
+        progress = True
+        while progress:
+            progress = False
+            for k in range(len(self.stages)):
+                while self._step(k):
+                    progress = True
+        return self._result()
+
+    def run_threaded(self, iq):
+        """The same flowgraph under a thread-per-block scheduler, which is what GNU Radio's is (gr::thread_body_wrapper / tpb_thread_body: every block's
+        general_work runs in its own thread, woken when a neighbour has produced or consumed).  The ten blocks' calls -- host copies, launches, the
+        synchronisation at the end of a host-pointer call -- overlap; the throughput is the slowest block's, not the sum.  (ctypes releases the GIL for the
+        duration of a call; the output buffers hold the whole stream, so no block ever waits for room.)  host mode only: device-mode blocks share one HIP stream."""
+        import threading
+        self._setup(iq)
+        n = len(self.stages)
+        lock = threading.Lock()
+        cv = threading.Condition(lock)
+        done = [False] * n
+        errors = []
+
+        def body(k):
+            try:
+                while True:
+                    if self._step(k, lock):
+                        with cv:
+                            cv.notify_all()
+                        continue
+                    with cv:
+                        # nothing to do: finished if upstream is (and a last look found nothing), else wait for upstream to produce
+                        if k == 0 or done[k - 1]:
+                            upstream_final = True
+                        else:
+                            upstream_final = False
+                            cv.wait(0.002)
+                    if upstream_final:
+                        if not self._step(k, lock):
+                            break
+                        with cv:
+                            cv.notify_all()
+            except Exception as e:        # pragma: no cover
+                errors.append(e)
+            finally:
+                with cv:
+                    done[k] = True
+                    cv.notify_all()
+
+        ths = [threading.Thread(target=body, args=(k,)) for k in range(n)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        if errors:
+            raise errors[0]
+        return self._result()
 
     def close(self):
         for st in self.stages:

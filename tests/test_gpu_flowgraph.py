@@ -26,3 +26,21 @@ def test_block_by_block_equals_the_oracle(po, const, cr, mode_t, nsf, mode, call
     n = min(len(ts), len(ref))
     assert n > 0.9 * len(ref) and abs(len(ts) - len(ref)) <= 64 * 1504
     assert (ts[:n] == ref[:n]).all()
+
+
+@pytest.mark.parametrize("const,cr,mode_t,nsf,call_symbols", [(g.QAM16, g.C1_2, g.T2k, 3, 16), (g.QAM64, g.C7_8, g.T8k, 3, 64)])
+def test_thread_per_block_scheduler_equals_the_oracle(po, const, cr, mode_t, nsf, call_symbols):
+    """the ten blocks under a thread-per-block scheduler (what GNU Radio's is): every block's general_work in its own thread, calls of whatever size its input
+    allows at that moment, host buffers.  The TS must be the oracle's whatever the interleaving of the calls was."""
+    c = po.cfg(const, cr, mode_t)
+    iq = po.stream_slice(c, nsf, 9)
+    ref = po.rx(c, iq, want=("ts",))["ts"]
+    for _ in range(2):                                                     # two runs: two different interleavings
+        fg = RxFlowgraph(const, cr, mode_t, len(iq), mode="host", call_symbols=call_symbols)
+        ts = fg.run_threaded(iq)
+        calls = [st.calls for st in fg.stages]
+        fg.close()
+        assert min(calls) > 0
+        n = min(len(ts), len(ref))
+        assert n > 0.9 * len(ref) and abs(len(ts) - len(ref)) <= 64 * 1504
+        assert (ts[:n] == ref[:n]).all()
