@@ -427,6 +427,7 @@ struct EnqOpt {
   bool keep_last = false;     // a later period delivers items: the last item of this one leaves the demodulator too
   size_t vit_off = 0;         // where this period's decoded bytes go in the Viterbi stream of the segment
   bool tail = true;           // byte de-interleaver + RS + descrambler right behind (single period)
+  long long avail = 0;        // samples in memory from iq[0] on (0: nsamples): a period of a longer segment is given a look-ahead window, the stream goes on behind it
   bool no_small = false;      // acq_only: not through acq_small_kernel (it has handed the period back: RxState.small_viol)
 };
 
@@ -472,7 +473,7 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
   if (nsamples < (size_t)(2 * d.N + d.cp + 16)) return fail(DVBT_ERR_INVALID, "segment shorter than one acquisition window");
   FrontParams fp = h->fp;
   fp.ncalls = (int)((nsamples - (2 * d.N + d.cp + 16)) / (d.N + d.cp) + 1);
-  fp.hist = o.hist; fp.keep_last = o.keep_last ? 1 : 0;
+  fp.hist = o.hist; fp.keep_last = o.keep_last ? 1 : 0; fp.avail = o.avail > 0 ? o.avail : (long long)nsamples;
   const int C = fp.ncalls, N = d.N;
   h->cur_stream = s;
   const bool tm = h->timing && !o.acq_only;
@@ -729,7 +730,7 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
     bk.total_symbols += per[p].n_symbols;
     if (usable < 1) return DVBT_OK;
     if (!reuse) { int r = acq_ctx(); if (r) return r; }
-    EnqOpt o; o.use_carry = per[p].carry; o.carry_avg = per[p].avg_in; o.hist = (long long)per[p].off; o.continuation = bk.processed > 0; o.keep_last = later; o.tail = false; o.skip_acq = reuse;
+    EnqOpt o; o.use_carry = per[p].carry; o.carry_avg = per[p].avg_in; o.hist = (long long)per[p].off; o.avail = (long long)(chain_n - per[p].off); o.continuation = bk.processed > 0; o.keep_last = later; o.tail = false; o.skip_acq = reuse;
     o.vit_off = bk.delivering > 0 ? (bk.acc / 3264) * 3264 : 0;   // convolutional_deinterleaver_impl.cc:109-120: the tag realigns the input
     o.init_tries = std::min(ACQ_INIT_TRIES_MAX, std::max(ACQ_INIT_TRIES, per[p].call0 + 1));   // (a second acquisition must reach the window the wide search found the peak in)
     // a period that ends in a lost lock is decoded over its own calls and the one that lost the lock, not over the whole rest of the segment
@@ -755,7 +756,7 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
     for (int guard = 0; off + win <= chain_n; guard++) {
       if (guard >= 4096) { capped = true; break; }
       { int r = acq_ctx(); if (r) return r; }
-      EnqOpt o; o.acq_only = true; o.use_carry = carry; o.carry_avg = avg; o.hist = (long long)off;
+      EnqOpt o; o.acq_only = true; o.use_carry = carry; o.carry_avg = avg; o.hist = (long long)off; o.avail = (long long)(chain_n - off);
       // searches that found nothing are followed by wider ones (4, 8, ... 64 windows per launch): dead air costs a launch sequence per 64 windows, not per 4
       o.init_tries = std::min(ACQ_INIT_TRIES_MAX, ACQ_INIT_TRIES << std::min(fails, 4));
       // the search and the tracker look at a window of the rest of the segment that grows while the lock holds to its end: a segment with many lock

@@ -49,6 +49,9 @@ struct FrontParams {
                          // (demod_reference_signals_impl.cc:88-94), so the last item of a stream never leaves it; the last item in front of
                          // a lost lock does, as soon as the re-acquired stream delivers its first item
   int pad1;
+  long long avail;       // samples in memory from the segment's first one on: a tracking window that has crept beyond its call's 2N + cp + 16 samples (the reference then
+                         // reads and WRITES past its d_norm / d_corr arrays, ofdm_sym_acquisition_impl.cc:166-186,416-419: undefined there) reads the stream's own
+                         // samples here, and zeros at or beyond this bound -- as oracle/o_acq.c does
   long long hist;        // samples of the stream that lie BEFORE the segment's first sample in memory (a restart inside a segment): a tracking
                          // window at the left edge of its call reads them, as the reference reads the history of its input buffer
 };
@@ -228,9 +231,10 @@ __global__ __launch_bounds__(256) void acq_track_metric_kernel(const float2 *__r
         const bool okc = cl < p.ncalls && cl >= st->call0;
         const int lag0c = centre[okc ? cl : st->call0] - p.R;
         const long long idx = (long long)cl * (N + cp) + lag0c - j0 - (T - 1) + i;   // sample x[lag0 + q - j] for q - (j - j0) = i - (T - 1)
-        av[k] = iq[okc && idx >= -p.hist ? idx : 0]; bv[k] = iq[okc && idx - N >= -p.hist ? idx - N : 0];
-        if (!(okc && idx >= -p.hist)) av[k] = make_float2(0.f, 0.f);
-        if (!(okc && idx - N >= -p.hist)) bv[k] = make_float2(0.f, 0.f);
+        const bool oka = okc && idx >= -p.hist && idx < p.avail, okb = okc && idx - N >= -p.hist && idx - N < p.avail;
+        av[k] = iq[oka ? idx : 0]; bv[k] = iq[okb ? idx - N : 0];
+        if (!oka) av[k] = make_float2(0.f, 0.f);
+        if (!okb) bv[k] = make_float2(0.f, 0.f);
       }
 #pragma unroll
       for (int k = 0; k < 4; k++) {
@@ -583,8 +587,8 @@ __global__ __launch_bounds__(64) void acq_track_kernel(FrontParams p, RxState *s
       const long long lo = (long long)call * (N + cp) + cur - 8 - (cp - 1);
       __syncthreads();
       for (int t = lane; t < cp + 15; t += 64) {
-        s_xa[t] = lo + t >= -p.hist ? iq[lo + t] : make_float2(0.f, 0.f);
-        s_xb[t] = lo - N + t >= -p.hist ? iq[lo - N + t] : make_float2(0.f, 0.f);
+        s_xa[t] = lo + t >= -p.hist && lo + t < p.avail ? iq[lo + t] : make_float2(0.f, 0.f);
+        s_xb[t] = lo - N + t >= -p.hist && lo - N + t < p.avail ? iq[lo - N + t] : make_float2(0.f, 0.f);
       }
       __syncthreads();
       if (lane < 16) {
@@ -665,8 +669,8 @@ __global__ __launch_bounds__(64) void acq_track_light_kernel(FrontParams p, RxSt
       const long long lo = (long long)call * L + cur - 8 - (cp - 1);
       __syncthreads();
       for (int t = lane; t < cp + 15; t += 64) {
-        s_xa[t] = lo + t >= -p.hist ? iq[lo + t] : make_float2(0.f, 0.f);
-        s_xb[t] = lo - N + t >= -p.hist ? iq[lo - N + t] : make_float2(0.f, 0.f);
+        s_xa[t] = lo + t >= -p.hist && lo + t < p.avail ? iq[lo + t] : make_float2(0.f, 0.f);
+        s_xb[t] = lo - N + t >= -p.hist && lo - N + t < p.avail ? iq[lo - N + t] : make_float2(0.f, 0.f);
       }
       __syncthreads();
       if (lane < 16) {
@@ -747,8 +751,8 @@ __global__ __launch_bounds__(576) void acq_small_kernel(const float2 *__restrict
 #pragma unroll
       for (int u = 0; u < 5; u++) {
         const int t = t0 + 32 * u; const bool in = t < span;
-        ra[u] = in && lo + t >= -p.hist ? iq[lo + t] : make_float2(0.f, 0.f);
-        rb[u] = in && lo - N + t >= -p.hist ? iq[lo - N + t] : make_float2(0.f, 0.f);
+        ra[u] = in && lo + t >= -p.hist && lo + t < p.avail ? iq[lo + t] : make_float2(0.f, 0.f);
+        rb[u] = in && lo - N + t >= -p.hist && lo - N + t < p.avail ? iq[lo - N + t] : make_float2(0.f, 0.f);
       }
 #pragma unroll
       for (int u = 0; u < 5; u++) {
@@ -806,7 +810,7 @@ __global__ __launch_bounds__(576) void acq_small_kernel(const float2 *__restrict
             if (at - cp + 1 - N < -p.hist) { s_dl[lane] = -3.0e38f; s_dg[lane] = make_float2(0.f, 0.f); }
             else {
               for (int j = 0; j < cp; j++) {
-                const float2 a = iq[at - j], b = iq[at - j - N];
+                const float2 a = at - j < p.avail ? iq[at - j] : make_float2(0.f, 0.f), b = at - j - N < p.avail ? iq[at - j - N] : make_float2(0.f, 0.f);
                 gr += a.x * b.x + a.y * b.y; gi += a.y * b.x - a.x * b.y; phi += (a.x * a.x + a.y * a.y) + (b.x * b.x + b.y * b.y);
               }
               s_dg[lane] = make_float2(gr, gi); s_dl[lane] = sqrtf(gr * gr + gi * gi) - phi * p.half_rho;

@@ -105,7 +105,7 @@ template <bool TAPS, bool DRIFT> __global__ __launch_bounds__(S2_T * S2_Q, 4) vo
   v2f vin[16];
   {
     const long long low = (long long)(call0 + sc) * (N + cp) + m.cp_start - N + 1;
-    const s8_i4 rs = s8_rsrc(iq + low);
+    const s8_i4 rs = s8_rsrc_lim(iq, low, p.avail);
 #pragma unroll
     for (int i = S2_TOP; i < 16; i++) vin[i] = s2_sample(rs, i, t0);
   }
@@ -122,7 +122,7 @@ template <bool TAPS, bool DRIFT> __global__ __launch_bounds__(S2_T * S2_Q, 4) vo
     const bool outp = act && !(!p.keep_last && s + 1 >= nsym);    // no output for the last item (the reference's demod consumes n+1 items)
     {
       const long long low = (long long)(call0 + sc) * (N + cp) + m.cp_start - N + 1;
-      const s8_i4 rs = s8_rsrc(iq + low);
+      const s8_i4 rs = s8_rsrc_lim(iq, low, p.avail);
 #pragma unroll
       for (int i = 0; i < S2_TOP; i++) vin[i] = s2_sample(rs, i, t);
     }
@@ -254,7 +254,7 @@ template <bool TAPS, bool DRIFT> __global__ __launch_bounds__(S2_T * S2_Q, 4) vo
     if (t == 0 && outp) { SymInfo si; si.freq_offset = fo; si.mod_index = mod; si.cfc = 0.f; si.pad = 0; info[s] = si; }
     if (more) {
       const long long low = (long long)(call0 + sc_next) * (N + cp) + mn.cp_start - N + 1;
-      const s8_i4 rs = s8_rsrc(iq + low);
+      const s8_i4 rs = s8_rsrc_lim(iq, low, p.avail);
 #pragma unroll
       for (int i = S2_TOP; i < 16; i++) vin[i] = s2_sample(rs, i, t);
     }

@@ -217,6 +217,15 @@ __device__ __forceinline__ s8_i4 s8_rsrc(const v2f *base)
   r.z = 0x7fffffff; r.w = 0x00020000;                                                                                                  // no range limit that matters; gfx9 raw 32-bit format
   return r;
 }
+// the same with the buffer's range set to what is really in memory behind `low` (FrontParams.avail): a symbol whose window has crept beyond the segment's
+// end (k_frontend.hpp) reads zeros there -- the hardware's range check, no instruction in the load path
+__device__ __forceinline__ s8_i4 s8_rsrc_lim(const v2f *iq, long long low, long long avail)
+{
+  s8_i4 r = s8_rsrc(iq + low);
+  long long bytes = (avail - low) * 8; bytes = bytes < 0 ? 0 : (bytes > 0x7fffffffll ? 0x7fffffffll : bytes);
+  r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+  return r;
+}
 __device__ __forceinline__ v2f s8_sample(s8_i4 rsrc, int i, int tid) { return s8_raw_buffer_load_v2f32(rsrc, tid * 8, i * S8_T * 8, 0); }
 
 // TAPS: the debug taps (derotated samples, spectrum, equalised carriers) are compiled in; the production instantiation has none of that code
@@ -270,7 +279,7 @@ template <bool TAPS, bool DRIFT> __global__ __launch_bounds__(S8_T, 4) void symb
   v2f vin[16];
   {
     const long long low = (long long)(call0 + s) * (N + cp) + m.cp_start - N + 1;
-    const s8_i4 rs = s8_rsrc(iq + low);
+    const s8_i4 rs = s8_rsrc_lim(iq, low, p.avail);
 #pragma unroll
     for (int i = S8_TOP; i < 16; i++) vin[i] = s8_sample(rs, i, tid);
   }
@@ -290,7 +299,7 @@ template <bool TAPS, bool DRIFT> __global__ __launch_bounds__(S8_T, 4) void symb
     {   // the samples that did not fit into the registers next to the equaliser (the compiler spilled them, each behind a full wait): they are
         // requested now and used last in the derotation below
       const long long low = (long long)(call0 + s) * (N + cp) + m.cp_start - N + 1;
-      const s8_i4 rs = s8_rsrc(iq + low);
+      const s8_i4 rs = s8_rsrc_lim(iq, low, p.avail);
 #pragma unroll
       for (int i = 0; i < ((S8_EXP & 4) ? 16 : S8_TOP); i++) vin[i] = s8_sample(rs, i, tid);
     }
@@ -392,7 +401,7 @@ template <bool TAPS, bool DRIFT> __global__ __launch_bounds__(S8_T, 4) void symb
     if (S8_EXP & 1) {
       if (more) {
         const long long low = (long long)(call0 + s_next) * (N + cp) + mn.cp_start - N + 1;
-        const s8_i4 rs = s8_rsrc(iq + low);
+        const s8_i4 rs = s8_rsrc_lim(iq, low, p.avail);
 #pragma unroll
         for (int i = S8_TOP; i < 16; i++) vin[i] = s8_sample(rs, i, tid);
       }
@@ -450,7 +459,7 @@ template <bool TAPS, bool DRIFT> __global__ __launch_bounds__(S8_T, 4) void symb
     // the next symbol's samples start travelling now (all but the S8_TOP that are requested at the top of its iteration)
     if (more && !(S8_EXP & (4 | 64))) {
       const long long low = (long long)(call0 + s_next) * (N + cp) + mn.cp_start - N + 1;
-      const s8_i4 rs = s8_rsrc(iq + low);
+      const s8_i4 rs = s8_rsrc_lim(iq, low, p.avail);
 #pragma unroll
       for (int i = S8_TOP; i < 16; i++) vin[i] = s8_sample(rs, i, tid);
     }
@@ -517,7 +526,7 @@ template <bool TAPS, bool DRIFT> __global__ __launch_bounds__(S8_T, 4) void symb
     }
     if (more && (S8_EXP & 64)) {
       const long long low = (long long)(call0 + s_next) * (N + cp) + mn.cp_start - N + 1;
-      const s8_i4 rs = s8_rsrc(iq + low);
+      const s8_i4 rs = s8_rsrc_lim(iq, low, p.avail);
 #pragma unroll
       for (int i = S8_TOP; i < 16; i++) vin[i] = s8_sample(rs, i, tid);
     }

@@ -134,6 +134,7 @@ int o_acq_work(o_acq *a, const ocf *in, ocf *out, int *consumed, int *sync_start
                int *cp_start, float *epsilon);
 
 /* the same when `hist` samples of the stream lie in memory in front of in[0] (GNU Radio's circular buffer keeps what was consumed) */
+void o_acq_set_avail(o_acq *a, long long avail);   /* samples of the stream in memory from in[0] of the next call on: reads at and beyond give 0 */
 int o_acq_work_hist(o_acq *a, const ocf *in, long long hist, ocf *out, int *consumed, int *sync_start,
                     int *cp_start, float *epsilon);
 

@@ -26,7 +26,9 @@ struct o_acq {
   ocf *gamma, *derot, *corr; float *lambda, *norm, *phi; int *peak_pos;
   float last_eps;
   long long hist;            /* samples of the stream in memory in front of in[0] of the current call */
+  long long avail;           /* samples of the stream in memory from in[0] on (o_acq_set_avail; 0 = unknown: everything asked for is read) */
 };
+#define O_ACQ_FWD 65536      /* how far beyond 2N+cp the tracking window may creep before the restatement stops following it */
 
 o_acq *o_acq_new(const o_cfg *c, float snr_db)
 {
@@ -42,7 +44,10 @@ o_acq *o_acq_new(const o_cfg *c, float snr_db)
   a->derot = calloc(a->N + a->cp, sizeof(ocf));
   /* +16: in tracking the look-up window reaches cp_start + 8, and cp_start may sit at the very end of the 2N+cp samples the
    * reference forecasts (its own d_norm/d_corr are W long: it would write past them there); o_rx_run keeps 16 more samples visible */
-  a->norm = (float *)calloc(W + 16 + O_ACQ_BACK, sizeof(float)) + O_ACQ_BACK; a->corr = (ocf *)calloc(W + 16 + O_ACQ_BACK, sizeof(ocf)) + O_ACQ_BACK;
+  /* ... and beyond: the tracker follows its own peak, +-7 per call, and under noise it creeps past the window's end.  The reference then reads `in` beyond
+   * what its forecast asked for (GNU Radio's buffer holds more) and WRITES beyond d_norm / d_corr (heap overflow: undefined).  Defined here as "the arrays are
+   * long enough": the stream's own samples are read, zeros at and beyond its end (o_acq_set_avail); the product does the same (FrontParams.avail) */
+  a->norm = (float *)calloc(W + 16 + O_ACQ_FWD + O_ACQ_BACK, sizeof(float)) + O_ACQ_BACK; a->corr = (ocf *)calloc(W + 16 + O_ACQ_FWD + O_ACQ_BACK, sizeof(ocf)) + O_ACQ_BACK;
   return a;
 }
 
@@ -94,15 +99,19 @@ static int ml_sync(o_acq *a, const ocf *in, int lookup_start, int lookup_stop)
   const int N = a->N, cp = a->cp;
   const int back = a->hist < O_ACQ_BACK ? (int)a->hist : O_ACQ_BACK;      /* how far in front of in[0] there are samples */
   int low = lookup_stop - (cp + N - 1);
+  const long long avail = a->avail > 0 ? a->avail : (1ll << 62);
+#define O_IN(i) ((long long)(i) < avail ? in[i] : (ocf)0.0f)
   for (int i = low < -back ? -back : low; i <= lookup_start; i++) {
-    float re = crealf(in[i]), im = cimagf(in[i]);
+    const ocf x = O_IN(i);
+    float re = crealf(x), im = cimagf(x);
     a->norm[i] = re * re + im * im;
   }
   low = lookup_stop - cp - 1;
   for (int i = low; i <= lookup_start; i++) {
     if (i - N < -back) continue;
-    a->corr[i - N] = in[i] * conjf(in[i - N]);
+    a->corr[i - N] = O_IN(i) * conjf(O_IN(i - N));
   }
+#undef O_IN
   for (int i = lookup_start - 1; i >= lookup_stop; i--) {
     int k = i - lookup_stop;
     float phi = 0.0f; ocf g = 0.0f;
@@ -151,6 +160,8 @@ int o_acq_work(o_acq *a, const ocf *in, ocf *out, int *consumed, int *sync_start
                int *cp_start, float *epsilon)
 { return o_acq_work_hist(a, in, 0, out, consumed, sync_start, cp_start, epsilon); }
 
+void o_acq_set_avail(o_acq *a, long long avail) { a->avail = avail; }
+
 int o_acq_work_hist(o_acq *a, const ocf *in, long long hist, ocf *out, int *consumed, int *sync_start,
                     int *cp_start, float *epsilon)
 {
@@ -166,7 +177,8 @@ int o_acq_work_hist(o_acq *a, const ocf *in, long long hist, ocf *out, int *cons
     if (found) {
       a->freq_count = 0;
       int low = a->cp_start - N + 1;
-      for (int j = 0; j < N; j++) out[j] = a->derot[j] * in[low + j];
+      const long long av = a->avail > 0 ? a->avail : (1ll << 62);
+      for (int j = 0; j < N; j++) out[j] = a->derot[j] * ((long long)(low + j) < av ? in[low + j] : (ocf)0.0f);
     } else if (++a->freq_count > a->freq_timeout) {
       a->initial_acq = 0; a->freq_count = 0;
       a->to_consume = a->to_consume / 2;

@@ -52,6 +52,7 @@ int o_rx_run_cut(const o_cfg *c, const ocf *iq, size_t nsamples, float snr_db, i
     /* forecast :474-481 asks for 2N+cp; 16 more keeps the +-8 tracking window in range */
     while (pos + (size_t)(2 * N + cp) + 16 <= nsamples && nacq < max_sym) {
       int consumed, sync, cps; float eps;
+      o_acq_set_avail(a, (long long)(nsamples - pos));
       int produced = o_acq_work_hist(a, iq + pos, (long long)pos, acq + nacq * (size_t)N, &consumed, &sync, &cps, &eps);
       if (sync) pending = 1;
       if (produced) {

@@ -37,3 +37,36 @@ def test_snr_sweep_equals_the_oracle(po):
     assert 5e-3 < by[8.0]["pre_viterbi_ber"] < 2e-2 and by[8.0]["oracle"]["packet_error_rate"] > 0.5
     assert by[8.0]["oracle"]["lock_periods"] >= 2
     assert by[5.0]["oracle"]["ts_bytes"] == 0
+
+
+@pytest.mark.parametrize("mode,guard", [(0, 1), (0, 2), (0, 3), (1, 1), (1, 2), (1, 3), (0, 0)],
+                         ids=["2k 1/16", "2k 1/8", "2k 1/4", "8k 1/16", "8k 1/8", "8k 1/4", "2k 1/32"])
+def test_lock_period_walk_on_every_guard_interval(po, mode, guard):
+    """The lock-period walk's one-launch tracker (acq_small_kernel: chunks of 16 calls for a short guard interval down to 2 for cp = 2048, the products of a call's
+    lags staged in LDS) on a stream whose CP lock is lost again and again, for every guard interval and both modes: the same lock periods (where each began, how many
+    items it delivered) as the oracle's sequential restatement of ofdm_sym_acquisition, the same byte counts, and -- QPSK 1/2, where the RS decoder still corrects --
+    the same bytes behind the RS decoder."""
+    import gr_dvbt_amd as g
+    import numpy as np
+    c = po.cfg(po.QPSK, po.C1_2, mode, guard=guard)
+    nsf = 3 if mode == 1 else 6
+    clean = po.stream_slice(c, nsf, 31 + guard)
+    for snr in (14.0, 12.0, 11.0, 10.0, 9.0, 8.0, 7.0, 6.0):       # the noise level at which the reference's detector loses and finds the lock again and again
+        iq = po.channel(clean, c.N, snr_db=snr, seed=7)
+        o = po.rx(c, iq, snr_db=snr, want=("vit", "rs", "ts"))
+        if len(o["lock_periods"]) >= (4 if mode == 1 or guard == 0 else 2):
+            break
+    else:
+        pytest.skip("no noise level with repeated lock losses for this guard interval")
+    rx = g.Rx(po.QPSK, po.C1_2, mode, max_samples=len(iq), guard=guard, snr_db=snr)
+    rep = rx.run(iq)
+    L = c.N + c.cp
+    got = [(off + fc * L, n) for (off, fc, cp0, n, fo) in rx.lock_periods() if n > 0]
+    assert got == o["lock_periods"], (len(got), len(o["lock_periods"]))
+    assert len(got) >= 2, "the point is meant to lie where the lock is lost and found again"
+    assert rep.total_symbols == o["n_acquired"]
+    assert rep.n_viterbi_bytes == len(o["vit"]) and rep.n_rs_bytes == len(o["rs"]) and rep.n_ts_bytes == len(o["ts"])
+    if len(o["rs"]):
+        a = rx.tap(g.TAP_RS)
+        assert (a != o["rs"]).mean() < 1e-3                        # identical but for what failed RS words pass through (a decision within float rounding of a boundary)
+    rx.close()
