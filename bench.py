@@ -657,7 +657,9 @@ def main():
                                       + ((" + one RCCL gather of TS per step" if a.backend == "nccl" else " + one gloo gather of TS per step (host staged)") if dist else ""),
                        "ranks": int(dist.get_world_size()) if dist else 1, "backend": (dist.get_backend() if dist else None),
                        "devices": ("all ranks on device 0 (--ranks-share-gpu: functional run, not a measurement)" if a.ranks_share_gpu and world > 1 else "one process per GPU"),
-                       "ts_bytes_per_step": n_ts, "status": [int(r.status) for r in reps], "rs_fail_words": [int(r.rs_fail_words) for r in reps],
+                       "ts_bytes_per_step": n_ts, "status": [int(r.status) for r in reps],
+                       "status_note": "dvbt_rx_report.status of each piece; bit 1 (value 2) = the CP lock ended where the finite synthetic stream's signal ends (the zeros behind its last symbol), not a loss inside it",
+                       "rs_fail_words": [int(r.rs_fail_words) for r in reps],
                        **check},
             "roofline": {"bound": "valu", "kernel": "viterbi3_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,

@@ -2,7 +2,7 @@
 import csv, glob, collections, json, os, shutil, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
-tag = args[0] if args else "r03"
+tag = args[0] if args else "r04"
 pmc_only = "--pmc-only" in sys.argv
 
 
@@ -38,7 +38,10 @@ if os.path.exists(os.path.join(root, "gpurun_out", "pipeline_depth.jsonl")):
 soft = sorted(glob.glob(os.path.join(root, "gpurun_out", "prof_soft", "*kernel_stats.csv")), key=os.path.getmtime)
 if soft:
     shutil.copy(soft[-1], os.path.join(root, "profiles", f"{tag}_kernel_stats_soft_8k_qam64_7_8_17sf.csv"))   # tools/soft_prof.py: the soft-decision chain
-for extra in ("snr_sweep.jsonl", "rs_load.jsonl", "ubench_mfma.json", "soft_gain.jsonl"):
+cfg5 = sorted(glob.glob(os.path.join(root, "gpurun_out", "prof_cfg5", "*kernel_stats.csv")), key=os.path.getmtime)
+if cfg5:
+    shutil.copy(cfg5[-1], os.path.join(root, "profiles", f"{tag}_kernel_stats_config5_8dB.csv"))                  # tools/period_prof.py 8 16: BASELINE config 5 at the prescribed noise
+for extra in ("config5_walk.jsonl", "snr_sweep.jsonl", "rs_load.jsonl", "ubench_mfma.json", "soft_gain.jsonl"):
     if os.path.exists(os.path.join(root, "gpurun_out", extra)) and os.path.getsize(os.path.join(root, "gpurun_out", extra)) > 0:
         shutil.copy(os.path.join(root, "gpurun_out", extra), os.path.join(root, "profiles", f"{tag}_{extra}"))
 b = json.load(open(os.path.join(root, "gpurun_out", "bench_final.json")))
