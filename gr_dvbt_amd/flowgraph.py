@@ -95,7 +95,7 @@ class RxFlowgraph:
         self.per_call = [cs, cs, cs, cs, cs, cs, vit_blocks * self.vit_out_mult, max(2, (cs * d.info_bits_per_symbol // 8 // 1632) & ~1),
                          max(2, cs * d.info_bits_per_symbol // 8 // 1632), max(1, cs * d.info_bits_per_symbol // 8 // (4 * 1504)) * 4 * 1504]
 
-    def _step(self, k, lock=None):
+    def _step(self, k, lock=None, drain=False):
         """one general_work call of stage k if its input allows one; returns True when something was consumed or produced.  lock: a threading.Lock that
         guards what neighbouring stages share (items available, the tag list) in the threaded driver."""
         d = self.dims
@@ -113,10 +113,11 @@ class RxFlowgraph:
             return False
         need = st.blk.forecast(nout)
         # GNU Radio's executor halves the output request (down to the block's output multiple) while the forecast cannot be met
-        # (gnuradio-runtime/lib/block_executor.cc "try_again"); only then is the block blocked on input.  At the stream's end the block is offered what is
-        # there and decides itself
+        # (gnuradio-runtime/lib/block_executor.cc "try_again"); only then is the block blocked on input.  Here that is done once the upstream block has
+        # finished (drain): while the stream flows a block is simply offered what has arrived (its buffer would hold more than one call's worth in a
+        # flowgraph), so that the steady-state call size stays `call_symbols`
         mult = self.out_mult[k]
-        while need > avail and nout // 2 >= mult:
+        while drain and need > avail and nout // 2 >= mult:
             nout = (nout // 2) // mult * mult
             need = st.blk.forecast(nout)
         if k == 0:
@@ -167,12 +168,13 @@ class RxFlowgraph:
     def run(self, iq):
         """iq: complex64 samples (numpy).  Returns the TS bytes (numpy uint8).  ONE thread calls the ten blocks in turn."""
         self._setup(iq)
-        progress = True
-        while progress:
-            progress = False
-            for k in range(len(self.stages)):
-                while self._step(k):
-                    progress = True
+        for drain in (False, True):                      # the stream flows; then every block finishes on what is left
+            progress = True
+            while progress:
+                progress = False
+                for k in range(len(self.stages)):
+                    while self._step(k, None, drain):
+                        progress = True
         return self._result()
 
     def run_threaded(self, iq):
@@ -203,7 +205,7 @@ class RxFlowgraph:
                             upstream_final = False
                             cv.wait(0.002)
                     if upstream_final:
-                        if not self._step(k, lock):
+                        if not self._step(k, lock, True):
                             break
                         with cv:
                             cv.notify_all()
