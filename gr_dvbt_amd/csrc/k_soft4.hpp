@@ -29,7 +29,10 @@ constexpr int S4_BMAX = 304;               // largest chunk (decoded bytes)
 constexpr int S4_LOOK = 128;               // steps decoded behind a chunk, at least (the reference's depth 8 ntraceback is 40 steps at rate 1/2: the output
                                            // DELAY stays the reference's, the decision depth need not)
 constexpr int S4_G0 = 30;                  // first decision group that is kept (groups of the warm-up are never traced; a multiple of 6 below S4_WARM / 8)
-constexpr int S4_NSEG = 8;                 // traceback segments per decoder
+#ifndef S4_NSEG_N
+#define S4_NSEG_N 8                        /* tools/soft_nseg.py builds 4 beside it: the re-read factor of the decisions against the length of the dependent traceback chains */
+#endif
+constexpr int S4_NSEG = S4_NSEG_N;         // traceback segments per decoder
 constexpr int S4_PRE = 24;                 // groups a segment's chain starts behind the segment's end (192 steps = the reference's depth at rate 7/8)
 constexpr int S4_MAXSTEPS = ((S4_WARM + 8 * S4_BMAX + 8 * 24 + 16 + S4_BLK - 1) / S4_BLK) * S4_BLK;
 static_assert(((S4_WARM + 8 * S4_BMAX + 8 * 24 + S4_BLK - 1) / S4_BLK) * S4_BLK <= S4_MAXSTEPS, "the largest plan (s4_plan: B = S4_BMAX, look = 8 x 24) must fit the decision slots and the best-cell table");
