@@ -481,7 +481,40 @@ def per_block_abi(g, workload, nsf=4):
         out["variants"][f"{mode_name}_pointers_{cs}_symbols_per_call" + ("_thread_per_block" if threaded else "")] = {
             "value": round(len(iq) / best / 1e6, 2), "x_realtime": round(len(iq) / best / 1e6 / REALTIME_MSPS, 1), "block_calls": calls,
             "ts_identical_to_segment_api": bool(n > 0 and (ts[:n] == want[:n]).all()), "ts_bytes": int(len(ts))}
+    out["cpp_driver"] = per_block_cpp(po.stream_slice(c, 17, 77) if workload == "8k_qam64_7_8" else iq, workload)
     return out
+
+
+def per_block_cpp(iq, workload):
+    """the same ten blocks driven from C++ (gr_dvbt_amd/host/rx_blocks_bench.cpp: host pointers, 64 symbols per call): one thread calling them in turn, and a thread per
+    block as under GNU Radio's scheduler -- no interpreter between the calls.  17 superframes (a handle's buffers are allocated in its first calls: a 5-superframe run
+    is a third start-up); the baseband goes through a file in /dev/shm (read before the clock starts)."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "gr_dvbt_amd", "host", "rx_blocks_bench")
+    if not os.path.exists(exe) or workload != "8k_qam64_7_8":
+        return None
+    tmp = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    fin, fout = os.path.join(tmp, "bb.cf32"), os.path.join(tmp, "out.ts")
+    res = {}
+    try:
+        iq.tofile(fin)
+        for cs, thr in ((64, 0), (64, 1), (256, 1)):
+            best = None
+            for _ in range(2):
+                r = subprocess.run([exe, "8k", "qam64", "7/8", fin, fout, str(cs), str(thr)], capture_output=True, text=True, timeout=300)
+                if r.returncode != 0:
+                    return {"error": r.stderr[-300:]}
+                d = json.loads(r.stdout.strip().splitlines()[-1])
+                best = d if best is None or d["msamples_per_s"] > best["msamples_per_s"] else best
+            res[f"host_pointers_{cs}_symbols_per_call" + ("_thread_per_block" if thr else "")] = {"value": best["msamples_per_s"], "x_realtime": round(best["msamples_per_s"] / REALTIME_MSPS, 1),
+                                                                                              "block_calls": best["block_calls"], "ts_bytes": best["ts_bytes"]}
+    finally:
+        for f in (fin, fout):
+            if os.path.exists(f):
+                os.remove(f)
+        os.rmdir(tmp)
+    return res
 
 
 def timed_run(job, steps, warmup):

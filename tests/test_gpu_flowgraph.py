@@ -44,3 +44,24 @@ def test_thread_per_block_scheduler_equals_the_oracle(po, const, cr, mode_t, nsf
         n = min(len(ts), len(ref))
         assert n > 0.9 * len(ref) and abs(len(ts) - len(ref)) <= 64 * 1504
         assert (ts[:n] == ref[:n]).all()
+
+
+@pytest.mark.parametrize("threads", [1, 0], ids=["a thread per block", "one thread"])
+def test_cpp_thread_per_block_driver_equals_the_oracle(po, tmp_path, threads):
+    """gr_dvbt_amd/host/rx_blocks_bench: the ten blocks over dvbt_<blk>_work (host buffers) under a thread-per-block scheduler written in C++ (the form the
+    drop-in path's throughput is measured in: no interpreter between the calls).  The TS file must be the oracle's."""
+    import subprocess, json
+    from conftest import host_example
+    exe = host_example("rx_blocks_bench")
+    const, cr, mode_t = g.QAM64, g.C7_8, g.T8k
+    c = po.cfg(const, cr, mode_t)
+    iq = po.stream_slice(c, 3, 9)
+    ref = po.rx(c, iq, want=("ts",))["ts"]
+    fin, fout = tmp_path / "bb.cf32", tmp_path / "out.ts"
+    iq.tofile(fin)
+    out = subprocess.check_output([exe, "8k", "qam64", "7/8", str(fin), str(fout), "64", str(threads)], text=True)
+    info = json.loads(out.strip().splitlines()[-1])
+    ts = np.fromfile(fout, np.uint8)
+    n = min(len(ts), len(ref))
+    assert info["samples"] == len(iq) and n > 0.9 * len(ref) and abs(len(ts) - len(ref)) <= 64 * 1504
+    assert (ts[:n] == ref[:n]).all()
