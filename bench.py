@@ -499,15 +499,15 @@ def per_block_cpp(iq, workload):
     res = {}
     try:
         iq.tofile(fin)
-        for cs, thr in ((64, 0), (64, 1), (256, 1)):
+        for cs, thr, reg in ((64, 0, 0), (64, 1, 0), (64, 0, 1), (64, 1, 1), (256, 1, 1)):
             best = None
             for _ in range(2):
-                r = subprocess.run([exe, "8k", "qam64", "7/8", fin, fout, str(cs), str(thr)], capture_output=True, text=True, timeout=300)
+                r = subprocess.run([exe, "8k", "qam64", "7/8", fin, fout, str(cs), str(thr), str(reg)], capture_output=True, text=True, timeout=300)
                 if r.returncode != 0:
                     return {"error": r.stderr[-300:]}
                 d = json.loads(r.stdout.strip().splitlines()[-1])
                 best = d if best is None or d["msamples_per_s"] > best["msamples_per_s"] else best
-            res[f"host_pointers_{cs}_symbols_per_call" + ("_thread_per_block" if thr else "")] = {"value": best["msamples_per_s"], "x_realtime": round(best["msamples_per_s"] / REALTIME_MSPS, 1),
+            res[f"host_pointers_{cs}_symbols_per_call" + ("_thread_per_block" if thr else "") + ("_registered_buffers" if reg else "")] = {"value": best["msamples_per_s"], "x_realtime": round(best["msamples_per_s"] / REALTIME_MSPS, 1),
                                                                                               "block_calls": best["block_calls"], "ts_bytes": best["ts_bytes"]}
     finally:
         for f in (fin, fout):

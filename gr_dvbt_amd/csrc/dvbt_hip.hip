@@ -46,6 +46,10 @@ static int need_device()
   return DVBT_OK;
 }
 
+// page-lock a host buffer the caller will hand to dvbt_<blk>_work / dvbt_rx_stream_push again and again (a GNU Radio block's input / output buffer): the DMA
+// engines then move the items straight from / to it (~50 GB/s, asynchronously) instead of through the handle's pinned staging (one host memcpy each way)
+extern "C" int dvbt_host_register(void *p, size_t bytes) { if (!p || !bytes) return fail(DVBT_ERR_INVALID, "null argument"); int r = need_device(); if (r) return r; HIPCHK(hipHostRegister(p, bytes, hipHostRegisterDefault)); return DVBT_OK; }
+extern "C" int dvbt_host_unregister(void *p) { if (!p) return fail(DVBT_ERR_INVALID, "null argument"); HIPCHK(hipHostUnregister(p)); return DVBT_OK; }
 extern "C" int dvbt_get_dims(int constellation, int hierarchy, int code_rate, int guard, int mode, dvbt_dims *o)
 {
   Dims d = make_dims(constellation, hierarchy, code_rate, guard, mode);

@@ -37,8 +37,12 @@ class RxFlowgraph:
     bit_inner_deinterleaver -> [vector_to_stream] -> viterbi_decoder -> convolutional_deinterleaver -> reed_solomon_dec ->
     energy_descramble, with the parameters of the demo flowgraphs."""
 
-    def __init__(self, constellation, code_rate, mode_t, n_samples, mode="device", call_symbols=4, snr_db=30.0, bsize=768):
+    def __init__(self, constellation, code_rate, mode_t, n_samples, mode="device", call_symbols=4, snr_db=30.0, bsize=768, register_buffers=False):
+        """register_buffers (host mode): page-lock the source and every block's output buffer once (dvbt_host_register), as a GNU Radio shell would its
+        flowgraph buffers: the host-pointer entries then DMA straight from / to them instead of staging every item through pinned memory of the handle"""
         self.mode = mode
+        self.registered = []
+        self.register_buffers = register_buffers and mode == "host"
         self.torch = None
         if mode == "device":
             import torch
@@ -67,6 +71,17 @@ class RxFlowgraph:
         ]
         self.vit_in_block = vit_in_block
         self.input = None
+        if self.register_buffers:
+            for st in self.stages:
+                self._register(st.out)
+
+    def _register(self, arr):
+        import ctypes as C
+        L = b.lib()
+        L.dvbt_host_register.argtypes = [C.c_void_p, C.c_size_t]
+        L.dvbt_host_unregister.argtypes = [C.c_void_p]
+        if L.dvbt_host_register(arr.ctypes.data, arr.nbytes) == 0:
+            self.registered.append(arr.ctypes.data)
 
     # ---- buffers
     def _ptr(self, buf, byte_off):
@@ -88,6 +103,8 @@ class RxFlowgraph:
             self.src = self.torch.from_numpy(np.ascontiguousarray(iq).view(np.uint8)).cuda()
         else:
             self.src = np.ascontiguousarray(iq).view(np.uint8)
+            if self.register_buffers:
+                self._register(self.src)
         self.stages[0].w = len(iq)
         # items per call, per stage (output side): `cs` OFDM symbols' worth
         vit_blocks = max(1, cs * P // self.vit_in_block)
@@ -226,5 +243,8 @@ class RxFlowgraph:
         return self._result()
 
     def close(self):
+        for p in self.registered:
+            b.lib().dvbt_host_unregister(p)
+        self.registered = []
         for st in self.stages:
             st.blk.close()

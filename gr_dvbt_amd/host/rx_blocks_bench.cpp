@@ -4,7 +4,9 @@
 // parity tests); this one exists so that the drop-in path's throughput is not measured through an interpreter: every block call here is a C call from its own
 // thread.  Tags travel with absolute item offsets; blocks with one output item per input item pass their input's tags on (GNU Radio's default propagation
 // policy); the stock vector_to_stream between the bit de-interleaver and the Viterbi decoder is the factor `payload` on item counts and tag offsets.
-//   rx_blocks_bench <2k|8k> <qpsk|qam16|qam64> <1/2|2/3|3/4|5/6|7/8> <baseband.cf32> <out.ts> [symbols per call] [threads 0|1]
+// [registered 1]: the source and every block's output buffer are page-locked once (dvbt_host_register), as a GNU Radio shell would register its flowgraph
+// buffers: the host-pointer entries then DMA straight from / to them instead of staging every item through pinned memory of the handle.
+//   rx_blocks_bench <2k|8k> <qpsk|qam16|qam64> <1/2|2/3|3/4|5/6|7/8> <baseband.cf32> <out.ts> [symbols per call] [threads 0|1] [registered 0|1]
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
@@ -43,6 +45,7 @@ int main(int argc, char **argv)
     int cr = 0; for (int i = 0; i < 5; i++) if (!std::strcmp(argv[3], rates[i])) cr = i;
     const int cs = argc > 6 ? std::atoi(argv[6]) : 64;
     const bool threaded = argc > 7 ? std::atoi(argv[7]) != 0 : true;
+    const bool registered = argc > 8 ? std::atoi(argv[8]) != 0 : false;
     dvbt_dims d; chk(dvbt_get_dims(con, DVBT_NH, cr, DVBT_G1_32, mode, &d));
     const int N = d.fft_length, cp = d.cp_length, P = d.payload_length, bsize = 768;
     std::FILE *f = std::fopen(argv[4], "rb"); if (!f) { std::perror("open"); return 1; }
@@ -83,6 +86,7 @@ int main(int argc, char **argv)
     BLK(8, reed_solomon_dec, pr, 1632, 1504, nbytes / 1632 + 2, std::max(2, cs * ib / 8 / 1632), 1)
     BLK(9, energy_descramble, pe, 1504, 1, nbytes, std::max(1, cs * ib / 8 / (4 * 1504)) * 4 * 1504, 4 * 1504)
     S[0].w = nsamp;
+    if (registered) { chk(dvbt_host_register(src.data(), src.size())); for (auto &st : S) chk(dvbt_host_register(st.out.data(), st.out.size())); }
     std::mutex mu; std::condition_variable cv; std::vector<char> done(10, 0);
     // one general_work call of stage k if its input allows one; true when something was consumed or produced
     auto step = [&](int k, bool drain) -> bool {
@@ -151,8 +155,9 @@ int main(int argc, char **argv)
     std::FILE *o = std::fopen(argv[5], "wb"); if (!o) { std::perror("open"); return 1; }
     std::fwrite(S[9].out.data(), 1, (size_t)S[9].produced, o); std::fclose(o);
     long long calls = 0; for (auto &st : S) calls += st.calls;
-    std::printf("{\"samples\": %lld, \"seconds\": %.5f, \"msamples_per_s\": %.2f, \"symbols_per_call\": %d, \"thread_per_block\": %s, \"block_calls\": %lld, \"ts_bytes\": %lld}\n",
-                nsamp, dt, nsamp / dt / 1e6, cs, threaded ? "true" : "false", calls, S[9].produced);
+    std::printf("{\"samples\": %lld, \"seconds\": %.5f, \"msamples_per_s\": %.2f, \"symbols_per_call\": %d, \"thread_per_block\": %s, \"registered_buffers\": %s, \"block_calls\": %lld, \"ts_bytes\": %lld}\n",
+                nsamp, dt, nsamp / dt / 1e6, cs, threaded ? "true" : "false", registered ? "true" : "false", calls, S[9].produced);
+    if (registered) { dvbt_host_unregister(src.data()); for (auto &st : S) dvbt_host_unregister(st.out.data()); }
     for (auto &st : S) st.destroy(st.h);
   } catch (const std::exception &e) { std::fprintf(stderr, "%s\n", e.what()); return 1; }
   return 0;

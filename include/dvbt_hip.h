@@ -71,6 +71,11 @@ void  dvbt_device_free(void *p);
 int   dvbt_copy_to_device(void *dst_device, const void *src_host, size_t bytes);
 int   dvbt_copy_to_host(void *dst_host, const void *src_device, size_t bytes);
 int   dvbt_synchronize(void *stream);
+/* page-lock a host buffer that will be handed to the host-pointer entries again and again (hipHostRegister / hipHostUnregister): a GNU Radio shell registers
+ * its input and output buffers once (they live as long as the flowgraph); dvbt_<blk>_work (and dvbt_rx_stream_push for calls of 2 MB and more) then let the DMA engines read and write
+ * them directly instead of staging every item through a pinned buffer of the handle (one host memcpy each way).  Buffers that are not registered work as before. */
+int   dvbt_host_register(void *p, size_t bytes);
+int   dvbt_host_unregister(void *p);
 int dvbt_device_count(void);                   /* HIP devices visible; <=0 means the library cannot run */
 const char *dvbt_version(void);
 

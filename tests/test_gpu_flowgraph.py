@@ -65,3 +65,28 @@ def test_cpp_thread_per_block_driver_equals_the_oracle(po, tmp_path, threads):
     n = min(len(ts), len(ref))
     assert info["samples"] == len(iq) and n > 0.9 * len(ref) and abs(len(ts) - len(ref)) <= 64 * 1504
     assert (ts[:n] == ref[:n]).all()
+
+
+def test_registered_host_buffers(po, tmp_path):
+    """dvbt_host_register: the flowgraph's buffers page-locked once; the host-pointer entries DMA straight from / to them (no staging).  Same TS -- from the Python
+    driver and from the C++ thread-per-block driver."""
+    import subprocess, json
+    from conftest import host_example
+    const, cr, mode_t = g.QAM64, g.C7_8, g.T8k
+    c = po.cfg(const, cr, mode_t)
+    iq = po.stream_slice(c, 3, 9)
+    ref = po.rx(c, iq, want=("ts",))["ts"]
+    fg = RxFlowgraph(const, cr, mode_t, len(iq), mode="host", call_symbols=64, register_buffers=True)
+    ts = fg.run_threaded(iq)
+    assert len(fg.registered) == 11                                   # the source and ten output buffers
+    fg.close()
+    n = min(len(ts), len(ref))
+    assert n > 0.9 * len(ref) and (ts[:n] == ref[:n]).all()
+    exe = host_example("rx_blocks_bench")
+    fin, fout = tmp_path / "bb.cf32", tmp_path / "out.ts"
+    iq.tofile(fin)
+    out = subprocess.check_output([exe, "8k", "qam64", "7/8", str(fin), str(fout), "64", "1", "1"], text=True)
+    assert json.loads(out.strip().splitlines()[-1])["registered_buffers"] is True
+    ts = np.fromfile(fout, np.uint8)
+    n = min(len(ts), len(ref))
+    assert n > 0.9 * len(ref) and (ts[:n] == ref[:n]).all()
