@@ -20,7 +20,9 @@ namespace gr {
     public:
       typedef boost::shared_ptr<rx_hip> sptr;
       /* snr: ofdm_sym_acquisition's parameter (30 in the demo flowgraphs); bsize: viterbi_decoder's (768);
-       * segment_superframes: superframes decoded per launch sequence (0 = 16);
+       * segment_superframes: superframes decoded per launch sequence (0 = 16).  The TS lags the input by about segment_superframes + 1 superframes (a piece is decoded
+       * when the next one is known to be viable): 4 (the GRC default) is ~1.4 s of signal at 8k, 0.35 s at 2k, and still > 200x real time; 16 is for files.  The end of a
+       * finite stream is delivered whatever the value (rx_hip_impl.cc);
        * soft_decision: soft demapper + soft-input Viterbi instead of the reference's hard decisions (2-3 dB less SNR needed, ~1.6x the time) */
       static sptr make(dvbt_constellation_t constellation, dvbt_hierarchy_t hierarchy, dvbt_code_rate_t code_rate,
                        dvbt_guard_interval_t guard_interval, dvbt_transmission_mode_t transmission_mode,
