@@ -90,6 +90,7 @@ struct Tables {          // device lookup tables for one configuration
   int16_t *cpilot = nullptr, *tps = nullptr; float *known = nullptr, *pref = nullptr;
   uint16_t *pay_c = nullptr, *pay_L = nullptr, *pay_R = nullptr, *tps_L = nullptr, *tps_R = nullptr;
   uint16_t *pil_k = nullptr, *pay_Li = nullptr, *pay_Ri = nullptr, *tps_Li = nullptr, *tps_Ri = nullptr; uint8_t *pay_d = nullptr, *tps_d = nullptr; int np[4] = {0, 0, 0, 0};
+  uint16_t *tps_bch = nullptr;               // [7][256]: the TPS word's BCH check as a bytewise table (tps_bch_table_host)
   uint32_t *pay_pack = nullptr;              // [4][payload]: carrier | rank of the left estimation carrier << 13 | distance to it << 23 (one word per payload carrier)
   uint16_t *H = nullptr, *Hinv = nullptr; float2 *points = nullptr; uint8_t *label_tab = nullptr; int nlev = 0; float inv_step = 0.f, guard = 0.f, hshift = 0.f;
   uint8_t *mul_alpha = nullptr, *gexp = nullptr, *glog = nullptr, *prbs = nullptr;
@@ -132,6 +133,7 @@ struct Tables {          // device lookup tables for one configuration
     if ((r = upload(pc, &pay_c)) || (r = upload(pl, &pay_L)) || (r = upload(prr, &pay_R)) || (r = upload(tl, &tps_L)) || (r = upload(trr, &tps_R))) return r;
     if ((r = upload(pk, &pil_k)) || (r = upload(pli, &pay_Li)) || (r = upload(pri, &pay_Ri)) || (r = upload(pd, &pay_d)) || (r = upload(tli, &tps_Li)) ||
         (r = upload(tri, &tps_Ri)) || (r = upload(td, &tps_d)) || (r = upload(pp, &pay_pack))) return r;
+    if ((r = upload(tps_bch_table_host(), &tps_bch))) return r;
     front = true;
     return DVBT_OK;
   }
@@ -188,7 +190,7 @@ struct Tables {          // device lookup tables for one configuration
   RsTables rs_tables() const { RsTables T; T.div_tab = mul_alpha; T.gexp = gexp; T.glog = glog; return T; }
   ~Tables()
   {
-    void *all[] = {tw, perm, cpilot, tps, known, pref, pay_c, pay_L, pay_R, tps_L, tps_R, pil_k, pay_Li, pay_Ri, pay_d, tps_Li, tps_Ri, tps_d, pay_pack, H, Hinv, points, label_tab, mul_alpha, gexp, glog, prbs};
+    void *all[] = {tw, perm, cpilot, tps, known, pref, pay_c, pay_L, pay_R, tps_L, tps_R, pil_k, pay_Li, pay_Ri, pay_d, tps_Li, tps_Ri, tps_d, pay_pack, tps_bch, H, Hinv, points, label_tab, mul_alpha, gexp, glog, prbs};
     for (void *q : all) if (q) (void)hipFree(q);
   }
 };
@@ -270,6 +272,7 @@ struct dvbt_rx {
   uint8_t *labels = nullptr, *symdeint_tap = nullptr, *bitdeint = nullptr, *vit = nullptr, *deint_tap = nullptr, *rs_out = nullptr, *ts_out = nullptr;
   uint8_t *bitdeint_lp = nullptr;           // hierarchical modes: the bit de-interleaver's second output
   size_t vit_cap = 0; RsDefer *rs_defer = nullptr; int rs_defer_cap = 0;
+  unsigned long long *rs_sync = nullptr;     // bit w: payload byte 0 of RS word w is 0xB8 (deint_rs_kernel / rs_fix_kernel -> descramble_scan_kernel)
   float *csi = nullptr; int8_t *soft_a = nullptr; uint16_t *soft_tab = nullptr; unsigned *soft_scratch = nullptr;   // soft-decision mode (k_soft.hpp): channel state per carrier, soft values, A5 + A6 gather table, decision slots
   bool timing = false, pending = false;
   hipEvent_t ev[ST_COUNT]; double acc_ms[ST_COUNT] = {0}; long n_timed = 0; bool ev_ready = false, ev_recorded = false;
@@ -285,7 +288,7 @@ struct dvbt_rx {
 
 static void rx_free(dvbt_rx *h)
 {
-  void *all[] = {h->bitdeint_lp, h->st_ctx[0], h->st_ctx[1], h->meta_ctx[0], h->meta_ctx[1], h->tps_prev_snap[0], h->tps_prev_snap[1], h->tps_snap[0], h->tps_snap[1], h->csi, h->soft_a, h->soft_tab, h->soft_scratch, h->rs_defer, h->drift_mem, h->drift.delta, h->drift.flags, h->tps_prev, h->descr_runs, h->descr_nruns, h->centre, h->anchor_pos, h->sym_ticket, h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags, h->trk_eps, h->d_iq, h->rs_iq, h->acq_carry, h->g_init, h->l_init, h->g_trk, h->l_trk, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
+  void *all[] = {h->bitdeint_lp, h->st_ctx[0], h->st_ctx[1], h->meta_ctx[0], h->meta_ctx[1], h->tps_prev_snap[0], h->tps_prev_snap[1], h->tps_snap[0], h->tps_snap[1], h->csi, h->soft_a, h->soft_tab, h->soft_scratch, h->rs_defer, h->rs_sync, h->drift_mem, h->drift.delta, h->drift.flags, h->tps_prev, h->descr_runs, h->descr_nruns, h->centre, h->anchor_pos, h->sym_ticket, h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags, h->trk_eps, h->d_iq, h->rs_iq, h->acq_carry, h->g_init, h->l_init, h->g_trk, h->l_trk, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
                  h->info, h->maj, h->sym_index, h->labels, h->symdeint_tap, h->bitdeint, h->vit, h->deint_tap, h->rs_out, h->ts_out};
   for (void *q : all) if (q) (void)hipFree(q);
   if (h->st_host) (void)hipHostFree(h->st_host);
@@ -347,6 +350,7 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   h->vit_cap = C * P * d.m * d.k / (8 * d.n) + 4096;
   h->rs_defer_cap = (int)((h->vit_cap / 204 / 64 + 2) * (RS_LANE_MIN - 1));
   RXHIP(hipMalloc((void **)&h->rs_defer, sizeof(RsDefer) * (size_t)h->rs_defer_cap));
+  RXHIP(hipMalloc((void **)&h->rs_sync, sizeof(unsigned long long) * (h->vit_cap / 204 / 64 + 2)));
   RXHIP(hipMalloc((void **)&h->vit, h->vit_cap)); RXHIP(hipMalloc((void **)&h->rs_out, h->vit_cap)); RXHIP(hipMalloc((void **)&h->ts_out, h->vit_cap));
   RXHIP(hipMemset(h->st, 0, sizeof(RxState)));
   for (int i = 0; i < ST_COUNT; i++) RXHIP(hipEventCreate(&h->ev[i]));
@@ -457,12 +461,14 @@ static int enqueue_tail(dvbt_rx *h, hipStream_t s, long long max_words, long lon
     hipLaunchKernelGGL(tail_patch_kernel, dim3(1), dim3(1), 0, s, h->st, items);
   }
   hipLaunchKernelGGL(deint_rs_kernel, dim3((unsigned)((max_words + 63) / 64)), dim3(64), 0, s, (const uint8_t *)h->vit, h->deint_tap, h->rs_out,
-                     h->st, 0ll, 0, 0ll, h->T.rs_tables(), h->prm.rs_oracle_compat, &h->st->rs_fail, &h->st->rs_corr, h->rs_defer, &h->st->rs_list_n, h->rs_defer_cap);
+                     h->st, 0ll, 0, 0ll, h->T.rs_tables(), h->prm.rs_oracle_compat, &h->st->rs_fail, &h->st->rs_corr, h->rs_defer, &h->st->rs_list_n, h->rs_defer_cap,
+                     h->rs_sync);
   // the few bad words of lightly loaded wavefronts, one wavefront each (the deint tap shows the words as received: patches go to the payload only)
   hipLaunchKernelGGL(rs_fix_kernel, dim3(512), dim3(64), 0, s, (const RsDefer *)h->rs_defer, (const int *)&h->st->rs_list_n, h->rs_defer_cap, h->rs_out,
-                     h->T.rs_tables(), h->prm.rs_oracle_compat, &h->st->rs_fail, &h->st->rs_corr);
+                     h->T.rs_tables(), h->prm.rs_oracle_compat, &h->st->rs_fail, &h->st->rs_corr, h->rs_sync);
   if (h->prm.descramble) {
-    hipLaunchKernelGGL(descramble_scan_kernel, dim3(1), dim3(1024), 0, s, (const uint8_t *)h->rs_out, h->st, h->descr_runs, h->descr_nruns);
+    hipLaunchKernelGGL(descramble_scan_kernel, dim3(1), dim3(1024), 0, s, (const uint8_t *)h->rs_out, h->st, h->descr_runs, h->descr_nruns,
+                       (const unsigned long long *)h->rs_sync);
     hipLaunchKernelGGL(descramble_runs_kernel, dim3(1024), dim3(256), 0, s, (const uint8_t *)h->rs_out, (const uint8_t *)h->T.prbs,
                        (const RxState *)h->st, (const DescrRun *)h->descr_runs, (const int *)h->descr_nruns, h->ts_out);
   }
@@ -504,22 +510,20 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
   {   // where the tracking metric is computed: CP position predicted per call from coarse estimates every ACQ_ANCHOR calls (sample-clock drift)
     const int n_anchors = (C - 1) / ACQ_ANCHOR;
     if (n_anchors > 0) hipLaunchKernelGGL(acq_anchor_kernel, dim3(n_anchors), dim3(1024), acq_anchor_lds_bytes(N, d.cp), s, iq, fp, (const RxState *)h->st, h->anchor_pos);
-    hipLaunchKernelGGL(acq_centre_kernel, dim3(1), dim3(1024), 0, s, fp, (const RxState *)h->st, h->anchor_pos, n_anchors, h->centre);
+    hipLaunchKernelGGL(acq_centre_kernel, dim3((C + 1023) / 1024), dim3(1024), 0, s, fp, (const RxState *)h->st, (const int *)h->anchor_pos, n_anchors, h->centre);
   }
   hipLaunchKernelGGL(acq_track_metric_kernel, dim3((C + ACQ_TM_CALLS - 1) / ACQ_TM_CALLS), dim3(256), 0, s, iq, fp, (const RxState *)h->st, (const int *)h->centre, h->g_trk, h->l_trk);
   constexpr int kIters = TRK_ROUNDS;            // Jacobi iterations of the window placement (one launch); flags[kIters] = need_seq
   hipLaunchKernelGGL(acq_track_fused_kernel, dim3((C + TRK_OWN - 1) / TRK_OWN), dim3(256), 0, s, fp, (const RxState *)h->st, (const float2 *)h->g_trk,
                      (const float *)h->l_trk, h->trk_cp_a, h->trk_eps, h->trk_flags, (const int *)h->centre);
-  hipLaunchKernelGGL(acq_finalize_kernel, dim3(1), dim3(1024), 0, s, fp, h->st, (const int *)h->trk_cp_a, (const float *)h->trk_eps,
-                     (const int *)h->trk_flags, kIters - 1, h->meta, h->trk_flags + kIters);
+  hipLaunchKernelGGL(acq_finalize_kernel, dim3((C + 1023) / 1024), dim3(1024), 0, s, fp, h->st, (const int *)h->trk_cp_a, (const float *)h->trk_eps,
+                     (const int *)h->trk_flags, kIters - 1, h->meta, h->trk_flags + kIters, (const float *)h->l_trk, (const int *)h->centre);
   // not settled: the sequential walk, positions and epsilon only (flags[kIters] = need_seq); flags[kIters + 1] = need_heavy, which it raises for a period
   // outside the closed form of the phase -- that one goes through the float-faithful tracker of the block API
   hipLaunchKernelGGL(acq_track_light_kernel, dim3(1), dim3(64), 0, s, fp, h->st, (const float2 *)h->g_trk, (const float *)h->l_trk, h->meta,
                      (const int *)(h->trk_flags + kIters), h->trk_flags + kIters + 1, (const int *)h->centre, iq);
   hipLaunchKernelGGL(acq_track_kernel, dim3(1), dim3(64), 0, s, fp, h->st, (const float2 *)h->g_trk, (const float *)h->l_trk, h->meta,
                      (const int *)(h->trk_flags + kIters + 1), (AcqState *)nullptr, (const int *)h->centre, iq);
-  hipLaunchKernelGGL(acq_lost_avg_kernel, dim3(1), dim3(64), 0, s, fp, h->st, (const int *)h->trk_cp_a, (const float *)h->l_trk, (const int *)h->centre,
-                     (const int *)(h->trk_flags + kIters));
   }
   if (o.acq_only) {
     HIPCHK(hipMemcpyAsync(h->st_host, h->st, sizeof(RxState), hipMemcpyDeviceToHost, s));
@@ -533,7 +537,9 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
   const bool drift_off = o.skip_acq && h->st_host->drift_known_off;
   if (!drift_off) {
     // the wander of the reference's float phase accumulator (k_drift.hpp): tables per call, the fixed point (one workgroup), the deviations per 32-sample block;
-    // every kernel returns at once when the lock period has no usable carrier offset (drift.flags, device side: no host round trip)
+    // every kernel returns at once when the lock period has no usable carrier offset (drift.flags, device side: no host round trip).  (Round 4 put the
+    // launches behind drift_exact_kernel and the DRIFT instantiation on a second stream, beside the plain symbol kernel: its persistent workgroups hold every
+    // VGPR of the machine, the empty launches waited for them to retire and the join cost what the fork had saved -- measured, taken out again.)
     const DriftBufs &D = h->drift;
     hipLaunchKernelGGL(drift_prep_kernel, dim3((C + 255) / 256), dim3(256), 0, s, fp, (const RxState *)h->st, (const SymMeta *)h->meta, D);
     hipLaunchKernelGGL(drift_exact_kernel, dim3(1), dim3(1024), 0, s, fp, (const RxState *)h->st, (const SymMeta *)h->meta, D);
@@ -572,19 +578,17 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
                        (const float2 *)nullptr, h->maj, fp.keep_last);
     // flags[8] = first superframe-start candidate (min), flags[9] = need_seq for the TPS bookkeeping (set by acq_init_fsm_kernel's reset)
     hipLaunchKernelGGL(tps_fsm_par_kernel, dim3((C + TPS_THREADS * TPS_SEG - 1) / (TPS_THREADS * TPS_SEG)), dim3(TPS_THREADS), 0, s, fp, (const RxState *)h->st, (const SymInfo *)h->info,
-                       (const int *)h->maj, h->sym_index, h->tps_edges, h->trk_flags + 8, &h->st->tps_bits);
-    hipLaunchKernelGGL(tps_finalize_kernel, dim3(1), dim3(256), 0, s, h->st, (const TpsEdge *)h->tps_edges, (const int *)(h->trk_flags + 8), h->trk_flags + 9, fp.keep_last, h->tps_state);
-    hipLaunchKernelGGL(tps_fsm_kernel, dim3(1), dim3(256), 0, s, fp, h->st, 0, (const SymInfo *)h->info, (const int *)h->maj, h->tps_state,
-                       h->sym_index, (int *)nullptr, (const unsigned char *)nullptr, (const int *)(h->trk_flags + 9));
+                       (const int *)h->maj, h->sym_index, h->tps_edges, h->trk_flags + 8, &h->st->tps_bits, (const unsigned short *)h->T.tps_bch);
+    hipLaunchKernelGGL(tps_tail_kernel, dim3(1), dim3(256), 0, s, fp, h->st, (const SymInfo *)h->info, (const int *)h->maj, h->tps_state, h->sym_index,
+                       (const TpsEdge *)h->tps_edges, (const int *)(h->trk_flags + 8), h->trk_flags + 9, 0, h->vp, (long long)h->cut.stream_symbol_offset);
   } else {
     // the pilot engine's members live on (FIFO, symbol and frame counters: reference_signals_impl.h); the sync_start tag on the period's first
     // item clears d_init (the superframe hunt starts over); DBPSK against the last symbol in front of the gap.  Sequential bookkeeping.
     hipLaunchKernelGGL(tps_vote_kernel, dim3((C + 63) / 64), dim3(256), 0, s, (const float2 *)h->tpsval, d.n_tps, (const RxState *)h->st, 0,
                        (const float2 *)h->tps_prev, h->maj, fp.keep_last);
-    hipLaunchKernelGGL(tps_fsm_kernel, dim3(1), dim3(256), 0, s, fp, h->st, 0, (const SymInfo *)h->info, (const int *)h->maj, h->tps_state,
-                       h->sym_index, (int *)nullptr, (const unsigned char *)nullptr, (const int *)nullptr, 1);
+    hipLaunchKernelGGL(tps_tail_kernel, dim3(1), dim3(256), 0, s, fp, h->st, (const SymInfo *)h->info, (const int *)h->maj, h->tps_state, h->sym_index,
+                       (const TpsEdge *)nullptr, (const int *)nullptr, (int *)nullptr, 1, h->vp, (long long)h->cut.stream_symbol_offset);
   }
-  hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(64), 0, s, h->st, h->vp, h->prm.descramble, (long long)h->cut.stream_symbol_offset);
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_INNER], s));
   InnerParams ip = h->T.inner_params(d.payload);
   long long max_vit = (long long)C * d.payload * d.m * d.k / (8 * d.n) + 1;

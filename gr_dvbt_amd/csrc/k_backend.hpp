@@ -218,9 +218,8 @@ struct VitParams {
 // (viterbi_decoder_impl.cc:198), the delay of ntraceback bytes and the even item count of the byte de-interleaver
 // (set_output_multiple(2)) are then taken in STREAM coordinates, so that the segments' outputs end exactly where
 // the outputs of one chain over the whole stream would.
-__global__ void plan_kernel(RxState *st, VitParams vp, int descramble, long long sym_off)
+__device__ __forceinline__ void plan_body(RxState *st, const VitParams &vp, long long sym_off)
 {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const long long ibits = (long long)vp.payload * vp.m * vp.k / vp.n;          // decoded bits per OFDM symbol
   const long long nin_g = (sym_off + (long long)st->n_out_symbols) * vp.payload;
   const long long nblocks_g = nin_g / vp.d_nsymbols;
@@ -242,7 +241,17 @@ __global__ void plan_kernel(RxState *st, VitParams vp, int descramble, long long
   st->n_rs_items = words / 8;
   st->sym_off = sym_off;
   st->n_ts_bytes = 0; st->rs_fail = 0; st->rs_corr = 0; st->ts_first_packet = 0; st->rs_list_n = 0;
-  (void)descramble;
+}
+// The tail of the TPS bookkeeping in one launch of one workgroup (three launches of ~5 us each before): the segment-parallel pass's neighbours compared
+// (edges != nullptr; tps_finalize_body), the sequential bookkeeping when they disagree -- or always, for a lock period that carries the pilot engine's members on
+// (edges == nullptr) --, then the sizes behind it (plan_body).
+__global__ __launch_bounds__(256) void tps_tail_kernel(FrontParams p, RxState *st, const SymInfo *info, const int *maj, TpsState *ts, int *sym_index,
+                                                      const TpsEdge *edges, const int *first_cand, int *need_seq, int clear_d_init, VitParams vp, long long sym_off)
+{
+  int seq = 1;
+  if (edges) seq = tps_finalize_body(st, edges, first_cand, need_seq, p.keep_last, ts);
+  if (seq) tps_fsm_body(p, st, 0, info, maj, ts, sym_index, (int *)nullptr, (const unsigned char *)nullptr, clear_d_init);
+  if (threadIdx.x == 0) plan_body(st, vp, sym_off);              // thread 0 wrote n_out_symbols itself in either branch
 }
 
 // ---------------------------------------------------------------- A8+A9 fused: Forney de-interleave gather + RS(204,188) decode
@@ -464,7 +473,8 @@ __global__ __launch_bounds__(64) void deint_rs_kernel(const uint8_t *__restrict_
                                                      uint8_t *__restrict__ out, RxState *st, long long words_fixed, int standalone,
                                                      long long hist_words /* words of real history before word 0 (block API) */,
                                                      RsTables T, int compat, int *fail_cnt, int *corr_cnt,
-                                                     RsDefer *__restrict__ defer = nullptr, int *defer_n = nullptr, int defer_cap = 0)
+                                                     RsDefer *__restrict__ defer = nullptr, int *defer_n = nullptr, int defer_cap = 0,
+                                                     unsigned long long *__restrict__ sync_bits = nullptr /* bit w: payload byte 0 of word w is the inverted sync byte 0xB8 (descramble_scan_kernel) */)
 {
   // codewords of the workgroup, one row of 204 bytes each; 11 spare rows on either side absorb the bytes of the 75
   // source words that belong to codewords of the neighbouring workgroups, so the scatter below needs no bounds test
@@ -580,6 +590,7 @@ __global__ __launch_bounds__(64) void deint_rs_kernel(const uint8_t *__restrict_
     if (tid == 0) { if (nf) atomicAdd(fail_cnt, nf); if (nc) atomicAdd(corr_cnt, nc); }
   }
   __syncthreads();
+  if (sync_bits) { const unsigned long long m = __ballot(tid < nw && s_cw[tid * 204] == 0xB8); if (tid == 0) sync_bits[blockIdx.x] = m; }
   // coalesced store of 64 x 188 payload bytes as dwords (reed_solomon_dec_impl.cc:102: output regardless of success)
   unsigned *o4 = reinterpret_cast<unsigned *>(out + w0 * 188);
   for (int i = tid; i < nw * 47; i += 64) { const int ww = i / 47, q = i - ww * 47; o4[i] = reinterpret_cast<const unsigned *>(s_cw + ww * 204)[q]; }
@@ -587,7 +598,7 @@ __global__ __launch_bounds__(64) void deint_rs_kernel(const uint8_t *__restrict_
 
 // second pass of A9: one wavefront per listed word (rs_decode_word_wave), the corrected payload written over the uncorrected one
 __global__ __launch_bounds__(64) void rs_fix_kernel(const RsDefer *__restrict__ list, const int *__restrict__ list_n, int list_cap, uint8_t *__restrict__ out,
-                                                   RsTables T, int compat, int *fail_cnt, int *corr_cnt)
+                                                   RsTables T, int compat, int *fail_cnt, int *corr_cnt, unsigned long long *sync_bits = nullptr)
 {
   __shared__ __attribute__((aligned(16))) uint8_t s_cw[208];
   __shared__ uint8_t s_exp[512], s_log[256], s_scr[64], s_syn[RS_SYN_STRIDE * 16];
@@ -608,6 +619,10 @@ __global__ __launch_bounds__(64) void rs_fix_kernel(const RsDefer *__restrict__ 
     // reed_solomon_dec_impl.cc:100-102: the payload leaves regardless of success, with the patches applied before a zero Forney denominator aborted
     // (reed_solomon.cc:470-486) -- as the first pass's wave and lane paths deliver it
     if (tid < 47) reinterpret_cast<unsigned *>(out + (size_t)d->word * 188)[tid] = reinterpret_cast<const unsigned *>(s_cw)[tid];
+    if (sync_bits && tid == 0) {                                 // the first pass recorded the word's sync bit as received
+      const unsigned long long m = 1ull << (d->word & 63);
+      if (s_cw[0] == 0xB8) atomicOr(&sync_bits[d->word >> 6], m); else atomicAnd(&sync_bits[d->word >> 6], ~m);
+    }
   }
   if (tid == 0) { if (nf) atomicAdd(fail_cnt, nf); if (nc) atomicAdd(corr_cnt, nc); }
 }
@@ -633,11 +648,18 @@ __global__ __launch_bounds__(256) void conv_deint_kernel(const uint8_t *__restri
 struct DescrRun { long long src_byte, dst_byte, nbytes; };
 constexpr int DESCR_MAX_RUNS = 1024;
 
-__global__ __launch_bounds__(1024) void descramble_scan_kernel(const uint8_t *__restrict__ in, RxState *st, DescrRun *runs, int *nruns)
+// sync_bits (the segment chain): bit w = payload byte 0 of RS word w is 0xB8, written by deint_rs_kernel / rs_fix_kernel -- the walk then reads one bit per
+// packet out of a few KB instead of one byte per 188 out of the whole TS (21,000 cache lines through ONE compute unit: 45 us of the 65-superframe step);
+// nullptr: the bytes themselves.
+__global__ __launch_bounds__(1024) void descramble_scan_kernel(const uint8_t *__restrict__ in, RxState *st, DescrRun *runs, int *nruns,
+                                                              const unsigned long long *__restrict__ sync_bits = nullptr)
 {
   __shared__ long long s_first;
   __shared__ long long s_base, s_written; __shared__ int s_dindex, s_nr, s_stop;
   const int tid = threadIdx.x;
+  auto nsync = [&](long long pkt) -> bool {                        // is the first byte of packet `pkt` the inverted sync byte?
+    return sync_bits ? ((sync_bits[pkt >> 6] >> (pkt & 63)) & 1ull) != 0 : in[pkt * 188] == 0xB8;
+  };
   if (tid == 0) { st->n_ts_bytes = 0; st->descr_base = 0; st->descr_index = 0; st->ts_first_packet = 0; *nruns = 0; }
   if (st->sym_off > 0) {
     // continuation of a cut stream: the descrambler of the whole-stream chain locked long ago; this segment delivers
@@ -648,7 +670,7 @@ __global__ __launch_bounds__(1024) void descramble_scan_kernel(const uint8_t *__
     if (tid == 0) {
       const long long nw = st->n_rs_words;
       long long q = 0;
-      while (q < nw && in[q * 188] != 0xB8) q++;
+      while (q < nw && !nsync(q)) q++;
       if (q < nw) {
         st->descr_index = (int)(q * 188); st->ts_first_packet = q;
         st->n_ts_bytes = ((nw - q) / 8) * 1504;
@@ -661,14 +683,19 @@ __global__ __launch_bounds__(1024) void descramble_scan_kernel(const uint8_t *__
   if (tid == 0) { s_base = 0; s_written = 0; s_dindex = 0; s_nr = 0; s_stop = 0; }
   __syncthreads();
   while (true) {
-    const long long base = s_base; const int d_index = s_dindex;
+    const long long base = s_base; const int d_index = s_dindex, d_pkt = d_index / 188;
     const long long ncalls = nitems - base >= 4 ? (nitems - base - 4) / 2 + 1 : 0;      // calls that still see 4 items
     if (ncalls == 0 || s_stop) break;
     if (tid == 0) s_first = ncalls;
     __syncthreads();
     long long mine = ncalls;
-    for (long long k = tid; k < ncalls && k < mine; k += 1024)
-      if (in[(base + 2 * k) * 1504 + d_index] != 0xB8) { mine = k; break; }
+    for (long long k0 = tid; k0 < ncalls && mine == ncalls; k0 += 8 * 1024) {       // 8 clamped loads per lane in flight
+      bool v[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) { const long long k = k0 + j * 1024; v[j] = nsync((base + 2 * (k < ncalls ? k : ncalls - 1)) * 8 + d_pkt); }
+#pragma unroll
+      for (int j = 7; j >= 0; j--) { const long long k = k0 + j * 1024; if (k < ncalls && !v[j]) mine = k; }
+    }
     if (mine < ncalls) atomicMin((unsigned long long *)&s_first, (unsigned long long)mine);
     __syncthreads();
     if (tid == 0) {
@@ -683,11 +710,11 @@ __global__ __launch_bounds__(1024) void descramble_scan_kernel(const uint8_t *__
         s_base = base + 2 * kf;
       }
       if (kf < ncalls) {                                           // the call at s_base: search on, or give up and drop two items
-        const uint8_t *p = in + s_base * 1504;
-        int di = d_index;
-        while (di < 2 * 1504 && p[di] != 0xB8) di += 188;
-        if (di >= 2 * 1504) { di = 0; s_base += 2; }
-        s_dindex = di;
+        const long long p0 = s_base * 8;
+        int dp = d_pkt;
+        while (dp < 16 && !nsync(p0 + dp)) dp++;
+        if (dp >= 16) { dp = 0; s_base += 2; }
+        s_dindex = dp * 188;
       }
     }
     __syncthreads();

@@ -124,76 +124,108 @@ constexpr int ACQ_ANCHOR = 256;                // calls between anchors
 constexpr int ACQ_ANCHOR_LAGS = 8;             // lags per thread in acq_anchor_kernel
 
 // One workgroup per anchor.  The products x[i] conj(x[i-N]) and the energies of the window are formed once (coalesced loads) and kept
-// in LDS; a thread then owns ACQ_ANCHOR_LAGS consecutive lags: direct sum over the cp products of its first lag, sliding sum for the rest.
+// in LDS together with their sums over blocks of 8; a thread then owns ACQ_ANCHOR_LAGS = 8 consecutive lags: cp / 8 block sums for its first lag,
+// sliding sum for the rest.  An anchor is a hint (above): its sums need not be formed in the reference's order.  Product i lives at LDS index
+// i + i / 8, so that the threads' reads (8 products apart) fall on distinct banks (unpadded, 32 lanes of a wavefront shared one bank pair: 39 us per launch).
+__device__ __forceinline__ int acq_anchor_pad(int i) { return i + (i >> 3); }
 __global__ __launch_bounds__(1024) void acq_anchor_kernel(const float2 *__restrict__ iq, FrontParams p, const RxState *st, int *__restrict__ anchor_pos)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float2 *s_c = reinterpret_cast<float2 *>(smem_raw);            // [N + cp]  product at sample N + i
-  float *s_e = reinterpret_cast<float *>(s_c + (p.N + p.cp));    // [N + cp]  energy pair
-  __shared__ float s_best[1024]; __shared__ int s_arg[1024];
   const int k = blockIdx.x + 1, tid = threadIdx.x, N = p.N, cp = p.cp;          // anchor 0 is the initial acquisition itself
+  const int np = N + cp, nb = np / 8, P = acq_anchor_pad(np) + 8;                // N, cp: multiples of 8
+  float2 *s_c = reinterpret_cast<float2 *>(smem_raw);            // [P]   product at sample N + i
+  float2 *sb_c = s_c + P;                                        // [nb]  sums of 8 products
+  float *s_e = reinterpret_cast<float *>(sb_c + nb);             // [P]   energy pair
+  float *sb_e = s_e + P;                                         // [nb]
+  __shared__ float s_best[16]; __shared__ int s_arg[16];
   if (st->status & 1) return;
   const int call = st->call0 + k * ACQ_ANCHOR;
   if (call >= p.ncalls) { if (tid == 0) anchor_pos[k] = -1; return; }
   const float2 *w = iq + (long long)call * (N + cp);
-  for (int i = tid; i < N + cp - 1; i += 1024) {                  // samples N .. 2N+cp-2 of the window
-    const float2 a = w[N + i], b = w[i];
-    s_c[i] = make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
-    s_e[i] = (a.x * a.x + a.y * a.y) + (b.x * b.x + b.y * b.y);
+  for (int i = tid; i < np; i += 1024) {                          // samples N .. 2N+cp-2 of the window (product N+cp-1 does not exist: zero)
+    float2 c = make_float2(0.f, 0.f); float e = 0.f;
+    if (i < np - 1) {
+      const float2 a = w[N + i], b = w[i];
+      c = make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+      e = (a.x * a.x + a.y * a.y) + (b.x * b.x + b.y * b.y);
+    }
+    s_c[acq_anchor_pad(i)] = c; s_e[acq_anchor_pad(i)] = e;
+  }
+  __syncthreads();
+  for (int bq = tid; bq < nb; bq += 1024) {
+    float gr = 0.f, gi = 0.f, phi = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { const float2 c = s_c[9 * bq + j]; gr += c.x; gi += c.y; phi += s_e[9 * bq + j]; }
+    sb_c[bq] = make_float2(gr, gi); sb_e[bq] = phi;
   }
   __syncthreads();
   float best = -3.0e38f; int arg = 0;
-  for (int q0 = tid * ACQ_ANCHOR_LAGS; q0 < N; q0 += 1024 * ACQ_ANCHOR_LAGS) {
-    // lag q (sample index N+cp-1+q) sums the products at i = q .. q+cp-1 (i counted from sample N)
+  for (int t = tid; t * ACQ_ANCHOR_LAGS < N; t += 1024) {
+    // lag q (sample index N+cp-1+q) sums the products at i = q .. q+cp-1 (i counted from sample N); q0 = 8 t: blocks t .. t + cp/8 - 1
+    const int q0 = t * ACQ_ANCHOR_LAGS;
     float gr = 0.f, gi = 0.f, phi = 0.f;
-    for (int j = 0; j < cp; j++) { const float2 c = s_c[q0 + j]; gr += c.x; gi += c.y; phi += s_e[q0 + j]; }
-    for (int u = 0; u < ACQ_ANCHOR_LAGS && q0 + u < N; u++) {
+    for (int m = 0; m < cp / 8; m++) { const float2 c = sb_c[t + m]; gr += c.x; gi += c.y; phi += sb_e[t + m]; }
+    const int lo = 9 * t, hi = 9 * (t + cp / 8);                 // padded indices of products q0 and q0 + cp
+#pragma unroll
+    for (int u = 0; u < ACQ_ANCHOR_LAGS; u++) {
       const float lam = sqrtf(gr * gr + gi * gi) - phi * p.half_rho;
       if (lam > best) { best = lam; arg = q0 + u; }
-      if (q0 + u + 1 < N) {
-        const float2 a = s_c[q0 + u + cp], c = s_c[q0 + u];         // enters / leaves
-        gr += a.x - c.x; gi += a.y - c.y; phi += s_e[q0 + u + cp] - s_e[q0 + u];
+      if (u + 1 < ACQ_ANCHOR_LAGS) {
+        const float2 a = s_c[hi + u], c = s_c[lo + u];             // enters / leaves
+        gr += a.x - c.x; gi += a.y - c.y; phi += s_e[hi + u] - s_e[lo + u];
       }
     }
   }
-  s_best[tid] = best; s_arg[tid] = arg;
-  __syncthreads();
-  for (int o = 512; o > 0; o >>= 1) {
-    if (tid < o && (s_best[tid + o] > s_best[tid] || (s_best[tid + o] == s_best[tid] && s_arg[tid + o] < s_arg[tid]))) { s_best[tid] = s_best[tid + o]; s_arg[tid] = s_arg[tid + o]; }
-    __syncthreads();
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o); const int oa = __shfl_xor(arg, o);
+    if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
   }
-  if (tid == 0) anchor_pos[k] = s_arg[0] + N + cp - 1;
+  if ((tid & 63) == 0) { s_best[tid >> 6] = best; s_arg[tid >> 6] = arg; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int wv = 1; wv < 16; wv++) if (s_best[wv] > best || (s_best[wv] == best && s_arg[wv] < arg)) { best = s_best[wv]; arg = s_arg[wv]; }
+    anchor_pos[k] = arg + N + cp - 1;
+  }
 }
-inline size_t acq_anchor_lds_bytes(int N, int cp) { return (size_t)(N + cp) * 12 + 64; }
+inline size_t acq_anchor_lds_bytes(int N, int cp) { const size_t np = (size_t)(N + cp); return (np + np / 8 + 8 + np / 8) * 12 + 64; }
 
 // centre[call] for every call from call0 on.  n_anchors: anchors computed (slots 1..n_anchors of anchor_pos); 0 = none (block API: the
-// window of one work() call is short, every call is centred on the carried CP position)
-__global__ __launch_bounds__(1024) void acq_centre_kernel(FrontParams p, const RxState *st, int *anchor_pos, int n_anchors, int *__restrict__ centre)
+// window of one work() call is short, every call is centred on the carried CP position).  Any grid: a workgroup takes 1024 calls at a time and filters
+// the anchors for itself in LDS (a few dozen values; one workgroup walking 17,680 calls after a serial pass over the anchors in global memory was 23 us).
+constexpr int ACQ_CENTRE_MAX_ANCHORS = 4096;
+__global__ __launch_bounds__(1024) void acq_centre_kernel(FrontParams p, const RxState *st, const int *__restrict__ anchor_pos, int n_anchors, int *__restrict__ centre)
 {
+  __shared__ int s_a[ACQ_CENTRE_MAX_ANCHORS + 1];
   if (st->status & 1) return;
   const int tid = threadIdx.x, c0 = st->cp_start0, call0 = st->call0;
+  if ((long long)call0 + (long long)blockIdx.x * 1024 >= p.ncalls) return;
+  if (n_anchors > ACQ_CENTRE_MAX_ANCHORS) n_anchors = ACQ_CENTRE_MAX_ANCHORS;
+  for (int k = 1 + tid; k <= n_anchors; k += 1024) s_a[k] = anchor_pos[k];
+  __syncthreads();
   if (tid == 0) {
-    anchor_pos[0] = c0;
+    s_a[0] = c0;
     int acc = c0, kacc = 0;
     for (int k = 1; k <= n_anchors; k++) {
-      const int v = anchor_pos[k];
+      const int v = s_a[k];
       // a sample clock off by more than ~100 ppm moves the peak by more than one sample per symbol: anything faster is not drift
-      if (v >= 0 && abs(v - acc) <= (k - kacc) * ACQ_ANCHOR) { acc = v; kacc = k; } else anchor_pos[k] = -1;
+      if (v >= 0 && abs(v - acc) <= (k - kacc) * ACQ_ANCHOR) { acc = v; kacc = k; } else s_a[k] = -1;
     }
   }
   __syncthreads();
-  for (int call = call0 + tid; call < p.ncalls; call += 1024) {
+  for (long long cl = (long long)call0 + (long long)blockIdx.x * 1024 + tid; cl < p.ncalls; cl += (long long)gridDim.x * 1024) {
+    const int call = (int)cl;
     const int s = call - call0, k = s / ACQ_ANCHOR, f = s - k * ACQ_ANCHOR;
-    int k0 = k; while (k0 > 0 && (k0 > n_anchors || anchor_pos[k0] < 0)) k0--;          // last accepted anchor at or before the call
-    int k1 = k + 1; while (k1 <= n_anchors && anchor_pos[k1] < 0) k1++;                   // next accepted anchor after it
-    const int p0 = anchor_pos[k0];
+    int k0 = k; while (k0 > 0 && (k0 > n_anchors || s_a[k0] < 0)) k0--;                 // last accepted anchor at or before the call
+    int k1 = k + 1; while (k1 <= n_anchors && s_a[k1] < 0) k1++;                          // next accepted anchor after it
+    const int p0 = s_a[k0];
     int c = p0;
     if (k1 <= n_anchors) {
-      const long long num = (long long)(anchor_pos[k1] - p0) * ((long long)(k - k0) * ACQ_ANCHOR + f), den = (long long)(k1 - k0) * ACQ_ANCHOR;
+      const long long num = (long long)(s_a[k1] - p0) * ((long long)(k - k0) * ACQ_ANCHOR + f), den = (long long)(k1 - k0) * ACQ_ANCHOR;
       c = p0 + (int)((num >= 0 ? num + den / 2 : num - den / 2) / den);
     } else if (k0 > 0) {                                                                  // beyond the last anchor: keep the last slope
-      int kp = k0 - 1; while (kp > 0 && anchor_pos[kp] < 0) kp--;
-      const long long num = (long long)(p0 - anchor_pos[kp]) * ((long long)(k - k0) * ACQ_ANCHOR + f), den = (long long)(k0 - kp) * ACQ_ANCHOR;
+      int kp = k0 - 1; while (kp > 0 && s_a[kp] < 0) kp--;
+      const long long num = (long long)(p0 - s_a[kp]) * ((long long)(k - k0) * ACQ_ANCHOR + f), den = (long long)(k0 - kp) * ACQ_ANCHOR;
       c = p0 + (int)((num >= 0 ? num + den / 2 : num - den / 2) / den);
     }
     centre[call] = c;
@@ -959,110 +991,10 @@ __global__ __launch_bounds__(256) void acq_track_fused_kernel(FrontParams p, con
   if (own) { cp_out[s] = res; eps_out[s] = eps; }
 }
 
-// bookkeeping after the fixed point: n_symbols = calls before the first miss; derotation phase
-// parameters per symbol (ml_sync :285-313).  One workgroup; prefix sum of the per-call phase
-// advance in double.  Falls back to nothing when the Jacobi iteration did not converge
-// (acq_track_kernel then overwrites everything).
-__global__ __launch_bounds__(1024) void acq_finalize_kernel(FrontParams p, RxState *st, const int *__restrict__ cp, const float *__restrict__ eps,
-                                                           const int *changed, int last_iter, SymMeta *__restrict__ meta, int *need_seq)
-{
-  __shared__ double s_tot[1024];
-  __shared__ int s_first_bad, s_viol;
-  const int tid = threadIdx.x;
-  if (st->status & 1) { if (tid == 0) *need_seq = 0; return; }
-  bool converged = false;
-  for (int i = 0; i <= last_iter; i++) if (changed[i] == 0) converged = true;
-  if (!converged) { if (tid == 0) *need_seq = 1; return; }
-  if (tid == 0) { *need_seq = 0; s_first_bad = p.ncalls - st->call0; s_viol = 0; }
-  __syncthreads();
-  const int ntot = p.ncalls - st->call0, N = p.N, cpl = p.cp, c0 = st->cp_start0;
-  // first call without a peak; 8 clamped loads per lane in flight
-  for (int s0 = tid; s0 < ntot; s0 += 8 * 1024) {
-    int cv[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) { const int s = s0 + k * 1024; cv[k] = cp[s < ntot ? s : ntot - 1]; }
-#pragma unroll
-    for (int k = 0; k < 8; k++) { const int s = s0 + k * 1024; if (s < ntot && cv[k] < 0) atomicMin(&s_first_bad, s); }
-  }
-  __syncthreads();
-  const int nsym = s_first_bad;
-  if (nsym < ntot && cp[nsym] == -2) { if (tid == 0) *need_seq = 1; return; }   // the placement ran out of precomputed lags: sequential tracker
-  // the closed form below needs every phase-increment switch to fall inside its call
-  for (int s0 = tid; s0 < nsym; s0 += 8 * 1024) {
-    int cv[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) { const int s = s0 + k * 1024; cv[k] = (s == 0 || s >= nsym) ? c0 : cp[s - 1]; }
-#pragma unroll
-    for (int k = 0; k < 8; k++) { const int s = s0 + k * 1024; const int sw = cv[k] - (N + cpl); if (s < nsym && (sw < 0 || sw >= N + cpl)) s_viol = 1; }
-  }
-  __syncthreads();
-  if (s_viol) { if (tid == 0) *need_seq = 1; return; }
-  // per-call quantities: entering call s: nextpos = cp[s-1]-(N+cp), incB = -eps[s-1]/N, incA = -eps[s-2]/N
-  // (valid when every switch position lies inside the call, i.e. N+cp <= cp < 2N+2cp: always true
-  //  for a tracked peak, which lives in [N+cp-1+8, 2N+cp-2]; cp == N+cp-1.. is guarded below)
-  auto epsm = [&](int s) -> double { return s < 0 ? (s == -1 ? (double)st->eps_init : 0.0) : (double)eps[s]; };
-  auto cpm = [&](int s) -> int { return s < 0 ? c0 : cp[s]; };
-  const int per = (nsym + 1023) / 1024;
-  const int sbeg = tid * per, cnt = sbeg >= nsym ? 0 : (nsym - sbeg < per ? nsym - sbeg : per);
-  // a thread owns `per` consecutive calls; their cp/eps values are fetched 8 calls at a time with independent loads
-  // (the dependent one-by-one walk cost ~70 us of pure memory latency), then consumed in the original order
-  auto chunk = [&](int i0, int (&cv)[9], double (&ev)[10]) {
-#pragma unroll
-    for (int k = 0; k < 9; k++) { const int s = sbeg + i0 + k - 1; cv[k] = (i0 + k - 1 < cnt) ? cpm(s) : 0; }     // cp[s-1] .. cp[s+7]
-#pragma unroll
-    for (int k = 0; k < 10; k++) { const int s = sbeg + i0 + k - 2; ev[k] = (i0 + k - 2 < cnt) ? epsm(s) : 0.0; }  // eps[s-2] .. eps[s+7]
-  };
-  double local = 0.0;
-  for (int i0 = 0; i0 < cnt; i0 += 8) {
-    int cv[9]; double ev[10];
-    chunk(i0, cv, ev);
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const int s = sbeg + i0 + k;
-      if (i0 + k < cnt) {
-        const int sw = cv[k] - (N + cpl);
-        const double A = s == 0 ? 0.0 : (-1.0 / N) * ev[k], B = (-1.0 / N) * ev[k + 1];
-        local += (sw >= 0 && sw < N + cpl) ? sw * A + (N + cpl - sw) * B : (double)(N + cpl) * A;
-      }
-    }
-  }
-  s_tot[tid] = local;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {                     // inclusive scan
-    double v = tid >= off ? s_tot[tid - off] : 0.0;
-    __syncthreads();
-    s_tot[tid] += v;
-    __syncthreads();
-  }
-  double base = tid == 0 ? 0.0 : s_tot[tid - 1];
-  for (int i0 = 0; i0 < cnt; i0 += 8) {
-    int cv[9]; double ev[10];
-    chunk(i0, cv, ev);
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const int s = sbeg + i0 + k;
-      if (i0 + k < cnt) {
-        const int sw = cv[k] - (N + cpl);
-        const double A = s == 0 ? 0.0 : (-1.0 / N) * ev[k], B = (-1.0 / N) * ev[k + 1];
-        SymMeta m; m.cp_start = cv[k + 1]; m.eps = (float)ev[k + 2]; m.sw = sw; m.incA = A; m.incB = B; m.ph_base = wrap_pi(base);
-        meta[s] = m;
-        base += (sw >= 0 && sw < N + cpl) ? sw * A + (N + cpl - sw) * B : (double)(N + cpl) * A;
-      }
-    }
-  }
-  if (tid == 0) {
-    st->n_symbols = nsym;
-    if (nsym < ntot) st->status |= 2;
-  }
-}
-
 // d_avg after the call in which the tracker lost the lock: the reference re-acquires in the next call with this value
 // (ofdm_sym_acquisition_impl.cc:545-559; d_avg persists).  IIR over the last two windows (see acq_track_par_kernel).
-__global__ void acq_lost_avg_kernel(FrontParams p, RxState *st, const int *__restrict__ cp, const float *__restrict__ lambda, const int *__restrict__ centre,
-                                    const int *need_seq)
+__device__ inline void acq_lost_avg_body(FrontParams p, RxState *st, const int *__restrict__ cp, const float *__restrict__ lambda, const int *__restrict__ centre)
 {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (need_seq && *need_seq) return;                             // the sequential tracker has written avg_lost itself
   st->avg_lost = st->avg;
   if (!(st->status & 2) || (st->status & 1)) return;
   const int f = st->n_symbols, R = p.R, c0 = st->cp_start0;      // f: first call (relative to call0) without a peak
@@ -1078,6 +1010,93 @@ __global__ void acq_lost_avg_kernel(FrontParams p, RxState *st, const int *__res
   }
   st->avg_lost = avg;
 }
+
+// bookkeeping after the fixed point: n_symbols = calls before the first miss; derotation phase
+// parameters per symbol (ml_sync :285-313).  Falls back to nothing when the Jacobi iteration did not converge
+// (acq_track_kernel then overwrites everything).  A workgroup owns 1024 consecutive calls (a call per thread: coalesced loads, SymMeta
+// records stored side by side); the checks and the phase accumulated in front of its calls (a sum in double over the per-call advance) it forms
+// for itself from ALL calls -- a few hundred KB out of L2 -- so the workgroups need nothing from each other.  (One workgroup with a thread per
+// run of consecutive calls: 51 us on 17,680 calls, most of it strided loads and stores on one compute unit.)  Workgroup 0 reports, and when the
+// placement stands it also leaves d_avg as the reference holds it after a lost lock (acq_lost_avg_body; the sequential trackers write it themselves).
+__global__ __launch_bounds__(1024) void acq_finalize_kernel(FrontParams p, RxState *st, const int *__restrict__ cp, const float *__restrict__ eps,
+                                                           const int *changed, int last_iter, SymMeta *__restrict__ meta, int *need_seq,
+                                                           const float *__restrict__ lambda, const int *__restrict__ centre)
+{
+  __shared__ double s_w[2][16];
+  __shared__ int s_first_bad, s_viol;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const bool lead = blockIdx.x == 0 && tid == 0;
+  if (st->status & 1) { if (lead) { *need_seq = 0; acq_lost_avg_body(p, st, cp, lambda, centre); } return; }
+  bool converged = false;
+  for (int i = 0; i <= last_iter; i++) if (changed[i] == 0) converged = true;
+  if (!converged) { if (lead) *need_seq = 1; return; }
+  const int ntot = p.ncalls - st->call0, N = p.N, L = p.N + p.cp, c0 = st->cp_start0, base = blockIdx.x * 1024;
+  if (base >= ntot && blockIdx.x != 0) return;
+  const float eps_init = st->eps_init;
+  if (tid == 0) { s_first_bad = ntot; s_viol = ntot; }
+  __syncthreads();
+  // per-call quantities: entering call s: nextpos = cp[s-1]-(N+cp), incB = -eps[s-1]/N, incA = -eps[s-2]/N (cp[-1] = the initial position, eps[-1] = the
+  // initial estimate, eps[-2] = 0); the call advances the phase by sw * incA + (L - sw) * incB
+  // (valid when every switch position lies inside the call, i.e. N+cp <= cp < 2N+2cp: always true
+  //  for a tracked peak, which lives in [N+cp-1+8, 2N+cp-2]; anything else hands the period to the sequential tracker)
+  auto advance = [&](int s, int cprev, float e2, float e1, int &sw, double &A, double &B) -> double {
+    sw = cprev - L;
+    A = s == 0 ? 0.0 : (-1.0 / N) * (double)e2; B = (-1.0 / N) * (double)e1;
+    return (sw >= 0 && sw < L) ? sw * A + (L - sw) * B : (double)L * A;
+  };
+  // one pass over all calls, 4 clamped loads of each array per lane in flight: first call without a peak, first switch outside its call, phase in front of `base`
+  double front = 0.0;
+  for (int s0 = tid; s0 < ntot; s0 += 4 * 1024) {
+    int cc[4], cm[4]; float e1[4], e2[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int s = s0 + k * 1024, sc = s < ntot ? s : ntot - 1;
+      cc[k] = cp[sc]; cm[k] = sc >= 1 ? cp[sc - 1] : c0; e1[k] = sc >= 1 ? eps[sc - 1] : eps_init; e2[k] = sc >= 2 ? eps[sc - 2] : (sc == 1 ? eps_init : 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int s = s0 + k * 1024;
+      if (s < ntot) {
+        if (cc[k] < 0) atomicMin(&s_first_bad, s);
+        int sw; double A, B;
+        const double adv = advance(s, cm[k], e2[k], e1[k], sw, A, B);
+        if (sw < 0 || sw >= L) atomicMin(&s_viol, s);
+        if (s < base) front += adv;                               // only used when base < n_symbols: every call in front of it is a tracked one
+      }
+    }
+  }
+  __syncthreads();
+  const int nsym = s_first_bad;
+  if (nsym < ntot && cp[nsym] == -2) { if (lead) *need_seq = 1; return; }      // the placement ran out of precomputed lags: sequential tracker
+  if (s_viol < nsym) { if (lead) *need_seq = 1; return; }                      // the closed form needs every phase-increment switch to fall inside its call
+  if (lead) { *need_seq = 0; st->n_symbols = nsym; if (nsym < ntot) st->status |= 2; acq_lost_avg_body(p, st, cp, lambda, centre); }
+  if (base >= nsym) return;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) front += __shfl_xor(front, o);
+  if (lane == 0) s_w[0][wv] = front;
+  // this workgroup's calls
+  const int s = base + tid;
+  const bool own = s < nsym;
+  int sw = 0, cs = 0; float es = 0.f; double A = 0.0, B = 0.0, adv = 0.0;
+  if (own) {
+    cs = cp[s]; es = eps[s];
+    adv = advance(s, s >= 1 ? cp[s - 1] : c0, s >= 2 ? eps[s - 2] : (s == 1 ? eps_init : 0.f), s >= 1 ? eps[s - 1] : eps_init, sw, A, B);
+  }
+  double incl = adv;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const double u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+  double excl = __shfl_up(incl, 1); if (lane == 0) excl = 0.0;
+  if (lane == 63) s_w[1][wv] = incl;
+  __syncthreads();
+  double before = 0.0;
+  for (int w = 0; w < 16; w++) before += s_w[0][w];
+  for (int w = 0; w < wv; w++) before += s_w[1][w];
+  if (own) {
+    SymMeta m; m.cp_start = cs; m.eps = es; m.sw = sw; m.incA = A; m.incB = B; m.ph_base = wrap_pi(before + excl);
+    meta[s] = m;
+  }
+}
+
 
 // LDS image of a symbol: one float2 of padding after every 32 keeps the stride-4/16/64 accesses of the
 // late radix-4 stages conflict-free (bank = float2 index mod 32 for ds_read_b64)
@@ -1440,10 +1459,9 @@ __device__ inline int bch_check(unsigned long long lo, unsigned hi)
 // nature (68-bit FIFO + counters); the per-symbol inputs are staged through LDS in tiles by the
 // whole workgroup so the walking lane never waits on HBM.
 constexpr int TPS_TILE = 2048;
-__global__ __launch_bounds__(256) void tps_fsm_kernel(FrontParams p, RxState *st, int nitems_fixed, const SymInfo *info, const int *maj,
-                               TpsState *ts, int *sym_index, int *superframe_flag, const unsigned char *sync_flags, const int *need_seq, int clear_d_init = 0)
+__device__ __forceinline__ void tps_fsm_body(FrontParams p, RxState *st, int nitems_fixed, const SymInfo *info, const int *maj,
+                               TpsState *ts, int *sym_index, int *superframe_flag, const unsigned char *sync_flags, int clear_d_init)
 {
-  if (need_seq && *need_seq == 0) return;
   __shared__ signed char s_mod[TPS_TILE];
   __shared__ short s_maj[TPS_TILE];
   __shared__ unsigned char s_sync[TPS_TILE], s_si[TPS_TILE], s_flag[TPS_TILE];
@@ -1514,6 +1532,12 @@ __global__ __launch_bounds__(256) void tps_fsm_kernel(FrontParams p, RxState *st
     }
   }
 }
+__global__ __launch_bounds__(256) void tps_fsm_kernel(FrontParams p, RxState *st, int nitems_fixed, const SymInfo *info, const int *maj,
+                               TpsState *ts, int *sym_index, int *superframe_flag, const unsigned char *sync_flags, const int *need_seq, int clear_d_init = 0)
+{
+  if (need_seq && *need_seq == 0) return;
+  tps_fsm_body(p, st, nitems_fixed, info, maj, ts, sym_index, superframe_flag, sync_flags, clear_d_init);
+}
 
 
 // ---- the same bookkeeping, segment-parallel (segment path only: no sync_start tags, fresh state).
@@ -1530,7 +1554,7 @@ struct TpsEdge { TpsState start, end; };
 
 // verify_bch_code (:385-425) as a linear map: the LFSR register after the 53 data bits (fifo bits 1..53; the 60
 // leading zero clocks leave it at zero) is the XOR of one 14-bit response per set bit, looked up bytewise in a
-// table the kernel builds in LDS (tps_bch_table); the word is valid when it equals fifo bits 54..67.
+// table built on the host (tps_bch_table_host) that the kernel copies into LDS; the word is valid when it equals fifo bits 54..67.
 __device__ __forceinline__ int bch_check_tab(const unsigned short *T, unsigned long long lo, unsigned hi)
 {
   const unsigned long long data = (lo >> 1) & ((1ull << 53) - 1);
@@ -1540,63 +1564,76 @@ __device__ __forceinline__ int bch_check_tab(const unsigned short *T, unsigned l
   const unsigned parity = (unsigned)((lo >> 54) | ((unsigned long long)hi << 10)) & 0x3fffu;
   return reg == parity ? 0 : -1;
 }
-__device__ inline void tps_bch_table(unsigned short *T, unsigned short *R, int tid, int nthreads)
+// built once on the host (the kernel used to build it in LDS at every launch: 56 x 53 dependent register steps, ~10 us of its 64)
+inline std::vector<uint16_t> tps_bch_table_host()
 {
-  for (int i = tid; i < 56; i += nthreads) {
+  unsigned R[56];
+  for (int i = 0; i < 56; i++) {
     unsigned reg = 0;
     for (int it = 0; it < 53; it++) {                             // response to a single 1 at data bit i
       const unsigned d = it == i ? 1u : 0u, fb = 1u & (d ^ reg);
       reg >>= 1; reg |= fb << 13;
       reg ^= (fb << 12) ^ (fb << 11) ^ (fb << 9) ^ (fb << 8) ^ (fb << 7) ^ (fb << 5) ^ (fb << 4);
     }
-    R[i] = (unsigned short)(i < 53 ? reg : 0);
+    R[i] = i < 53 ? reg : 0;
   }
-  __syncthreads();
-  for (int e = tid; e < 7 * 256; e += nthreads) {
+  std::vector<uint16_t> T(7 * 256);
+  for (int e = 0; e < 7 * 256; e++) {
     unsigned r = 0;
     for (int j = 0; j < 8; j++) if ((e >> j) & 1) r ^= R[(e >> 8) * 8 + j];
-    T[e] = (unsigned short)r;
+    T[e] = (uint16_t)r;
   }
-  __syncthreads();
+  return T;
 }
 
-__device__ __forceinline__ void tps_advance(TpsState &t, int mod, int majv, int fi_start, unsigned mask_even, unsigned mask_odd,
+// One symbol of the bookkeeping on registers: the 68-bit FIFO as three 32-bit words (v_alignbit shifts), no branch outside the sync-word match.
+// (The first version walked a TpsState with 64-bit variable shifts and fetched every symbol's two values from LDS inside the dependent chain:
+// ~600 cycles per symbol, 236 symbols per lane = 61 us.)
+struct TpsRegs { unsigned f0, f1, f2; int symbol_index, known, frame_index, prev_mod; };
+__device__ __forceinline__ void tps_advance(TpsRegs &t, int mod, unsigned neg, int fi_start, unsigned mask_even, unsigned mask_odd,
                                             int &si_out, int &cand, const unsigned short *T, unsigned long long *tps_bits)
 {
-  int diff = (mod - t.prev_mod + 4) & 3;
+  const int diff = (mod - t.prev_mod) & 3;
   t.prev_mod = mod;
-  t.symbol_index += diff; if (t.symbol_index >= 68) t.symbol_index -= 68;
-  const int si = t.symbol_index, fi = t.frame_index;
-  const int use = (!t.symbol_index_known || t.symbol_index != 0);
-  const unsigned bitv = use ? (majv >= 0 ? 0u : 1u) : 0u;
-  // `diff` shifts of the 68-bit FIFO, each inserting bitv at the top (process_tps_data :952-960), in closed form
-  if (diff) {
-    t.fifo_lo = (t.fifo_lo >> diff) | ((unsigned long long)t.fifo_hi << (64 - diff));
-    t.fifo_hi = (t.fifo_hi >> diff) | (bitv ? (((1u << diff) - 1u) << (4 - diff)) : 0u);
-  }
-  const unsigned low16 = (unsigned)(t.fifo_lo & 0xFFFEull);
+  int si = t.symbol_index + diff; if (si >= 68) si -= 68;
+  t.symbol_index = si;
+  const int fi = t.frame_index;
+  const unsigned bitv = (!t.known || si != 0) ? neg : 0u;
+  // `diff` shifts of the 68-bit FIFO, each inserting bitv at the top (process_tps_data :952-960), in closed form: bits 3 .. 4 - diff of the top word
+  t.f0 = __builtin_amdgcn_alignbit(t.f1, t.f0, diff);
+  t.f1 = __builtin_amdgcn_alignbit(t.f2, t.f1, diff);
+  t.f2 = (t.f2 >> diff) | (((0xEC80u >> (4 * diff)) & 0xFu) & (0u - bitv));
+  const unsigned low16 = t.f0 & 0xFFFEu;
   if (low16 == mask_even || low16 == mask_odd) {
-    if (bch_check_tab(T, t.fifo_lo, t.fifo_hi) == 0) {
-      t.frame_index = (int)(((t.fifo_lo >> 23) & 1ull) << 1 | ((t.fifo_lo >> 24) & 1ull));
-      t.symbol_index_known = 1; t.symbol_index = 67;
-      if (tps_bits) *tps_bits = (t.fifo_lo & TPS_STATIC_MASK) | (1ull << 63);   // every valid frame of a stream stores the same word
-    } else t.symbol_index_known = 0;
-    t.fifo_lo = 0; t.fifo_hi = 0;
+    const unsigned long long lo = (unsigned long long)t.f0 | ((unsigned long long)t.f1 << 32);
+    if (bch_check_tab(T, lo, t.f2) == 0) {
+      t.frame_index = (int)(((lo >> 23) & 1ull) << 1 | ((lo >> 24) & 1ull));
+      t.known = 1; t.symbol_index = 67;
+      if (tps_bits) *tps_bits = (lo & TPS_STATIC_MASK) | (1ull << 63);   // every valid frame of a stream stores the same word
+    } else t.known = 0;
+    t.f0 = 0; t.f1 = 0; t.f2 = 0;
   }
   si_out = si;
   cand = (si == 0) && ((fi & 3) == fi_start);
 }
+__device__ __forceinline__ TpsState tps_pack(const TpsRegs &r)
+{
+  TpsState t; t.fifo_lo = (unsigned long long)r.f0 | ((unsigned long long)r.f1 << 32); t.fifo_hi = r.f2; t.symbol_index = r.symbol_index;
+  t.symbol_index_known = r.known; t.frame_index = r.frame_index; t.prev_mod = r.prev_mod; t.d_init = 0;
+  return t;
+}
 
 __global__ __launch_bounds__(TPS_THREADS) void tps_fsm_par_kernel(FrontParams p, const RxState *st, const SymInfo *__restrict__ info, const int *__restrict__ maj,
-                                                                 int *__restrict__ sym_index, TpsEdge *__restrict__ edges, int *first_cand, unsigned long long *tps_bits)
+                                                                 int *__restrict__ sym_index, TpsEdge *__restrict__ edges, int *first_cand, unsigned long long *tps_bits,
+                                                                 const unsigned short *__restrict__ bch_tab)
 {
-  // symbol streams in LDS; padding per TPS_SEG entries keeps the lanes (TPS_SEG symbols apart) on distinct banks
+  // the symbol stream in LDS, a byte per symbol: pattern index | (TPS vote negative) << 2; four bytes of padding per TPS_SEG entries keep the lanes
+  // (TPS_SEG symbols apart) on distinct banks.  A lane's first symbol is a multiple of four symbols from `lo`, so it reads its stream a dword at a time.
   constexpr int NS = TPS_THREADS * TPS_SEG + TPS_WARM;
-  __shared__ signed char s_mod[NS + (NS / TPS_SEG) * 4 + 4];
-  __shared__ short s_maj[NS + (NS / TPS_SEG) * 2 + 2];
-  __shared__ unsigned short s_T[7 * 256], s_R[56];
+  __shared__ __attribute__((aligned(16))) unsigned char s_pk[NS + (NS / TPS_SEG) * 4 + 8];
+  __shared__ unsigned short s_T[7 * 256];
   auto pm = [](int i) { return i + (i / TPS_SEG) * 4; };
-  auto pj = [](int i) { return i + (i / TPS_SEG) * 2; };
+  static_assert(TPS_WARM % 4 == 0 && TPS_SEG % 4 == 0, "a lane reads whole dwords");
   const int tid = threadIdx.x;
   const int nsym = st->n_symbols, ntot = p.keep_last ? nsym : (nsym > 0 ? nsym - 1 : 0);
   const int blk0 = blockIdx.x * TPS_THREADS * TPS_SEG;
@@ -1608,9 +1645,10 @@ __global__ __launch_bounds__(TPS_THREADS) void tps_fsm_par_kernel(FrontParams p,
 #pragma unroll
     for (int k = 0; k < 8; k++) { const int i = i0 + k * TPS_THREADS, ic = i < hi ? i : hi - 1; mv[k] = info[ic].mod_index; jv[k] = maj[ic]; }
 #pragma unroll
-    for (int k = 0; k < 8; k++) { const int i = i0 + k * TPS_THREADS; if (i < hi) { s_mod[pm(i - lo)] = (signed char)mv[k]; s_maj[pj(i - lo)] = (short)jv[k]; } }
+    for (int k = 0; k < 8; k++) { const int i = i0 + k * TPS_THREADS; if (i < hi) s_pk[pm(i - lo)] = (unsigned char)((mv[k] & 3) | (jv[k] < 0 ? 4 : 0)); }
   }
-  tps_bch_table(s_T, s_R, tid, TPS_THREADS);
+  for (int i = tid; i < 7 * 128; i += TPS_THREADS) reinterpret_cast<unsigned *>(s_T)[i] = reinterpret_cast<const unsigned *>(bch_tab)[i];
+  __syncthreads();
   unsigned mask_even = 0, mask_odd = 0;
   {
     const unsigned char se[15] = {0, 0, 1, 1, 0, 1, 0, 1, 1, 1, 1, 0, 1, 1, 1};
@@ -1620,23 +1658,38 @@ __global__ __launch_bounds__(TPS_THREADS) void tps_fsm_par_kernel(FrontParams p,
   if (s0 >= ntot) return;
   const int s1 = s0 + TPS_SEG < ntot ? s0 + TPS_SEG : ntot;
   int sw = s0 - TPS_WARM; if (sw < 0) sw = 0;
-  TpsState t; t.fifo_lo = 0; t.fifo_hi = 0; t.symbol_index = 0; t.symbol_index_known = 0; t.frame_index = 0; t.prev_mod = 0; t.d_init = 0;
+  TpsRegs t; t.f0 = 0; t.f1 = 0; t.f2 = 0; t.symbol_index = 0; t.known = 0; t.frame_index = 0; t.prev_mod = 0;
   int si, cand;
-#pragma unroll 4
-  for (int s = sw; s < s0; s++) tps_advance(t, s_mod[pm(s - lo)], s_maj[pj(s - lo)], p.fi_start, mask_even, mask_odd, si, cand, s_T, nullptr);
-  const int seg = s0 / TPS_SEG;
-  edges[seg].start = t;
-  int first = 0x7fffffff;
-  for (int s = s0; s < s1; s++) {
-    tps_advance(t, s_mod[pm(s - lo)], s_maj[pj(s - lo)], p.fi_start, mask_even, mask_odd, si, cand, s_T, tps_bits);
-    sym_index[s] = si;
-    if (cand && first == 0x7fffffff) first = s;
+  auto word = [&](int s) -> unsigned { return *reinterpret_cast<const unsigned *>(&s_pk[pm(s - lo)]); };   // symbols s .. s + 3 (s - lo: a multiple of 4)
+  unsigned nxt = word(sw);
+  for (int g = sw; g < s0; g += 4) {                               // warm-up: whole dwords (s0 - sw is a multiple of 4)
+    const unsigned w = nxt;
+    nxt = word(g + 4);                                             // the next dword is on its way while this one is walked (the array has 8 spare bytes)
+#pragma unroll
+    for (int k = 0; k < 4; k++) tps_advance(t, (int)((w >> (8 * k)) & 3u), (w >> (8 * k + 2)) & 1u, p.fi_start, mask_even, mask_odd, si, cand, s_T, nullptr);
   }
-  edges[seg].end = t;
+  const int seg = s0 / TPS_SEG;
+  edges[seg].start = tps_pack(t);
+  int first = 0x7fffffff;
+  for (int g = s0; g < s1; g += 4) {
+    const unsigned w = nxt;
+    nxt = word(g + 4 < s1 ? g + 4 : g);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int s = g + k;
+      if (s < s1) {
+        tps_advance(t, (int)((w >> (8 * k)) & 3u), (w >> (8 * k + 2)) & 1u, p.fi_start, mask_even, mask_odd, si, cand, s_T, tps_bits);
+        sym_index[s] = si;
+        if (cand && first == 0x7fffffff) first = s;
+      }
+    }
+  }
+  edges[seg].end = tps_pack(t);
   if (first != 0x7fffffff) atomicMin(first_cand, first);
 }
 
-__global__ __launch_bounds__(256) void tps_finalize_kernel(RxState *st, const TpsEdge *edges, const int *first_cand, int *need_seq, int keep_last, TpsState *ts)
+// (all 256 threads of the workgroup; returns whether the sequential bookkeeping has to run -- the same value in every thread)
+__device__ __forceinline__ int tps_finalize_body(RxState *st, const TpsEdge *edges, const int *first_cand, int *need_seq, int keep_last, TpsState *ts)
 {
   __shared__ int s_bad;
   const int tid = threadIdx.x;
@@ -1659,6 +1712,8 @@ __global__ __launch_bounds__(256) void tps_finalize_kernel(RxState *st, const Tp
       if (ts && nseg > 0) { TpsState e = edges[nseg - 1].end; e.d_init = fo != 0x7fffffff; *ts = e; }   // the members a later lock period starts from
     }
   }
+  __syncthreads();
+  return s_bad;
 }
 
 }  // namespace dvbt
