@@ -214,7 +214,8 @@ class Rx:
         return self.L.dvbt_rx_tap_device_ptr(self.h, tap)
 
     def enable_timing(self, on=True):
-        _chk(self.L.dvbt_rx_enable_timing(self.h, 1 if on else 0))
+        """True / 1: HIP events around every stage; 2: around the decoder only (stage_ms("viterbi")); False / 0: none"""
+        _chk(self.L.dvbt_rx_enable_timing(self.h, int(on)))
 
     def stage_ms(self, name):
         return self.L.dvbt_rx_stage_ms(self.h, name.encode())

@@ -274,7 +274,8 @@ struct dvbt_rx {
   size_t vit_cap = 0; RsDefer *rs_defer = nullptr; int rs_defer_cap = 0;
   unsigned long long *rs_sync = nullptr;     // bit w: payload byte 0 of RS word w is 0xB8 (deint_rs_kernel / rs_fix_kernel -> descramble_scan_kernel)
   float *csi = nullptr; int8_t *soft_a = nullptr; uint16_t *soft_tab = nullptr; unsigned *soft_scratch = nullptr;   // soft-decision mode (k_soft.hpp): channel state per carrier, soft values, A5 + A6 gather table, decision slots
-  bool timing = false, pending = false;
+  int timing = 0;             // 0 off, 1 events around every stage, 2 around the decoder only (dvbt_rx_enable_timing)
+  bool pending = false;
   hipEvent_t ev[ST_COUNT]; double acc_ms[ST_COUNT] = {0}; long n_timed = 0; bool ev_ready = false, ev_recorded = false;
   dvbt_rx_report last; bool have_last = false;
   dvbt_rx_cut cut = {0};
@@ -395,7 +396,7 @@ extern "C" int dvbt_rx_set_cut(dvbt_rx *h, const dvbt_rx_cut *cut)
 extern "C" int dvbt_rx_enable_timing(dvbt_rx *h, int enable)
 {
   if (!h) return DVBT_ERR_INVALID;
-  h->timing = enable != 0;
+  h->timing = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
   if (enable) { for (int i = 0; i <= ST_END; i++) h->acc_ms[i] = 0.0; h->n_timed = 0; }     // a new measurement window: dvbt_rx_stage_ms averages from here on
   return DVBT_OK;
 }
@@ -486,7 +487,7 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
   fp.hist = o.hist; fp.keep_last = o.keep_last ? 1 : 0; fp.avail = o.avail > 0 ? o.avail : (long long)nsamples;
   const int C = fp.ncalls, N = d.N;
   h->cur_stream = s;
-  const bool tm = h->timing && !o.acq_only;
+  const bool tm = h->timing == 1 && !o.acq_only, tmv = h->timing != 0 && !o.acq_only;   // an event record costs ~6 us of an otherwise idle stream
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_ACQ], s));
   if (o.skip_acq) {
     // what acq_init_fsm_kernel's reset would have done on top of the acq_only run's (tracker flags and the symbol ticket are still clear)
@@ -598,7 +599,7 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
     const float step = 2.0f * d.norm;
     hipLaunchKernelGGL(soft_demap_kernel, dim3(C), dim3(256), (size_t)d.payload * d.m, s, (const float2 *)h->eq, (const float *)h->csi, (const RxState *)h->st, ip, (const float2 *)h->T.points,
                        1.0f / (step * step), (const int *)h->sym_index, (const uint16_t *)h->soft_tab, h->soft_a);
-    if (tm) HIPCHK(hipEventRecord(h->ev[ST_VIT], s));
+    if (tmv) HIPCHK(hipEventRecord(h->ev[ST_VIT], s));
     // the decoder: four chunks per wavefront, chunk size for whole rounds of the wavefront slots
     const S4Plan sp = s4_plan(max_vit, d.ntb);
     const unsigned grid = s4_grid(max_vit, d.ntb);             // <= the grid the scratch was sized for at create (C <= max_calls)
@@ -609,7 +610,7 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
   hipLaunchKernelGGL(inner_kernel<6>, dim3(C), dim3(INNER_THREADS), inner_lds_bytes((size_t)d.payload), s, (const float2 *)nullptr, (const uint8_t *)h->labels, ip,
                      (const RxState *)h->st, 0, (const int *)h->sym_index, (const float2 *)nullptr, (const unsigned char *)nullptr,
                      (const uint16_t *)h->T.H, (const uint16_t *)h->T.Hinv, (uint8_t *)nullptr, h->symdeint_tap, h->bitdeint, h->bitdeint_lp);
-  if (tm) HIPCHK(hipEventRecord(h->ev[ST_VIT], s));
+  if (tmv) HIPCHK(hipEventRecord(h->ev[ST_VIT], s));
   VitParams vp = h->vp;
   if (h->prm.viterbi_chunk_bytes <= 0) {
     // chunk size chosen per segment so that the wavefront count is a whole number of "rounds" of the resident
@@ -636,9 +637,10 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
   // bits of every byte either way (viterbi_decoder_impl.cc:93,236-243: the reference's decoder knows no priority streams)
   launch_viterbi(s, (const uint8_t *)((h->prm.hier_stream && h->bitdeint_lp) ? h->bitdeint_lp : h->bitdeint), h->vit + o.vit_off, (const RxState *)h->st, 0ll, vp, 0ll, 0ll, max_vit);
   }
-  if (tm) HIPCHK(hipEventRecord(h->ev[ST_RS], s));
+  if (tmv) HIPCHK(hipEventRecord(h->ev[ST_RS], s));
   if (o.tail) { int r = enqueue_tail(h, s, max_vit / 204 + 1, -1); if (r) return r; }
-  if (tm) { HIPCHK(hipEventRecord(h->ev[ST_END], s)); h->ev_recorded = true; }
+  if (tm) HIPCHK(hipEventRecord(h->ev[ST_END], s));
+  if (tmv) h->ev_recorded = true;
   HIPCHK(hipMemcpyAsync(h->st_host, h->st, sizeof(RxState), hipMemcpyDeviceToHost, s));
   HIPCHK(hipGetLastError());
   h->pending = true;
@@ -688,8 +690,8 @@ extern "C" int dvbt_rx_segment_finish(dvbt_rx *h, dvbt_rx_report *rep)
   HIPCHK(hipStreamSynchronize(h->cur_stream));
   h->pending = false;
   if (h->timing && h->ev_recorded) {
-    for (int i = 0; i < ST_END; i++) { float ms = 0; if (hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]) == hipSuccess) h->acc_ms[i] += ms; }
-    float ms = 0; if (hipEventElapsedTime(&ms, h->ev[0], h->ev[ST_END]) == hipSuccess) h->acc_ms[ST_END] += ms;
+    for (int i = h->timing == 2 ? ST_VIT : 0; i < (h->timing == 2 ? ST_RS : ST_END); i++) { float ms = 0; if (hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]) == hipSuccess) h->acc_ms[i] += ms; }
+    float ms = 0; if (h->timing == 1 && hipEventElapsedTime(&ms, h->ev[0], h->ev[ST_END]) == hipSuccess) h->acc_ms[ST_END] += ms;
     h->n_timed++; h->ev_recorded = false;
   }
   dvbt_rx_report r;
@@ -990,8 +992,8 @@ extern "C" int dvbt_rx_lock_periods(dvbt_rx *h, dvbt_lock_period *out, int cap)
 extern "C" double dvbt_rx_stage_ms(dvbt_rx *h, const char *stage)
 {
   if (!h || !stage || h->n_timed == 0) return -1.0;
-  if (!strcmp(stage, "total")) return h->acc_ms[ST_END] / h->n_timed;
-  for (int i = 0; i < ST_END; i++) if (!strcmp(stage, kStageNames[i])) return h->acc_ms[i] / h->n_timed;
+  if (!strcmp(stage, "total")) return h->timing == 2 ? -1.0 : h->acc_ms[ST_END] / h->n_timed;
+  for (int i = 0; i < ST_END; i++) if (!strcmp(stage, kStageNames[i])) return (h->timing == 2 && i != ST_VIT) ? -1.0 : h->acc_ms[i] / h->n_timed;
   return -1.0;
 }
 

@@ -539,6 +539,9 @@ __global__ __launch_bounds__(64) void deint_rs_kernel(const uint8_t *__restrict_
         R1 = ((R1 << 8) | (R0 >> 24)) ^ t.y; R0 = ((R0 << 8) | ((d >> (8 * k)) & 0xffu)) ^ t.x;
       }
     }
+    // (Four bytes per step on four tables of four-step rows -- one dependent LDS round trip per dword instead of four -- was built and measured in round 4:
+    // 117 us against 92: the 16 KB of tables leave room for four workgroups per compute unit instead of six, and the launch is bound by how many words a
+    // compute unit has in flight, not by the chain.)
     const int any = (R0 | R1 | R2 | R3) != 0;
     if (any) {                                                    // syndromes from the remainder: S_i = sum_k R_k alpha^(i k)
       const unsigned Rw[4] = {R0, R1, R2, R3};
@@ -689,6 +692,9 @@ __global__ __launch_bounds__(1024) void descramble_scan_kernel(const uint8_t *__
     if (tid == 0) s_first = ncalls;
     __syncthreads();
     long long mine = ncalls;
+    // the call at `base` itself first (every lane reads the same bit): without its NSYNC there is nothing to scan for -- the first round of every stream,
+    // whose offset 0 is not a packet start of the descrambler's phase
+    if (!nsync(base * 8 + d_pkt)) mine = 0;
     for (long long k0 = tid; k0 < ncalls && mine == ncalls; k0 += 8 * 1024) {       // 8 clamped loads per lane in flight
       bool v[8];
 #pragma unroll
@@ -696,7 +702,7 @@ __global__ __launch_bounds__(1024) void descramble_scan_kernel(const uint8_t *__
 #pragma unroll
       for (int j = 7; j >= 0; j--) { const long long k = k0 + j * 1024; if (k < ncalls && !v[j]) mine = k; }
     }
-    if (mine < ncalls) atomicMin((unsigned long long *)&s_first, (unsigned long long)mine);
+    if (mine < ncalls && (mine > 0 || tid == 0)) atomicMin((unsigned long long *)&s_first, (unsigned long long)mine);
     __syncthreads();
     if (tid == 0) {
       const long long kf = s_first;
@@ -722,24 +728,28 @@ __global__ __launch_bounds__(1024) void descramble_scan_kernel(const uint8_t *__
   if (tid == 0) { st->n_ts_bytes = s_written; *nruns = s_nr; }
 }
 
-// one workgroup pass per 8-packet group (1504 bytes = 376 dwords; every run starts on a multiple of 188 bytes)
+// a dword per thread and pass over the delivered bytes (an 8-packet group is 1504 bytes = 376 dwords of the PRBS pattern; every run starts on a multiple
+// of 188 bytes); a workgroup per group left a third of its lanes idle in the second of its two passes
 __global__ __launch_bounds__(256) void descramble_runs_kernel(const uint8_t *__restrict__ in, const uint8_t *__restrict__ seq, const RxState *st,
                                                              const DescrRun *__restrict__ runs, const int *nruns, uint8_t *__restrict__ out)
 {
-  const long long ngroups = st->n_ts_bytes / 1504;
+  const unsigned long long ndw = (unsigned long long)(st->n_ts_bytes / 1504) * 376ull;
   const unsigned *sq = reinterpret_cast<const unsigned *>(seq);
   const int nr = *nruns;
-  for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
-    const long long dst = g * 1504;
-    int r = 0;
-    while (r + 1 < nr && runs[r + 1].dst_byte <= dst) r++;
-    const unsigned *p = reinterpret_cast<const unsigned *>(in + runs[r].src_byte + (dst - runs[r].dst_byte));
-    unsigned *o = reinterpret_cast<unsigned *>(out + dst);
-    for (int t = threadIdx.x; t < 376; t += 256) {
-      unsigned v = p[t] ^ sq[t];
-      if (t % 47 == 0) v = (v & 0xffffff00u) | 0x47u;              // sync byte restored (:151)
-      o[t] = v;
+  const long long src0 = nr > 0 ? runs[0].src_byte : 0;
+#pragma unroll 4
+  for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < ndw; i += (unsigned long long)gridDim.x * 256) {
+    const unsigned long long g = i / 376ull; const unsigned t = (unsigned)(i - g * 376ull);
+    const long long dst = (long long)g * 1504;
+    long long src = src0 + dst;                                  // one run (the usual case): it starts at destination byte 0
+    if (nr > 1) {
+      int r = 0;
+      while (r + 1 < nr && runs[r + 1].dst_byte <= dst) r++;
+      src = runs[r].src_byte + (dst - runs[r].dst_byte);
     }
+    unsigned v = reinterpret_cast<const unsigned *>(in + src)[t] ^ sq[t];
+    if (t % 47u == 0u) v = (v & 0xffffff00u) | 0x47u;              // sync byte restored (:151)
+    reinterpret_cast<unsigned *>(out + dst)[t] = v;
   }
 }
 

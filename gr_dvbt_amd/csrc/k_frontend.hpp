@@ -232,7 +232,7 @@ __global__ __launch_bounds__(1024) void acq_centre_kernel(FrontParams p, const R
   }
 }
 
-// tracking metric (mode 1 of acq_metric_kernel) with the samples staged through LDS and register blocking: a workgroup
+// tracking metric (mode 1 of acq_metric_kernel) with the samples' products staged through LDS and register blocking: a workgroup
 // owns 32 calls x 32 lags; a thread owns 4 consecutive lags of a call.  Per tile of 64 correlation taps the workgroup
 // loads the 95 samples (and their partners N earlier) each call needs, once and coalesced; a thread then walks the tile's
 // samples downwards: sample i is tap (q + 63 - i) of lag q, so every sample is read once per thread and feeds up to 4
@@ -242,7 +242,9 @@ constexpr int ACQ_TM_CALLS = 32, ACQ_TM_TILE = 64, ACQ_TM_SPAN = ACQ_TM_TILE + 2
 __global__ __launch_bounds__(256) void acq_track_metric_kernel(const float2 *__restrict__ iq, FrontParams p, const RxState *st, const int *__restrict__ centre,
                                                               float2 *__restrict__ gamma, float *__restrict__ lambda)
 {
-  __shared__ float2 sA[ACQ_TM_CALLS][ACQ_TM_SPAN], sB[ACQ_TM_CALLS][ACQ_TM_SPAN];
+  // what the taps sum: the product x[i] conj(x[i - N]) and the energy pair of a sample, formed once while staging (a sample feeds up to 4 lags of up to 4
+  // threads; the expressions are the per-tap ones of acq_metric_kernel and the build has no FP contraction, so gamma / lambda stay bit-identical)
+  __shared__ float2 sC[ACQ_TM_CALLS][ACQ_TM_SPAN]; __shared__ float sE[ACQ_TM_CALLS][ACQ_TM_SPAN];
   if (st->status & 1) return;
   const int N = p.N, cp = p.cp, tid = threadIdx.x, c = tid >> 3, g4 = (tid & 7) * 4;
   const int call0 = blockIdx.x * ACQ_TM_CALLS, call = call0 + c;
@@ -271,15 +273,19 @@ __global__ __launch_bounds__(256) void acq_track_metric_kernel(const float2 *__r
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const int e = e0 + k * 256;
-        if (e < ACQ_TM_CALLS * ACQ_TM_SPAN) { const int cc = e / ACQ_TM_SPAN, i = e - cc * ACQ_TM_SPAN; sA[cc][i] = av[k]; sB[cc][i] = bv[k]; }
+        if (e < ACQ_TM_CALLS * ACQ_TM_SPAN) {
+          const int cc = e / ACQ_TM_SPAN, i = e - cc * ACQ_TM_SPAN;
+          const float2 a = av[k], b = bv[k];
+          sC[cc][i] = make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); sE[cc][i] = (a.x * a.x + a.y * a.y) + (b.x * b.x + b.y * b.y);
+        }
       }
     }
     __syncthreads();
     // step s reads sample i = g4 + 3 + (T - 1) - s, which is tap (s - 3 + u) of lag g4 + u
     auto step = [&](int s, bool all) {
       const int i = g4 + 3 + (T - 1) - s;
-      const float2 a = sA[c][i], b = sB[c][i];
-      const float cr = a.x * b.x + a.y * b.y, ci = a.y * b.x - a.x * b.y, en = (a.x * a.x + a.y * a.y) + (b.x * b.x + b.y * b.y);
+      const float2 pr = sC[c][i];
+      const float cr = pr.x, ci = pr.y, en = sE[c][i];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const int jj = s - 3 + u;
@@ -1603,8 +1609,9 @@ __device__ __forceinline__ void tps_advance(TpsRegs &t, int mod, unsigned neg, i
   t.f0 = __builtin_amdgcn_alignbit(t.f1, t.f0, diff);
   t.f1 = __builtin_amdgcn_alignbit(t.f2, t.f1, diff);
   t.f2 = (t.f2 >> diff) | (((0xEC80u >> (4 * diff)) & 0xFu) & (0u - bitv));
-  const unsigned low16 = t.f0 & 0xFFFEu;
-  if (low16 == mask_even || low16 == mask_odd) {
+  const unsigned x16 = (t.f0 ^ mask_even) & 0xFFFEu;             // mask_odd is mask_even's complement on bits 1..15
+  (void)mask_odd;
+  if (((x16 + 2u) & 0xFFFCu) == 0u) {                            // x16 (even) is 0 or 0xFFFE: the even or the odd frame's sync word
     const unsigned long long lo = (unsigned long long)t.f0 | ((unsigned long long)t.f1 << 32);
     if (bch_check_tab(T, lo, t.f2) == 0) {
       t.frame_index = (int)(((lo >> 23) & 1ull) << 1 | ((lo >> 24) & 1ull));
@@ -1632,7 +1639,7 @@ __global__ __launch_bounds__(TPS_THREADS) void tps_fsm_par_kernel(FrontParams p,
   constexpr int NS = TPS_THREADS * TPS_SEG + TPS_WARM;
   __shared__ __attribute__((aligned(16))) unsigned char s_pk[NS + (NS / TPS_SEG) * 4 + 8];
   __shared__ unsigned short s_T[7 * 256];
-  auto pm = [](int i) { return i + (i / TPS_SEG) * 4; };
+  auto pm = [](int i) { return (int)((unsigned)i + ((unsigned)i / (unsigned)TPS_SEG) * 4u); };
   static_assert(TPS_WARM % 4 == 0 && TPS_SEG % 4 == 0, "a lane reads whole dwords");
   const int tid = threadIdx.x;
   const int nsym = st->n_symbols, ntot = p.keep_last ? nsym : (nsym > 0 ? nsym - 1 : 0);
