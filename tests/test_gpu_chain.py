@@ -13,14 +13,14 @@ pytestmark = pytest.mark.gpu
 WANT = ("acq", "fft", "eq", "demap", "symdeint", "bitdeint", "vit", "deint", "rs", "ts")
 
 
-def _make(po, const, cr, mode, nsf, seed, lead=1000, snr=None):
+def _make(po, const, cr, mode, nsf, seed, lead=1000, snr=None, noise_seed=5):
     c = po.cfg(const, cr, mode)
     ibits = c.payload * c.m * c.k // c.n
     npk = (272 * ibits * nsf) // (204 * 8)
     ts = po.make_ts(npk, seed)
     iq = po.tx(c, ts, lead_in=lead, tail=3 * c.N)
     if snr is not None:
-        rng = np.random.RandomState(5)
+        rng = np.random.RandomState(noise_seed)
         p = np.mean(np.abs(iq[lead:lead + 100000]) ** 2)
         sig = np.sqrt(p / (10 ** (snr / 10)) / 2)
         iq = (iq + sig * (rng.randn(len(iq)) + 1j * rng.randn(len(iq)))).astype(np.complex64)
@@ -106,6 +106,54 @@ def test_awgn_qam64_post_rs_equal(po, g):
     assert o["rs_corr"] > 1000 and abs(rep.rs_corrected_symbols - o["rs_corr"]) <= 0.01 * o["rs_corr"] + 20
     assert rep.rs_fail_words == o["rs_fail"]
     assert (rx.tap(g.TAP_RS) == o["rs"]).all()
+    rx.close()
+
+
+def test_corrected_sync_bytes_reach_the_descrambler(po, g):
+    """The descrambler's NSYNC walk reads one bit per packet (payload byte 0 == 0xB8) that the RS kernels leave behind: deint_rs_kernel writes it with the
+    word as decoded in its own pass, rs_fix_kernel patches it for the words it decodes.  2k QAM16 1/2 at 12.3 dB with this noise seed: ~1,400 corrected
+    symbols in sparse words (the wavefronts defer them to the second pass), among them inverted sync bytes that arrive corrupted in packets the walk looks at
+    (it tests every 16th packet: energy_descramble_impl.cc:121-141 consumes two items per call) -- a bit left as received would end the descrambler's run
+    there and the TS would differ from the oracle's (checked once by taking the patch out: the test fails)."""
+    c, iq = _make(po, 1, 0, 0, 12, 41, snr=12.3, noise_seed=27)
+    o = po.rx(c, iq, snr_db=12.3, want=("deint", "rs", "ts"))
+    d, r = np.asarray(o["deint"]).reshape(-1, 204), np.asarray(o["rs"]).reshape(-1, 188)
+    n = min(len(d), len(r))
+    corrected = (d[:n, :188] != r[:n]).any(axis=1)
+    q = [p for p in range(16) if r[p, 0] == 0xB8][0]               # where the walk locks: the first NSYNC of the first two items
+    restored = [w for w in np.nonzero((r[:n, 0] == 0xB8) & (d[:n, 0] != 0xB8))[0]
+                if corrected[w // 64 * 64:w // 64 * 64 + 64].sum() < 24 and (w - q) % 16 == 0]
+    assert len(restored) >= 1, "the stream no longer carries the case this test is about"
+    rx = g.Rx(1, 0, 0, max_samples=len(iq), snr_db=12.3, taps=True)
+    rep = rx.run(iq)
+    assert (rx.tap(g.TAP_CP_START) == o["cp_start"]).all()
+    assert rep.rs_fail_words == o["rs_fail"] and abs(rep.rs_corrected_symbols - o["rs_corr"]) <= 20      # a hard decision within float rounding of a boundary may differ
+    gd = rx.tap(g.TAP_DEINT).reshape(-1, 204)[:n]
+    assert all(gd[w, 0] != 0xB8 for w in restored)                  # the GPU, too, received these sync bytes corrupted
+    assert (rx.tap(g.TAP_RS) == o["rs"]).all()
+    ts = rx.tap(g.TAP_TS)
+    assert ts.size == o["ts"].size and (ts == o["ts"]).all()
+    rx.close()
+
+
+def test_stage_timing_modes(po, g):
+    """dvbt_rx_enable_timing: 1 = HIP events around every stage, 2 = around the decoder only (the bench's timed region), 0 = none; the decoded bytes do not depend on it"""
+    c, iq = _make(po, 1, 0, 0, 3, 9)
+    o = po.rx(c, iq, want=("ts",))
+    import torch
+    dev = torch.from_numpy(iq.view(np.float32)).cuda()
+    rx = g.Rx(1, 0, 0, max_samples=len(iq))
+    assert rx.stage_ms("viterbi") < 0                               # nothing timed yet
+    for mode in (2, 1, 0):
+        rx.enable_timing(mode)
+        rx.enqueue_device(dev.data_ptr(), len(iq))                  # the asynchronous entry is the one that carries the events
+        rx.finish()
+        assert (rx.tap(g.TAP_TS) == o["ts"]).all()
+        if mode == 2:
+            assert rx.stage_ms("viterbi") > 0 and rx.stage_ms("fft") < 0 and rx.stage_ms("total") < 0
+        if mode == 1:
+            v = {k: rx.stage_ms(k) for k in ("acq", "fft", "demod", "inner", "viterbi", "rs", "total")}
+            assert all(x > 0 for x in v.values()) and v["total"] >= v["viterbi"]
     rx.close()
 
 
