@@ -11,6 +11,7 @@
 #include <algorithm>
 #include "../../include/dvbt_hip.h"
 #include "dvbt_tables.hpp"
+#include "ts_ring.hpp"
 #include "k_frontend.hpp"
 #include "k_drift.hpp"
 #include "k_backend.hpp"
