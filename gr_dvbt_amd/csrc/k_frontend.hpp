@@ -1551,7 +1551,7 @@ __global__ __launch_bounds__(256) void tps_fsm_kernel(FrontParams p, RxState *st
 // from the TPS bits, FIFO cleared: :978-1028,1240-1241), so a lane that starts TPS_WARM symbols
 // early from a blank state holds the sequential state when it reaches its own segment, provided
 // a frame end with an intact TPS word lies in the warm-up.  Every lane records its state at the
-// start and at the end of its segment; tps_finalize_kernel checks that neighbours agree and
+// start and at the end of its segment; tps_tail_kernel (tps_finalize_body) checks that neighbours agree and
 // otherwise requests the sequential kernel (need_seq), so the result is always the sequential one.
 constexpr int TPS_SEG = 32;           // symbols per lane
 constexpr int TPS_THREADS = 256;      // lanes per workgroup (a workgroup covers TPS_THREADS * TPS_SEG symbols)
