@@ -51,6 +51,8 @@ summary = {"command": "tools/pmc.sh: rocprofv3 --pmc <group> --output-format csv
            "workload": pb["config"],
            "note": "FETCH_SIZE/WRITE_SIZE in KB per dispatch. gfx950: FETCH_SIZE counts 64 B per 128 B request on coalesced streams, so it is doubled in hbm_bytes_corrected (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported. SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* count quad-cycles.",
            "viterbi_algorithmic_bytes": pb["roofline"]["algorithmic_bytes_per_launch"], "kernels": {}}
+if os.path.getmtime(os.path.join(root, "gpurun_out", "pmc", "FETCH_SIZE.json")) < os.path.getmtime(prof) - 3600:   # counters from an earlier run than the kernel stats
+    summary["note"] += "  The PMC passes are older than the kernel stats beside them (tools/final_short.sh does not repeat them): small kernels may have changed since."
 for k, c in out.items():
     e = dict(c)
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
