@@ -274,6 +274,7 @@ struct dvbt_rx {
   uint8_t *bitdeint_lp = nullptr;           // hierarchical modes: the bit de-interleaver's second output
   size_t vit_cap = 0; RsDefer *rs_defer = nullptr; int rs_defer_cap = 0;
   unsigned long long *rs_sync = nullptr;     // bit w: payload byte 0 of RS word w is 0xB8 (deint_rs_kernel / rs_fix_kernel -> descramble_scan_kernel)
+  unsigned soft_grid = 0;     // workgroups the decision scratch has slots for
   float *csi = nullptr; int8_t *soft_a = nullptr; uint16_t *soft_tab = nullptr; unsigned *soft_scratch = nullptr;   // soft-decision mode (k_soft.hpp): channel state per carrier, soft values, A5 + A6 gather table, decision slots
   int timing = 0;             // 0 off, 1 events around every stage, 2 around the decoder only (dvbt_rx_enable_timing)
   bool pending = false;
@@ -364,7 +365,8 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
     // decision slots: one per resident wavefront of the largest launch this handle can make (max_samples), not of the largest launch there is
     // (2048 workgroups = 704 MB: what a 17-superframe segment of 8k QAM64 7/8 uses; a 2-superframe handle of the streaming entry needs 1/8 of that)
     const long long max_vit_soft = (long long)C * P * d.m * d.k / (8 * d.n) + 1;
-    RXHIP(hipMalloc((void **)&h->soft_scratch, sizeof(unsigned) * (size_t)s4_grid(max_vit_soft, d.ntb) * S4_WAVES * S4_SLOT_WORDS));
+    h->soft_grid = s4_grid_bound(max_vit_soft);               // (s4_grid itself is not monotone in the stream's length: ADVICE r04)
+    RXHIP(hipMalloc((void **)&h->soft_scratch, sizeof(unsigned) * (size_t)h->soft_grid * S4_WAVES * S4_SLOT_WORDS));
     hipLaunchKernelGGL(soft_tab_kernel, dim3(64), dim3(256), 0, h->own_stream, h->T.inner_params(d.payload), (const uint16_t *)h->T.H, (const uint16_t *)h->T.Hinv, h->soft_tab);
     RXHIP(hipStreamSynchronize(h->own_stream));
   }
@@ -603,7 +605,7 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
     if (tmv) HIPCHK(hipEventRecord(h->ev[ST_VIT], s));
     // the decoder: four chunks per wavefront, chunk size for whole rounds of the wavefront slots
     const S4Plan sp = s4_plan(max_vit, d.ntb);
-    const unsigned grid = s4_grid(max_vit, d.ntb);             // <= the grid the scratch was sized for at create (C <= max_calls)
+    const unsigned grid = std::min(s4_grid(max_vit, d.ntb), h->soft_grid);   // never more slots than the scratch has (the kernel strides its tasks by gridDim)
     hipLaunchKernelGGL(viterbi_soft4_kernel, dim3(grid), dim3(64 * S4_WAVES), 0, s, (const int8_t *)h->soft_a, h->vit + o.vit_off, (const RxState *)h->st, h->vp,
                        h->soft_scratch, sp.B, sp.nsteps);
   } else {

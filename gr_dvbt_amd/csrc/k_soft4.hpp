@@ -58,12 +58,20 @@ inline S4Plan s4_plan(long long total_out, int ntb)
   return p;
 }
 
-// workgroups of the launch for a stream of total_out bytes (monotone in total_out: the decision scratch of a handle is sized for its largest segment)
+// workgroups of the launch for a stream of total_out bytes.  NOT monotone in total_out: s4_plan raises B with the stream's length, so the task count drops
+// each time B increments (total = 64 * 32768: 2048 workgroups, one byte more: 2017).
 inline unsigned s4_grid(long long total_out, int ntb)
 {
   const S4Plan sp = s4_plan(total_out, ntb);
   const long long tasks = (total_out + 4ll * sp.B - 1) / (4ll * sp.B);
   const long long g = (tasks + S4_WAVES - 1) / S4_WAVES;
+  return (unsigned)(g < 1 ? 1 : (g > S4_GRID ? S4_GRID : g));
+}
+// the largest grid any stream of at most max_total bytes launches (B >= 64 always): what a handle's decision scratch is sized for.  The launch is clamped to
+// it as well (the kernel strides its tasks by gridDim), so the scratch can never be indexed beyond its end whatever s4_plan does
+inline unsigned s4_grid_bound(long long max_total)
+{
+  const long long tasks = (max_total + 255) / 256, g = (tasks + S4_WAVES - 1) / S4_WAVES;
   return (unsigned)(g < 1 ? 1 : (g > S4_GRID ? S4_GRID : g));
 }
 
