@@ -2,6 +2,7 @@
 // every entry point fails with DVBT_ERR_NO_DEVICE when no HIP device is usable.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdarg>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -280,7 +281,7 @@ struct dvbt_rx {
   bool pending = false;
   hipEvent_t ev[ST_COUNT]; double acc_ms[ST_COUNT] = {0}; long n_timed = 0; bool ev_ready = false, ev_recorded = false;
   dvbt_rx_report last; bool have_last = false;
-  dvbt_rx_cut cut = {0};
+  dvbt_rx_cut cut = {0, 0, 0};
   float2 *tps_prev = nullptr, *tps_prev_snap[2] = {nullptr, nullptr}; TpsState *tps_snap[2] = {nullptr, nullptr};  DescrRun *descr_runs = nullptr; int *descr_nruns = nullptr;
   int n_periods = 1; size_t seg_offset = 0;
   std::vector<dvbt_lock_period> periods;    // phase A of the last synchronous run
@@ -350,7 +351,7 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   RXHIP(hipMalloc((void **)&h->maj, sizeof(int) * C)); RXHIP(hipMalloc((void **)&h->sym_index, sizeof(int) * C));
   RXHIP(hipMalloc((void **)&h->bitdeint, C * P + 64));
   if (d.hierarchy != 0) RXHIP(hipMalloc((void **)&h->bitdeint_lp, C * P + 64));
-  h->vit_cap = C * P * d.m * d.k / (8 * d.n) + 4096;
+  h->vit_cap = C * P * d.m * d.k / (8 * d.n) + 4096 + (2u << 20);   // (+ 2 MB: a walk of the streaming entry carries the tail of its Viterbi stream from window to window)
   h->rs_defer_cap = (int)((h->vit_cap / 204 / 64 + 2) * (RS_LANE_MIN - 1));
   RXHIP(hipMalloc((void **)&h->rs_defer, sizeof(RsDefer) * (size_t)h->rs_defer_cap));
   RXHIP(hipMalloc((void **)&h->rs_sync, sizeof(unsigned long long) * (h->vit_cap / 204 / 64 + 2)));
@@ -392,6 +393,7 @@ extern "C" int dvbt_rx_set_cut(dvbt_rx *h, const dvbt_rx_cut *cut)
 {
   if (!h || !cut) return fail(DVBT_ERR_INVALID, "null argument");
   if (cut->stream_symbol_offset < 0 || cut->stream_symbol_offset % 272) return fail(DVBT_ERR_INVALID, "stream_symbol_offset must be a non-negative multiple of 272 (whole superframes)");
+  if (cut->start_delay_symbols < 0 || cut->start_delay_symbols >= 272 || cut->descr_call_phase < 0 || cut->descr_call_phase > 16) return fail(DVBT_ERR_INVALID, "start_delay_symbols must lie in [0, 272), descr_call_phase in [0, 16]");
   h->cut = *cut;
   return DVBT_OK;
 }
@@ -441,6 +443,8 @@ struct EnqOpt {
   bool tail = true;           // byte de-interleaver + RS + descrambler right behind (single period)
   long long avail = 0;        // samples in memory from iq[0] on (0: nsamples): a period of a longer segment is given a look-ahead window, the stream goes on behind it
   bool no_small = false;      // acq_only: not through acq_small_kernel (it has handed the period back: RxState.small_viol)
+  bool cut_set = false;       // the cut of this period is given here instead of by the handle (walk_window: a cut belongs to the first period of its window) ...
+  long long sym_off = 0; int delay = 0;   // ... dvbt_rx_cut.stream_symbol_offset, .start_delay_symbols
 };
 
 // samples at the OFDM elementary rate: the segment itself, or its resampled image (next row 2)
@@ -472,7 +476,7 @@ static int enqueue_tail(dvbt_rx *h, hipStream_t s, long long max_words, long lon
                      h->T.rs_tables(), h->prm.rs_oracle_compat, &h->st->rs_fail, &h->st->rs_corr, h->rs_sync);
   if (h->prm.descramble) {
     hipLaunchKernelGGL(descramble_scan_kernel, dim3(1), dim3(1024), 0, s, (const uint8_t *)h->rs_out, h->st, h->descr_runs, h->descr_nruns,
-                       (const unsigned long long *)h->rs_sync);
+                       (const unsigned long long *)h->rs_sync, h->cut.descr_call_phase - 1);
     hipLaunchKernelGGL(descramble_runs_kernel, dim3(1024), dim3(256), 0, s, (const uint8_t *)h->rs_out, (const uint8_t *)h->T.prbs,
                        (const RxState *)h->st, (const DescrRun *)h->descr_runs, (const int *)h->descr_nruns, h->ts_out);
   }
@@ -486,6 +490,10 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
   if (nsamples > h->chain_max) return fail(DVBT_ERR_CAPACITY, "segment longer than max_samples");
   if (nsamples < (size_t)(2 * d.N + d.cp + 16)) return fail(DVBT_ERR_INVALID, "segment shorter than one acquisition window");
   FrontParams fp = h->fp;
+  const long long cut_sym_off = o.cut_set ? o.sym_off : (long long)h->cut.stream_symbol_offset;
+  const int cut_delay = o.cut_set ? o.delay : h->cut.start_delay_symbols;
+  fp.hunt_known = cut_delay > 0 ? 1 : 0;
+  fp.si_start = cut_delay % 68; fp.fi_start = (d.fi_start + cut_delay / 68) % 4;     // dvbt_rx_cut.start_delay_symbols: the hunt fires that many symbols behind the true start
   fp.ncalls = (int)((nsamples - (2 * d.N + d.cp + 16)) / (d.N + d.cp) + 1);
   fp.hist = o.hist; fp.keep_last = o.keep_last ? 1 : 0; fp.avail = o.avail > 0 ? o.avail : (long long)nsamples;
   const int C = fp.ncalls, N = d.N;
@@ -584,14 +592,14 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
     hipLaunchKernelGGL(tps_fsm_par_kernel, dim3((C + TPS_THREADS * TPS_SEG - 1) / (TPS_THREADS * TPS_SEG)), dim3(TPS_THREADS), 0, s, fp, (const RxState *)h->st, (const SymInfo *)h->info,
                        (const int *)h->maj, h->sym_index, h->tps_edges, h->trk_flags + 8, &h->st->tps_bits, (const unsigned short *)h->T.tps_bch);
     hipLaunchKernelGGL(tps_tail_kernel, dim3(1), dim3(256), 0, s, fp, h->st, (const SymInfo *)h->info, (const int *)h->maj, h->tps_state, h->sym_index,
-                       (const TpsEdge *)h->tps_edges, (const int *)(h->trk_flags + 8), h->trk_flags + 9, 0, h->vp, (long long)h->cut.stream_symbol_offset);
+                       (const TpsEdge *)h->tps_edges, (const int *)(h->trk_flags + 8), h->trk_flags + 9, 0, h->vp, cut_sym_off);
   } else {
     // the pilot engine's members live on (FIFO, symbol and frame counters: reference_signals_impl.h); the sync_start tag on the period's first
     // item clears d_init (the superframe hunt starts over); DBPSK against the last symbol in front of the gap.  Sequential bookkeeping.
     hipLaunchKernelGGL(tps_vote_kernel, dim3((C + 63) / 64), dim3(256), 0, s, (const float2 *)h->tpsval, d.n_tps, (const RxState *)h->st, 0,
                        (const float2 *)h->tps_prev, h->maj, fp.keep_last);
     hipLaunchKernelGGL(tps_tail_kernel, dim3(1), dim3(256), 0, s, fp, h->st, (const SymInfo *)h->info, (const int *)h->maj, h->tps_state, h->sym_index,
-                       (const TpsEdge *)nullptr, (const int *)nullptr, (int *)nullptr, 1, h->vp, (long long)h->cut.stream_symbol_offset);
+                       (const TpsEdge *)nullptr, (const int *)nullptr, (int *)nullptr, 1, h->vp, cut_sym_off);
   }
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_INNER], s));
   InnerParams ip = h->T.inner_params(d.payload);
@@ -892,6 +900,148 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
   h->n_periods = delivering; h->seg_offset = last_off;
   h->last = r; h->have_last = true;
   if (rep) *rep = r;
+  return DVBT_OK;
+}
+
+// ---- one WINDOW of a walk (the streaming entry, dvbt_stream.inc): the lock-period walk of segment_periods over a stretch of a stream that goes on behind it,
+// with what the reference's blocks hold between two work() calls carried in and out.  Two phases: A finds the window's lock periods with the acquisition alone
+// (as segment_periods does), B decodes them in order up to the Viterbi decoder, every one with its own acquisition and with the TRUE answer to "does a later
+// period deliver an item" (the period's last item leaves the demodulator only then, demod_reference_signals_impl.cc:88-94) -- no guess, nothing decoded twice.
+// partial: the stream goes on.  The last period that has items is not final then (its end, and whether its last item is delivered, lie in samples to come): it is
+// left to the next window, which starts its search where that period's search started, with that search's carried average.  The exception is an OPEN period (the
+// lock holds to the window's end) whose superframe start lies at least `establish_calls` calls before the window's last call: it is decoded and kept -- the stream
+// goes over to pieces from it (the head of an epoch).
+// A8, A9 and the descrambler are the caller's (walk flush): the window only appends to the handle's Viterbi stream.
+struct WalkPeriod {
+  size_t off = 0; int n_symbols = 0, call0 = 0, cp_start0 = 0; float avg_in = 0.f; bool carry = false, lost = false;
+  size_t behind = 0; float avg_lost = 0.f;                           // where the reference searches on after this period, and with which average
+  bool decoded = false; int first_out = -1; int n_out_symbols = 0; size_t vit_off = 0; long long n_vit_bytes = 0;
+};
+struct WalkIO {
+  // in
+  bool partial = false;
+  bool carry = false; float avg = 0.f;                               // ofdm_sym_acquisition: d_avg of the call that lost the lock before this window
+  long long hist = 0;                                                // samples of the stream in memory in front of chain[0]
+  bool continuation = false;                                         // the pilot engine has processed items before this window (TpsState / tps_prev are in the handle)
+  size_t acc = 0; int delivering = 0;                                // the walk's Viterbi stream so far (bytes in h->vit), periods that delivered so far
+  bool cut = false; long long cut_sym_off = 0; int cut_delay = 0; size_t vit_pad = 0;   // the first decoded period continues a cut stream; its bytes go to h->vit + vit_pad
+  long long establish_calls = 0;
+  // out
+  std::vector<WalkPeriod> per;
+  size_t next_off = 0; bool next_carry = false; float next_avg = 0.f;   // partial, not established: the next window's search starts here (offset in this window)
+  bool established = false; int head = -1; RxState head_st; long long head_ncalls = 0;   // calls of the head's grid that the window holds
+  bool any_decoded = false; int status_or = 0;
+  int total_symbols = 0;
+};
+
+static int walk_window(dvbt_rx *h, const float2 *chain, size_t chain_n, hipStream_t s, WalkIO &io)
+{
+  const Dims &d = h->d;
+  const size_t L = (size_t)(d.N + d.cp), win = (size_t)(2 * d.N + d.cp + 16);
+  const size_t maxn = h->chain_max;                                  // what one launch sequence of the handle can take: a longer window is looked at through this much
+  std::vector<WalkPeriod> &per = io.per;
+  per.clear(); h->periods.clear();
+  io.established = false; io.head = -1; io.any_decoded = false; io.status_or = 0; io.total_symbols = 0;
+  // ---- phase A: the acquisition alone
+  size_t off = 0; bool carry = io.carry; float avg = io.avg; int fails = 0; bool open = false;
+  for (int guard = 0; off + win <= chain_n; guard++) {
+    if (guard >= 8192 || per.size() >= 4096) { io.status_or |= 256; break; }
+    EnqOpt o; o.acq_only = true; o.use_carry = carry; o.carry_avg = avg; o.hist = io.hist + (long long)off; o.avail = (long long)(chain_n - off);
+    o.init_tries = std::min(ACQ_INIT_TRIES_MAX, ACQ_INIT_TRIES << std::min(fails, 4));
+    size_t look_calls = 767;
+    if (!per.empty()) look_calls = std::min<size_t>(767, std::max<size_t>(47, 4 * (size_t)std::max(per.back().n_symbols, 0)));
+    const size_t rest = std::min(chain_n - off, maxn);
+    size_t look = std::min(rest, win + look_calls * L);
+    if (per.size() < 3 && guard < 8) look = rest;
+    for (;;) {
+      int r = enqueue(h, chain + off, look, s, o); if (r) return r;
+      HIPCHK(hipStreamSynchronize(s));
+      if (!(h->st_host->status & 1) && h->st_host->small_viol && !o.no_small) { o.no_small = true; continue; }
+      if ((h->st_host->status & 3) || look >= rest) break;
+      look = std::min(rest, win + 4 * (look - win) + 3 * L);
+    }
+    const RxState st = *h->st_host;
+    const int tries = (int)std::min<size_t>((size_t)o.init_tries, (look - win) / L + 1);
+    if (st.status & 1) { off += (size_t)tries * L; avg = st.avg; carry = true; fails++; continue; }
+    fails = 0;
+    WalkPeriod p; p.off = off; p.n_symbols = st.n_symbols; p.call0 = st.call0; p.cp_start0 = st.cp_start0; p.avg_in = avg; p.carry = carry; p.lost = (st.status & 2) != 0;
+    p.behind = off + (size_t)(st.call0 + st.n_symbols) * L + L / 2; p.avg_lost = st.avg_lost;
+    per.push_back(p);
+    h->periods.push_back(dvbt_lock_period{(int64_t)off, st.call0, st.cp_start0, st.n_symbols, 0});
+    io.total_symbols += st.n_symbols;
+    if (!p.lost && rest < chain_n - off && !io.partial) io.status_or |= 256;   // (a final window longer than the handle's capacity: cannot happen with the stream's sizing)
+    if (!p.lost || p.behind + win > chain_n) { open = true; break; }   // the lock holds to the window's end, or is lost where its samples run out
+    off = p.behind; avg = p.avg_lost; carry = true;
+  }
+  int zl = -1;                                                       // the last period that has items
+  for (size_t q = 0; q < per.size(); q++) if (per[q].n_symbols >= 1) zl = (int)q;
+  // ---- phase B: the chain over the periods that are final
+  size_t acc = io.acc; int delivering = io.delivering; bool processed = io.continuation; bool cut_pending = io.cut;
+  auto decode = [&](size_t p, bool later) -> int {
+    WalkPeriod &w = per[p];
+    if (p != 0) cut_pending = false;                                 // a cut belongs to the lock period that reaches into the window from the stream before it
+    const int usable = w.n_symbols - (later ? 0 : 1);                // items that leave the demodulator
+    if (usable < 1) return DVBT_OK;
+    EnqOpt o; o.use_carry = w.carry; o.carry_avg = w.avg_in; o.hist = io.hist + (long long)w.off; o.avail = (long long)(chain_n - w.off);
+    o.continuation = processed; o.keep_last = later; o.tail = false;
+    o.cut_set = true; o.sym_off = cut_pending ? io.cut_sym_off : 0; o.delay = cut_pending ? io.cut_delay : 0;
+    // convolutional_deinterleaver_impl.cc:109-120: the tag realigns the block's input to a pair of items (3264 bytes of the walk's stream: h->vit[0] is a multiple of
+    // 3264 bytes into it, the caller sees to that with vit_pad and by compacting in such multiples)
+    o.vit_off = delivering > 0 ? (acc / 3264) * 3264 : (cut_pending ? io.vit_pad : acc);
+    o.init_tries = std::min(ACQ_INIT_TRIES_MAX, std::max(ACQ_INIT_TRIES, w.call0 + 1));
+    size_t span = std::min(chain_n - w.off, maxn);
+    if (w.lost) span = std::min(span, win + (size_t)(w.call0 + w.n_symbols) * L);
+    int r = enqueue(h, chain + w.off, span, s, o); if (r) return r;
+    HIPCHK(hipMemcpyAsync(h->tps_prev, h->tpsval + (size_t)(usable - 1) * d.n_tps, sizeof(float2) * d.n_tps, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    h->pending = false;
+    const RxState &st = *h->st_host;
+    if (st.n_symbols != w.n_symbols || st.call0 != w.call0) io.status_or |= 512;   // (the period's own acquisition must repeat what the walk found)
+    processed = true; cut_pending = false; io.any_decoded = true;
+    w.decoded = true; w.first_out = st.first_out; w.n_out_symbols = st.n_out_symbols; w.vit_off = o.vit_off; w.n_vit_bytes = st.first_out >= 0 ? st.n_vit_bytes : 0;
+    io.status_or |= st.status & ~(1 | 2 | 4);
+    h->periods[p].first_out_symbol = st.first_out >= 0 ? st.first_out + 1 : 0;
+    if (st.first_out >= 0) { acc = o.vit_off + (size_t)st.n_vit_bytes; delivering++; }
+    io.head_st = st;
+    return DVBT_OK;
+  };
+  if (!io.partial) {
+    for (size_t q = 0; q < per.size(); q++) { int r = decode(q, zl > (int)q); if (r) return r; }
+  } else {
+    for (int q = 0; q < zl; q++) { int r = decode((size_t)q, true); if (r) return r; }
+    // (a period that continues a cut stream is never a head: its roundings are the old epoch's)
+    const bool head_cand = zl >= 0 && zl == (int)per.size() - 1 && open && !per[zl].lost && !(cut_pending && zl == 0);
+    if (head_cand) {
+      const long long ncalls = (long long)((std::min(chain_n - per[zl].off, maxn) - win) / L) + 1;
+      io.head_ncalls = ncalls;
+      if (ncalls - per[zl].call0 >= io.establish_calls) {
+        // keep what the pilot engine holds in front of the period: it is handed to the next window when the superframe start comes too late for the stream to go over to pieces
+        HIPCHK(hipMemcpyAsync(h->tps_snap[0], h->tps_state, sizeof(TpsState), hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(h->tps_prev_snap[0], h->tps_prev, sizeof(float2) * d.n_tps, hipMemcpyDeviceToDevice, s));
+        const size_t acc0 = acc; const int del0 = delivering; const bool proc0 = processed, cut0 = cut_pending; const bool any0 = io.any_decoded;
+        int r = decode((size_t)zl, false); if (r) return r;
+        const WalkPeriod &w = per[zl];
+        if (w.decoded && w.first_out >= 0 && ncalls - (w.call0 + w.first_out) >= io.establish_calls) { io.established = true; io.head = zl; }
+        else {
+          acc = acc0; delivering = del0; processed = proc0; cut_pending = cut0; io.any_decoded = any0;
+          per[zl].decoded = false;
+          HIPCHK(hipMemcpyAsync(h->tps_state, h->tps_snap[0], sizeof(TpsState), hipMemcpyDeviceToDevice, s));
+          HIPCHK(hipMemcpyAsync(h->tps_prev, h->tps_prev_snap[0], sizeof(float2) * d.n_tps, hipMemcpyDeviceToDevice, s));
+          HIPCHK(hipStreamSynchronize(s));
+        }
+      }
+    }
+    if (!io.established) {
+      if (zl >= 0) { io.next_off = per[zl].off; io.next_carry = per[zl].carry; io.next_avg = per[zl].avg_in; }
+      else if (open && !per.empty()) { io.next_off = per.back().behind; io.next_carry = true; io.next_avg = per.back().avg_lost; }   // (a lock lost at once where the samples run out)
+      else { io.next_off = off; io.next_carry = carry; io.next_avg = avg; }
+      if (io.next_off > chain_n) io.next_off = chain_n;
+      // the periods from zl on belong to the next window
+      if (zl >= 0) { for (size_t q = (size_t)zl; q < per.size(); q++) io.total_symbols -= per[q].n_symbols; per.resize((size_t)zl); h->periods.resize((size_t)zl); }
+    }
+  }
+  io.acc = acc; io.delivering = delivering; io.continuation = processed; io.cut = cut_pending;
+  h->n_periods = delivering; h->seg_offset = 0;
   return DVBT_OK;
 }
 

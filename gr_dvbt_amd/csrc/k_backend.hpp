@@ -655,23 +655,35 @@ constexpr int DESCR_MAX_RUNS = 1024;
 // packet out of a few KB instead of one byte per 188 out of the whole TS (21,000 cache lines through ONE compute unit: 45 us of the 65-superframe step);
 // nullptr: the bytes themselves.
 __global__ __launch_bounds__(1024) void descramble_scan_kernel(const uint8_t *__restrict__ in, RxState *st, DescrRun *runs, int *nruns,
-                                                              const unsigned long long *__restrict__ sync_bits = nullptr)
+                                                              const unsigned long long *__restrict__ sync_bits = nullptr, int phase16 = -1)
 {
   __shared__ long long s_first;
-  __shared__ long long s_base, s_written; __shared__ int s_dindex, s_nr, s_stop;
+  __shared__ long long s_base, s_written; __shared__ int s_dindex, s_nr, s_stop, s_bad;
   const int tid = threadIdx.x;
   auto nsync = [&](long long pkt) -> bool {                        // is the first byte of packet `pkt` the inverted sync byte?
     return sync_bits ? ((sync_bits[pkt >> 6] >> (pkt & 63)) & 1ull) != 0 : in[pkt * 188] == 0xB8;
   };
-  if (tid == 0) { st->n_ts_bytes = 0; st->descr_base = 0; st->descr_index = 0; st->ts_first_packet = 0; *nruns = 0; }
+  if (tid == 0) { st->n_ts_bytes = 0; st->descr_base = 0; st->descr_index = 0; st->ts_first_packet = 0; st->descr_unclean = 0; *nruns = 0; }
   if (st->sym_off > 0) {
     // continuation of a cut stream: the descrambler of the whole-stream chain locked long ago; this segment delivers
     // every whole 8-packet group from its first NSYNC on (the words before it mix the de-interleaver's zero fill with
     // data, exactly like the first words of a stream; their sync positions hold zeros).  Which of them the stitched
     // stream keeps is the host's decision (gr_dvbt_amd/multi.py::stitch_ts): the two-item hold-back of :139-141
     // belongs to the stream's end, not to a cut.
+    // phase16 >= 0: the whole-stream descrambler runs in calls of two items whose first packets are == phase16 (mod 16) among this segment's RS words (the
+    // streaming entry knows that phase): every such call that lies inside the segment's valid words must find its NSYNC, else the stream's descrambler
+    // searches again here and "every whole group" is not what it delivers -- reported (descr_unclean), the host then walks the calls itself
+    const long long nw = st->n_rs_words;
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    if (phase16 >= 0) {
+      long long s0 = phase16 & 15; while (s0 < 11) s0 += 16;
+      int bad = 0;
+      for (long long c = s0 + 16ll * tid; c + 32 <= nw; c += 16ll * 1024) if (!nsync(c)) bad = 1;
+      if (bad) s_bad = 1;
+    }
+    __syncthreads();
     if (tid == 0) {
-      const long long nw = st->n_rs_words;
       long long q = 0;
       while (q < nw && !nsync(q)) q++;
       if (q < nw) {
@@ -679,6 +691,7 @@ __global__ __launch_bounds__(1024) void descramble_scan_kernel(const uint8_t *__
         st->n_ts_bytes = ((nw - q) / 8) * 1504;
         runs[0].src_byte = q * 188; runs[0].dst_byte = 0; runs[0].nbytes = st->n_ts_bytes; *nruns = st->n_ts_bytes > 0 ? 1 : 0;
       }
+      st->descr_unclean = s_bad;
     }
     return;
   }

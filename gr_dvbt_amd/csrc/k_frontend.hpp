@@ -36,6 +36,9 @@ struct RxState {
   int small_viol;              // acq_small_kernel met a phase-increment switch outside its call: the period goes through the general kernels
   int drift_known_off;         // acq_small_kernel has established that the float-accumulator model (k_drift.hpp) does not apply to this period (increments of both
                                // signs / too small): the host, which reads this block back before it decodes the period, launches none of the drift kernels
+  int descr_unclean;           // a piece of a cut stream (descramble_scan_kernel, sym_off > 0): 1 = not every 16-packet call of the whole-stream descrambler's phase
+                               // (dvbt_rx_cut.descr_phase16) finds its NSYNC inside this piece -- the stream's descrambler re-searches here (energy_descramble_impl.cc:121-141)
+                               // and the host follows it call by call instead of taking the piece's packets in whole groups
 };
 // fields of a TPS word that are the same in every frame (reference_signals_impl.cc:883-916): s17-s22 length, s25-s53 parameters
 constexpr unsigned long long TPS_STATIC_MASK = ((1ull << 54) - 1) & ~((1ull << 17) - 1) & ~(3ull << 23);
@@ -48,7 +51,12 @@ struct FrontParams {
   int keep_last;         // 1: the last acquired symbol is demodulated too.  The reference's demod needs the NEXT item to process one
                          // (demod_reference_signals_impl.cc:88-94), so the last item of a stream never leaves it; the last item in front of
                          // a lost lock does, as soon as the re-acquired stream delivers its first item
-  int pad1;
+  int si_start;          // symbol of the frame at which the superframe hunt fires (with fi_start: the frame).  0 = the reference's test (symbol_index % 68 == 0 in frame
+                         // d_fi_start, demod_reference_signals_impl.cc:122).  Non-zero only for a piece of a cut stream whose epoch began at a superframe start that the
+                         // reference declared on stale counters (dvbt_rx_cut.start_delay_symbols): the piece delivers from that many symbols behind the true start
+  int hunt_known;        // 1 (with si_start / a shifted fi_start: a piece of an epoch on a shifted grid): the hunt fires only once a frame end with a valid TPS word has
+                         // set the counters -- a chain that starts from blank counters holds frame_index 0, which a shifted target frame may be
+  int pad2;
   long long avail;       // samples in memory from the segment's first one on: a tracking window that has crept beyond its call's 2N + cp + 16 samples (the reference then
                          // reads and WRITES past its d_norm / d_corr arrays, ofdm_sym_acquisition_impl.cc:166-186,416-419: undefined there) reads the stream's own
                          // samples here, and zeros at or beyond this bound -- as oracle/o_acq.c does
@@ -1517,7 +1525,7 @@ __device__ __forceinline__ void tps_fsm_body(FrontParams p, RxState *st, int nit
         s_si[i] = (unsigned char)si;
         if (s_sync[i]) t.d_init = 0;                             // sync_start tag: hunt the superframe start again (:115-116)
         int sf = 0;
-        if (!t.d_init && (si % 68) == 0 && (fi % 4) == p.fi_start) { t.d_init = 1; sf = 1; if (s_first_out < 0) s_first_out = base + i; }
+        if (!t.d_init && (si % 68) == p.si_start && (fi % 4) == p.fi_start && (!p.hunt_known || t.symbol_index_known)) { t.d_init = 1; sf = 1; if (s_first_out < 0) s_first_out = base + i; }
         s_flag[i] = t.d_init ? (sf ? 2 : 1) : 0;                 // 0 dropped, 1 produced, 2 produced + superframe_start
       }
       s_t = t;
@@ -1596,7 +1604,7 @@ inline std::vector<uint16_t> tps_bch_table_host()
 // (The first version walked a TpsState with 64-bit variable shifts and fetched every symbol's two values from LDS inside the dependent chain:
 // ~600 cycles per symbol, 236 symbols per lane = 61 us.)
 struct TpsRegs { unsigned f0, f1, f2; int symbol_index, known, frame_index, prev_mod; };
-__device__ __forceinline__ void tps_advance(TpsRegs &t, int mod, unsigned neg, int fi_start, unsigned mask_even, unsigned mask_odd,
+__device__ __forceinline__ void tps_advance(TpsRegs &t, int mod, unsigned neg, int fi_start, int si_start, int hunt_known, unsigned mask_even, unsigned mask_odd,
                                             int &si_out, int &cand, const unsigned short *T, unsigned long long *tps_bits)
 {
   const int diff = (mod - t.prev_mod) & 3;
@@ -1621,7 +1629,7 @@ __device__ __forceinline__ void tps_advance(TpsRegs &t, int mod, unsigned neg, i
     t.f0 = 0; t.f1 = 0; t.f2 = 0;
   }
   si_out = si;
-  cand = (si == 0) && ((fi & 3) == fi_start);
+  cand = (si == si_start) && ((fi & 3) == fi_start) && (!hunt_known || t.known);
 }
 __device__ __forceinline__ TpsState tps_pack(const TpsRegs &r)
 {
@@ -1673,7 +1681,7 @@ __global__ __launch_bounds__(TPS_THREADS) void tps_fsm_par_kernel(FrontParams p,
     const unsigned w = nxt;
     nxt = word(g + 4);                                             // the next dword is on its way while this one is walked (the array has 8 spare bytes)
 #pragma unroll
-    for (int k = 0; k < 4; k++) tps_advance(t, (int)((w >> (8 * k)) & 3u), (w >> (8 * k + 2)) & 1u, p.fi_start, mask_even, mask_odd, si, cand, s_T, nullptr);
+    for (int k = 0; k < 4; k++) tps_advance(t, (int)((w >> (8 * k)) & 3u), (w >> (8 * k + 2)) & 1u, p.fi_start, p.si_start, p.hunt_known, mask_even, mask_odd, si, cand, s_T, nullptr);
   }
   const int seg = s0 / TPS_SEG;
   edges[seg].start = tps_pack(t);
@@ -1685,7 +1693,7 @@ __global__ __launch_bounds__(TPS_THREADS) void tps_fsm_par_kernel(FrontParams p,
     for (int k = 0; k < 4; k++) {
       const int s = g + k;
       if (s < s1) {
-        tps_advance(t, (int)((w >> (8 * k)) & 3u), (w >> (8 * k + 2)) & 1u, p.fi_start, mask_even, mask_odd, si, cand, s_T, tps_bits);
+        tps_advance(t, (int)((w >> (8 * k)) & 3u), (w >> (8 * k + 2)) & 1u, p.fi_start, p.si_start, p.hunt_known, mask_even, mask_odd, si, cand, s_T, tps_bits);
         sym_index[s] = si;
         if (cand && first == 0x7fffffff) first = s;
       }

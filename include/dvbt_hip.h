@@ -370,7 +370,20 @@ int  dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out);
  * de-interleaver's zero fill with data, as at a stream start: the piece before delivers those packets (post-roll).
  * gr_dvbt_amd/multi.py (plan_cuts / stitch_ts) holds the host side: concatenating the trimmed pieces gives, byte for byte,
  * the TS of one chain over the whole stream.  offset 0 (the default) = the piece holds the beginning of the stream. */
-typedef struct { int64_t stream_symbol_offset; } dvbt_rx_cut;
+typedef struct {
+  int64_t stream_symbol_offset;
+  /* the two fields below are what the streaming entry (dvbt_rx_stream_*) knows about the stream a piece continues; 0 / 0 = the plain cut above.
+   * start_delay_symbols (0..271): the piece delivers from this many OFDM symbols BEHIND the superframe start its own pilot engine finds.  The reference's
+   * demodulator re-hunts the superframe start after a lost CP lock on counters that went on counting through the gap (lib/demod_reference_signals_impl.cc:115-136,
+   * the pilot engine's members live on): when no whole TPS frame lies between the new lock and the counters' next "frame d_fi_start, symbol 0", it declares the
+   * start there -- a whole number of symbols off the transmitted grid -- and decodes from that symbol until the next loss.  Pieces that continue such a lock
+   * period must start where the reference's chain counts from.
+   * descr_call_phase: 1 + (first packet of the whole-stream descrambler's two-item calls, mod 16, counted in this piece's RS words); 0 = unknown.  When known
+   * the piece checks that every such call inside it finds its NSYNC (lib/energy_descramble_impl.cc:121-141 re-searches otherwise) and reports the outcome
+   * to the streaming entry, which then follows the descrambler call by call. */
+  int32_t start_delay_symbols;
+  int32_t descr_call_phase;
+} dvbt_rx_cut;
 int  dvbt_rx_set_cut(dvbt_rx *h, const dvbt_rx_cut *cut);   /* applies to the segments enqueued afterwards */
 /* iq: host pointer to nsamples complex64 (copied to the device first) */
 int  dvbt_rx_segment_run(dvbt_rx *h, const void *iq_host, size_t nsamples, dvbt_rx_report *report);
@@ -442,6 +455,9 @@ typedef struct {
    * pulls its own packets with their index in the stream (dvbt_rx_stream_pull_chunk); all ranks' chunks ordered by that index are the single chain's TS:
    * gathering them is the design's one exchange step (RCCL over xGMI in bench.py / gr_dvbt_amd/multi.py).  world = 0 or 1: no sharding. */
   int rank, world;
+  /* page-locked ring the decoded TS waits in until it is pulled (0 = 96 MB, ~24 s of the fastest DVB-T transport stream); allocated at the first delivery; a
+   * consumer that falls further behind than this is served from heap chunks */
+  int64_t ts_ring_bytes;
 } dvbt_rx_stream_params;
 typedef struct {
   int32_t status;              /* dvbt_rx_report.status bits of the pieces, OR-ed (bit 1 only when the lock was lost inside a piece) | bit 5: a piece
@@ -453,6 +469,7 @@ typedef struct {
   int64_t first_ts_packet;         /* RS word (counted from that superframe start) of the first TS packet, -1 before it is known */
   int32_t constellation, hierarchy, code_rate;   /* the parameters the chains run with; -1 while they are being detected (DVBT_AUTO) */
   int32_t auto_configured;         /* 1: they were taken from the stream's TPS word */
+  int32_t in_walk;                 /* 1: no lock period is established (the stream's beginning, or behind a lost CP lock): the stream is being walked window by window */
 } dvbt_rx_stream_info;
 typedef struct dvbt_rx_stream dvbt_rx_stream;
 int  dvbt_rx_stream_create(const dvbt_rx_stream_params *p, dvbt_rx_stream **out);
@@ -469,6 +486,9 @@ int64_t dvbt_rx_stream_pull_chunk(dvbt_rx_stream *s, void *ts_host, size_t cap, 
  * the reference's run) and waits for it; pull then drains the rest */
 int  dvbt_rx_stream_finish(dvbt_rx_stream *s);
 int  dvbt_rx_stream_status(const dvbt_rx_stream *s, dvbt_rx_stream_info *info);
+/* what the stream did, as text: one line per walk window, per epoch that was established, per piece that left its epoch (a lost CP lock) or whose descrambler
+ * had to be followed on the host; returns the trace's length (the text is cut to cap - 1 characters, 0-terminated).  Bounded at 64 KB. */
+int64_t dvbt_rx_stream_trace(const dvbt_rx_stream *s, char *dst, size_t cap);
 void dvbt_rx_stream_destroy(dvbt_rx_stream *s);
 
 /* ------------------------------------------------------------------ the exchange step of a sharded stream

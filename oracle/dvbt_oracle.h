@@ -186,6 +186,8 @@ typedef struct {
   long long *call_pos;        /* optional, meta_cap entries: sample at which the general_work call that delivered acquired symbol i began */
   unsigned char *sync_flag;   /* optional, meta_cap entries: 1 = the item carries the sync_start tag (first item of a lock period) */
   unsigned char *bitdeint_lp_out; /* optional, sym_cap symbols: the bit de-interleaver's second output (hierarchical modes; port 0 = bitdeint_out feeds the decoder) */
+  unsigned char *sf_flag;     /* optional, meta_cap entries: 1 = demod_reference_signals put the superframe_start tag on this acquired item (the start of a lock
+                                 period's delivery: demod_reference_signals_impl.cc:118-136), 2 = the item was delivered downstream without one */
 } o_rx_taps;
 
 int o_rx_run(const o_cfg *c, const ocf *iq, size_t nsamples, float snr_db, int bsize,

@@ -93,6 +93,7 @@ int o_rx_run_cut(const o_cfg *c, const ocf *iq, size_t nsamples, float snr_db, i
       int produced = o_demod_work(d, fft + j * (size_t)N, eq + nout * (size_t)P, sync_tag[j], &sf, &si, info);
       if (t->sym_index && j < t->meta_cap) t->sym_index[j] = si;
       if (t->freq_offset && j < t->meta_cap) t->freq_offset[j] = info[0];
+      if (t->sf_flag && j < t->meta_cap) t->sf_flag[j] = (unsigned char)(sf ? 1 : (produced ? 2 : 0));
       if (sf) {
         if (t->first_out_symbol < 0) t->first_out_symbol = (int)j; else truncated++;
         if (nper < O_MAX_PERIODS) per_start[nper++] = nout;        /* output item at which this lock period starts */

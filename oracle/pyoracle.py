@@ -63,7 +63,7 @@ class Taps(C.Structure):
         ("first_out_symbol", C.c_int), ("n_acquired", C.c_int),
         ("rs_fail", C.c_int), ("rs_corr", C.c_int),
         ("t_stage", C.c_double * 10), ("ts_first_packet", C.c_longlong), ("stream_rs_items", C.c_longlong),
-        ("freq_offset", C.c_void_p), ("call_pos", C.c_void_p), ("sync_flag", C.c_void_p), ("bitdeint_lp_out", C.c_void_p)]
+        ("freq_offset", C.c_void_p), ("call_pos", C.c_void_p), ("sync_flag", C.c_void_p), ("bitdeint_lp_out", C.c_void_p), ("sf_flag", C.c_void_p)]
 
 
 _lib = None
@@ -347,6 +347,7 @@ def rx(c, iq, snr_db=30.0, bsize=768, rs_compat=0, want=("rs",), max_sym_taps=No
     t.freq_offset = alloc("freq_offset", (nsym,), np.int32)
     t.call_pos = alloc("call_pos", (nsym,), np.int64)
     t.sync_flag = alloc("sync_flag", (nsym,), np.uint8)
+    t.sf_flag = alloc("sf_flag", (nsym,), np.uint8)
     t.meta_cap = nsym
     trunc = L.o_rx_run_cut(C.byref(c), _p(iq), len(iq), C.c_float(snr_db), bsize, rs_compat, sym_off, C.byref(t))
     out = {"truncated": trunc, "n_acquired": t.n_acquired, "first_out_symbol": t.first_out_symbol,
@@ -357,7 +358,7 @@ def rx(c, iq, snr_db=30.0, bsize=768, rs_compat=0, want=("rs",), max_sym_taps=No
                  ("rs", t.rs_n), ("ts", t.ts_n)):
         if k in bufs:
             out[k] = bufs[k][:n]
-    for k in ("cp_start", "epsilon", "sym_index", "freq_offset", "call_pos", "sync_flag"):
+    for k in ("cp_start", "epsilon", "sym_index", "freq_offset", "call_pos", "sync_flag", "sf_flag"):
         out[k] = bufs[k][:t.n_acquired]
     starts = np.flatnonzero(out["sync_flag"])
     out["lock_periods"] = [(int(out["call_pos"][a]), int(b - a)) for a, b in zip(starts, list(starts[1:]) + [t.n_acquired])]
