@@ -210,6 +210,15 @@ class Rx:
         _chk(self.L.dvbt_rx_lock_periods(self.h, buf, n))
         return [(b.offset, b.first_call, b.cp_start0, b.n_symbols, b.first_out_symbol) for b in buf[:n]]
 
+    def walk_stats(self):
+        """(passes through the one-launch tracker, passes through the general kernels, calls per chunk of the one-launch tracker, its longest window)"""
+        class W(C.Structure):
+            _fields_ = [("small_passes", C.c_int64), ("general_passes", C.c_int64), ("small_chunk_calls", C.c_int32), ("small_max_calls", C.c_int32)]
+        w = W()
+        self.L.dvbt_rx_walk_stats.argtypes = [C.c_void_p, C.POINTER(W)]
+        _chk(self.L.dvbt_rx_walk_stats(self.h, C.byref(w)))
+        return w.small_passes, w.general_passes, w.small_chunk_calls, w.small_max_calls
+
     def tap_device_ptr(self, tap):
         return self.L.dvbt_rx_tap_device_ptr(self.h, tap)
 

@@ -286,6 +286,7 @@ struct dvbt_rx {
   int n_periods = 1; size_t seg_offset = 0;
   std::vector<dvbt_lock_period> periods;    // phase A of the last synchronous run
   DriftBufs drift = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; double *drift_mem = nullptr;   // k_drift.hpp
+  long long n_small = 0, n_general = 0;     // acquisition-only passes of the lock-period walk through acq_small_kernel / through the general kernels (dvbt_rx_walk_stats)
   int sym_grid = 512;                       // workgroups of symbol8k_kernel (two per CU)
   int *sym_ticket = nullptr;                // its symbol counter
 };
@@ -517,8 +518,10 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
   if (o.acq_only && !o.no_small && C <= ACQ_SMALL_MAX_CALLS) {
     // the lock-period walk's short look-ahead windows: everything behind the initial search in one launch, work in proportion to the symbols the lock holds
     const int cpc = acq_small_cpc(d.cp);
+    h->n_small++;
     hipLaunchKernelGGL(acq_small_kernel, dim3(1), dim3(64 * (1 + cpc / 2)), (size_t)cpc * 2 * (d.cp + 2 * ACQ_R) * sizeof(float2), s, iq, fp, h->st, h->meta, cpc, h->drift.flags);
   } else {
+  if (o.acq_only) h->n_general++;
   {   // where the tracking metric is computed: CP position predicted per call from coarse estimates every ACQ_ANCHOR calls (sample-clock drift)
     const int n_anchors = (C - 1) / ACQ_ANCHOR;
     if (n_anchors > 0) hipLaunchKernelGGL(acq_anchor_kernel, dim3(n_anchors), dim3(1024), acq_anchor_lds_bytes(N, d.cp), s, iq, fp, (const RxState *)h->st, h->anchor_pos);
@@ -1140,6 +1143,13 @@ extern "C" int dvbt_rx_lock_periods(dvbt_rx *h, dvbt_lock_period *out, int cap)
   const int n = (int)h->periods.size();
   for (int i = 0; i < n && i < cap && out; i++) out[i] = h->periods[i];
   return n;
+}
+
+extern "C" int dvbt_rx_walk_stats(dvbt_rx *h, dvbt_walk_stats *out)
+{
+  if (!h || !out) return fail(DVBT_ERR_INVALID, "null argument");
+  out->small_passes = h->n_small; out->general_passes = h->n_general; out->small_chunk_calls = acq_small_cpc(h->d.cp); out->small_max_calls = ACQ_SMALL_MAX_CALLS;
+  return DVBT_OK;
 }
 
 extern "C" double dvbt_rx_stage_ms(dvbt_rx *h, const char *stage)

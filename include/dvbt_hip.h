@@ -410,6 +410,11 @@ typedef struct {
   int32_t first_out_symbol;   /* 1 + symbol of the period at which superframe_start fired, 0 if it delivered nothing downstream */
 } dvbt_lock_period;
 int  dvbt_rx_lock_periods(dvbt_rx *h, dvbt_lock_period *out, int cap);
+/* how the handle's lock-period walks ran so far: acquisition-only passes through the one-launch tracker (acq_small_kernel: look-ahead windows of up to
+ * small_max_calls calls, the tracking metric in chunks of small_chunk_calls calls -- 16 for a short guard interval down to 2 for cp = 2048, what fits the LDS) and
+ * through the general kernels (long windows, periods the one-launch tracker handed back) */
+typedef struct { int64_t small_passes, general_passes; int32_t small_chunk_calls, small_max_calls; } dvbt_walk_stats;
+int  dvbt_rx_walk_stats(dvbt_rx *h, dvbt_walk_stats *out);
 /* copy a tap of the last finished segment to host memory; returns bytes written */
 int64_t dvbt_rx_read_tap(dvbt_rx *h, int tap, void *dst_host, size_t cap_bytes);
 /* device pointer of a tap's buffer (for RCCL gathers of the decoded packets) */

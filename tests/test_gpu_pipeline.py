@@ -1,6 +1,7 @@
 """Segments in flight (bench.py --pipeline): several handles, each on its own HIP stream, decode at the same time and
 share the machine -- the persistent 8k symbol kernel takes its symbols from an atomic counter and its workgroups start whenever the other
-segments' Viterbi workgroups make room.  Every handle must deliver exactly what a handle that has the GPU to itself delivers."""
+segments' Viterbi workgroups make room.  Every handle must deliver exactly what a handle that has the GPU to itself delivers -- and that is the
+ORACLE's chain over the same samples (po.rx), so the test never compares the HIP path with itself alone."""
 import numpy as np
 import pytest
 import torch
@@ -18,9 +19,12 @@ def test_handles_in_flight_equal_a_handle_alone(po, const, cr, mode, nsf):
     iqs = [po.tx(c, po.make_ts((272 * ibits * nsf) // (204 * 8), 100 + k), lead_in=500 + 700 * k, tail=3 * c.N) for k in range(3)]
     alone = []
     for iq in iqs:
+        o = po.rx(c, iq, want=("vit", "ts"))                   # the reference bytes: the oracle's chain (clean loopback: bit-exact at every integer tap)
         rx = g.Rx(const, cr, mode, max_samples=len(iq))
         rep = rx.run(iq)
-        alone.append((rep.n_symbols, rep.first_out_symbol, int(rep.n_ts_bytes), rx.tap(g.TAP_VITERBI).copy(), rx.tap(g.TAP_TS).copy()))
+        assert (rep.n_symbols, rep.first_out_symbol) == (o["n_acquired"], o["first_out_symbol"])
+        assert len(o["ts"]) == rep.n_ts_bytes > 0 and (rx.tap(g.TAP_TS) == o["ts"]).all() and (rx.tap(g.TAP_VITERBI) == o["vit"]).all()
+        alone.append((rep.n_symbols, rep.first_out_symbol, int(rep.n_ts_bytes), o["vit"].copy(), o["ts"].copy()))
         rx.close()
     devs = [torch.from_numpy(iq.view(np.float32)).cuda() for iq in iqs]
     torch.cuda.synchronize()

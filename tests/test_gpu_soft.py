@@ -72,10 +72,7 @@ def test_soft_mode_through_the_streaming_entry(po, const, cr, mode, nsf, seg_sf,
     too; on a clean stream the TS pulled is the hard chain's over the whole stream"""
     c = po.cfg(const, cr, mode)
     iq = po.stream_slice(c, nsf, 9)
-    rx = g.Rx(const, cr, mode, max_samples=len(iq))
-    rx.run(iq)
-    ref = rx.tap(g.TAP_TS).copy()
-    rx.close()
+    ref = po.rx(c, iq, want=("ts",))["ts"].copy()                  # the oracle's chain over the whole stream (a clean stream: soft and hard decisions decode the same bytes)
     st = g.RxStream(const, cr, mode, segment_superframes=seg_sf, soft_decision=1)
     out = []
     for pos in range(0, len(iq), call):
@@ -87,6 +84,40 @@ def test_soft_mode_through_the_streaming_entry(po, const, cr, mode, nsf, seg_sf,
     st.close()
     ts = np.concatenate(out)
     assert info.status & ~2 == 0 and len(ts) == len(ref) > 0 and (ts == ref).all()
+
+
+def _sharded(po, iq, world, call, **kw):
+    """world stream objects in one process (one GPU), every rank pushed the same stream; the ranks' chunks ordered by their packet index"""
+    ranks = [g.RxStream(rank=r, world=world, **kw) for r in range(world)]
+    chunks = []
+    for pos in range(0, len(iq), call):
+        for st in ranks:
+            st.push(iq[pos:pos + call])
+        for r, st in enumerate(ranks):
+            chunks += [(fp, r, b) for fp, b in st.pull_chunks()]
+    for r, st in enumerate(ranks):
+        st.finish()
+        chunks += [(fp, r, b) for fp, b in st.pull_chunks()]
+    infos = [st.info() for st in ranks]
+    for st in ranks:
+        st.close()
+    chunks.sort(key=lambda t: t[0])
+    at = chunks[0][0]
+    for fp, r, b in chunks:                                        # contiguous, no packet twice
+        assert fp == at, (fp, at, r)
+        at += len(b) // 188
+    return np.concatenate([b for _, _, b in chunks]), infos, {r for _, r, _ in chunks}
+
+
+def test_soft_mode_sharded(po):
+    """soft decisions with rank / world: the pieces of a sharded stream go through the soft decoder on every rank; the chunks in packet order are the oracle's TS"""
+    const, cr, mode = g.QAM64, g.C7_8, g.T8k
+    c = po.cfg(const, cr, mode)
+    iq = po.stream_slice(c, 8, 9)
+    ref = po.rx(c, iq, want=("ts",))["ts"]
+    ts, infos, who = _sharded(po, iq, 2, 40 * 8448 + 3, constellation=const, code_rate=cr, mode=mode, segment_superframes=1, soft_decision=1)
+    assert all(i.status & ~2 == 0 for i in infos) and who == {0, 1}
+    assert len(ts) == len(ref) > 0 and (ts == ref).all()
 
 
 # ---------------------------------------------------------------- the soft path against an independent model (oracle/o_soft.c: a MODEL of the kernels' specification,

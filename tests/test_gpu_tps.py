@@ -137,3 +137,35 @@ def test_auto_short_stream_and_no_signal(po):
             st.push(noise[a:a + 200000])
     assert st.info().status & 4
     st.close()
+
+
+def test_auto_configured_sharded_stream(po):
+    """DVBT_AUTO with rank / world: every rank probes the head of the (same) stream by itself, builds its chains for what the TPS word names and replays the head;
+    the ranks' chunks ordered by their packet index are the oracle's TS with the true parameters"""
+    const, cr, mode = g.QAM64, g.C7_8, g.T8k
+    c = po.cfg(const, cr, mode)
+    iq = po.stream_slice(c, 9, 21)
+    want = po.rx(c, iq, want=("ts",))["ts"]
+    world = 2
+    ranks = [g.RxStream(g.AUTO, g.AUTO, mode, segment_superframes=1, hierarchy=g.AUTO, rank=r, world=world) for r in range(world)]
+    chunks, step = [], 40 * (c.N + c.cp) + 3
+    for a in range(0, len(iq), step):
+        for st in ranks:
+            st.push(iq[a:a + step])
+        for r, st in enumerate(ranks):
+            chunks += [(fp, r, b) for fp, b in st.pull_chunks()]
+    for r, st in enumerate(ranks):
+        st.finish()
+        chunks += [(fp, r, b) for fp, b in st.pull_chunks()]
+    infos = [st.info() for st in ranks]
+    for st in ranks:
+        st.close()
+    assert all(i.auto_configured == 1 and (i.constellation, i.hierarchy, i.code_rate) == (const, g.NH, cr) and i.status & ~2 == 0 for i in infos)
+    chunks.sort(key=lambda t: t[0])
+    at = chunks[0][0]
+    for fp, r, b in chunks:
+        assert fp == at, (fp, at, r)
+        at += len(b) // 188
+    assert {r for _, r, _ in chunks} == {0, 1}
+    ts = np.concatenate([b for _, _, b in chunks])
+    assert len(ts) == len(want) > 0 and (ts == want).all()
