@@ -443,10 +443,21 @@ void dvbt_rx_destroy(dvbt_rx *h);
  * chains' own buffers).  rx.max_samples, rx.resample_* are ignored / must be 0 (no resampler in front).
  * A piece is decoded once the stream is known to go on far enough for the next piece to stand on its own (one superframe + 76 symbols behind its begin), so the
  * TS lags the input by about segment_superframes + 1 superframes.
- * Limits: the stream's head must reach its first superframe start within the first piece (segment_superframes + 2 superframes), else that
- * much of it is dropped (status bit 2, the stream's origin moves); a CP lock lost inside a later piece is reported (status bit 1, and bit 5: packets
- * are missing) and the piece goes on from the next superframe start it can reach from the sample where the reference's search resumes -- one or two
- * superframes are not delivered (the reference itself loses the acquisition, a TPS frame and the wait for a superframe start there).
+ * A lost CP lock: the stream follows the reference through it, byte for byte (tests/test_gpu_stream.py, tests/test_gpu_stream_loss.py: dropouts, noise bursts,
+ * BASELINE config 5 at 9 dB).  While no lock period is established -- at the stream's beginning and from a piece in which the lock is lost -- the stream is WALKED
+ * window by window (the lock-period walk of dvbt_rx_segment_run with the blocks' state carried from window to window: the peak detector's average, the pilot engine's
+ * counters that go on counting through the gap, the byte de-interleaver's alignment and contents, the descrambler's call phase), synchronously; once a lock period
+ * has held for two superframes behind its superframe start the stream goes back to pieces, cut on the superframe grid the reference's chain counts on -- also when
+ * that grid is a whole number of symbols off the transmitted one (a superframe start declared on stale counters, lib/demod_reference_signals_impl.cc:115-136: the
+ * reference decodes garbage from there to the next loss, and so does the stream).  status bit 1 reports the loss; dvbt_rx_stream_trace tells what was done.
+ * Sharded streams (world > 1): a rank walks a lost lock to the end of its own piece's samples; the result is the single chain's whenever the reference's chain is
+ * back in a lock period on the transmitted grid by the next piece's begin (status bit 5 otherwise: the other ranks cannot know).  A stream that never establishes a
+ * lock period (config 5 at 9 dB) is walked by every rank and delivered by rank 0.
+ * Memory per stream object (S = segment_superframes, sf = one superframe of samples = 272 (N + cp) x 8 bytes: 18.4 MB at 8k, 4.6 MB at 2k, guard 1/32):
+ *   device: two sample buffers of (S + 3.7) sf each + the two chains' own buffers (~0.55 x a sample buffer each; x 2.2 in soft-decision mode);
+ *   S = 16 at 8k: 2 x 362 MB + 2 x ~200 MB.  The first lost lock adds two walk buffers of twice a sample buffer each (2 x 725 MB at S = 16, 8k);
+ *   page-locked host: the TS ring (ts_ring_bytes, default 96 MB, allocated at the first delivery; a consumer that falls further behind is served from the heap) and
+ *   32 MB of staging for host pushes below 2 MB (allocated at the first such push; dvbt_rx_stream_push_device never needs it).
  * Threading: like every handle, one thread at a time. */
 /* TPS auto-configuration (gr-dvbt's TODO.txt:28 "Autodetect transmission params"): rx.constellation, rx.hierarchy and / or rx.code_rate = DVBT_AUTO.  The
  * transmission mode and the guard interval must be given (the front end is built from them); everything else the stream says itself: the head of the stream
