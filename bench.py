@@ -521,6 +521,45 @@ def per_block_cpp(iq, workload):
     return res
 
 
+def cpp_multi_host(workload, loops=6, seg_sf=64):
+    """BASELINE config 4's host in C++ (gr_dvbt_amd/host/rx_multi_example.cpp, one rank: one GPU per box) on the bench line's workload: the baseband resident in
+    device memory (uploaded before the clock starts), pushed through dvbt_rx_stream_push_device in calls of eight superframes, pieces of 64 superframes, ONE
+    asynchronous double-buffered RCCL step per push (dvbt_rx_stream_gather_enqueue / _wait, the packets device resident until the root's download).  The stretch of
+    64 superframes behind the first one is pushed `loops` times (a seamless stream but for the encoder's memory at the seam)."""
+    import subprocess
+    import tempfile
+    from oracle import pyoracle as po
+    exe = os.path.join(ROOT, "gr_dvbt_amd", "host", "rx_multi_example")
+    if not os.path.exists(exe) or workload != "8k_qam64_7_8":
+        return None
+    c = po.cfg(po.QAM64, po.C7_8, po.T8k)
+    sf = 272 * (c.N + c.cp)
+    iq = po.stream_slice(c, 66, 77)
+    tmp = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    fin, idf = os.path.join(tmp, "bb.cf32"), os.path.join(tmp, "nccl.id")
+    try:
+        iq.tofile(fin)
+        best = None
+        for _ in range(2):
+            if os.path.exists(idf):
+                os.remove(idf)
+            r = subprocess.run([exe, "0", "1", idf, "8k", "qam64", "7/8", fin, os.path.join(tmp, "none.ts"), str(seg_sf), "0", "bench", str(loops),
+                                str(po.STREAM_LEAD_IN + sf), str(64 * sf), str(8 * sf)], capture_output=True, text=True, timeout=600,
+                               env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+            if r.returncode != 0:
+                return {"error": (r.stdout[-200:] + r.stderr[-300:])}
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            best = d if best is None or d["msamples_per_s"] > best["msamples_per_s"] else best
+        return {"value": best["msamples_per_s"], "unit": "Msamples/s", "x_realtime": round(best["msamples_per_s"] / REALTIME_MSPS, 1), "world": 1, "samples": best["samples"],
+                "seconds": best["seconds"], "exchange_steps": best["exchange_steps"], "ts_bytes": best["ts_bytes"], "status": best["status"],
+                "entry": "dvbt_rx_stream_push_device + dvbt_rx_stream_gather_enqueue / _wait (RCCL, one rank)", "segment_superframes": seg_sf, "superframes_per_push": 8}
+    finally:
+        for f in (fin, idf):
+            if os.path.exists(f):
+                os.remove(f)
+        os.rmdir(tmp)
+
+
 def timed_run(job, steps, warmup):
     torch, dist = job.torch, job.dist
     for _ in range(warmup):
@@ -721,6 +760,7 @@ def main():
         out["extra_workloads"]["config5_8k_qpsk_7_8_at_the_prescribed_noise"] = config5_noise(torch, g)
         out["stream_abi"] = stream_abi(g)
         out["per_block_abi"] = per_block_abi(g, a.workload)
+        out["cpp_multi_host"] = cpp_multi_host(a.workload)
     if rank == 0:
         if not a.no_cpu_baseline and world == 1:             # the contract: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_superframes)

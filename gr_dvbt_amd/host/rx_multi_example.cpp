@@ -1,11 +1,18 @@
 // rx_multi_example.cpp -- BASELINE config 4's host without Python: ONE baseband stream decoded by `world` processes, one per GPU, the decoded packets brought
-// to rank 0 by the design's single exchange per step (dvbt_rx_stream_gather: grouped ncclSend / ncclRecv on device buffers = an RCCL gather over xGMI).
+// to rank 0 by the design's single exchange per step (dvbt_rx_stream_gather_enqueue / _wait: ONE group of ncclSend / ncclRecv on device buffers = an RCCL gather
+// over xGMI, asynchronous and double-buffered: step k + 1 is issued before step k's packets are consumed, the packets stay in device memory until the root
+// downloads them: dvbt_rx_stream_set_device_output).
 // Every process reads the same file (a flowgraph would fan the source out), pushes it into its own dvbt_rx_stream (rank / world: it copies and decodes only
-// the pieces k % world == rank), and joins a gather every GATHER_EVERY work() calls; rank 0 orders the runs it receives by their packet index -- that is the
+// the pieces k % world == rank), and joins a step every GATHER_EVERY work() calls; rank 0 orders the runs it receives by their packet index -- that is the
 // TS of one chain over the whole stream -- and writes the file.  No RCCL headers: the communicator comes from the library (dvbt_rccl_unique_id on rank 0, the
 // 128 bytes carried to the others through a file, dvbt_rccl_comm_create everywhere).
 //   rx_multi_example <rank> <world> <id file> <2k|8k> <qpsk|qam16|qam64> <1/2|2/3|3/4|5/6|7/8> <baseband.cf32> <out.ts> [superframes per piece] [device]
+//                    [bench <loops> <loop_from> <loop_len> <samples per push>]
 // started once per rank (e.g. `for r in 0 1 ... ; do rx_multi_example $r 8 /tmp/id ... & done`); rank r uses device r unless told otherwise.
+// bench: the throughput of this host on samples that are RESIDENT in device memory (what bench.py's line measures for the Python host): the file is uploaded
+// once, then pushed from device memory (dvbt_rx_stream_push_device) -- its first loop_from + loop_len samples, then the stretch [loop_from, loop_from + loop_len)
+// `loops` - 1 more times (a whole number of superframes from a superframe start on: the stream goes on seamlessly but for the encoder's and interleaver's
+// memory at the seam); Msamples/s from the first push to the last packet at rank 0; out.ts is not written.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -53,34 +60,76 @@ int main(int argc, char **argv)
     dvbt_rx_stream *st = nullptr;
     check(dvbt_rx_stream_create(&p, &st));
     dvbt_dims d; check(dvbt_get_dims(con, DVBT_NH, cr, DVBT_G1_32, mode, &d));
+    check(dvbt_rx_stream_set_device_output(st, 0));                    // the decoded TS waits in device memory for the exchange step
+    const bool bench = argc > 15 && !std::strcmp(argv[11], "bench");
     std::FILE *f = std::fopen(argv[7], "rb"); if (!f) { std::perror("open"); return 1; }
     const size_t call = (size_t)64 * (d.fft_length + d.cp_length);
-    const int GATHER_EVERY = 8, SLOT_PACKETS = 4096;
+    const int GATHER_EVERY = 8, SLOT_PACKETS = bench ? 1 << 16 : 4096;
     std::vector<float> in(2 * call);
     std::vector<unsigned char> got((size_t)world * SLOT_PACKETS * 188);
     std::vector<dvbt_gather_chunk> chunks((size_t)world);
     std::map<long long, std::vector<unsigned char>> runs;            // rank 0: first packet -> bytes
-    long long calls = 0, steps = 0, samples = 0;
-    int all_done = 0;
-    auto step = [&]() {
-      const long long n = dvbt_rx_stream_gather(st, comm, 0, SLOT_PACKETS, rank == 0 ? got.data() : nullptr, got.size(), rank == 0 ? chunks.data() : nullptr, &all_done);
+    long long calls = 0, steps = 0, samples = 0, ts_bytes = 0, order_errors = 0, last_end = -1;
+    int all_done = 0, in_flight = 0;
+    auto take = [&]() {                                              // the oldest step in flight
+      const long long n = dvbt_rx_stream_gather_wait(st, comm, rank == 0 ? got.data() : nullptr, got.size(), rank == 0 ? chunks.data() : nullptr, &all_done);
       check((int)(n < 0 ? n : 0));
-      steps++;
-      if (rank == 0) for (int r = 0; r < world; r++) if (chunks[r].nbytes > 0)
-        runs[chunks[r].first_packet].assign(got.begin() + chunks[r].offset, got.begin() + chunks[r].offset + chunks[r].nbytes);
+      in_flight--;
+      if (rank == 0) for (int r = 0; r < world; r++) if (chunks[r].nbytes > 0) {
+        ts_bytes += chunks[r].nbytes;
+        if (bench) { if (world == 1 && last_end >= 0 && chunks[r].first_packet != last_end) order_errors++; last_end = chunks[r].first_packet + chunks[r].nbytes / 188; }
+        else runs[chunks[r].first_packet].assign(got.begin() + chunks[r].offset, got.begin() + chunks[r].offset + chunks[r].nbytes);
+      }
     };
-    size_t n;
-    while ((n = std::fread(in.data(), 8, call, f)) > 0) {
-      check(dvbt_rx_stream_push(st, in.data(), n));
-      samples += (long long)n;
-      if (++calls % GATHER_EVERY == 0) step();
+    auto step = [&]() {                                              // issue a step; consume the one before it while this one travels
+      check(dvbt_rx_stream_gather_enqueue(st, comm, 0, SLOT_PACKETS));
+      in_flight++; steps++;
+      if (in_flight == 2) take();
+    };
+    double seconds = 0.0;
+    if (bench) {
+      const long long loops = std::atoll(argv[12]), loop_from = std::atoll(argv[13]), loop_len = std::atoll(argv[14]); const size_t per_push = (size_t)std::atoll(argv[15]);
+      std::fseek(f, 0, SEEK_END); const size_t total = (size_t)std::ftell(f) / 8; std::fseek(f, 0, SEEK_SET);
+      if ((size_t)(loop_from + loop_len) > total || loops < 1 || per_push < call) { std::fprintf(stderr, "bench: bad loop arguments\n"); return 2; }
+      std::vector<float> all(2 * total);
+      if (std::fread(all.data(), 8, total, f) != total) { std::perror("read"); return 1; }
+      void *dev = dvbt_device_malloc(total * 8); if (!dev) { std::fprintf(stderr, "device allocation failed\n"); return 1; }
+      check(dvbt_copy_to_device(dev, all.data(), total * 8));
+      const auto t0 = std::chrono::steady_clock::now();
+      auto push_range = [&](size_t a, size_t e) {
+        for (size_t at = a; at < e; at += per_push) {
+          const size_t n = std::min(per_push, e - at);
+          check(dvbt_rx_stream_push_device(st, (const char *)dev + 8 * at, n, nullptr));
+          samples += (long long)n;
+          step();
+        }
+      };
+      push_range(0, (size_t)(loop_from + loop_len));
+      for (long long k = 1; k < loops; k++) push_range((size_t)loop_from, (size_t)(loop_from + loop_len));
+      check(dvbt_rx_stream_finish(st));
+      while (!all_done) { step(); }
+      while (in_flight) take();
+      seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      dvbt_device_free(dev);
+    } else {
+      size_t n;
+      while ((n = std::fread(in.data(), 8, call, f)) > 0) {
+        check(dvbt_rx_stream_push(st, in.data(), n));
+        samples += (long long)n;
+        if (++calls % GATHER_EVERY == 0) step();
+      }
+      check(dvbt_rx_stream_finish(st));
+      while (!all_done) step();
+      while (in_flight) take();
     }
     std::fclose(f);
-    check(dvbt_rx_stream_finish(st));
-    while (!all_done) step();
     dvbt_rx_stream_info inf; check(dvbt_rx_stream_status(st, &inf));
     int rc = 0;
-    if (rank == 0) {
+    if (rank == 0 && bench) {
+      std::printf("{\"world\": %d, \"samples\": %lld, \"seconds\": %.4f, \"msamples_per_s\": %.1f, \"ts_bytes\": %lld, \"exchange_steps\": %lld, \"order_errors\": %lld, \"status\": %d}\n",
+                  world, samples, seconds, samples / seconds / 1e6, ts_bytes, steps, order_errors, inf.status);
+      if (order_errors) rc = 1;
+    } else if (rank == 0) {
       std::FILE *o = std::fopen(argv[8], "wb"); if (!o) { std::perror("open"); return 1; }
       long long at = -1, total = 0, gaps = 0;
       for (auto &kv : runs) {                                        // ordered by packet index: the single chain's TS

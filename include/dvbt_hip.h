@@ -511,8 +511,8 @@ void dvbt_rx_stream_destroy(dvbt_rx_stream *s);
  * north_star: "C++ host code ... a single RCCL gather of decoded TS packets over xGMI".  One process per GPU; every process creates a dvbt_rx_stream with its
  * rank / world, is pushed the same stream and decodes its own pieces (no data-path collective).  Per step, dvbt_rx_stream_gather moves every rank's next run
  * of finished packets to `root` in ONE group of ncclSend / ncclRecv on device buffers (a gather of fixed-stride slots: 64-byte header {first packet index,
- * byte count, drained flag} + packets, the layout of gr_dvbt_amd/multi.py) and hands root the runs with their packet indices; ordered by that index they are
- * the single chain's TS.  librccl.so is opened with dlopen at first use (no link-time dependency).  The communicator can come from here
+ * byte count, drained flag, error flag} + packets, the layout of gr_dvbt_amd/multi.py; the headers go to every rank in the same group) and hands root the runs
+ * with their packet indices; ordered by that index they are the single chain's TS.  librccl.so is opened with dlopen at first use (no link-time dependency).  The communicator can come from here
  * (dvbt_rccl_unique_id on one rank, its 128 bytes carried to the others by the host -- a file, a socket, MPI --, then dvbt_rccl_comm_create everywhere:
  * ncclGetUniqueId / ncclCommInitRank), so a host needs no RCCL headers.  gr_dvbt_amd/host/rx_multi_example.cpp is such a host. */
 typedef struct dvbt_rccl_comm dvbt_rccl_comm;
@@ -520,10 +520,19 @@ int  dvbt_rccl_unique_id(void *id128_out);                                    /*
 int  dvbt_rccl_comm_create(const void *id128, int rank, int world, int device, dvbt_rccl_comm **out);   /* collective over the `world` processes */
 void dvbt_rccl_comm_destroy(dvbt_rccl_comm *c);
 typedef struct { int64_t first_packet; int64_t nbytes; int64_t offset; } dvbt_gather_chunk;   /* rank r's run: packet index in the stream's TS, bytes, where they sit in ts_host */
-/* collective: every rank calls it with the same root and slot_packets (the stride of the exchange in 188-byte packets; a rank gives at most that much per step).
- * root: ts_host (cap bytes) receives the runs in rank order, chunks[world] describes them; returns the bytes written.  Others: ts_host / chunks may be NULL;
- * returns 0.  *all_done (every rank) = 1 once every rank's stream is finished and drained -- root reads that from the headers and returns it to the others in
- * the same call.  Negative: dvbt_status. */
+/* The step, asynchronous and double-buffered (what a host that wants the exchange behind its decode calls; bench.py's Python path does the same with
+ * torch.distributed).  dvbt_rx_stream_set_device_output (before the first push): the decoded TS stays in device memory (a ring of ring_bytes, 0 = 64 MB; pull /
+ * pull_chunk then refuse) and a step copies its run device to device into the send slot -- no PCIe hop on any rank but the root's one download.
+ * dvbt_rx_stream_gather_enqueue: collective (the same root and slot_packets on every rank; a rank gives at most slot_packets packets per step); issues ONE group of
+ * ncclSend / ncclRecv on the communicator's own HIP stream -- the slot to the root, the 64-byte header to every rank -- and returns at once; at most two steps in
+ * flight.  dvbt_rx_stream_gather_wait: the oldest step in flight.  root: ts_host (cap >= world * slot_packets * 188) receives the runs in rank order, chunks[world]
+ * describes them; returns the bytes written.  Others: ts_host / chunks may be NULL; returns 0.  *all_done (every rank, from the headers of the same step) = 1 once
+ * every rank's stream is finished and drained.  A rank that fails in front of a step's group sends an empty slot with an error flag: the step completes
+ * everywhere and fails on every rank (DVBT_ERR_STATE) -- no rank is left waiting.  Receive space is allocated on the root only. */
+int  dvbt_rx_stream_set_device_output(dvbt_rx_stream *s, size_t ring_bytes);
+int  dvbt_rx_stream_gather_enqueue(dvbt_rx_stream *s, dvbt_rccl_comm *c, int root, int slot_packets);
+int64_t dvbt_rx_stream_gather_wait(dvbt_rx_stream *s, dvbt_rccl_comm *c, void *ts_host, size_t cap, dvbt_gather_chunk *chunks, int *all_done);
+/* the two at once (blocking): one group and one synchronisation per step */
 int64_t dvbt_rx_stream_gather(dvbt_rx_stream *s, dvbt_rccl_comm *c, int root, int slot_packets, void *ts_host, size_t cap, dvbt_gather_chunk *chunks, int *all_done);
 
 /* ------------------------------------------------------------------ test hooks (used by tests/ only)

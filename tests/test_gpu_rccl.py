@@ -86,7 +86,8 @@ def test_bench_refuses_more_ranks_than_devices():
 def test_cpp_host_gathers_over_rccl(tmp_path):
     """gr_dvbt_amd/host/rx_multi_example: BASELINE config 4's host in C++ -- a sharded dvbt_rx_stream per process, the communicator from the library
     (dvbt_rccl_unique_id / dvbt_rccl_comm_create = ncclGetUniqueId / ncclCommInitRank through dlopen'd librccl), the packets brought to rank 0 by
-    dvbt_rx_stream_gather (ONE group of ncclSend / ncclRecv on device buffers per step + the step's control word), ordered by packet index and written out.
+    dvbt_rx_stream_gather_enqueue / _wait (ONE group of ncclSend / ncclRecv on device buffers per step, asynchronous and double-buffered, the packets device
+    resident until the root's download), ordered by packet index and written out.
     One rank here (one GPU per test box); the TS file must be the oracle's chain over the whole stream."""
     import numpy as np
     sys.path.insert(0, ROOT)
@@ -105,3 +106,30 @@ def test_cpp_host_gathers_over_rccl(tmp_path):
     assert "0 gaps (status 0)" in r.stdout and "exchange steps" in r.stdout, r.stdout
     got = np.fromfile(fout, np.uint8)
     assert len(got) == len(want) > 0 and (got == want).all()
+
+
+def test_cpp_host_bench_mode_on_resident_samples(tmp_path):
+    """the same host on samples that are resident in device memory (what bench.py's cpp_multi_host line runs): the stretch behind the first superframe pushed three
+    times from device memory, a step per push; every packet arrives in order and their number is what three passes deliver"""
+    import json
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from oracle import pyoracle as po
+    import gr_dvbt_amd as g
+    from conftest import host_example
+    exe = host_example("rx_multi_example")
+    c = po.cfg(g.QAM64, g.C7_8, g.T8k)
+    sf = 272 * (c.N + c.cp)
+    nsf = 6
+    iq = po.stream_slice(c, nsf, 6)
+    fin, idf = tmp_path / "bb.cf32", tmp_path / "nccl.id"
+    iq.tofile(fin)
+    loops = 3
+    r = subprocess.run([exe, "0", "1", str(idf), "8k", "qam64", "7/8", str(fin), str(tmp_path / "none.ts"), "2", "0", "bench", str(loops), str(po.STREAM_LEAD_IN + sf),
+                        str(4 * sf), str(sf)], capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    pps = po.packets_per_superframe(c)
+    assert d["order_errors"] == 0 and d["samples"] == po.STREAM_LEAD_IN + sf + loops * 4 * sf
+    # the stream: 1 + 3 x 4 superframes, the reference's chain starts one frame early and holds two items back at the end
+    assert abs(d["ts_bytes"] // 188 - (1 + loops * 4) * pps) <= pps, d
