@@ -7,7 +7,7 @@
 // TS of one chain over the whole stream -- and writes the file.  No RCCL headers: the communicator comes from the library (dvbt_rccl_unique_id on rank 0, the
 // 128 bytes carried to the others through a file, dvbt_rccl_comm_create everywhere).
 //   rx_multi_example <rank> <world> <id file> <2k|8k> <qpsk|qam16|qam64> <1/2|2/3|3/4|5/6|7/8> <baseband.cf32> <out.ts> [superframes per piece] [device]
-//                    [bench <loops> <loop_from> <loop_len> <samples per push>]
+//                    [bench <loops> <loop_from> <loop_len> <samples per push> [pushes per exchange step] [slot packets]]
 // started once per rank (e.g. `for r in 0 1 ... ; do rx_multi_example $r 8 /tmp/id ... & done`); rank r uses device r unless told otherwise.
 // bench: the throughput of this host on samples that are RESIDENT in device memory (what bench.py's line measures for the Python host): the file is uploaded
 // once, then pushed from device memory (dvbt_rx_stream_push_device) -- its first loop_from + loop_len samples, then the stretch [loop_from, loop_from + loop_len)
@@ -64,7 +64,8 @@ int main(int argc, char **argv)
     const bool bench = argc > 15 && !std::strcmp(argv[11], "bench");
     std::FILE *f = std::fopen(argv[7], "rb"); if (!f) { std::perror("open"); return 1; }
     const size_t call = (size_t)64 * (d.fft_length + d.cp_length);
-    const int GATHER_EVERY = 8, SLOT_PACKETS = bench ? 1 << 16 : 4096;
+    const int GATHER_EVERY = 8, SLOT_PACKETS = bench ? (argc > 17 ? std::atoi(argv[17]) : 1 << 16) : 4096;
+    const long long pushes_per_step = bench && argc > 16 ? std::max(1, std::atoi(argv[16])) : 1;
     std::vector<float> in(2 * call);
     std::vector<unsigned char> got((size_t)world * SLOT_PACKETS * 188);
     std::vector<dvbt_gather_chunk> chunks((size_t)world);
@@ -72,7 +73,8 @@ int main(int argc, char **argv)
     long long calls = 0, steps = 0, samples = 0, ts_bytes = 0, order_errors = 0, last_end = -1;
     int all_done = 0, in_flight = 0;
     auto take = [&]() {                                              // the oldest step in flight
-      const long long n = dvbt_rx_stream_gather_wait(st, comm, rank == 0 ? got.data() : nullptr, got.size(), rank == 0 ? chunks.data() : nullptr, &all_done);
+      // (bench: the runs are looked at where the step's download put them, dvbt_rccl_step_buffer: no copy on the host)
+      const long long n = dvbt_rx_stream_gather_wait(st, comm, rank == 0 && !bench ? got.data() : nullptr, got.size(), rank == 0 ? chunks.data() : nullptr, &all_done);
       check((int)(n < 0 ? n : 0));
       in_flight--;
       if (rank == 0) for (int r = 0; r < world; r++) if (chunks[r].nbytes > 0) {
@@ -95,13 +97,20 @@ int main(int argc, char **argv)
       if (std::fread(all.data(), 8, total, f) != total) { std::perror("read"); return 1; }
       void *dev = dvbt_device_malloc(total * 8); if (!dev) { std::fprintf(stderr, "device allocation failed\n"); return 1; }
       check(dvbt_copy_to_device(dev, all.data(), total * 8));
+      {   // warm-up: one pass of a stream of its own (the exchange buffers, the ring, the kernels' code are in place when the clock starts)
+        dvbt_rx_stream *w = nullptr; check(dvbt_rx_stream_create(&p, &w)); check(dvbt_rx_stream_set_device_output(w, 0));
+        check(dvbt_rx_stream_push_device(w, dev, (size_t)(loop_from + loop_len), nullptr)); check(dvbt_rx_stream_finish(w));
+        int wd = 0, fl = 0;
+        while (!wd) { check(dvbt_rx_stream_gather_enqueue(w, comm, 0, SLOT_PACKETS)); fl++; const long long r = dvbt_rx_stream_gather_wait(w, comm, nullptr, 0, rank == 0 ? chunks.data() : nullptr, &wd); check((int)(r < 0 ? r : 0)); fl--; }
+        dvbt_rx_stream_destroy(w);
+      }
       const auto t0 = std::chrono::steady_clock::now();
       auto push_range = [&](size_t a, size_t e) {
         for (size_t at = a; at < e; at += per_push) {
           const size_t n = std::min(per_push, e - at);
           check(dvbt_rx_stream_push_device(st, (const char *)dev + 8 * at, n, nullptr));
           samples += (long long)n;
-          step();
+          if (++calls % pushes_per_step == 0) step();
         }
       };
       push_range(0, (size_t)(loop_from + loop_len));

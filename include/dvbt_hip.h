@@ -532,6 +532,9 @@ typedef struct { int64_t first_packet; int64_t nbytes; int64_t offset; } dvbt_ga
 int  dvbt_rx_stream_set_device_output(dvbt_rx_stream *s, size_t ring_bytes);
 int  dvbt_rx_stream_gather_enqueue(dvbt_rx_stream *s, dvbt_rccl_comm *c, int root, int slot_packets);
 int64_t dvbt_rx_stream_gather_wait(dvbt_rx_stream *s, dvbt_rccl_comm *c, void *ts_host, size_t cap, dvbt_gather_chunk *chunks, int *all_done);
+/* root, after a wait with ts_host = NULL: the runs stay where the step's download put them -- chunks[r].offset then counts from this page-locked buffer (valid
+ * until the second next wait): a root that writes the packets on needs no copy of its own (at the headline rate the TS is ~15 GB/s) */
+const void *dvbt_rccl_step_buffer(const dvbt_rccl_comm *c);
 /* the two at once (blocking): one group and one synchronisation per step */
 int64_t dvbt_rx_stream_gather(dvbt_rx_stream *s, dvbt_rccl_comm *c, int root, int slot_packets, void *ts_host, size_t cap, dvbt_gather_chunk *chunks, int *all_done);
 
