@@ -161,6 +161,7 @@ class Job:
         from oracle import pyoracle as po
         from gr_dvbt_amd import multi
         self.torch, self.g, self.dist, self.rank, self.world, self.local, self.multi, self.po = torch, g, dist, rank, world, local, multi, po
+        self.args = a
         # where the collectives' tensors live: device memory under RCCL (backend nccl), host memory under gloo (the gather is then staged through pinned host buffers)
         self.host_staged = bool(dist) and dist.get_backend() == "gloo"
         self.cdev = "cpu" if self.host_staged else f"cuda:{local}"
@@ -221,7 +222,7 @@ class Job:
             depth = max(1, getattr(a, "pipeline", 1))            # handles (each with its own HIP stream) that take this piece's steps in turn
             rxs, streams, views = [], [], []
             for _ in range(depth):
-                rx = g.Rx(const, cr, mode, max_samples=len(iq), device=local, viterbi_chunk_bytes=chunk, snr_db=snr_db, **kw)
+                rx = g.Rx(const, cr, mode, max_samples=len(iq), device=local, viterbi_chunk_bytes=chunk, snr_db=snr_db, launch_graph=1 if getattr(a, "graph", False) else 0, **kw)
                 rx.set_cut(cu["sym_off"])
                 rxs.append(rx); streams.append(_stream(torch, i * depth + len(streams)))
                 views.append(torch.as_tensor(_DevView(rx.tap_device_ptr(g.TAP_TS), cap), device=f"cuda:{local}"))
@@ -567,10 +568,13 @@ def timed_run(job, steps, warmup):
     for _ in range(warmup):
         job.step()
     job.drain()
-    for p in job.pieces:
-        for rx in p["rxs"]:
-            rx.enable_timing(2)                     # HIP events around the dominant kernel only (the roofline's launch duration): every further event record
-                                                    # holds an idle stream for ~6 us, which shows in a step that runs alone (--pipeline 1)
+    if not getattr(job.args, "graph", False):
+        for p in job.pieces:
+            for rx in p["rxs"]:
+                rx.enable_timing(2)                 # HIP events around the dominant kernel only (the in-flight launch interval): every further event record
+                                                    # holds an idle stream for ~6 us, which shows in a step that runs alone (--pipeline 1).  With the step replayed as a
+                                                    # HIP graph (the default) the timed region carries no events at all: the kernel's own duration (roofline.solo_launch_ms)
+                                                    # is measured with events right behind it, launch by launch
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -649,6 +653,8 @@ def main():
     ap.add_argument("--superframes", type=int, default=64, help="payload superframes per GPU per step (SURVEY 8d: >= 64 for throughput runs)")
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--segments", type=int, default=1, help="pieces per GPU: the rank's part of the stream is cut again, one handle + HIP stream per piece")
+    ap.add_argument("--graph", action="store_true", help="replay every step as ONE HIP graph launch (dvbt_rx_params.launch_graph) instead of enqueueing it launch by launch; measured: no "
+                    "difference (4.673 vs 4.670 ms with one step in flight, 4.379 vs 4.369 with three: the step is a chain of DEPENDENT kernels, not of launch calls), so it is not the default")
     ap.add_argument("--pipeline", type=int, default=3, help="steps in flight per piece: handles (own HIP stream each) that take the piece's steps in turn")
     ap.add_argument("--from-file-rate", action="store_true",
                     help="feed the 10 Msps file format: rational_resampler 64/70 + multiply_const run on the device in front of the chain "
@@ -716,10 +722,10 @@ def main():
         d = job.dims
         depth = len(job.pieces[0]["rxs"])
         vit_ms = job.stage_avg("viterbi")                         # average over the timed steps' launches
-        stage_avg = {"viterbi": round(vit_ms, 4)}                 # the timed region carries events around the decoder only
+        stage_avg = {"viterbi": round(vit_ms, 4)} if vit_ms > 0 else None   # (the timed region carries events around the decoder only; none with --graph)
         solo = job.solo_stage_ms()                                # every stage, one step in flight, right after the timed region
         alg_bytes = sum(r.n_out_symbols * d.payload_length + r.n_viterbi_bytes for r in reps) / nseg
-        solo_ms = solo["viterbi"] if depth > 1 else vit_ms       # the kernel's own duration: one step in flight
+        solo_ms = solo["viterbi"] if (depth > 1 or vit_ms <= 0) else vit_ms       # the kernel's own duration: one step in flight
         achieved = alg_bytes / (solo_ms * 1e-3) / 1e9 if solo_ms > 0 else 0.0
         traffic, traffic_src = profiled_traffic(a.workload, job.nsf, int(alg_bytes))
         n_ts = check.get("ts_bytes") or sum(int(r.n_ts_bytes) for r in reps)
@@ -749,7 +755,7 @@ def main():
                                  "config.steps_in_flight steps shared the machine; traffic = PMC bytes per launch (FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE), "
                                  "taken by separate rocprofv3 --pmc passes of this command: " + str(traffic_src),
                          "algorithmic_bytes_per_launch": int(alg_bytes), "solo_launch_ms": round(solo_ms, 4),
-                         "in_flight_launch_ms": round(vit_ms, 4), "in_flight_achieved": round(alg_bytes / (vit_ms * 1e-3) / 1e9, 2) if vit_ms > 0 else None,
+                         "in_flight_launch_ms": round(vit_ms, 4) if vit_ms > 0 else None, "in_flight_achieved": round(alg_bytes / (vit_ms * 1e-3) / 1e9, 2) if vit_ms > 0 else None,
                          "chain_frac": round(msps / world * 1e6 * (8 + n_ts / n_stream) / 1e9 / HBM_PEAK_GBS, 6),
                          "hbm_copy_gbs": hbm_copy_gbs(torch, f"cuda:{local}")},
             "ms_per_step_dispersion": job.step_ms,

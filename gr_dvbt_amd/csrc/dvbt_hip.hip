@@ -286,6 +286,9 @@ struct dvbt_rx {
   int n_periods = 1; size_t seg_offset = 0;
   std::vector<dvbt_lock_period> periods;    // phase A of the last synchronous run
   DriftBufs drift = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; double *drift_mem = nullptr;   // k_drift.hpp
+  struct GraphEntry { const void *iq; size_t n; hipStream_t s; long long sym_off; int delay, phase; hipGraphExec_t exec; };
+  std::vector<GraphEntry> graphs;           // launch_graph: the captured launch sequences (a handful: a receiver's ring of segments)
+  int ncu = 256;
   long long n_small = 0, n_general = 0;     // acquisition-only passes of the lock-period walk through acq_small_kernel / through the general kernels (dvbt_rx_walk_stats)
   int sym_grid = 512;                       // workgroups of symbol8k_kernel (two per CU)
   int *sym_ticket = nullptr;                // its symbol counter
@@ -296,6 +299,7 @@ static void rx_free(dvbt_rx *h)
   void *all[] = {h->bitdeint_lp, h->st_ctx[0], h->st_ctx[1], h->meta_ctx[0], h->meta_ctx[1], h->tps_prev_snap[0], h->tps_prev_snap[1], h->tps_snap[0], h->tps_snap[1], h->csi, h->soft_a, h->soft_tab, h->soft_scratch, h->rs_defer, h->rs_sync, h->drift_mem, h->drift.delta, h->drift.flags, h->tps_prev, h->descr_runs, h->descr_nruns, h->centre, h->anchor_pos, h->sym_ticket, h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags, h->trk_eps, h->d_iq, h->rs_iq, h->acq_carry, h->g_init, h->l_init, h->g_trk, h->l_trk, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
                  h->info, h->maj, h->sym_index, h->labels, h->symdeint_tap, h->bitdeint, h->vit, h->deint_tap, h->rs_out, h->ts_out};
   for (void *q : all) if (q) (void)hipFree(q);
+  for (auto &ge : h->graphs) if (ge.exec) (void)hipGraphExecDestroy(ge.exec);
   if (h->st_host) (void)hipHostFree(h->st_host);
   if (h->ev_ready) for (int i = 0; i < ST_COUNT; i++) (void)hipEventDestroy(h->ev[i]);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -382,7 +386,7 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   RXCHK(set_lds((const void *)symbol8k_kernel<true, false>, S8_LDS_BYTES)); RXCHK(set_lds((const void *)symbol8k_kernel<true, true>, S8_LDS_BYTES));
   RXCHK(set_lds((const void *)symbol2k_kernel<false, false>, S2_LDS_BYTES)); RXCHK(set_lds((const void *)symbol2k_kernel<false, true>, S2_LDS_BYTES));
   RXCHK(set_lds((const void *)symbol2k_kernel<true, false>, S2_LDS_BYTES)); RXCHK(set_lds((const void *)symbol2k_kernel<true, true>, S2_LDS_BYTES));
-  { int ncu = 256; (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->prm.device); h->sym_grid = s8_grid(ncu); }
+  { int ncu = 256; (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->prm.device); h->sym_grid = s8_grid(ncu); h->ncu = ncu; }
   RXCHK(set_lds((const void *)inner_kernel<6>, inner_lds_bytes(P)));
   RXCHK(set_lds((const void *)acq_anchor_kernel, acq_anchor_lds_bytes((int)N, d.cp)));
   RXCHK(set_lds((const void *)acq_small_kernel, (size_t)acq_small_cpc(d.cp) * 2 * (d.cp + 2 * ACQ_R) * sizeof(float2)));
@@ -633,7 +637,7 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
     // traceback overlap (V3_WARM + ntraceback - 1 windows per chunk).  Measured on 65 superframes: 3 rounds of
     // ~2900-byte chunks beat 5 rounds of ~1700 (less overlap) and 1 round of ~8600 (the SIMD's arbiter favours the older of its
     // two wavefronts, which then finishes long before the other: profiles/r02_viterbi_attribution.jsonl)
-    int ncu = 256; (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->prm.device);
+    const int ncu = h->ncu;                                        // (read at create: nothing but stream operations inside enqueue, which may be under capture)
     const long long slots = (long long)ncu * V3_WAVES_PER_CU * 4;   // chunks resident at once
     constexpr long long kMaxChunk = 3000;
     long long rounds = (max_vit + slots * kMaxChunk - 1) / (slots * kMaxChunk);
@@ -669,6 +673,30 @@ extern "C" int dvbt_rx_segment_enqueue_device(dvbt_rx *h, const void *iq_device,
   const float2 *chain; size_t chain_n;
   int r = prepare_chain(h, (const float2 *)iq_device, nsamples, s, &chain, &chain_n); if (r) return r;
   h->n_periods = 1; h->seg_offset = 0;
+  if (h->prm.launch_graph && !h->timing && !h->rsd.ri) {
+    // the launch sequence as ONE graph launch: captured the first time this (segment, length, stream, cut) is seen
+    for (auto &ge : h->graphs)
+      if (ge.iq == chain && ge.n == chain_n && ge.s == s && ge.sym_off == h->cut.stream_symbol_offset && ge.delay == h->cut.start_delay_symbols && ge.phase == h->cut.descr_call_phase) {
+        HIPCHK(hipGraphLaunch(ge.exec, s));
+        h->cur_stream = s; h->pending = true;
+        return DVBT_OK;
+      }
+    if (h->graphs.size() < 16) {
+      hipGraph_t gr = nullptr; hipGraphExec_t ex = nullptr;
+      HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      const int r = enqueue(h, chain, chain_n, s);
+      const hipError_t e = hipStreamEndCapture(s, &gr);
+      if (r) { if (gr) (void)hipGraphDestroy(gr); return r; }
+      if (e != hipSuccess || !gr) return fail(DVBT_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+      const hipError_t e2 = hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(gr);
+      if (e2 != hipSuccess) return fail(DVBT_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e2));
+      h->graphs.push_back(dvbt_rx::GraphEntry{chain, chain_n, s, (long long)h->cut.stream_symbol_offset, h->cut.start_delay_symbols, h->cut.descr_call_phase, ex});
+      HIPCHK(hipGraphLaunch(ex, s));
+      h->cur_stream = s; h->pending = true;
+      return DVBT_OK;
+    }
+  }
   return enqueue(h, chain, chain_n, s);
 }
 

@@ -291,6 +291,10 @@ typedef struct {
                               The decoder behind it is the reference's: it unpacks d_m bits of every byte whatever the stream carries
                               (lib/viterbi_decoder_impl.cc:93,236-243), so -- as with gr-dvbt itself -- no transport stream comes out of a hierarchical
                               transmission; what is reproduced is every block's output */
+  int launch_graph;        /* 1: the ~30 launches of dvbt_rx_segment_enqueue_device are captured in a HIP graph the first time a (segment pointer, length, stream, cut) is
+                              seen and replayed as ONE graph launch afterwards (a receiver that works through a resident ring of segments sees the same few
+                              over and over).  The graph holds what the launch sequence holds: every size that depends on the data lives in the device-side
+                              state block, the grids are worst case.  Not used while stage timing is on (dvbt_rx_enable_timing) or with a resampler in front. */
 } dvbt_rx_params;
 
 typedef struct {

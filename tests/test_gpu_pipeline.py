@@ -40,3 +40,25 @@ def test_handles_in_flight_equal_a_handle_alone(po, const, cr, mode, nsf):
             assert (rx.tap(g.TAP_VITERBI) == vit).all() and (rx.tap(g.TAP_TS) == ts).all(), (rnd, k)
     for rx in rxs:
         rx.close()
+
+
+def test_step_replayed_as_a_hip_graph(po):
+    """dvbt_rx_params.launch_graph: the launch sequence of dvbt_rx_segment_enqueue_device captured once per (segment, length, stream, cut) and replayed as one graph
+    launch -- the same bytes as launch by launch (the oracle's), for a second segment on the same handle too, and again after the first one's turn"""
+    const, cr, mode = g.QAM64, g.C7_8, g.T8k
+    c = po.cfg(const, cr, mode)
+    ibits = c.payload * c.m * c.k // c.n
+    iqs = [po.tx(c, po.make_ts((272 * ibits * 3) // (204 * 8), 300 + k), lead_in=400 + 300 * k, tail=3 * c.N) for k in range(2)]
+    refs = [po.rx(c, iq, want=("ts",))["ts"] for iq in iqs]
+    n = max(len(iq) for iq in iqs)
+    devs = [torch.from_numpy(iq.view(np.float32)).cuda() for iq in iqs]
+    torch.cuda.synchronize()
+    rx = g.Rx(const, cr, mode, max_samples=n, launch_graph=1)
+    st = torch.cuda.Stream()
+    for rnd in range(3):
+        for k in (0, 1):
+            rx.enqueue_device(devs[k].data_ptr(), len(iqs[k]), st.cuda_stream)
+            rep = rx.finish()
+            ts = rx.tap(g.TAP_TS)
+            assert rep.n_ts_bytes == len(refs[k]) > 0 and (ts == refs[k]).all(), (rnd, k)
+    rx.close()
