@@ -267,7 +267,13 @@ struct dvbt_rx {
   SymMeta *meta = nullptr; RxState *st = nullptr, *st_host = nullptr; TpsState *tps_state = nullptr;
   // two acquisition contexts (state block + per-symbol tracker results): `st` / `meta` point at the one in use.  The lock-period walk searches on in the
   // other one, so that what the last decoded period left behind stays valid for the byte de-interleaver, the report and the taps (segment_periods)
-  RxState *st_ctx[2] = {nullptr, nullptr}; SymMeta *meta_ctx[2] = {nullptr, nullptr}; int ctx = 0;
+  static constexpr int NCTX = 3;            // (segment_periods uses two; the streaming entry's walk keeps a found period, decodes the one before it and searches for the next one at once)
+  RxState *st_ctx[NCTX] = {nullptr, nullptr, nullptr}; SymMeta *meta_ctx[NCTX] = {nullptr, nullptr, nullptr}; int ctx = 0;
+  // ... and what else an acquisition of one period and the decode of the period before it would share if they ran at the same time -- which they do (segment_periods:
+  // the search for period p + 1 on the caller's stream, the decode of period p on aux_stream): the trackers' flag words, the symbol kernel's ticket, the drift
+  // model's verdict, the page-locked copy of the state block.  trk_flags / sym_ticket / drift.flags / st_host point at the context in use (set_ctx)
+  int *trk_flags_ctx[NCTX] = {nullptr, nullptr, nullptr}, *sym_ticket_ctx[NCTX] = {nullptr, nullptr, nullptr}, *drift_flags_ctx[NCTX] = {nullptr, nullptr, nullptr}; RxState *st_host_ctx[NCTX] = {nullptr, nullptr, nullptr};
+  hipStream_t aux_stream = nullptr; hipEvent_t aux_ev = nullptr;
   int *trk_cp_a = nullptr, *trk_cp_b = nullptr, *trk_flags = nullptr; float *trk_eps = nullptr; TpsEdge *tps_edges = nullptr;
   int *centre = nullptr, *anchor_pos = nullptr;   // predicted CP position per call / coarse estimates every ACQ_ANCHOR calls
   float2 *acq_tap = nullptr, *fft_out = nullptr, *eq = nullptr, *tpsval = nullptr; SymInfo *info = nullptr; int *maj = nullptr, *sym_index = nullptr;
@@ -296,11 +302,13 @@ struct dvbt_rx {
 
 static void rx_free(dvbt_rx *h)
 {
-  void *all[] = {h->bitdeint_lp, h->st_ctx[0], h->st_ctx[1], h->meta_ctx[0], h->meta_ctx[1], h->tps_prev_snap[0], h->tps_prev_snap[1], h->tps_snap[0], h->tps_snap[1], h->csi, h->soft_a, h->soft_tab, h->soft_scratch, h->rs_defer, h->rs_sync, h->drift_mem, h->drift.delta, h->drift.flags, h->tps_prev, h->descr_runs, h->descr_nruns, h->centre, h->anchor_pos, h->sym_ticket, h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags, h->trk_eps, h->d_iq, h->rs_iq, h->acq_carry, h->g_init, h->l_init, h->g_trk, h->l_trk, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
+  void *all[] = {h->bitdeint_lp, h->st_ctx[0], h->st_ctx[1], h->st_ctx[2], h->meta_ctx[0], h->meta_ctx[1], h->meta_ctx[2], h->tps_prev_snap[0], h->tps_prev_snap[1], h->tps_snap[0], h->tps_snap[1], h->csi, h->soft_a, h->soft_tab, h->soft_scratch, h->rs_defer, h->rs_sync, h->drift_mem, h->drift.delta, h->drift_flags_ctx[0], h->drift_flags_ctx[1], h->drift_flags_ctx[2], h->tps_prev, h->descr_runs, h->descr_nruns, h->centre, h->anchor_pos, h->sym_ticket_ctx[0], h->sym_ticket_ctx[1], h->sym_ticket_ctx[2], h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags_ctx[0], h->trk_flags_ctx[1], h->trk_flags_ctx[2], h->trk_eps, h->d_iq, h->rs_iq, h->acq_carry, h->g_init, h->l_init, h->g_trk, h->l_trk, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
                  h->info, h->maj, h->sym_index, h->labels, h->symdeint_tap, h->bitdeint, h->vit, h->deint_tap, h->rs_out, h->ts_out};
   for (void *q : all) if (q) (void)hipFree(q);
   for (auto &ge : h->graphs) if (ge.exec) (void)hipGraphExecDestroy(ge.exec);
-  if (h->st_host) (void)hipHostFree(h->st_host);
+  for (int i = 0; i < dvbt_rx::NCTX; i++) if (h->st_host_ctx[i]) (void)hipHostFree(h->st_host_ctx[i]);
+  if (h->aux_ev) (void)hipEventDestroy(h->aux_ev);
+  if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
   if (h->ev_ready) for (int i = 0; i < ST_COUNT; i++) (void)hipEventDestroy(h->ev[i]);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
@@ -341,16 +349,21 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   const size_t C = (size_t)h->max_calls, N = d.N, P = d.payload;
   RXHIP(hipMalloc((void **)&h->g_init, sizeof(float2) * ACQ_INIT_TRIES_MAX * N)); RXHIP(hipMalloc((void **)&h->l_init, sizeof(float) * ACQ_INIT_TRIES_MAX * N));
   RXHIP(hipMalloc((void **)&h->g_trk, sizeof(float2) * C * 2 * ACQ_R)); RXHIP(hipMalloc((void **)&h->l_trk, sizeof(float) * C * 2 * ACQ_R));
-  for (int i = 0; i < 2; i++) { RXHIP(hipMalloc((void **)&h->meta_ctx[i], sizeof(SymMeta) * C)); RXHIP(hipMalloc((void **)&h->st_ctx[i], sizeof(RxState))); RXHIP(hipMemset(h->st_ctx[i], 0, sizeof(RxState))); }
+  for (int i = 0; i < dvbt_rx::NCTX; i++) { RXHIP(hipMalloc((void **)&h->meta_ctx[i], sizeof(SymMeta) * C)); RXHIP(hipMalloc((void **)&h->st_ctx[i], sizeof(RxState))); RXHIP(hipMemset(h->st_ctx[i], 0, sizeof(RxState))); }
   h->meta = h->meta_ctx[0]; h->st = h->st_ctx[0]; h->ctx = 0;
   RXHIP(hipMalloc((void **)&h->trk_cp_a, sizeof(int) * C)); RXHIP(hipMalloc((void **)&h->trk_cp_b, sizeof(int) * C));
-  RXHIP(hipMalloc((void **)&h->trk_eps, sizeof(float) * C)); RXHIP(hipMalloc((void **)&h->trk_flags, sizeof(int) * 16));
+  RXHIP(hipMalloc((void **)&h->trk_eps, sizeof(float) * C));
+  for (int i = 0; i < dvbt_rx::NCTX; i++) { RXHIP(hipMalloc((void **)&h->trk_flags_ctx[i], sizeof(int) * 16)); RXHIP(hipMemset(h->trk_flags_ctx[i], 0, sizeof(int) * 16)); }
+  h->trk_flags = h->trk_flags_ctx[0];
+  RXHIP(hipStreamCreate(&h->aux_stream)); RXHIP(hipEventCreateWithFlags(&h->aux_ev, hipEventDisableTiming));
   RXHIP(hipMalloc((void **)&h->tps_prev, sizeof(float2) * d.n_tps)); RXHIP(hipMemset(h->tps_prev, 0, sizeof(float2) * d.n_tps));
   for (int i = 0; i < 2; i++) { RXHIP(hipMalloc((void **)&h->tps_prev_snap[i], sizeof(float2) * d.n_tps)); RXHIP(hipMalloc((void **)&h->tps_snap[i], sizeof(TpsState))); }
   RXHIP(hipMalloc((void **)&h->descr_runs, sizeof(DescrRun) * DESCR_MAX_RUNS)); RXHIP(hipMalloc((void **)&h->descr_nruns, sizeof(int)));
   RXHIP(hipMalloc((void **)&h->centre, sizeof(int) * (C + 1))); RXHIP(hipMalloc((void **)&h->anchor_pos, sizeof(int) * (C / ACQ_ANCHOR + 4)));
   RXHIP(hipMalloc((void **)&h->tps_edges, sizeof(TpsEdge) * (C / TPS_SEG + 2)));
-  RXHIP(hipHostMalloc((void **)&h->st_host, sizeof(RxState))); RXHIP(hipMalloc((void **)&h->acq_carry, sizeof(AcqState))); RXHIP(hipMalloc((void **)&h->tps_state, sizeof(TpsState)));
+  for (int i = 0; i < dvbt_rx::NCTX; i++) { RXHIP(hipHostMalloc((void **)&h->st_host_ctx[i], sizeof(RxState))); memset(h->st_host_ctx[i], 0, sizeof(RxState)); }
+  h->st_host = h->st_host_ctx[0];
+  RXHIP(hipMalloc((void **)&h->acq_carry, sizeof(AcqState))); RXHIP(hipMalloc((void **)&h->tps_state, sizeof(TpsState)));
   RXHIP(hipMalloc((void **)&h->labels, C * P + 64));   // A1..A4 are one kernel: a symbol reaches HBM as label bytes; fft_out and eq exist only as debug taps
   RXHIP(hipMalloc((void **)&h->tpsval, sizeof(float2) * C * d.n_tps)); RXHIP(hipMalloc((void **)&h->info, sizeof(SymInfo) * C));
   RXHIP(hipMalloc((void **)&h->maj, sizeof(int) * C)); RXHIP(hipMalloc((void **)&h->sym_index, sizeof(int) * C));
@@ -364,7 +377,8 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   RXHIP(hipMemset(h->st, 0, sizeof(RxState)));
   for (int i = 0; i < ST_COUNT; i++) RXHIP(hipEventCreate(&h->ev[i]));
   h->ev_ready = true;
-  RXHIP(hipMalloc((void **)&h->sym_ticket, 64));
+  for (int i = 0; i < dvbt_rx::NCTX; i++) { RXHIP(hipMalloc((void **)&h->sym_ticket_ctx[i], 64)); RXHIP(hipMemset(h->sym_ticket_ctx[i], 0, 64)); }
+  h->sym_ticket = h->sym_ticket_ctx[0];
   if (p->soft_decision) {
     RXHIP(hipMalloc((void **)&h->eq, sizeof(float2) * C * P)); RXHIP(hipMalloc((void **)&h->csi, sizeof(float) * C * P));
     RXHIP(hipMalloc((void **)&h->soft_a, C * P * d.m + 64)); RXHIP(hipMalloc((void **)&h->soft_tab, sizeof(uint16_t) * 2 * P * d.m));
@@ -380,7 +394,8 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
     RXHIP(hipMalloc((void **)&h->drift_mem, sizeof(double) * (C * (DRIFT_TAB + 4) + 8)));
     h->drift.tabs = h->drift_mem; h->drift.ex_run = h->drift.tabs + C * DRIFT_TAB; h->drift.ex_entry = h->drift.ex_run + C;
     h->drift.d = h->drift.ex_entry + C; h->drift.S = h->drift.d + C; h->drift.A0 = h->drift.S + C;
-    RXHIP(hipMalloc((void **)&h->drift.delta, sizeof(float) * C * (N / 32))); RXHIP(hipMalloc((void **)&h->drift.flags, 16)); RXHIP(hipMemset(h->drift.flags, 0, 16));
+    RXHIP(hipMalloc((void **)&h->drift.delta, sizeof(float) * C * (N / 32))); for (int i = 0; i < dvbt_rx::NCTX; i++) { RXHIP(hipMalloc((void **)&h->drift_flags_ctx[i], 16)); RXHIP(hipMemset(h->drift_flags_ctx[i], 0, 16)); }
+    h->drift.flags = h->drift_flags_ctx[0];
   }
   RXCHK(set_lds((const void *)symbol8k_kernel<false, false>, S8_LDS_BYTES)); RXCHK(set_lds((const void *)symbol8k_kernel<false, true>, S8_LDS_BYTES));
   RXCHK(set_lds((const void *)symbol8k_kernel<true, false>, S8_LDS_BYTES)); RXCHK(set_lds((const void *)symbol8k_kernel<true, true>, S8_LDS_BYTES));
@@ -751,6 +766,11 @@ extern "C" int dvbt_rx_segment_finish(dvbt_rx *h, dvbt_rx_report *rep)
 // item kept when a later period follows, every period's Viterbi stream appended to the segment's at a multiple of two de-interleaver items.
 // Then the byte de-interleaver, RS and the descrambler run once over the whole stream.
 struct LockPeriod { size_t off; int n_symbols; float avg_in; bool carry; int call0, cp_start0; bool lost; };
+static void set_ctx(dvbt_rx *h, int k)
+{
+  h->ctx = k; h->st = h->st_ctx[k]; h->meta = h->meta_ctx[k]; h->trk_flags = h->trk_flags_ctx[k]; h->sym_ticket = h->sym_ticket_ctx[k]; h->drift.flags = h->drift_flags_ctx[k];
+  h->st_host = h->st_host_ctx[k];
+}
 
 static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipStream_t s, dvbt_rx_report *rep)
 {
@@ -768,16 +788,39 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
   bool snap_assumed[2] = {false, false};                          // ... and were decoded on the assumption that a later period has items
   bool need_full = false;
   int ctx_last = -1;                                              // acquisition context of the last decoded period (-1: none yet): acquisitions go to the other one
-  auto acq_ctx = [&]() -> int {                                   // switch to the context an acquisition may write; the state block travels along (fields that
-    const int k = ctx_last < 0 ? h->ctx : (ctx_last ^ 1);         // live through the periods of a segment keep doing so)
-    if (k != h->ctx) { HIPCHK(hipMemcpyAsync(h->st_ctx[k], h->st, sizeof(RxState), hipMemcpyDeviceToDevice, s)); h->ctx = k; h->st = h->st_ctx[k]; h->meta = h->meta_ctx[k]; }
+  auto acq_ctx = [&]() -> int {                                   // switch to the context an acquisition may write (the other one may be in use by a decode in flight;
+    const int k = ctx_last < 0 ? h->ctx : (ctx_last ^ 1);         // what has to live through the periods of a segment -- the stream's TPS word -- is kept on the host)
+    if (k != h->ctx) set_ctx(h, k);
     return DVBT_OK;
   };
+  // The decode of period p runs on the handle's second stream WHILE the caller's stream searches for period p + 1 (the search needs the samples and the average
+  // the lost call left, nothing of the decode): a period costs the longer of the two instead of their sum.  The decode's outcome (its Viterbi byte count: where
+  // the next period's bytes go; whether it delivered) is read before the NEXT decode is launched.
+  hipStream_t s2 = h->aux_stream;
+  HIPCHK(hipEventRecord(h->aux_ev, s)); HIPCHK(hipStreamWaitEvent(s2, h->aux_ev, 0));   // (whatever made the samples ready on the caller's stream)
+  struct Pend { bool on = false; size_t p = 0, vit_off = 0; int ctx = 0; hipStream_t st = nullptr; } pend;
+  unsigned long long tps_keep = 0;
   int snap_period[2] = {-1, -1}, sn = 0;                          // the last two decoded periods: snap[] and the device-side copies of the pilot engine's state were taken in front of
                                                                   // them (snap[sn]: the last one, snap[sn ^ 1]: the one before)
   // one period through the chain up to the Viterbi decoder.  later: a later period delivers items (the last item of this one leaves the demodulator too);
   // reuse: the acquisition results of the acq_only run just before are still in the handle (the period is decoded right behind its discovery)
-  auto decode = [&](size_t p, bool later, bool reuse) -> int {
+  auto decode_finish = [&]() -> int {
+    if (!pend.on) return DVBT_OK;
+    HIPCHK(hipStreamSynchronize(pend.st));
+    pend.on = false; h->pending = false;
+    const size_t p = pend.p;
+    const RxState &st = *h->st_host_ctx[pend.ctx];
+    if (st.tps_bits) tps_keep = st.tps_bits;
+    bk.processed++; bk.any = true; bk.last_st = st; bk.last_off = per[p].off;
+    h->periods[p].first_out_symbol = 0;
+    if (st.first_out >= 0) {
+      h->periods[p].first_out_symbol = st.first_out + 1;
+      if (bk.delivering == 0) { fill_report(h, st, bk.first_rep); bk.first_rep.segment_offset = (int64_t)per[p].off; }
+      bk.acc = pend.vit_off + (size_t)st.n_vit_bytes; bk.delivering++;
+    }
+    return DVBT_OK;
+  };
+  auto decode_launch = [&](size_t p, bool later, bool reuse, hipStream_t ds) -> int {
     const int usable = per[p].n_symbols - (later ? 0 : 1);       // items that leave the demodulator
     bk.total_symbols += per[p].n_symbols;
     if (usable < 1) return DVBT_OK;
@@ -788,53 +831,65 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
     // a period that ends in a lost lock is decoded over its own calls and the one that lost the lock, not over the whole rest of the segment
     size_t span = chain_n - per[p].off;
     if (per[p].lost) span = std::min(span, win + (size_t)(per[p].call0 + per[p].n_symbols) * L);
-    int r = enqueue(h, chain + per[p].off, span, s, o); if (r) return r;
+    int r = enqueue(h, chain + per[p].off, span, ds, o); if (r) return r;
     // the TPS carriers of the last demodulated symbol are the DBPSK reference of the next period's first one
-    HIPCHK(hipMemcpyAsync(h->tps_prev, h->tpsval + (size_t)(usable - 1) * d.n_tps, sizeof(float2) * d.n_tps, hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));
-    h->pending = false;
-    const RxState &st = *h->st_host;
-    bk.processed++; bk.any = true; bk.last_st = st; bk.last_off = per[p].off; ctx_last = h->ctx;
-    h->periods[p].first_out_symbol = 0;
-    if (st.first_out >= 0) {
-      h->periods[p].first_out_symbol = st.first_out + 1;
-      if (bk.delivering == 0) { fill_report(h, st, bk.first_rep); bk.first_rep.segment_offset = (int64_t)per[p].off; }
-      bk.acc = o.vit_off + (size_t)st.n_vit_bytes; bk.delivering++;
-    }
+    HIPCHK(hipMemcpyAsync(h->tps_prev, h->tpsval + (size_t)(usable - 1) * d.n_tps, sizeof(float2) * d.n_tps, hipMemcpyDeviceToDevice, ds));
+    pend.on = true; pend.p = p; pend.vit_off = o.vit_off; pend.ctx = h->ctx; pend.st = ds;
+    ctx_last = h->ctx;
     return DVBT_OK;
   };
+  auto decode = [&](size_t p, bool later, bool reuse) -> int {     // the synchronous form (periods decoded again behind the walk)
+    int r = decode_finish(); if (r) return r;
+    r = decode_launch(p, later, reuse, s); if (r) return r;
+    return decode_finish();
+  };
   {   // ---- the walk: find a period (acquisition alone over a growing window), decode it, go on behind the call that lost the lock
-    size_t off = 0; bool carry = false; float avg = 0.f; int fails = 0;
-    for (int guard = 0; off + win <= chain_n; guard++) {
-      if (guard >= 4096) { capped = true; break; }
+    size_t off = 0; bool carry = false; float avg = 0.f; int fails = 0, guard = 0;
+    EnqOpt so; size_t slook = 0;                                   // the search in flight on the caller's stream
+    // the search for the next period is ENQUEUED before the host turns to the launches of the last period's decode: the device looks for period p + 1 while
+    // the host is busy with the ~15 launches of period p's decode and while that decode runs
+    auto launch_search = [&]() -> int {
       { int r = acq_ctx(); if (r) return r; }
-      EnqOpt o; o.acq_only = true; o.use_carry = carry; o.carry_avg = avg; o.hist = (long long)off; o.avail = (long long)(chain_n - off);
+      so = EnqOpt(); so.acq_only = true; so.use_carry = carry; so.carry_avg = avg; so.hist = (long long)off; so.avail = (long long)(chain_n - off);
       // searches that found nothing are followed by wider ones (4, 8, ... 64 windows per launch): dead air costs a launch sequence per 64 windows, not per 4
-      o.init_tries = std::min(ACQ_INIT_TRIES_MAX, ACQ_INIT_TRIES << std::min(fails, 4));
+      so.init_tries = std::min(ACQ_INIT_TRIES_MAX, ACQ_INIT_TRIES << std::min(fails, 4));
       // the search and the tracker look at a window of the rest of the segment that grows while the lock holds to its end: a segment with many lock
       // periods costs its length a few times over, not its length times the number of periods (a call's outcome depends on the samples before it only)
       // (first window: 768 calls, or four times the previous period's length when the lock is being lost every few dozen symbols -- the metric, anchor and
       // tracker launches cost in proportion to the window)
       size_t look_calls = 767;
       if (!per.empty()) look_calls = std::min<size_t>(767, std::max<size_t>(47, 4 * (size_t)std::max(per.back().n_symbols, 0)));
-      size_t look = std::min(chain_n - off, win + look_calls * L);
+      slook = std::min(chain_n - off, win + look_calls * L);
       // the first attempts take the whole rest of the segment: a lock that holds to its end (the usual case, possibly behind a start-up transient of a
       // few symbols) is one pass; only a stream that keeps losing the lock goes over to the short windows
-      if (per.size() < 3 && guard < 8) look = chain_n - off;
+      if (per.size() < 3 && guard < 8) slook = chain_n - off;
+      return enqueue(h, chain + off, slook, s, so);
+    };
+    auto complete_search = [&]() -> int {
       for (;;) {
-        int r = enqueue(h, chain + off, look, s, o); if (r) return r;
         HIPCHK(hipStreamSynchronize(s));
-        if (!(h->st_host->status & 1) && h->st_host->small_viol && !o.no_small) { o.no_small = true; continue; }   // outside acq_small_kernel's closed form: the general kernels
-        if ((h->st_host->status & 3) || look >= chain_n - off) break;
-        look = std::min(chain_n - off, win + 4 * (look - win) + 3 * L);
+        if (!(h->st_host->status & 1) && h->st_host->small_viol && !so.no_small) { so.no_small = true; }   // outside acq_small_kernel's closed form: the general kernels
+        else if ((h->st_host->status & 3) || slook >= chain_n - off) return DVBT_OK;
+        else slook = std::min(chain_n - off, win + 4 * (slook - win) + 3 * L);
+        int r = enqueue(h, chain + off, slook, s, so); if (r) return r;
       }
+    };
+    bool searching = off + win <= chain_n;
+    if (searching) { int r = launch_search(); if (r) return r; }
+    while (searching) {
+      if (guard++ >= 4096) { capped = true; HIPCHK(hipStreamSynchronize(s)); break; }
+      { int r = complete_search(); if (r) return r; }
       const RxState st = *h->st_host;
-      const int tries = (int)std::min<size_t>((size_t)o.init_tries, (look - win) / L + 1);      // what enqueue() examined
+      const int tries = (int)std::min<size_t>((size_t)so.init_tries, (slook - win) / L + 1);      // what enqueue() examined
       if (st.status & 1) {                                       // no peak in these windows: the reference consumes them one by one and searches on
         off += (size_t)tries * L; avg = st.avg; carry = true; fails++;
+        searching = off + win <= chain_n;
+        if (searching) { int r = launch_search(); if (r) return r; }   // (the same context again: ctx_last has not moved)
         continue;
       }
       fails = 0;
+      const int ctx_found = h->ctx;                               // the period's acquisition results live here until its decode has run
+      { int r = decode_finish(); if (r) return r; }               // the decode of the period before has had this search's time
       // a period with items behind one that was decoded as the last one (the guess near the segment's end, below): everything is decoded again in order
       if (st.n_symbols >= 1 && snap_period[sn] >= 0 && !snap_assumed[sn]) need_full = true;
       const bool lost = (st.status & 2) != 0;
@@ -849,16 +904,30 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
       // ... and with less than 16 symbols left behind the first or second loss of a segment a later period with items is the less likely outcome (a stream
       // that simply ends; where the lock is being lost all the time, another short period is the likely one)
       const bool later_guess = !final_period && !(per.size() <= 2 && behind + win + 16 * L > chain_n);
-      if (st.n_symbols - (later_guess ? 0 : 1) >= 1) {           // it will be decoded: keep the state in front of it
-        sn ^= 1; snap[sn] = bk; snap_period[sn] = (int)per.size() - 1; snap_assumed[sn] = later_guess;
-        HIPCHK(hipMemcpyAsync(h->tps_snap[sn], h->tps_state, sizeof(TpsState), hipMemcpyDeviceToDevice, s));
-        HIPCHK(hipMemcpyAsync(h->tps_prev_snap[sn], h->tps_prev, sizeof(float2) * d.n_tps, hipMemcpyDeviceToDevice, s));
+      const size_t pidx = per.size() - 1;
+      // the next search starts now, in the other context (free: the decode that used it has just been read back)
+      searching = !final_period && per.size() < 1024;
+      if (!final_period && per.size() >= 1024) capped = true;
+      const bool will_decode = st.n_symbols - (later_guess ? 0 : 1) >= 1;
+      if (searching) {
+        off = behind; avg = st.avg_lost; carry = true;
+        // a period that is going to be decoded keeps its context: the search takes the other one (that of the period decoded before: its decode has been read
+        // back, the new period's takes its place as the last one).  A period that launches no decode leaves everything as it is
+        const int keep = ctx_last; if (will_decode) ctx_last = ctx_found;
+        int r = launch_search(); if (r) return r;
+        ctx_last = keep;
       }
-      { int r = decode(per.size() - 1, later_guess, true); if (r) return r; }
-      if (final_period) break;                                    // the lock held to the end of the segment (or to where its samples end)
-      off += (size_t)(st.call0 + st.n_symbols) * L + L / 2; avg = st.avg_lost; carry = true;
-      if (per.size() >= 1024) { capped = true; break; }
+      const int ctx_search = h->ctx;
+      set_ctx(h, ctx_found);
+      if (will_decode) {                                         // keep the state in front of it
+        sn ^= 1; snap[sn] = bk; snap_period[sn] = (int)pidx; snap_assumed[sn] = later_guess;
+        HIPCHK(hipMemcpyAsync(h->tps_snap[sn], h->tps_state, sizeof(TpsState), hipMemcpyDeviceToDevice, s2));
+        HIPCHK(hipMemcpyAsync(h->tps_prev_snap[sn], h->tps_prev, sizeof(float2) * d.n_tps, hipMemcpyDeviceToDevice, s2));
+      }
+      { int r = decode_launch(pidx, later_guess, true, s2); if (r) return r; }   // ... and runs while that search does
+      set_ctx(h, ctx_search);
     }
+    { int r = decode_finish(); if (r) return r; }
     int last_items = -1;                                          // the last period that has items at all
     for (size_t q = 0; q < per.size(); q++) if (per[q].n_symbols >= 1) last_items = (int)q;
     // The byte de-interleaver, the RS decoder and the report read the device-side state of the LAST decoded period, and that period's last item depends on
@@ -897,7 +966,7 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
       }
     }
   }
-  if (ctx_last >= 0 && ctx_last != h->ctx) { h->ctx = ctx_last; h->st = h->st_ctx[ctx_last]; h->meta = h->meta_ctx[ctx_last]; }   // the searches behind the last decoded period ran in the other context
+  if (ctx_last >= 0 && ctx_last != h->ctx) set_ctx(h, ctx_last);   // the searches behind the last decoded period ran in the other context
   size_t acc = bk.acc; const int delivering = bk.delivering, processed = bk.processed; const bool any = bk.any;
   const dvbt_rx_report first_rep = bk.first_rep; const RxState last_st = bk.last_st; const int total_symbols = bk.total_symbols; const size_t last_off = bk.last_off;
   dvbt_rx_report r;
@@ -919,6 +988,7 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
   HIPCHK(hipMemcpyAsync(h->st_host, h->st, sizeof(RxState), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   RxState fin = *h->st_host;
+  if (!fin.tps_bits) fin.tps_bits = tps_keep;                     // (the stream's TPS word: a period that saw no whole frame does not take it away)
   if (delivering > 1 || processed > 1) fin.n_vit_bytes = (long long)acc;
   fill_report(h, fin, r);
   // the front-end fields describe the LAST processed period (the debug taps hold it); the stream fields the whole segment
@@ -973,73 +1043,126 @@ static int walk_window(dvbt_rx *h, const float2 *chain, size_t chain_n, hipStrea
   std::vector<WalkPeriod> &per = io.per;
   per.clear(); h->periods.clear();
   io.established = false; io.head = -1; io.any_decoded = false; io.status_or = 0; io.total_symbols = 0;
-  // ---- phase A: the acquisition alone
-  size_t off = 0; bool carry = io.carry; float avg = io.avg; int fails = 0; bool open = false;
-  for (int guard = 0; off + win <= chain_n; guard++) {
-    if (guard >= 8192 || per.size() >= 4096) { io.status_or |= 256; break; }
-    EnqOpt o; o.acq_only = true; o.use_carry = carry; o.carry_avg = avg; o.hist = io.hist + (long long)off; o.avail = (long long)(chain_n - off);
-    o.init_tries = std::min(ACQ_INIT_TRIES_MAX, ACQ_INIT_TRIES << std::min(fails, 4));
-    size_t look_calls = 767;
-    if (!per.empty()) look_calls = std::min<size_t>(767, std::max<size_t>(47, 4 * (size_t)std::max(per.back().n_symbols, 0)));
-    const size_t rest = std::min(chain_n - off, maxn);
-    size_t look = std::min(rest, win + look_calls * L);
-    if (per.size() < 3 && guard < 8) look = rest;
-    for (;;) {
-      int r = enqueue(h, chain + off, look, s, o); if (r) return r;
-      HIPCHK(hipStreamSynchronize(s));
-      if (!(h->st_host->status & 1) && h->st_host->small_viol && !o.no_small) { o.no_small = true; continue; }
-      if ((h->st_host->status & 3) || look >= rest) break;
-      look = std::min(rest, win + 4 * (look - win) + 3 * L);
-    }
-    const RxState st = *h->st_host;
-    const int tries = (int)std::min<size_t>((size_t)o.init_tries, (look - win) / L + 1);
-    if (st.status & 1) { off += (size_t)tries * L; avg = st.avg; carry = true; fails++; continue; }
-    fails = 0;
-    WalkPeriod p; p.off = off; p.n_symbols = st.n_symbols; p.call0 = st.call0; p.cp_start0 = st.cp_start0; p.avg_in = avg; p.carry = carry; p.lost = (st.status & 2) != 0;
-    p.behind = off + (size_t)(st.call0 + st.n_symbols) * L + L / 2; p.avg_lost = st.avg_lost;
-    per.push_back(p);
-    h->periods.push_back(dvbt_lock_period{(int64_t)off, st.call0, st.cp_start0, st.n_symbols, 0});
-    io.total_symbols += st.n_symbols;
-    if (!p.lost && rest < chain_n - off && !io.partial) io.status_or |= 256;   // (a final window longer than the handle's capacity: cannot happen with the stream's sizing)
-    if (!p.lost || p.behind + win > chain_n) { open = true; break; }   // the lock holds to the window's end, or is lost where its samples run out
-    off = p.behind; avg = p.avg_lost; carry = true;
-  }
-  int zl = -1;                                                       // the last period that has items
-  for (size_t q = 0; q < per.size(); q++) if (per[q].n_symbols >= 1) zl = (int)q;
-  // ---- phase B: the chain over the periods that are final
+  // One pass, three acquisition contexts: the period found last that has items is KEPT undecoded (whether its last item leaves the demodulator depends on a later
+  // period having items, demod_reference_signals_impl.cc:88-94) -- when the next one with items is found, the kept one is decoded (later = true, on the acquisition
+  // results that are still in its context, on the handle's second stream) while the caller's stream already searches for the one after: a period costs the longer
+  // of search and decode, every acquisition runs once, nothing is guessed.
+  hipStream_t s2 = h->aux_stream;
+  HIPCHK(hipEventRecord(h->aux_ev, s)); HIPCHK(hipStreamWaitEvent(s2, h->aux_ev, 0));
   size_t acc = io.acc; int delivering = io.delivering; bool processed = io.continuation; bool cut_pending = io.cut;
-  auto decode = [&](size_t p, bool later) -> int {
+  struct Pend { bool on = false; size_t p = 0, vit_off = 0; int ctx = 0; hipStream_t st = nullptr; } pend;
+  std::vector<int> pctx;                                             // context of every period's acquisition
+  int kept = -1;                                                     // the period that waits for its successor
+  auto decode_finish = [&]() -> int {
+    if (!pend.on) return DVBT_OK;
+    HIPCHK(hipStreamSynchronize(pend.st));
+    pend.on = false; h->pending = false;
+    WalkPeriod &w = per[pend.p];
+    const RxState &st = *h->st_host_ctx[pend.ctx];
+    if (st.n_symbols != w.n_symbols || st.call0 != w.call0) io.status_or |= 512;
+    processed = true; cut_pending = false; io.any_decoded = true;
+    w.decoded = true; w.first_out = st.first_out; w.n_out_symbols = st.n_out_symbols; w.vit_off = pend.vit_off; w.n_vit_bytes = st.first_out >= 0 ? st.n_vit_bytes : 0;
+    io.status_or |= st.status & ~(1 | 2 | 4);
+    h->periods[pend.p].first_out_symbol = st.first_out >= 0 ? st.first_out + 1 : 0;
+    if (st.first_out >= 0) { acc = pend.vit_off + (size_t)st.n_vit_bytes; delivering++; }
+    io.head_st = st;
+    return DVBT_OK;
+  };
+  // period p from the acquisition results in its context (the handle points at another one meanwhile: switched for the launches, switched back)
+  auto decode_launch = [&](size_t p, bool later, hipStream_t ds) -> int {
     WalkPeriod &w = per[p];
     if (p != 0) cut_pending = false;                                 // a cut belongs to the lock period that reaches into the window from the stream before it
     const int usable = w.n_symbols - (later ? 0 : 1);                // items that leave the demodulator
     if (usable < 1) return DVBT_OK;
+    const int back = h->ctx;
+    set_ctx(h, pctx[p]);
     EnqOpt o; o.use_carry = w.carry; o.carry_avg = w.avg_in; o.hist = io.hist + (long long)w.off; o.avail = (long long)(chain_n - w.off);
-    o.continuation = processed; o.keep_last = later; o.tail = false;
+    o.continuation = processed; o.keep_last = later; o.tail = false; o.skip_acq = true;
     o.cut_set = true; o.sym_off = cut_pending ? io.cut_sym_off : 0; o.delay = cut_pending ? io.cut_delay : 0;
     // convolutional_deinterleaver_impl.cc:109-120: the tag realigns the block's input to a pair of items (3264 bytes of the walk's stream: h->vit[0] is a multiple of
     // 3264 bytes into it, the caller sees to that with vit_pad and by compacting in such multiples)
     o.vit_off = delivering > 0 ? (acc / 3264) * 3264 : (cut_pending ? io.vit_pad : acc);
-    o.init_tries = std::min(ACQ_INIT_TRIES_MAX, std::max(ACQ_INIT_TRIES, w.call0 + 1));
     size_t span = std::min(chain_n - w.off, maxn);
     if (w.lost) span = std::min(span, win + (size_t)(w.call0 + w.n_symbols) * L);
-    int r = enqueue(h, chain + w.off, span, s, o); if (r) return r;
-    HIPCHK(hipMemcpyAsync(h->tps_prev, h->tpsval + (size_t)(usable - 1) * d.n_tps, sizeof(float2) * d.n_tps, hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));
-    h->pending = false;
-    const RxState &st = *h->st_host;
-    if (st.n_symbols != w.n_symbols || st.call0 != w.call0) io.status_or |= 512;   // (the period's own acquisition must repeat what the walk found)
-    processed = true; cut_pending = false; io.any_decoded = true;
-    w.decoded = true; w.first_out = st.first_out; w.n_out_symbols = st.n_out_symbols; w.vit_off = o.vit_off; w.n_vit_bytes = st.first_out >= 0 ? st.n_vit_bytes : 0;
-    io.status_or |= st.status & ~(1 | 2 | 4);
-    h->periods[p].first_out_symbol = st.first_out >= 0 ? st.first_out + 1 : 0;
-    if (st.first_out >= 0) { acc = o.vit_off + (size_t)st.n_vit_bytes; delivering++; }
-    io.head_st = st;
+    int r = enqueue(h, chain + w.off, span, ds, o);
+    if (!r) { hipError_t e = hipMemcpyAsync(h->tps_prev, h->tpsval + (size_t)(usable - 1) * d.n_tps, sizeof(float2) * d.n_tps, hipMemcpyDeviceToDevice, ds); if (e != hipSuccess) r = fail(DVBT_ERR_HIP, "tps_prev copy"); }
+    set_ctx(h, back);
+    if (r) return r;
+    pend.on = true; pend.p = p; pend.vit_off = o.vit_off; pend.ctx = pctx[p]; pend.st = ds;
     return DVBT_OK;
   };
+  auto free_ctx = [&]() -> int {                                      // a context that neither the kept period nor the decode in flight lives in
+    for (int k = 0; k < dvbt_rx::NCTX; k++) if (!(kept >= 0 && pctx[(size_t)kept] == k) && !(pend.on && pend.ctx == k)) return k;
+    return 0;
+  };
+  // ---- the walk
+  size_t off = 0; bool carry = io.carry; float avg = io.avg; int fails = 0, guard = 0; bool open = false;
+  EnqOpt so; size_t slook = 0, srest = 0;
+  auto launch_search = [&]() -> int {
+    set_ctx(h, free_ctx());
+    so = EnqOpt(); so.acq_only = true; so.use_carry = carry; so.carry_avg = avg; so.hist = io.hist + (long long)off; so.avail = (long long)(chain_n - off);
+    so.init_tries = std::min(ACQ_INIT_TRIES_MAX, ACQ_INIT_TRIES << std::min(fails, 4));
+    size_t look_calls = 767;
+    if (!per.empty()) look_calls = std::min<size_t>(767, std::max<size_t>(47, 4 * (size_t)std::max(per.back().n_symbols, 0)));
+    srest = std::min(chain_n - off, maxn);
+    slook = std::min(srest, win + look_calls * L);
+    if (per.size() < 3 && guard < 8) slook = srest;
+    return enqueue(h, chain + off, slook, s, so);
+  };
+  auto complete_search = [&]() -> int {
+    for (;;) {
+      HIPCHK(hipStreamSynchronize(s));
+      if (!(h->st_host->status & 1) && h->st_host->small_viol && !so.no_small) so.no_small = true;
+      else if ((h->st_host->status & 3) || slook >= srest) return DVBT_OK;
+      else slook = std::min(srest, win + 4 * (slook - win) + 3 * L);
+      int r = enqueue(h, chain + off, slook, s, so); if (r) return r;
+    }
+  };
+  bool searching = off + win <= chain_n;
+  if (searching) { int r = launch_search(); if (r) return r; }
+  while (searching) {
+    if (guard++ >= 8192 || per.size() >= 4096) { io.status_or |= 256; HIPCHK(hipStreamSynchronize(s)); break; }
+    { int r = complete_search(); if (r) return r; }
+    const RxState st = *h->st_host;
+    const int tries = (int)std::min<size_t>((size_t)so.init_tries, (slook - win) / L + 1);
+    if (st.status & 1) {
+      off += (size_t)tries * L; avg = st.avg; carry = true; fails++;
+      searching = off + win <= chain_n;
+      if (searching) { int r = launch_search(); if (r) return r; }
+      continue;
+    }
+    fails = 0;
+    WalkPeriod p; p.off = off; p.n_symbols = st.n_symbols; p.call0 = st.call0; p.cp_start0 = st.cp_start0; p.avg_in = avg; p.carry = carry; p.lost = (st.status & 2) != 0;
+    p.behind = off + (size_t)(st.call0 + st.n_symbols) * L + L / 2; p.avg_lost = st.avg_lost;
+    per.push_back(p); pctx.push_back(h->ctx);
+    h->periods.push_back(dvbt_lock_period{(int64_t)off, st.call0, st.cp_start0, st.n_symbols, 0});
+    io.total_symbols += st.n_symbols;
+    if (!p.lost && srest < chain_n - off && !io.partial) io.status_or |= 256;   // (a final window longer than the handle's capacity: cannot happen with the stream's sizing)
+    const bool last_period = !p.lost || p.behind + win > chain_n;      // the lock holds to the window's end, or is lost where its samples run out
+    const size_t pidx = per.size() - 1;
+    int to_decode = -1;
+    if (p.n_symbols >= 1) {
+      { int r = decode_finish(); if (r) return r; }                    // (its context becomes free, its byte count is where the next decode's bytes go)
+      to_decode = kept; kept = (int)pidx;                              // the period kept so far has a successor with items: it is decoded now
+    }
+    if (last_period) { open = true; searching = false; }
+    else {
+      off = p.behind; avg = p.avg_lost; carry = true;
+      searching = off + win <= chain_n;
+    }
+    // the kept period's decode is LAUNCHED behind the next search (the host's ~15 launches ride on the search's device time), in its own context
+    if (to_decode >= 0 && searching) {
+      pend.on = true; pend.ctx = pctx[(size_t)to_decode];              // (reserve its context for free_ctx)
+      int r = launch_search(); pend.on = false; if (r) return r;
+    } else if (searching) { int r = launch_search(); if (r) return r; }
+    if (to_decode >= 0) { int r = decode_launch((size_t)to_decode, true, s2); if (r) return r; }
+  }
+  { int r = decode_finish(); if (r) return r; }
+  // ---- the period that is still kept: the last one with items
+  const int zl = kept;
   if (!io.partial) {
-    for (size_t q = 0; q < per.size(); q++) { int r = decode(q, zl > (int)q); if (r) return r; }
+    if (zl >= 0) { int r = decode_launch((size_t)zl, false, s); if (r) return r; r = decode_finish(); if (r) return r; }
   } else {
-    for (int q = 0; q < zl; q++) { int r = decode((size_t)q, true); if (r) return r; }
     // (a period that continues a cut stream is never a head: its roundings are the old epoch's)
     const bool head_cand = zl >= 0 && zl == (int)per.size() - 1 && open && !per[zl].lost && !(cut_pending && zl == 0);
     if (head_cand) {
@@ -1050,9 +1173,9 @@ static int walk_window(dvbt_rx *h, const float2 *chain, size_t chain_n, hipStrea
         HIPCHK(hipMemcpyAsync(h->tps_snap[0], h->tps_state, sizeof(TpsState), hipMemcpyDeviceToDevice, s));
         HIPCHK(hipMemcpyAsync(h->tps_prev_snap[0], h->tps_prev, sizeof(float2) * d.n_tps, hipMemcpyDeviceToDevice, s));
         const size_t acc0 = acc; const int del0 = delivering; const bool proc0 = processed, cut0 = cut_pending; const bool any0 = io.any_decoded;
-        int r = decode((size_t)zl, false); if (r) return r;
+        { int r = decode_launch((size_t)zl, false, s); if (r) return r; r = decode_finish(); if (r) return r; }
         const WalkPeriod &w = per[zl];
-        if (w.decoded && w.first_out >= 0 && ncalls - (w.call0 + w.first_out) >= io.establish_calls) { io.established = true; io.head = zl; }
+        if (w.decoded && w.first_out >= 0 && ncalls - (w.call0 + w.first_out) >= io.establish_calls) { io.established = true; io.head = zl; set_ctx(h, pctx[(size_t)zl]); }
         else {
           acc = acc0; delivering = del0; processed = proc0; cut_pending = cut0; io.any_decoded = any0;
           per[zl].decoded = false;
