@@ -381,6 +381,31 @@ def extra_workloads(a, torch, g, local):
     return res
 
 
+def hierarchical_line(torch, g, nsf=4, reps=3):
+    """A hierarchical transmission (2k 64-QAM, alpha = 2, rate 2/3; rows A0 / A4 / A6 of the scope table) through the segment API, samples resident: the demapper on the
+    shifted grid and the bit de-interleaver's two outputs run at the chain's speed, but the reference's Viterbi decoder knows no priority streams (it unpacks d_m bits of
+    every byte): two thirds of its input are constant, the chunked decoder's warm-up argument does not hold, and ONE decoder runs from the stream's start (DESIGN.md 7:
+    "exact, slow").  This line is the number behind "slow"."""
+    from oracle import pyoracle as po
+    c = po.cfg(po.QAM64, po.C2_3, po.T2k, hierarchy=g.ALPHA2)
+    ibits = c.payload * c.m * c.k // c.n
+    iq = po.tx(c, po.make_ts((272 * ibits * nsf) // (204 * 8), 5), lead_in=500, tail=3 * c.N)
+    dev = torch.from_numpy(iq.view(np.float32)).cuda()
+    torch.cuda.synchronize()
+    rx = g.Rx(po.QAM64, po.C2_3, po.T2k, max_samples=len(iq), hierarchy=g.ALPHA2)
+    rx.enable_timing(True)
+    rx.enqueue_device(dev.data_ptr(), len(iq)); rep = rx.finish()
+    rx.enable_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        rx.enqueue_device(dev.data_ptr(), len(iq)); rep = rx.finish()
+    dt = (time.perf_counter() - t0) / reps
+    stages = {k: round(rx.stage_ms(k), 3) for k in STAGES}
+    rx.close()
+    return {"workload": "2k QAM64 alpha 2 rate 2/3, %d superframes" % nsf, "value": round(len(iq) / dt / 1e6, 2), "unit": "Msamples/s", "x_realtime": round(len(iq) / dt / 1e6 / REALTIME_MSPS, 2),
+            "ms_per_run": round(dt * 1e3, 3), "stage_ms": stages, "samples": int(len(iq)), "viterbi_bytes": int(rep.n_viterbi_bytes), "symbols": int(rep.n_symbols)}
+
+
 def config5_noise(torch, g, nsf=16, snrs=(9.0, 8.0), reps=5):
     """BASELINE config 5 at the noise level SURVEY 8d prescribes (pre-Viterbi BER ~ 1e-2 = 8 dB for 8k QPSK 7/8; 9 dB = where the RS decoder still
     holds): the reference's CP tracker loses the lock again and again there, so the stream goes through dvbt_rx_segment_run_device (synchronous: every
@@ -450,9 +475,35 @@ def host_pointer_ceiling(g, c):
         rates.append(20 * nb / (time.perf_counter() - t0) / 1e9)
     L.dvbt_device_free(dev)
     per_sym_s = h2d / (rates[0] * 1e9) + d2h / (rates[1] * 1e9)
+    # the regime dvbt_host_register creates: page-locked buffers, both DMA directions busy at once (a thread per block: one block's download runs beside another's
+    # upload).  The bound is then the slower direction's time, not the sum
+    import torch
+    hp_up, hp_dn = torch.ones(nb, dtype=torch.uint8).pin_memory(), torch.empty(nb, dtype=torch.uint8).pin_memory()
+    d_up, d_dn = torch.empty(nb, dtype=torch.uint8, device="cuda"), torch.ones(nb, dtype=torch.uint8, device="cuda")
+    s_up, s_dn = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    reps = 40
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(2)]
+    with torch.cuda.stream(s_up):
+        ev[0][0].record()
+        for _ in range(reps):
+            d_up.copy_(hp_up, non_blocking=True)
+        ev[0][1].record()
+    with torch.cuda.stream(s_dn):
+        ev[1][0].record()
+        for _ in range(reps):
+            hp_dn.copy_(d_dn, non_blocking=True)
+        ev[1][1].record()
+    torch.cuda.synchronize()
+    both = [reps * nb / (ev[k][0].elapsed_time(ev[k][1]) * 1e-3) / 1e9 for k in range(2)]
+    per_sym_reg = max(h2d / (both[0] * 1e9), d2h / (both[1] * 1e9))
     return {"bytes_per_symbol_host_to_device": int(h2d), "bytes_per_symbol_device_to_host": int(d2h), "bytes_per_sample_over_pcie": round((h2d + d2h) / (N + cp), 1),
             "pageable_copy_gbs": {"host_to_device": round(rates[0], 1), "device_to_host": round(rates[1], 1), "bytes_per_copy": nb},
-            "copies_alone_msamples_per_s": round((N + cp) / per_sym_s / 1e6, 1)}
+            "copies_alone_msamples_per_s": round((N + cp) / per_sym_s / 1e6, 1),
+            "page_locked_copy_gbs_both_directions_busy": {"host_to_device": round(both[0], 1), "device_to_host": round(both[1], 1), "bytes_per_copy": nb},
+            "page_locked_copies_alone_msamples_per_s": round((N + cp) / per_sym_reg / 1e6, 1),
+            "note": "with registered buffers the copies bound the ten blocks at page_locked_copies_alone_msamples_per_s, far above what is measured: what bounds a thread-per-block "
+                    "run is the busiest block's time inside work() (cpp_driver.*.busiest_block_bound): its ~25 dependent small launches and its one synchronisation per call"}
 
 
 def per_block_abi(g, workload, nsf=4):
@@ -513,7 +564,9 @@ def per_block_cpp(iq, workload):
                 d = json.loads(r.stdout.strip().splitlines()[-1])
                 best = d if best is None or d["msamples_per_s"] > best["msamples_per_s"] else best
             res[f"host_pointers_{cs}_symbols_per_call" + ("_thread_per_block" if thr else "") + ("_registered_buffers" if reg else "")] = {"value": best["msamples_per_s"], "x_realtime": round(best["msamples_per_s"] / REALTIME_MSPS, 1),
-                                                                                              "block_calls": best["block_calls"], "ts_bytes": best["ts_bytes"]}
+                                                                                              "block_calls": best["block_calls"], "ts_bytes": best["ts_bytes"],
+                                                                                              "busiest_block": best.get("busiest_block"), "busiest_block_bound": best.get("busiest_block_bound_msamples_per_s"),
+                                                                                              "ms_per_call_of_the_busiest_block": best.get("ms_per_call_busiest")}
     finally:
         for f in (fin, fout):
             if os.path.exists(f):
@@ -766,6 +819,7 @@ def main():
     if rank == 0 and world == 1 and not a.no_extras and not a.from_file_rate:
         out["extra_workloads"] = extra_workloads(a, torch, g, local)
         out["extra_workloads"]["config5_8k_qpsk_7_8_at_the_prescribed_noise"] = config5_noise(torch, g)
+        out["extra_workloads"]["hierarchical_2k_qam64_alpha2_2_3"] = hierarchical_line(torch, g)
         out["stream_abi"] = stream_abi(g)
         out["per_block_abi"] = per_block_abi(g, a.workload)
         out["cpp_multi_host"] = cpp_multi_host(a.workload)

@@ -30,6 +30,7 @@ struct Stage {
   size_t in_item = 1, out_item = 1; long long out_cap = 0;
   std::vector<unsigned char> out;
   long long r = 0, w = 0, produced = 0, calls = 0;      // items consumed / available (written by upstream) / produced
+  double busy = 0.0;                                     // seconds spent inside work(): under a thread-per-block scheduler the run cannot be shorter than the busiest block's
   std::deque<Tag> tags;                                  // on the INPUT, absolute item offsets, ascending
   int per_call = 1, mult = 1;
 };
@@ -109,7 +110,9 @@ int main(int argc, char **argv)
       tin.resize(nt);
       std::vector<dvbt_tag> tout(4096);
       dvbt_sideband sb; sb.in_tags = tin.data(); sb.n_in_tags = (int)tin.size(); sb.out_tags = tout.data(); sb.out_cap = (int)tout.size(); sb.n_out_tags = 0; sb.n_consumed = 0;
+      const auto w0 = std::chrono::steady_clock::now();
       const int produced = st.work(st.h, (int)nout, (int)nin, in_buf + (size_t)st.r * st.in_item, st.out.data() + (size_t)st.produced * st.out_item, &sb);
+      st.busy += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
       chk(produced);
       st.calls++;
       const int consumed = sb.n_consumed;
@@ -155,8 +158,14 @@ int main(int argc, char **argv)
     std::FILE *o = std::fopen(argv[5], "wb"); if (!o) { std::perror("open"); return 1; }
     std::fwrite(S[9].out.data(), 1, (size_t)S[9].produced, o); std::fclose(o);
     long long calls = 0; for (auto &st : S) calls += st.calls;
-    std::printf("{\"samples\": %lld, \"seconds\": %.5f, \"msamples_per_s\": %.2f, \"symbols_per_call\": %d, \"thread_per_block\": %s, \"registered_buffers\": %s, \"block_calls\": %lld, \"ts_bytes\": %lld}\n",
-                nsamp, dt, nsamp / dt / 1e6, cs, threaded ? "true" : "false", registered ? "true" : "false", calls, S[9].produced);
+    double busiest = 0.0, busy_sum = 0.0; int who = 0;
+    for (int k = 0; k < 10; k++) { busy_sum += S[k].busy; if (S[k].busy > busiest) { busiest = S[k].busy; who = k; } }
+    const char *names[] = {"ofdm_sym_acquisition", "fft", "demod_reference_signals", "dvbt_demap", "symbol_inner_interleaver", "bit_inner_deinterleaver", "viterbi_decoder",
+                           "convolutional_deinterleaver", "reed_solomon_dec", "energy_descramble"};
+    std::printf("{\"samples\": %lld, \"seconds\": %.5f, \"msamples_per_s\": %.2f, \"symbols_per_call\": %d, \"thread_per_block\": %s, \"registered_buffers\": %s, \"block_calls\": %lld, \"ts_bytes\": %lld, "
+                "\"busiest_block\": \"%s\", \"busiest_block_seconds\": %.5f, \"busiest_block_bound_msamples_per_s\": %.2f, \"all_blocks_busy_seconds\": %.5f, \"ms_per_call_busiest\": %.4f}\n",
+                nsamp, dt, nsamp / dt / 1e6, cs, threaded ? "true" : "false", registered ? "true" : "false", calls, S[9].produced,
+                names[who], busiest, nsamp / busiest / 1e6, busy_sum, 1e3 * busiest / (double)std::max<long long>(S[who].calls, 1));
     if (registered) { dvbt_host_unregister(src.data()); for (auto &st : S) dvbt_host_unregister(st.out.data()); }
     for (auto &st : S) st.destroy(st.h);
   } catch (const std::exception &e) { std::fprintf(stderr, "%s\n", e.what()); return 1; }
