@@ -463,6 +463,8 @@ struct EnqOpt {
   bool tail = true;           // byte de-interleaver + RS + descrambler right behind (single period)
   long long avail = 0;        // samples in memory from iq[0] on (0: nsamples): a period of a longer segment is given a look-ahead window, the stream goes on behind it
   bool no_small = false;      // acq_only: not through acq_small_kernel (it has handed the period back: RxState.small_viol)
+  bool tps_init = false;      // not a continuation, but the pilot engine's members in front of the first symbol are in the handle (TpsState: a piece of a stream whose
+                              // counters are known): the segment-parallel bookkeeping starts from them instead of from blank ones
   bool cut_set = false;       // the cut of this period is given here instead of by the handle (walk_window: a cut belongs to the first period of its window) ...
   long long sym_off = 0; int delay = 0;   // ... dvbt_rx_cut.stream_symbol_offset, .start_delay_symbols
 };
@@ -522,7 +524,7 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_ACQ], s));
   if (o.skip_acq) {
     // what acq_init_fsm_kernel's reset would have done on top of the acq_only run's (tracker flags and the symbol ticket are still clear)
-    if (!o.continuation) HIPCHK(hipMemsetAsync(h->tps_state, 0, sizeof(TpsState), s));
+    if (!o.continuation && !o.tps_init) HIPCHK(hipMemsetAsync(h->tps_state, 0, sizeof(TpsState), s));
   } else {
   const AcqState *carry = nullptr;
   int tries = C < o.init_tries ? C : o.init_tries;
@@ -531,7 +533,7 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
   // looked at; computing it unasked costs nothing on an otherwise idle device and saves two launches per lock period
   // (the FSM launch also clears the trackers' flag words, the symbol kernel's ticket and, for a period that starts the pilot engine afresh, its state)
   hipLaunchKernelGGL(acq_metric_kernel, dim3((N + 255) / 256, tries), dim3(256), 0, s, iq, fp, (const RxState *)h->st, 0, h->g_init, h->l_init, 0);
-  const AcqReset rz = {h->trk_flags, h->sym_ticket, (o.acq_only || o.continuation) ? nullptr : reinterpret_cast<int *>(h->tps_state), (int)(sizeof(TpsState) / 4),
+  const AcqReset rz = {h->trk_flags, h->sym_ticket, (o.acq_only || o.continuation || o.tps_init) ? nullptr : reinterpret_cast<int *>(h->tps_state), (int)(sizeof(TpsState) / 4),
                        o.carry_avg, o.use_carry ? 1 : 0};
   hipLaunchKernelGGL(acq_init_fsm_kernel, dim3(1), dim3(1024), (size_t)N * 5, s, fp, h->st, (const float2 *)h->g_init, (const float *)h->l_init, carry, 0, tries, rz);
   if (o.acq_only && !o.no_small && C <= ACQ_SMALL_MAX_CALLS) {
@@ -612,7 +614,8 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
                        (const float2 *)nullptr, h->maj, fp.keep_last);
     // flags[8] = first superframe-start candidate (min), flags[9] = need_seq for the TPS bookkeeping (set by acq_init_fsm_kernel's reset)
     hipLaunchKernelGGL(tps_fsm_par_kernel, dim3((C + TPS_THREADS * TPS_SEG - 1) / (TPS_THREADS * TPS_SEG)), dim3(TPS_THREADS), 0, s, fp, (const RxState *)h->st, (const SymInfo *)h->info,
-                       (const int *)h->maj, h->sym_index, h->tps_edges, h->trk_flags + 8, &h->st->tps_bits, (const unsigned short *)h->T.tps_bch);
+                       (const int *)h->maj, h->sym_index, h->tps_edges, h->trk_flags + 8, &h->st->tps_bits, (const unsigned short *)h->T.tps_bch,
+                       o.tps_init ? (const TpsState *)h->tps_state : (const TpsState *)nullptr);
     hipLaunchKernelGGL(tps_tail_kernel, dim3(1), dim3(256), 0, s, fp, h->st, (const SymInfo *)h->info, (const int *)h->maj, h->tps_state, h->sym_index,
                        (const TpsEdge *)h->tps_edges, (const int *)(h->trk_flags + 8), h->trk_flags + 9, 0, h->vp, cut_sym_off);
   } else {
@@ -1024,6 +1027,7 @@ struct WalkIO {
   bool carry = false; float avg = 0.f;                               // ofdm_sym_acquisition: d_avg of the call that lost the lock before this window
   long long hist = 0;                                                // samples of the stream in memory in front of chain[0]
   bool continuation = false;                                         // the pilot engine has processed items before this window (TpsState / tps_prev are in the handle)
+  bool tps_preset = false;                                           // it has not, but the members a chain in stable lock holds in front of the window are in the handle (TpsState)
   size_t acc = 0; int delivering = 0;                                // the walk's Viterbi stream so far (bytes in h->vit), periods that delivered so far
   bool cut = false; long long cut_sym_off = 0; int cut_delay = 0; size_t vit_pad = 0;   // the first decoded period continues a cut stream; its bytes go to h->vit + vit_pad
   long long establish_calls = 0;
@@ -1078,6 +1082,7 @@ static int walk_window(dvbt_rx *h, const float2 *chain, size_t chain_n, hipStrea
     set_ctx(h, pctx[p]);
     EnqOpt o; o.use_carry = w.carry; o.carry_avg = w.avg_in; o.hist = io.hist + (long long)w.off; o.avail = (long long)(chain_n - w.off);
     o.continuation = processed; o.keep_last = later; o.tail = false; o.skip_acq = true;
+    o.tps_init = !processed && io.tps_preset;
     o.cut_set = true; o.sym_off = cut_pending ? io.cut_sym_off : 0; o.delay = cut_pending ? io.cut_delay : 0;
     // convolutional_deinterleaver_impl.cc:109-120: the tag realigns the block's input to a pair of items (3264 bytes of the walk's stream: h->vit[0] is a multiple of
     // 3264 bytes into it, the caller sees to that with vit_pad and by compacting in such multiples)
@@ -1195,6 +1200,7 @@ static int walk_window(dvbt_rx *h, const float2 *chain, size_t chain_n, hipStrea
     }
   }
   io.acc = acc; io.delivering = delivering; io.continuation = processed; io.cut = cut_pending;
+  if (processed) io.tps_preset = false;
   h->n_periods = delivering; h->seg_offset = 0;
   return DVBT_OK;
 }

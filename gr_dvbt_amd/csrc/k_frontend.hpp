@@ -1640,7 +1640,8 @@ __device__ __forceinline__ TpsState tps_pack(const TpsRegs &r)
 
 __global__ __launch_bounds__(TPS_THREADS) void tps_fsm_par_kernel(FrontParams p, const RxState *st, const SymInfo *__restrict__ info, const int *__restrict__ maj,
                                                                  int *__restrict__ sym_index, TpsEdge *__restrict__ edges, int *first_cand, unsigned long long *tps_bits,
-                                                                 const unsigned short *__restrict__ bch_tab)
+                                                                 const unsigned short *__restrict__ bch_tab, const TpsState *__restrict__ init = nullptr /* the members in front of
+                                                                 symbol 0 when the chain does not start from blank ones (a piece of a stream whose counters are known) */)
 {
   // the symbol stream in LDS, a byte per symbol: pattern index | (TPS vote negative) << 2; four bytes of padding per TPS_SEG entries keep the lanes
   // (TPS_SEG symbols apart) on distinct banks.  A lane's first symbol is a multiple of four symbols from `lo`, so it reads its stream a dword at a time.
@@ -1674,6 +1675,11 @@ __global__ __launch_bounds__(TPS_THREADS) void tps_fsm_par_kernel(FrontParams p,
   const int s1 = s0 + TPS_SEG < ntot ? s0 + TPS_SEG : ntot;
   int sw = s0 - TPS_WARM; if (sw < 0) sw = 0;
   TpsRegs t; t.f0 = 0; t.f1 = 0; t.f2 = 0; t.symbol_index = 0; t.known = 0; t.frame_index = 0; t.prev_mod = 0;
+  if (init && sw == 0) {                                           // a lane whose warm-up begins with the stream's first symbol starts from what the chain holds there
+    const TpsState i0 = *init;
+    t.f0 = (unsigned)i0.fifo_lo; t.f1 = (unsigned)(i0.fifo_lo >> 32); t.f2 = i0.fifo_hi; t.symbol_index = i0.symbol_index; t.known = i0.symbol_index_known;
+    t.frame_index = i0.frame_index; t.prev_mod = i0.prev_mod;
+  }
   int si, cand;
   auto word = [&](int s) -> unsigned { return *reinterpret_cast<const unsigned *>(&s_pk[pm(s - lo)]); };   // symbols s .. s + 3 (s - lo: a multiple of 4)
   unsigned nxt = word(sw);

@@ -460,8 +460,8 @@ void dvbt_rx_destroy(dvbt_rx *h);
  * Memory per stream object (S = segment_superframes, sf = one superframe of samples = 272 (N + cp) x 8 bytes: 18.4 MB at 8k, 4.6 MB at 2k, guard 1/32):
  *   device: two sample buffers of (S + 3.7) sf each + the two chains' own buffers (~0.55 x a sample buffer each; x 2.2 in soft-decision mode);
  *   S = 16 at 8k: 2 x 362 MB + 2 x ~200 MB.  The first lost lock adds two walk buffers of twice a sample buffer each (2 x 725 MB at S = 16, 8k);
- *   page-locked host: the TS ring (ts_ring_bytes, default 96 MB, allocated at the first delivery; a consumer that falls further behind is served from the heap) and
- *   32 MB of staging for host pushes below 2 MB (allocated at the first such push; dvbt_rx_stream_push_device never needs it).
+ *   page-locked host: the TS ring (ts_ring_bytes, default 96 MB; a consumer that falls further behind is served from the heap) and 32 MB of staging for host
+ *   pushes below 2 MB; both taken at create (page-locking them takes ~10 ms: set-up, not the first piece's latency).
  * Threading: like every handle, one thread at a time. */
 /* TPS auto-configuration (gr-dvbt's TODO.txt:28 "Autodetect transmission params"): rx.constellation, rx.hierarchy and / or rx.code_rate = DVBT_AUTO.  The
  * transmission mode and the guard interval must be given (the front end is built from them); everything else the stream says itself: the head of the stream
@@ -475,8 +475,8 @@ typedef struct {
    * pulls its own packets with their index in the stream (dvbt_rx_stream_pull_chunk); all ranks' chunks ordered by that index are the single chain's TS:
    * gathering them is the design's one exchange step (RCCL over xGMI in bench.py / gr_dvbt_amd/multi.py).  world = 0 or 1: no sharding. */
   int rank, world;
-  /* page-locked ring the decoded TS waits in until it is pulled (0 = 96 MB, ~24 s of the fastest DVB-T transport stream); allocated at the first delivery; a
-   * consumer that falls further behind than this is served from heap chunks */
+  /* page-locked ring the decoded TS waits in until it is pulled (0 = 96 MB, ~24 s of the fastest DVB-T transport stream); a consumer that falls further behind
+   * than this -- and a stream that cannot have the ring -- is served from heap chunks; dvbt_rx_stream_set_device_output gives it back */
   int64_t ts_ring_bytes;
 } dvbt_rx_stream_params;
 typedef struct {
