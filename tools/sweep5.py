@@ -1,0 +1,106 @@
+"""Randomised parity sweep over what round 5 added (GPU box): `python tools/sweep5.py [cases] [seed]`.  Per case a stream with the CP lock shaken -- dropouts (1 to 4 holes of
+5 .. 60 symbols of silence at random places, clean signal: everything the reference does there is deterministic, a superframe start declared on stale counters and the
+garbage behind it included), or BASELINE config 5-like noise (8k / 2k QPSK 7/8 or 1/2 at a level where the reference's tracker drops the lock every few dozen symbols) --
+pushed through dvbt_rx_stream_* in random call sizes with random piece sizes, world 1 (sometimes pulled as chunks), against ONE chain over the whole stream
+(dvbt_rx_segment_run) and the oracle (po.rx); holes only: world 2 as well (equality asserted where no rank reports status bit 5)."""
+import os, sys, faulthandler
+faulthandler.enable()
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+import numpy as np
+import torch  # noqa: F401
+from oracle import pyoracle as po
+import gr_dvbt_amd as g
+
+
+def single(const, cr, mode, guard, iq, snr):
+    c = po.cfg(const, cr, mode, guard=guard)
+    o = po.rx(c, iq, snr_db=snr, want=("ts",))
+    rx = g.Rx(const, cr, mode, max_samples=len(iq), guard=guard, snr_db=snr)
+    rx.run(iq)
+    ts = rx.tap(g.TAP_TS).copy()
+    rx.close()
+    return o, ts
+
+
+def streamed(const, cr, mode, guard, iq, snr, seg_sf, rng, world=1):
+    ranks = [g.RxStream(const, cr, mode, segment_superframes=seg_sf, guard=guard, snr_db=snr, rank=r, world=world if world > 1 else 0) for r in range(world)]
+    chunks, pos, L = [], 0, 2112
+    lo, hi = int(rng.randint(500, 20000)), int(rng.randint(30000, 700000))
+    while pos < len(iq):
+        n = int(rng.randint(lo, hi))
+        for st in ranks:
+            st.push(iq[pos:pos + n])
+        pos += n
+        if rng.rand() < 0.5:
+            for r, st in enumerate(ranks):
+                chunks += [(fp, r, b) for fp, b in st.pull_chunks()]
+    for r, st in enumerate(ranks):
+        st.finish(); chunks += [(fp, r, b) for fp, b in st.pull_chunks()]
+    infos = [st.info() for st in ranks]
+    tr = "\n".join(f"--- rank {r} status {i.status}\n" + st.trace() for r, (st, i) in enumerate(zip(ranks, infos)))
+    if world > 1:
+        tr += "chunks " + str([(fp, r, len(b) // 188) for fp, r, b in sorted(chunks, key=lambda t: t[0])])
+    for st in ranks:
+        st.close()
+    chunks.sort(key=lambda t: t[0])
+    ts = np.concatenate([b for _, _, b in chunks]) if chunks else np.zeros(0, np.uint8)
+    return ts, infos, tr
+
+
+def case(rng, i):
+    kind = "holes" if i % 3 else "noise"
+    mode = int(rng.randint(0, 2)) if kind == "holes" else int(rng.rand() < 0.4)
+    guard = int(rng.randint(0, 4)) if rng.rand() < 0.3 else 0
+    if kind == "holes":
+        const, cr = int(rng.randint(0, 3)), int(rng.randint(0, 5))
+        nsf = int(rng.randint(5, 9)) if mode == 1 else int(rng.randint(8, 16))
+        c = po.cfg(const, cr, mode, guard=guard)
+        L = c.N + c.cp
+        iq = po.stream_slice(c, nsf, int(rng.randint(1, 1000))).copy()
+        holes = sorted(int(rng.randint(150, 272 * nsf - 100)) for _ in range(int(rng.randint(1, 5))))
+        for hs in holes:
+            a = po.STREAM_LEAD_IN + hs * L
+            iq[a:a + int(rng.randint(5, 61)) * L] = 0
+        snr, desc = 30.0, f"holes at {holes}"
+    else:
+        const, cr = po.QPSK, (po.C7_8 if rng.rand() < 0.6 else po.C1_2)
+        nsf = int(rng.randint(3, 6)) if mode == 1 else int(rng.randint(6, 12))
+        c = po.cfg(const, cr, mode, guard=guard)
+        snr = float(rng.choice([8.0, 9.0, 10.0, 11.0]))
+        iq = po.channel(po.stream_slice(c, nsf, int(rng.randint(1, 1000))), c.N, snr_db=snr, seed=int(rng.randint(1, 1000)))
+        desc = f"awgn {snr} dB"
+    seg_sf = int(rng.randint(1, 5))
+    o, one = single(const, cr, mode, guard, iq, snr)
+    ts, infos, tr = streamed(const, cr, mode, guard, iq, snr, seg_sf, rng)
+    ok = len(ts) == len(one) and (ts == one).all()
+    same_oracle = len(one) == len(o["ts"]) and (one == o["ts"]).all()
+    if kind == "holes":
+        ok = ok and same_oracle                                    # a clean signal: the HIP single chain is the oracle byte for byte, whatever the lock does
+    msg = f"{kind} const{const} cr{cr} mode{mode} gi{guard} {nsf} sf, pieces of {seg_sf}, {desc}: {len(o['lock_periods'])} lock periods, {len(one) // 188} packets, single chain == oracle {same_oracle}, status {infos[0].status}"
+    if not ok:
+        msg += "\n" + tr
+    if ok and kind == "holes" and rng.rand() < 0.5:
+        ts2, infos2, tr2 = streamed(const, cr, mode, guard, iq, snr, seg_sf, rng, world=2)
+        flagged = any(i.status & 32 for i in infos2)
+        ok2 = len(ts2) == len(one) and (ts2 == one).all()
+        msg += f"; world 2: {'equal' if ok2 else 'differs'}{' (status bit 5 raised)' if flagged else ''}"
+        if not ok2 and not flagged:
+            ok = False
+            n = min(len(ts2), len(one)); dd = np.flatnonzero(ts2[:n] != one[:n])
+            msg += f"\nlen {len(ts2) // 188} vs {len(one) // 188}, first differing packet {int(dd[0]) // 188 if len(dd) else -1}\n" + tr2
+    return msg, ok
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 55)
+    res = []
+    for i in range(n):
+        try:
+            msg, ok = case(rng, i)
+        except Exception as e:                                      # noqa
+            msg, ok = f"exception {type(e).__name__}: {str(e)[:300]}", False
+        res.append(ok)
+        print(f"[{i}] {msg} -> {'OK' if ok else 'MISMATCH'}", flush=True)
+    print("ALL OK" if all(res) else f"{res.count(False)} MISMATCHES", f"({len(res)} cases)")
