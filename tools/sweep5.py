@@ -13,24 +13,30 @@ from oracle import pyoracle as po
 import gr_dvbt_amd as g
 
 
-def single(const, cr, mode, guard, iq, snr):
+def single(const, cr, mode, guard, iq, snr, soft=0):
     c = po.cfg(const, cr, mode, guard=guard)
     o = po.rx(c, iq, snr_db=snr, want=("ts",))
-    rx = g.Rx(const, cr, mode, max_samples=len(iq), guard=guard, snr_db=snr)
+    rx = g.Rx(const, cr, mode, max_samples=len(iq), guard=guard, snr_db=snr, soft_decision=soft)
     rx.run(iq)
     ts = rx.tap(g.TAP_TS).copy()
     rx.close()
     return o, ts
 
 
-def streamed(const, cr, mode, guard, iq, snr, seg_sf, rng, world=1):
-    ranks = [g.RxStream(const, cr, mode, segment_superframes=seg_sf, guard=guard, snr_db=snr, rank=r, world=world if world > 1 else 0) for r in range(world)]
+def streamed(const, cr, mode, guard, iq, snr, seg_sf, rng, world=1, soft=0, device=False):
+    ranks = [g.RxStream(const, cr, mode, segment_superframes=seg_sf, guard=guard, snr_db=snr, rank=r, world=world if world > 1 else 0, soft_decision=soft) for r in range(world)]
     chunks, pos, L = [], 0, 2112
+    dev = torch.from_numpy(iq.view(np.float32)).cuda() if device else None
+    torch.cuda.synchronize()
     lo, hi = int(rng.randint(500, 20000)), int(rng.randint(30000, 700000))
     while pos < len(iq):
         n = int(rng.randint(lo, hi))
+        n = min(n, len(iq) - pos)
         for st in ranks:
-            st.push(iq[pos:pos + n])
+            if device:
+                st.push_device(dev.data_ptr() + 8 * pos, n)
+            else:
+                st.push(iq[pos:pos + n])
         pos += n
         if rng.rand() < 0.5:
             for r, st in enumerate(ranks):
@@ -71,9 +77,16 @@ def case(rng, i):
         iq = po.channel(po.stream_slice(c, nsf, int(rng.randint(1, 1000))), c.N, snr_db=snr, seed=int(rng.randint(1, 1000)))
         desc = f"awgn {snr} dB"
     seg_sf = int(rng.randint(1, 5))
-    o, one = single(const, cr, mode, guard, iq, snr)
-    ts, infos, tr = streamed(const, cr, mode, guard, iq, snr, seg_sf, rng)
+    soft = int(kind == "holes" and rng.rand() < 0.2)                # soft decisions: a clean signal decodes to the same bytes
+    device = bool(rng.rand() < 0.3)
+    o, one = single(const, cr, mode, guard, iq, snr, soft)
+    ts, infos, tr = streamed(const, cr, mode, guard, iq, snr, seg_sf, rng, soft=soft, device=device)
+    desc += f", soft {soft}, device pushes {device}"
     ok = len(ts) == len(one) and (ts == one).all()
+    if not ok and infos[0].status & 32:
+        # the one documented limit of a single stream object: a lock that holds for more than two pieces without ever reaching a superframe start (long guard intervals in
+        # noise: the reference's pilot engine never decodes a TPS frame) -- the walk starts afresh and says so
+        return f"{kind} const{const} cr{cr} mode{mode} gi{guard} {nsf} sf, pieces of {seg_sf}, {desc}: status bit 5 raised (status {infos[0].status})", True
     same_oracle = len(one) == len(o["ts"]) and (one == o["ts"]).all()
     if kind == "holes":
         ok = ok and same_oracle                                    # a clean signal: the HIP single chain is the oracle byte for byte, whatever the lock does
@@ -81,10 +94,11 @@ def case(rng, i):
     if not ok:
         msg += "\n" + tr
     if ok and kind == "holes" and rng.rand() < 0.5:
-        ts2, infos2, tr2 = streamed(const, cr, mode, guard, iq, snr, seg_sf, rng, world=2)
+        w2 = int(rng.randint(2, 4))
+        ts2, infos2, tr2 = streamed(const, cr, mode, guard, iq, snr, seg_sf, rng, world=w2, soft=soft)
         flagged = any(i.status & 32 for i in infos2)
         ok2 = len(ts2) == len(one) and (ts2 == one).all()
-        msg += f"; world 2: {'equal' if ok2 else 'differs'}{' (status bit 5 raised)' if flagged else ''}"
+        msg += f"; world {w2}: {'equal' if ok2 else 'differs'}{' (status bit 5 raised)' if flagged else ''}"
         if not ok2 and not flagged:
             ok = False
             n = min(len(ts2), len(one)); dd = np.flatnonzero(ts2[:n] != one[:n])
