@@ -442,6 +442,7 @@ def stream_abi(g):
     import stream_bench
     from oracle import pyoracle as po
     rows = [stream_bench.run(po, g, symbols=sym, device=dev) for sym, dev in ((4, False), (64, False), (64, True))]
+    rows.append(stream_bench.run(po, g, symbols=64, device=True, borrow=1, verify=True))   # the same from device memory with the samples lent to the stream (decoded in place)
     # BASELINE config 5 at the prescribed noise through the streaming entry: the reference's tracker drops the lock every few dozen symbols, no lock period is ever
     # established, the stream is walked window by window (csrc/dvbt_stream.inc); the TS is compared with the single chain's (dvbt_rx_segment_run on all samples)
     rows.append(stream_bench.run(po, g, workload=("QPSK", "C7_8", "T8k"), nsf=16, seg_sf=4, symbols=64, awgn_db=9.0, verify=True, reps=1))

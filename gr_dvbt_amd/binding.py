@@ -242,21 +242,21 @@ class Rx:
 
 
 class StreamParams(C.Structure):
-    _fields_ = [("rx", RxParams), ("segment_superframes", C.c_int), ("rank", C.c_int), ("world", C.c_int), ("ts_ring_bytes", C.c_int64)]
+    _fields_ = [("rx", RxParams), ("segment_superframes", C.c_int), ("rank", C.c_int), ("world", C.c_int), ("ts_ring_bytes", C.c_int64), ("borrow_device_pushes", C.c_int)]
 
 
 class StreamInfo(C.Structure):
     _fields_ = [("status", C.c_int32), ("pieces_in_flight", C.c_int32), ("finished", C.c_int32),
                 ("samples_pushed", C.c_int64), ("ts_bytes_decoded", C.c_int64), ("ts_bytes_ready", C.c_int64), ("ts_bytes_pulled", C.c_int64),
                 ("first_superframe_call", C.c_int64), ("first_ts_packet", C.c_int64),
-                ("constellation", C.c_int32), ("hierarchy", C.c_int32), ("code_rate", C.c_int32), ("auto_configured", C.c_int32), ("in_walk", C.c_int32)]
+                ("constellation", C.c_int32), ("hierarchy", C.c_int32), ("code_rate", C.c_int32), ("auto_configured", C.c_int32), ("samples_released", C.c_int64), ("in_walk", C.c_int32)]
 
 
 class RxStream:
     """dvbt_rx_stream_*: push samples in calls of any size, pull the TS in order; the bytes are those of one chain over the whole stream."""
 
     def __init__(self, constellation, code_rate, mode, segment_superframes=0, guard=G1_32, hierarchy=NH, snr_db=30.0, viterbi_bsize=768,
-                 rs_oracle_compat=0, device=0, rank=0, world=0, soft_decision=0, ts_ring_bytes=0):
+                 rs_oracle_compat=0, device=0, rank=0, world=0, soft_decision=0, ts_ring_bytes=0, borrow=0):
         self.L = lib()
         for fn in ("create", "push", "push_device", "finish", "status"):
             getattr(self.L, f"dvbt_rx_stream_{fn}").restype = C.c_int
@@ -269,7 +269,7 @@ class RxStream:
         self.L.dvbt_rx_stream_status.argtypes = [C.c_void_p, C.POINTER(StreamInfo)]
         self.L.dvbt_rx_stream_destroy.argtypes = [C.c_void_p]
         rx = RxParams(constellation, hierarchy, code_rate, guard, mode, 0, 0, snr_db, viterbi_bsize, rs_oracle_compat, 1, 0, device, 0, 0, 0, 0.0, soft_decision)
-        self.p = StreamParams(rx, segment_superframes, rank, world, ts_ring_bytes)
+        self.p = StreamParams(rx, segment_superframes, rank, world, ts_ring_bytes, borrow)
         self.L.dvbt_rx_stream_pull_chunk.restype = C.c_int64
         self.L.dvbt_rx_stream_pull_chunk.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int64)]
         self.h = C.c_void_p()

@@ -7,12 +7,13 @@
 // TS of one chain over the whole stream -- and writes the file.  No RCCL headers: the communicator comes from the library (dvbt_rccl_unique_id on rank 0, the
 // 128 bytes carried to the others through a file, dvbt_rccl_comm_create everywhere).
 //   rx_multi_example <rank> <world> <id file> <2k|8k> <qpsk|qam16|qam64> <1/2|2/3|3/4|5/6|7/8> <baseband.cf32> <out.ts> [superframes per piece] [device]
-//                    [bench <loops> <loop_from> <loop_len> <samples per push> [pushes per exchange step] [slot packets]]
+//                    [bench <loops> <loop_from> <loop_len> <samples per push> [pushes per exchange step] [slot packets] [copy]]
 // started once per rank (e.g. `for r in 0 1 ... ; do rx_multi_example $r 8 /tmp/id ... & done`); rank r uses device r unless told otherwise.
 // bench: the throughput of this host on samples that are RESIDENT in device memory (what bench.py's line measures for the Python host): the file is uploaded
 // once, then pushed from device memory (dvbt_rx_stream_push_device) -- its first loop_from + loop_len samples, then the stretch [loop_from, loop_from + loop_len)
 // `loops` - 1 more times (a whole number of superframes from a superframe start on: the stream goes on seamlessly but for the encoder's and interleaver's
-// memory at the seam); Msamples/s from the first push to the last packet at rank 0; out.ts is not written.
+// memory at the seam); the samples are LENT to the stream (dvbt_rx_stream_params.borrow_device_pushes: a piece that lies in one stretch of the buffer is decoded in place; "copy"
+// as the last argument: the default contract, every push copies); Msamples/s from the first push to the last packet at rank 0; out.ts is not written.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -57,6 +58,8 @@ int main(int argc, char **argv)
     dvbt_rx_stream_params p{};
     p.rx.constellation = con; p.rx.code_rate = cr; p.rx.transmission_mode = mode; p.rx.snr_db = 30.0f; p.rx.viterbi_bsize = 768; p.rx.descramble = 1; p.rx.device = device;
     p.segment_superframes = seg_sf; p.rank = rank; p.world = world;
+    const bool bench_mode = argc > 15 && !std::strcmp(argv[11], "bench");
+    p.borrow_device_pushes = bench_mode && !(argc > 18 && !std::strcmp(argv[18], "copy")) ? 1 : 0;   // bench: the resident samples are lent to the stream, not copied ("copy": the default contract)
     dvbt_rx_stream *st = nullptr;
     check(dvbt_rx_stream_create(&p, &st));
     dvbt_dims d; check(dvbt_get_dims(con, DVBT_NH, cr, DVBT_G1_32, mode, &d));

@@ -478,6 +478,11 @@ typedef struct {
   /* page-locked ring the decoded TS waits in until it is pulled (0 = 96 MB, ~24 s of the fastest DVB-T transport stream); a consumer that falls further behind
    * than this -- and a stream that cannot have the ring -- is served from heap chunks; dvbt_rx_stream_set_device_output gives it back */
   int64_t ts_ring_bytes;
+  /* 1: the samples handed to dvbt_rx_stream_push_device are BORROWED, not copied: the stream remembers where they are and reads them there -- a piece that lies in one
+   * contiguous stretch of the caller's memory is decoded in place, a piece across two stretches and the windows of a walk are gathered when they are needed.  The caller keeps
+   * the samples valid and unchanged until dvbt_rx_stream_info.samples_released has passed them (a ring of segments resident in HBM does).  dvbt_rx_stream_push (host memory)
+   * is refused on such a stream; not together with DVBT_AUTO.  0: every push copies (the default: the caller's buffer is free when the call returns). */
+  int borrow_device_pushes;
 } dvbt_rx_stream_params;
 typedef struct {
   int32_t status;              /* dvbt_rx_report.status bits of the pieces, OR-ed (bit 1 only when the lock was lost inside a piece) | bit 5: a piece
@@ -489,6 +494,7 @@ typedef struct {
   int64_t first_ts_packet;         /* RS word (counted from that superframe start) of the first TS packet, -1 before it is known */
   int32_t constellation, hierarchy, code_rate;   /* the parameters the chains run with; -1 while they are being detected (DVBT_AUTO) */
   int32_t auto_configured;         /* 1: they were taken from the stream's TPS word */
+  int64_t samples_released;        /* borrow_device_pushes: the stream will not read samples in front of this stream position again (else = samples_pushed) */
   int32_t in_walk;                 /* 1: no lock period is established (the stream's beginning, or behind a lost CP lock): the stream is being walked window by window */
 } dvbt_rx_stream_info;
 typedef struct dvbt_rx_stream dvbt_rx_stream;

@@ -105,3 +105,40 @@ def test_noise_bursts_between_long_lock_periods(po):
         ts, info = _streamed(const, cr, mode, iq, seg_sf, 64 * L, 30.0)
         assert info.status & 2
         assert len(ts) == len(single) > 0 and (ts == single).all(), (seg_sf, len(ts), len(single))
+
+
+@pytest.mark.parametrize("silence_sf,seg_sf", [(3, 1), (7, 2)])
+def test_silence_before_and_inside_the_stream(po, silence_sf, seg_sf):
+    """dead air in front of the signal (longer than the stream's first window: the walk's searches find nothing, window after window), the signal, half a superframe of dead air in
+    the middle of it, the signal again: the stream is the single chain's TS (which is the oracle's: a clean signal)"""
+    const, cr, mode = g.QAM16, g.C2_3, g.T2k
+    c = po.cfg(const, cr, mode)
+    L = c.N + c.cp
+    body = po.stream_slice(c, 10, 33)
+    iq = np.concatenate([np.zeros(silence_sf * 272 * L + 777, np.complex64), body[:po.STREAM_LEAD_IN + 5 * 272 * L + 40 * L], np.zeros(136 * L + 5, np.complex64),
+                         body[po.STREAM_LEAD_IN + 5 * 272 * L + 40 * L:]])
+    o, single = _single_chain(po, const, cr, mode, iq, 30.0)
+    assert len(single) == len(o["ts"]) > 0 and (single == o["ts"]).all(), "HIP single chain differs from the oracle"
+    ts, info = _streamed(const, cr, mode, iq, seg_sf, 50 * L + 3, 30.0)
+    assert len(ts) == len(single) and (ts == single).all(), (len(ts), len(single))
+
+
+def test_auto_configured_stream_through_a_lost_lock(po):
+    """DVBT_AUTO and a dropout behind the head: the chains built from the stream's TPS word follow the reference through the loss like configured ones"""
+    const, cr, mode = g.QAM64, g.C3_4, g.T2k
+    c = po.cfg(const, cr, mode)
+    L = c.N + c.cp
+    iq = po.stream_slice(c, 12, 9).copy()
+    a = po.STREAM_LEAD_IN + (272 * 6 + 130) * L
+    iq[a:a + 25 * L] = 0
+    o, single = _single_chain(po, const, cr, mode, iq, 30.0)
+    assert len(single) == len(o["ts"]) > 0 and (single == o["ts"]).all()
+    st = g.RxStream(g.AUTO, g.AUTO, mode, segment_superframes=2, hierarchy=g.AUTO)
+    out = []
+    for p in range(0, len(iq), 40 * L):
+        st.push(iq[p:p + 40 * L]); out.append(st.pull())
+    st.finish(); out.append(st.pull())
+    info = st.info(); st.close()
+    ts = np.concatenate(out)
+    assert info.auto_configured == 1 and (info.constellation, info.code_rate) == (const, cr) and info.status & 2
+    assert len(ts) == len(single) and (ts == single).all(), (len(ts), len(single))

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
 timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-/usr/bin/time -f "bench.py default run: %e s wall" timeout 900 python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err; tail -1 gpurun_out/bench_final.err; cut -c1-400 gpurun_out/bench_final.json
+T0=$(date +%s); timeout 900 python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err; echo "bench.py default run: $(( $(date +%s) - T0 )) s wall"; cut -c1-400 gpurun_out/bench_final.json
 rm -rf gpurun_out/prof_final gpurun_out/prof_solo
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_final -o r -- python bench.py --no-cpu-baseline --no-extras > gpurun_out/bench_prof.json 2> /dev/null
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_solo -o r -- python bench.py --pipeline 1 --no-cpu-baseline --no-extras > gpurun_out/bench_prof_solo.json 2> /dev/null

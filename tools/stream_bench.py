@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
 
-def run(po, g, workload=("QAM64", "C7_8", "T8k"), nsf=33, seg_sf=8, symbols=64, device=False, reps=2, awgn_db=None, verify=False):
+def run(po, g, workload=("QAM64", "C7_8", "T8k"), nsf=33, seg_sf=8, symbols=64, device=False, reps=2, awgn_db=None, verify=False, borrow=0):
     """awgn_db: AWGN at that SNR, ofdm_sym_acquisition's snr set to it (BASELINE config 5 at the prescribed noise: the reference's tracker drops the lock every few
     dozen symbols and the stream is walked window by window); verify: the TS pulled is compared with dvbt_rx_segment_run over the whole stream"""
     import torch
@@ -20,7 +20,7 @@ def run(po, g, workload=("QAM64", "C7_8", "T8k"), nsf=33, seg_sf=8, symbols=64, 
     torch.cuda.synchronize()
     best, nbytes = None, 0
     for _ in range(reps):
-        st = g.RxStream(const, cr, mode, segment_superframes=seg_sf, snr_db=snr)
+        st = g.RxStream(const, cr, mode, segment_superframes=seg_sf, snr_db=snr, borrow=borrow)
         t0 = time.perf_counter()
         got = 0; parts = []
         for a in range(0, len(iq), step):
@@ -37,7 +37,7 @@ def run(po, g, workload=("QAM64", "C7_8", "T8k"), nsf=33, seg_sf=8, symbols=64, 
         st.close()
         best = dt if best is None or dt < best else best
         nbytes = got
-    row = {"entry": "dvbt_rx_stream_push_device" if device else "dvbt_rx_stream_push (host samples)", "symbols_per_call": symbols, "segment_superframes": seg_sf,
+    row = {"entry": ("dvbt_rx_stream_push_device, samples borrowed (borrow_device_pushes)" if borrow else "dvbt_rx_stream_push_device") if device else "dvbt_rx_stream_push (host samples)", "symbols_per_call": symbols, "segment_superframes": seg_sf,
            "stream_superframes": nsf, "samples": int(len(iq)), "seconds": round(best, 4), "value": round(len(iq) / best / 1e6, 1), "unit": "Msamples/s",
            "x_realtime": round(len(iq) / best / 1e6 / (64 / 7), 1), "ts_bytes": int(nbytes), "status": int(info.status)}
     if awgn_db is not None:
