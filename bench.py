@@ -222,7 +222,8 @@ class Job:
             depth = max(1, getattr(a, "pipeline", 1))            # handles (each with its own HIP stream) that take this piece's steps in turn
             rxs, streams, views = [], [], []
             for _ in range(depth):
-                rx = g.Rx(const, cr, mode, max_samples=len(iq), device=local, viterbi_chunk_bytes=chunk, snr_db=snr_db, launch_graph=1 if getattr(a, "graph", False) else 0, **kw)
+                rx = g.Rx(const, cr, mode, max_samples=len(iq), device=local, viterbi_chunk_bytes=chunk, snr_db=snr_db, launch_graph=1 if getattr(a, "graph", False) else 0,
+                           front_priority=1 if getattr(a, "front_priority", False) else 0, **kw)
                 rx.set_cut(cu["sym_off"])
                 rxs.append(rx); streams.append(_stream(torch, i * depth + len(streams)))
                 views.append(torch.as_tensor(_DevView(rx.tap_device_ptr(g.TAP_TS), cap), device=f"cuda:{local}"))
@@ -576,13 +577,15 @@ def per_block_cpp(iq, workload):
     return res
 
 
-def cpp_multi_host(workload, loops=40, seg_sf=64):
+def cpp_multi_host(workload, loops=160, seg_sf=64):
     """BASELINE config 4's host in C++ (gr_dvbt_amd/host/rx_multi_example.cpp, one rank: one GPU per box) on the bench line's workload: the baseband resident in
     device memory (uploaded before the clock starts), pushed through dvbt_rx_stream_push_device in calls of eight superframes, pieces of 64 superframes, ONE
     asynchronous double-buffered RCCL step per piece's worth of pushes (dvbt_rx_stream_gather_enqueue / _wait, the packets device resident until the root's
     download; the root looks at them in the step's page-locked buffer).  The stretch of 64 superframes behind the first one is pushed `loops` times (a seamless
-    stream but for the encoder's memory at the seam); a warm-up stream runs first.  Unlike the Python line this host pays for the push contract (the samples are
-    COPIED into the library: 1.0 ms of blit kernels per piece, rocprofv3) and for the root's download of the TS (15 GB/s at the headline rate)."""
+    stream but for the encoder's memory at the seam); a warm-up stream runs first.  The samples are LENT to the stream (dvbt_rx_stream_params.borrow_device_pushes: the
+    stretch lies four times back to back in device memory and the pushes walk through that ring, so three pieces of four are decoded where they lie and the
+    fourth, across the ring's wrap, is gathered); `every_push_copies` is the same host under the default push contract (the samples are COPIED into the
+    library: 1.0 ms of blit kernels per piece, rocprofv3).  Both pay for the root's download of the TS (15 GB/s at the headline rate), which the Python line does not."""
     import subprocess
     import tempfile
     from oracle import pyoracle as po
@@ -596,20 +599,26 @@ def cpp_multi_host(workload, loops=40, seg_sf=64):
     fin, idf = os.path.join(tmp, "bb.cf32"), os.path.join(tmp, "nccl.id")
     try:
         iq.tofile(fin)
-        best = None
-        for _ in range(2):
-            if os.path.exists(idf):
-                os.remove(idf)
-            r = subprocess.run([exe, "0", "1", idf, "8k", "qam64", "7/8", fin, os.path.join(tmp, "none.ts"), str(seg_sf), "0", "bench", str(loops),
-                                str(po.STREAM_LEAD_IN + sf), str(64 * sf), str(8 * sf), "8", "400000"], capture_output=True, text=True, timeout=600,
-                               env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
-            if r.returncode != 0:
-                return {"error": (r.stdout[-200:] + r.stderr[-300:])}
-            d = json.loads(r.stdout.strip().splitlines()[-1])
-            best = d if best is None or d["msamples_per_s"] > best["msamples_per_s"] else best
+        res = {}
+        for mode in ("lent", "copy"):
+            best = None
+            for _ in range(2):
+                if os.path.exists(idf):
+                    os.remove(idf)
+                r = subprocess.run([exe, "0", "1", idf, "8k", "qam64", "7/8", fin, os.path.join(tmp, "none.ts"), str(seg_sf), "0", "bench", str(loops),
+                                    str(po.STREAM_LEAD_IN + sf), str(64 * sf), str(8 * sf), "8", "400000"] + (["copy"] if mode == "copy" else []),
+                                   capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+                if r.returncode != 0:
+                    return {"error": (r.stdout[-200:] + r.stderr[-300:])}
+                d = json.loads(r.stdout.strip().splitlines()[-1])
+                best = d if best is None or d["msamples_per_s"] > best["msamples_per_s"] else best
+            res[mode] = best
+        best = res["lent"]
         return {"value": best["msamples_per_s"], "unit": "Msamples/s", "x_realtime": round(best["msamples_per_s"] / REALTIME_MSPS, 1), "world": 1, "samples": best["samples"],
                 "seconds": best["seconds"], "exchange_steps": best["exchange_steps"], "ts_bytes": best["ts_bytes"], "status": best["status"],
-                "entry": "dvbt_rx_stream_push_device + dvbt_rx_stream_gather_enqueue / _wait (RCCL, one rank)", "segment_superframes": seg_sf, "superframes_per_push": 8, "pushes_per_exchange_step": 8}
+                "entry": "dvbt_rx_stream_push_device (samples lent: borrow_device_pushes) + dvbt_rx_stream_gather_enqueue / _wait (RCCL, one rank)", "segment_superframes": seg_sf,
+                "superframes_per_push": 8, "pushes_per_exchange_step": 8,
+                "every_push_copies": {"value": res["copy"]["msamples_per_s"], "seconds": res["copy"]["seconds"], "status": res["copy"]["status"]}}
     finally:
         for f in (fin, idf):
             if os.path.exists(f):
@@ -709,6 +718,7 @@ def main():
     ap.add_argument("--segments", type=int, default=1, help="pieces per GPU: the rank's part of the stream is cut again, one handle + HIP stream per piece")
     ap.add_argument("--graph", action="store_true", help="replay every step as ONE HIP graph launch (dvbt_rx_params.launch_graph) instead of enqueueing it launch by launch; measured: no "
                     "difference (4.673 vs 4.670 ms with one step in flight, 4.379 vs 4.369 with three: the step is a chain of DEPENDENT kernels, not of launch calls), so it is not the default")
+    ap.add_argument("--front-priority", action="store_true", help="dvbt_rx_params.front_priority: a step's front end on a high-priority stream of the handle's own")
     ap.add_argument("--pipeline", type=int, default=3, help="steps in flight per piece: handles (own HIP stream each) that take the piece's steps in turn")
     ap.add_argument("--from-file-rate", action="store_true",
                     help="feed the 10 Msps file format: rational_resampler 64/70 + multiply_const run on the device in front of the chain "

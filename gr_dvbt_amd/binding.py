@@ -47,7 +47,7 @@ class RxParams(C.Structure):
                 ("cell_id", C.c_int), ("snr_db", C.c_float), ("viterbi_bsize", C.c_int),
                 ("rs_oracle_compat", C.c_int), ("descramble", C.c_int), ("max_samples", C.c_size_t),
                 ("device", C.c_int), ("viterbi_chunk_bytes", C.c_int), ("resample_interp", C.c_int), ("resample_decim", C.c_int),
-                ("front_scale", C.c_float), ("soft_decision", C.c_int), ("hier_stream", C.c_int), ("launch_graph", C.c_int)]
+                ("front_scale", C.c_float), ("soft_decision", C.c_int), ("hier_stream", C.c_int), ("launch_graph", C.c_int), ("front_priority", C.c_int)]
 
 
 class RxReport(C.Structure):
@@ -139,10 +139,10 @@ class Rx:
 
     def __init__(self, constellation, code_rate, mode, max_samples, guard=G1_32, hierarchy=NH, snr_db=30.0,
                  viterbi_bsize=768, rs_oracle_compat=0, descramble=1, device=0, viterbi_chunk_bytes=0, taps=False,
-                 resample=(0, 0), front_scale=0.0, soft_decision=0, hier_stream=0, launch_graph=0):
+                 resample=(0, 0), front_scale=0.0, soft_decision=0, hier_stream=0, launch_graph=0, front_priority=0):
         self.L = lib()
         self.p = RxParams(constellation, hierarchy, code_rate, guard, mode, 0, 0, snr_db, viterbi_bsize,
-                          rs_oracle_compat, descramble, max_samples, device, viterbi_chunk_bytes, resample[0], resample[1], front_scale, soft_decision, hier_stream, launch_graph)
+                          rs_oracle_compat, descramble, max_samples, device, viterbi_chunk_bytes, resample[0], resample[1], front_scale, soft_decision, hier_stream, launch_graph, front_priority)
         self.h = C.c_void_p()
         _chk(self.L.dvbt_rx_create(C.byref(self.p), C.byref(self.h)))
         self.dims = get_dims(constellation, code_rate, mode, guard, hierarchy)

@@ -259,6 +259,7 @@ struct ResamplerDesign {
 struct dvbt_rx {
   dvbt_rx_params prm; Dims d; Tables T; FrontParams fp; VitParams vp;
   hipStream_t own_stream = nullptr, cur_stream = nullptr;
+  hipStream_t front_stream = nullptr; hipEvent_t front_ev[2] = {nullptr, nullptr};   // dvbt_rx_params.front_priority: the front end's high-priority stream, fork / join
   size_t max_samples = 0; int max_calls = 0;
   float2 *d_iq = nullptr;              // only when input comes from the host
   ResamplerDesign rsd; float2 *rs_iq = nullptr; size_t chain_max = 0;
@@ -311,6 +312,8 @@ static void rx_free(dvbt_rx *h)
   if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
   if (h->ev_ready) for (int i = 0; i < ST_COUNT; i++) (void)hipEventDestroy(h->ev[i]);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  for (int i = 0; i < 2; i++) if (h->front_ev[i]) (void)hipEventDestroy(h->front_ev[i]);
+  if (h->front_stream) (void)hipStreamDestroy(h->front_stream);
   delete h;
 }
 
@@ -345,6 +348,11 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
 #define RXHIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_err = std::string(#x) + ": " + hipGetErrorString(e_); rx_free(h); return DVBT_ERR_HIP; } } while (0)
   RXCHK(h->T.build_fft(d.N)); RXCHK(h->T.build_front()); RXCHK(h->T.build_inner(1.0f)); RXCHK(h->T.build_rs());
   RXHIP(hipStreamCreate(&h->own_stream));
+  if (p->front_priority) {
+    int least = 0, greatest = 0; RXHIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    RXHIP(hipStreamCreateWithPriority(&h->front_stream, hipStreamNonBlocking, greatest));
+    for (int i = 0; i < 2; i++) RXHIP(hipEventCreateWithFlags(&h->front_ev[i], hipEventDisableTiming));
+  }
   if (h->rsd.ri) RXHIP(hipMalloc((void **)&h->rs_iq, sizeof(float2) * (chain_max + 16)));
   const size_t C = (size_t)h->max_calls, N = d.N, P = d.payload;
   RXHIP(hipMalloc((void **)&h->g_init, sizeof(float2) * ACQ_INIT_TRIES_MAX * N)); RXHIP(hipMalloc((void **)&h->l_init, sizeof(float) * ACQ_INIT_TRIES_MAX * N));
@@ -520,6 +528,12 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
   fp.hist = o.hist; fp.keep_last = o.keep_last ? 1 : 0; fp.avail = o.avail > 0 ? o.avail : (long long)nsamples;
   const int C = fp.ncalls, N = d.N;
   h->cur_stream = s;
+  // dvbt_rx_params.front_priority: everything in front of the Viterbi decoder on the handle's high-priority stream (behind whatever the caller's stream holds), the
+  // decoder and the tail back on the caller's stream
+  hipStream_t const s_user = s;
+  const bool split = h->front_stream && !o.acq_only && !o.skip_acq && !o.continuation && h->timing != 1 && C >= 512 && !h->prm.launch_graph;
+  if (split) { HIPCHK(hipEventRecord(h->front_ev[0], s_user)); HIPCHK(hipStreamWaitEvent(h->front_stream, h->front_ev[0], 0)); s = h->front_stream; }
+  auto join_front = [&]() -> int { if (split && s != s_user) { HIPCHK(hipEventRecord(h->front_ev[1], s)); s = s_user; HIPCHK(hipStreamWaitEvent(s, h->front_ev[1], 0)); } return DVBT_OK; };
   const bool tm = h->timing == 1 && !o.acq_only, tmv = h->timing != 0 && !o.acq_only;   // an event record costs ~6 us of an otherwise idle stream
   if (tm) HIPCHK(hipEventRecord(h->ev[ST_ACQ], s));
   if (o.skip_acq) {
@@ -635,6 +649,7 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
     const float step = 2.0f * d.norm;
     hipLaunchKernelGGL(soft_demap_kernel, dim3(C), dim3(256), (size_t)d.payload * d.m, s, (const float2 *)h->eq, (const float *)h->csi, (const RxState *)h->st, ip, (const float2 *)h->T.points,
                        1.0f / (step * step), (const int *)h->sym_index, (const uint16_t *)h->soft_tab, h->soft_a);
+    { int r = join_front(); if (r) return r; }
     if (tmv) HIPCHK(hipEventRecord(h->ev[ST_VIT], s));
     // the decoder: four chunks per wavefront, chunk size for whole rounds of the wavefront slots
     const S4Plan sp = s4_plan(max_vit, d.ntb);
@@ -646,6 +661,7 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
   hipLaunchKernelGGL(inner_kernel<6>, dim3(C), dim3(INNER_THREADS), inner_lds_bytes((size_t)d.payload), s, (const float2 *)nullptr, (const uint8_t *)h->labels, ip,
                      (const RxState *)h->st, 0, (const int *)h->sym_index, (const float2 *)nullptr, (const unsigned char *)nullptr,
                      (const uint16_t *)h->T.H, (const uint16_t *)h->T.Hinv, (uint8_t *)nullptr, h->symdeint_tap, h->bitdeint, h->bitdeint_lp);
+  { int r = join_front(); if (r) return r; }
   if (tmv) HIPCHK(hipEventRecord(h->ev[ST_VIT], s));
   VitParams vp = h->vp;
   if (h->prm.viterbi_chunk_bytes <= 0) {

@@ -98,8 +98,13 @@ int main(int argc, char **argv)
       if ((size_t)(loop_from + loop_len) > total || loops < 1 || per_push < call) { std::fprintf(stderr, "bench: bad loop arguments\n"); return 2; }
       std::vector<float> all(2 * total);
       if (std::fread(all.data(), 8, total, f) != total) { std::perror("read"); return 1; }
-      void *dev = dvbt_device_malloc(total * 8); if (!dev) { std::fprintf(stderr, "device allocation failed\n"); return 1; }
-      check(dvbt_copy_to_device(dev, all.data(), total * 8));
+      // lent samples: the looped stretch lies RING times back to back behind the stream's head, the pushes walk through that ring -- as a receiver's resident ring of
+      // segments does: three of four seams between two passes are contiguous memory (their pieces are decoded where they lie), the fourth is the ring's wrap (gathered)
+      const long long RING = p.borrow_device_pushes ? 4 : 1;
+      const size_t dev_samples = p.borrow_device_pushes ? (size_t)(loop_from + RING * loop_len) : total;
+      void *dev = dvbt_device_malloc(dev_samples * 8); if (!dev) { std::fprintf(stderr, "device allocation failed\n"); return 1; }
+      check(dvbt_copy_to_device(dev, all.data(), std::min(total, dev_samples) * 8));
+      for (long long k = 1; k < RING; k++) check(dvbt_copy_to_device((char *)dev + 8 * (size_t)(loop_from + k * loop_len), all.data() + 2 * (size_t)loop_from, (size_t)loop_len * 8));
       {   // warm-up: one pass of a stream of its own (the exchange buffers, the ring, the kernels' code are in place when the clock starts)
         dvbt_rx_stream *w = nullptr; check(dvbt_rx_stream_create(&p, &w)); check(dvbt_rx_stream_set_device_output(w, 0));
         check(dvbt_rx_stream_push_device(w, dev, (size_t)(loop_from + loop_len), nullptr)); check(dvbt_rx_stream_finish(w));
@@ -117,7 +122,7 @@ int main(int argc, char **argv)
         }
       };
       push_range(0, (size_t)(loop_from + loop_len));
-      for (long long k = 1; k < loops; k++) push_range((size_t)loop_from, (size_t)(loop_from + loop_len));
+      for (long long k = 1; k < loops; k++) { const size_t a = (size_t)(loop_from + (k % RING) * loop_len); push_range(a, a + (size_t)loop_len); }
       check(dvbt_rx_stream_finish(st));
       while (!all_done) { step(); }
       while (in_flight) take();

@@ -295,6 +295,10 @@ typedef struct {
                               seen and replayed as ONE graph launch afterwards (a receiver that works through a resident ring of segments sees the same few
                               over and over).  The graph holds what the launch sequence holds: every size that depends on the data lives in the device-side
                               state block, the grids are worst case.  Not used while stage timing is on (dvbt_rx_enable_timing) or with a resampler in front. */
+  int front_priority;      /* 1: dvbt_rx_segment_enqueue_device launches a segment's front end (acquisition .. inner de-interleavers) on a stream of the handle's own
+                              with the device's highest priority and joins the caller's stream in front of the Viterbi decoder.  With several segments in flight the
+                              front end of segment k + 1 then gets the workgroup slots that segment k's decoder gives up instead of queueing behind them
+                              (DESIGN.md 8).  Same kernels, same order within a segment, same bytes. */
 } dvbt_rx_params;
 
 typedef struct {

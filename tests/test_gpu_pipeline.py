@@ -62,3 +62,25 @@ def test_step_replayed_as_a_hip_graph(po):
             ts = rx.tap(g.TAP_TS)
             assert rep.n_ts_bytes == len(refs[k]) > 0 and (ts == refs[k]).all(), (rnd, k)
     rx.close()
+
+
+def test_front_end_on_a_priority_stream(po):
+    """dvbt_rx_params.front_priority: the front end of a segment on the handle's own high-priority stream, joined in front of the Viterbi decoder -- two handles in
+    flight, the oracle's bytes from both, round after round"""
+    const, cr, mode = g.QAM64, g.C7_8, g.T8k
+    c = po.cfg(const, cr, mode)
+    ibits = c.payload * c.m * c.k // c.n
+    iqs = [po.tx(c, po.make_ts((272 * ibits * 3) // (204 * 8), 500 + k), lead_in=300 + 500 * k, tail=3 * c.N) for k in range(2)]
+    refs = [po.rx(c, iq, want=("ts",))["ts"] for iq in iqs]
+    devs = [torch.from_numpy(iq.view(np.float32)).cuda() for iq in iqs]
+    torch.cuda.synchronize()
+    rxs = [g.Rx(const, cr, mode, max_samples=len(iq), front_priority=1) for iq in iqs]
+    streams = [torch.cuda.Stream() for _ in iqs]
+    for rnd in range(3):
+        for rx, d, iq, st in zip(rxs, devs, iqs, streams):
+            rx.enqueue_device(d.data_ptr(), len(iq), st.cuda_stream)
+        for k, rx in enumerate(rxs):
+            rep = rx.finish()
+            assert rep.n_ts_bytes == len(refs[k]) > 0 and (rx.tap(g.TAP_TS) == refs[k]).all(), (rnd, k)
+    for rx in rxs:
+        rx.close()
