@@ -35,15 +35,29 @@ if solo:
     prof = solo[-1]
 if os.path.exists(os.path.join(root, "gpurun_out", "pipeline_depth.jsonl")):
     shutil.copy(os.path.join(root, "gpurun_out", "pipeline_depth.jsonl"), os.path.join(root, "profiles", f"{tag}_pipeline_depth.jsonl"))
-soft = sorted(glob.glob(os.path.join(root, "gpurun_out", "prof_soft", "*kernel_stats.csv")), key=os.path.getmtime)
+# (gpurun_out/ outlives a round: what tools/final.sh wrote in an earlier one -- the soft-mode profile, the SNR sweep, the RS load series, the MFMA microbenchmark -- is not this round's)
+fresh = lambda f: os.path.getmtime(f) > os.path.getmtime(os.path.join(root, "gpurun_out", "bench_final.json")) - 4 * 3600
+soft = [f for f in sorted(glob.glob(os.path.join(root, "gpurun_out", "prof_soft", "*kernel_stats.csv")), key=os.path.getmtime) if fresh(f)]
 if soft:
     shutil.copy(soft[-1], os.path.join(root, "profiles", f"{tag}_kernel_stats_soft_8k_qam64_7_8_17sf.csv"))   # tools/soft_prof.py: the soft-decision chain
 cfg5 = sorted(glob.glob(os.path.join(root, "gpurun_out", "prof_cfg5", "*kernel_stats.csv")), key=os.path.getmtime)
 if cfg5:
     shutil.copy(cfg5[-1], os.path.join(root, "profiles", f"{tag}_kernel_stats_config5_8dB.csv"))                  # tools/period_prof.py 8 16: BASELINE config 5 at the prescribed noise
 for extra in ("config5_walk.jsonl", "snr_sweep.jsonl", "rs_load.jsonl", "ubench_mfma.json", "soft_gain.jsonl"):
-    if os.path.exists(os.path.join(root, "gpurun_out", extra)) and os.path.getsize(os.path.join(root, "gpurun_out", extra)) > 0:
+    if os.path.exists(os.path.join(root, "gpurun_out", extra)) and os.path.getsize(os.path.join(root, "gpurun_out", extra)) > 0 and fresh(os.path.join(root, "gpurun_out", extra)):
         shutil.copy(os.path.join(root, "gpurun_out", extra), os.path.join(root, "profiles", f"{tag}_{extra}"))
+cpp = sorted(glob.glob(os.path.join(root, "gpurun_out", "prof_cpp_lent", "*kernel_stats.csv")), key=os.path.getmtime)
+if cpp:
+    shutil.copy(cpp[-1], os.path.join(root, "profiles", f"{tag}_kernel_stats_cpp_host.csv"))                     # tools/cpp_prof.py: the C++ multi-GPU host's bench mode, samples lent
+for src, dst in (("front_priority.jsonl", "front_priority.jsonl"), ("shard_scan.txt", "shard_scan.txt"), ("parity_sweep.txt", "parity_sweep.txt"), ("parity_sweep4.txt", "parity_sweep4.txt")):
+    if os.path.exists(os.path.join(root, "gpurun_out", src)) and os.path.getsize(os.path.join(root, "gpurun_out", src)) > 0:
+        shutil.copy(os.path.join(root, "gpurun_out", src), os.path.join(root, "profiles", f"{tag}_{dst}"))
+sw = sorted(glob.glob(os.path.join(root, "gpurun_out", "parity_sweep5_*.txt")))
+if sw:                                                                                                           # tools/sweep5.py, one file per seed: the streaming entry through lost locks
+    with open(os.path.join(root, "profiles", f"{tag}_parity_sweep_stream.txt"), "w") as o:
+        for f in sw:
+            o.write("==== tools/sweep5.py 60 %s\n" % os.path.basename(f)[len("parity_sweep5_"):-4])
+            o.write(open(f).read())
 b = json.load(open(os.path.join(root, "gpurun_out", "bench_final.json")))
 json.dump(b, open(os.path.join(root, "profiles", f"{tag}_bench_n1.json"), "w"), indent=1)
 pb = json.load(open(os.path.join(root, "gpurun_out", "pmc", "FETCH_SIZE.json")))
