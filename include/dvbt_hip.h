@@ -459,8 +459,11 @@ void dvbt_rx_destroy(dvbt_rx *h);
  * that grid is a whole number of symbols off the transmitted one (a superframe start declared on stale counters, lib/demod_reference_signals_impl.cc:115-136: the
  * reference decodes garbage from there to the next loss, and so does the stream).  status bit 1 reports the loss; dvbt_rx_stream_trace tells what was done.
  * Sharded streams (world > 1): a rank walks a lost lock to the end of its own piece's samples; the result is the single chain's whenever the reference's chain is
- * back in a lock period on the transmitted grid by the next piece's begin (status bit 5 otherwise: the other ranks cannot know).  A stream that never establishes a
- * lock period (config 5 at 9 dB) is walked by every rank and delivered by rank 0.
+ * back in a lock period on the transmitted grid in front of the next piece's first superframe start and its descrambler has found its NSYNC again on the epoch's
+ * own 16-packet call grid (status bit 5 otherwise: the other ranks cannot know).  A stream that never establishes a lock period (config 5 at 9 dB) is walked by
+ * every rank and delivered by rank 0.
+ * At the lock's edge a piece's fresh acquisition may drop -- or not find -- a lock that the chain before it has seen hold; the piece is then started again behind
+ * that loss (a few symbols later; the walk takes over beyond six): it is not a loss of the stream and is not reported as one.
  * Memory per stream object (S = segment_superframes, sf = one superframe of samples = 272 (N + cp) x 8 bytes: 18.4 MB at 8k, 4.6 MB at 2k, guard 1/32):
  *   device: two sample buffers of (S + 3.7) sf each + the two chains' own buffers (~0.55 x a sample buffer each; x 2.2 in soft-decision mode);
  *   S = 16 at 8k: 2 x 362 MB + 2 x ~200 MB.  The first lost lock adds two walk buffers of twice a sample buffer each (2 x 725 MB at S = 16, 8k);
