@@ -560,6 +560,11 @@ int64_t dvbt_rx_stream_gather(dvbt_rx_stream *s, dvbt_rccl_comm *c, int root, in
  * sequential trackers run) on n cases of 16 metric values + a carried d_avg each: out[4k] npk, out[4k+1] position (-1: none) of the first, out[4k+2..3]
  * of the second; avg_out[2k], avg_out[2k+1]: d_avg after the window */
 int dvbt_debug_peak_detect(const float *lambda_host, const float *avg_host, int n, int32_t *out_host, float *avg_out_host);
+/* the streaming entry's host-side follower of energy_descramble (lib/energy_descramble_impl.cc:121-141; csrc/dvbt_stream.inc::descr_walk), which a stream uses wherever the
+ * descrambler re-searches its NSYNC: rs = nitems items of 1504 bytes as they leave reed_solomon_dec; the follower is called once per entry of windows[] (items visible so
+ * far, ascending: the state it carries from window to window is what is under test) and reports the calls it delivers as runs of (first packet, packets) in runs[2 k],
+ * runs[2 k + 1].  Returns the number of runs, or a negative error.  No device needed. */
+int64_t dvbt_debug_descr_follow(const uint8_t *rs, size_t nitems, const int64_t *windows, int nwindows, int64_t *runs, size_t cap_runs);
 
 #ifdef __cplusplus
 }
