@@ -143,6 +143,41 @@ def profiled_traffic(workload, nsf, alg_bytes):
     return None, None
 
 
+def valu_issue(workload, nsf, alg_bytes, solo_ms, clock_hz, simds=1024, cycles_per_inst=4.0):
+    """What actually bounds the dominant kernel: the SIMDs' VALU issue port.  Every wave64 instruction of its mix (packed 16-bit, three-operand, DPP)
+    occupies a SIMD for 4 cycles (profiles/r02_ubench_valu.json), so the launch cannot take less than SQ_INSTS_VALU x 4 / 1024 SIMD-cycles.  `frac_pmc` = that
+    against the launch's own cycle count in the same PMC passes (GRBM_GUI_ACTIVE is summed over the 8 XCDs); `frac_live` = that against this run's
+    solo_launch_ms at the device's clock.  None when no PMC pass of this launch is committed.  Pure arithmetic on a committed file: never raises."""
+    import glob
+    try:
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_summary_{workload}_{nsf}sf.json")), reverse=True):
+            d = json.load(open(f))
+            k = d["kernels"]["viterbi3_kernel"]
+            if abs(d.get("viterbi_algorithmic_bytes", 0) - alg_bytes) > 0.01 * alg_bytes or "SQ_INSTS_VALU" not in k:
+                continue
+            insts = float(k["SQ_INSTS_VALU"])
+            floor_cycles = insts * cycles_per_inst / simds                  # SIMD-cycles the issue port needs
+            out = {"bound": "valu_issue", "wave_instructions_per_launch": int(insts), "cycles_per_instruction": cycles_per_inst, "simds": simds,
+                   "source": os.path.relpath(f, ROOT)}
+            if k.get("GRBM_GUI_ACTIVE"):
+                out["frac_pmc"] = round(floor_cycles / (float(k["GRBM_GUI_ACTIVE"]) / 8.0), 4)
+            if solo_ms and solo_ms > 0 and clock_hz and clock_hz > 0:
+                out["clock_mhz"] = round(clock_hz / 1e6, 1)
+                out["frac_live"] = round(floor_cycles / (solo_ms * 1e-3 * clock_hz), 4)
+            return out
+    except Exception:
+        pass
+    return None
+
+
+def device_clock_hz(torch, local):
+    """the device's peak shader clock as the runtime reports it (0 when it does not)"""
+    try:
+        return float(getattr(torch.cuda.get_device_properties(local), "clock_rate", 0) or 0) * 1e3      # kHz
+    except Exception:
+        return 0.0
+
+
 STAGES = ("acq", "fft", "demod", "inner", "viterbi", "rs", "total")
 _STREAMS = []                    # HIP streams of the process, reused by every Job: streams map onto a few hardware queues in creation order, and a
                                  # later Job's fresh streams may land on ONE queue (its steps in flight would then run one after the other)
@@ -821,7 +856,8 @@ def main():
                          "algorithmic_bytes_per_launch": int(alg_bytes), "solo_launch_ms": round(solo_ms, 4),
                          "in_flight_launch_ms": round(vit_ms, 4) if vit_ms > 0 else None, "in_flight_achieved": round(alg_bytes / (vit_ms * 1e-3) / 1e9, 2) if vit_ms > 0 else None,
                          "chain_frac": round(msps / world * 1e6 * (8 + n_ts / n_stream) / 1e9 / HBM_PEAK_GBS, 6),
-                         "hbm_copy_gbs": hbm_copy_gbs(torch, f"cuda:{local}")},
+                         "hbm_copy_gbs": hbm_copy_gbs(torch, f"cuda:{local}"),
+                         "valu_issue": valu_issue(a.workload, job.nsf, int(alg_bytes), solo_ms, device_clock_hz(torch, local))},
             "ms_per_step_dispersion": job.step_ms,
             "stage_ms_per_piece": stage_avg,
             "stage_ms_per_piece_solo": solo,
