@@ -38,7 +38,13 @@ namespace dvbt {
 
 #ifndef S8_EXP
 #define S8_EXP 0      // experiment builds only (tools/s8_attribution.sh; wrong output): 1 no pilot engine / demapper, 2 no passes 2 and 3, 4 the next symbol's samples are
-                      // loaded at the top of the loop (no prefetch), 8 no equaliser + demapper, 16 no integer-CFO / pattern search, 32 no derotation, 64 the next symbol's samples are requested after the demapper
+                      // loaded at the top of the loop (no prefetch), 8 no equaliser + demapper, 16 no integer-CFO / pattern search, 32 no derotation, 64 the next symbol's samples are requested after the demapper,
+                      // 128 only HALF of the symbol's LDS image is allocated (the small arrays in front of it; accesses to the other half fall outside the workgroup's allocation: reads
+                      // return 0, stores are dropped) and the demapper's slow path is off: what a kernel that needed 32 KB of LDS for its image would cost AT BEST -- with
+                      // -DS8_WG_PER_CU=3 -DS8_MIN_WAVES=6 the occupancy experiment of tools/s8_occupancy.sh
+#endif
+#ifndef S8_MIN_WAVES
+#define S8_MIN_WAVES 4  // __launch_bounds__' wavefronts per SIMD: 4 = 128 VGPRs = two 512-thread workgroups per CU own every register of its SIMDs; 5 -> 96, 6 -> 80 (experiment builds)
 #endif
 constexpr int S8_N = 8192, S8_T = 512, S8_PAY = 6048, S8_NCP = 177, S8_NTPS = 68, S8_ZL = 688;
 constexpr int S8_IT = (S8_PAY + S8_T - 1) / S8_T;             // payload carriers per thread (12)
@@ -46,7 +52,8 @@ constexpr int S8_IT = (S8_PAY + S8_T - 1) / S8_T;             // payload carrier
 #define S8_TOP_N 6
 #endif
 constexpr int S8_TOP = S8_TOP_N;                              // of a thread's 16 samples the first S8_TOP are requested at the top of the symbol's iteration (and used last), the others one symbol ahead
-constexpr size_t S8_LDS_BYTES = (size_t)S8_N * 8 + DEMOD_NP * 8 + 2 * 128 * 8 + 64 * 8 + 192 * 4 + 16 * 4 + 64 * 4 + 192 * 2 + 64 + 16;
+constexpr size_t S8_SMALL_BYTES = DEMOD_NP * 8 + 2 * 128 * 8 + 64 * 8 + 192 * 4 + 16 * 4 + 64 * 4 + 192 * 2 + 64 + 16;   // everything but the symbol's image
+constexpr size_t S8_LDS_BYTES = (size_t)((S8_EXP & 128) ? S8_N / 2 : S8_N) * 8 + S8_SMALL_BYTES;
 #ifndef S8_WG_PER_CU
 #define S8_WG_PER_CU 2
 #endif
@@ -232,7 +239,7 @@ __device__ __forceinline__ v2f s8_sample(s8_i4 rsrc, int i, int tid) { return s8
 // DRIFT: the instantiation that also reproduces the wander of the reference's float phase accumulator (k_drift.hpp): the derotation phasor of a sample is
 // multiplied by (1 + i delta) of its 32-sample block.  Both instantiations are launched; the device-side flag drift_flags[1] decides which one works
 // (the other returns before it takes a symbol), so the path without a carrier offset keeps its registers and instructions.
-template <bool TAPS, bool DRIFT> __global__ __launch_bounds__(S8_T, 4) void symbol8k_kernel(const float2 *__restrict__ iq_, FrontParams p, const RxState *st,
+template <bool TAPS, bool DRIFT> __global__ __launch_bounds__(S8_T, S8_MIN_WAVES) void symbol8k_kernel(const float2 *__restrict__ iq_, FrontParams p, const RxState *st,
                                                            const SymMeta *__restrict__ meta, const float2 *__restrict__ tw, float2 *__restrict__ acq_tap,
                                                            float2 *__restrict__ fft_tap, DemodTables T, float2 *__restrict__ eq_tap,
                                                            float2 *__restrict__ tpsval, SymInfo *__restrict__ info, InnerParams ip,
@@ -242,8 +249,8 @@ template <bool TAPS, bool DRIFT> __global__ __launch_bounds__(S8_T, 4) void symb
 {
   if ((drift_flags[1] != 0) != DRIFT) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  v2f *x = reinterpret_cast<v2f *>(smem_raw);
-  v2f *gtab = x + S8_N;                                          // LS gains at the estimation carriers
+  v2f *x = reinterpret_cast<v2f *>((S8_EXP & 128) ? smem_raw + S8_SMALL_BYTES : smem_raw);
+  v2f *gtab = (S8_EXP & 128) ? reinterpret_cast<v2f *>(smem_raw) : x + S8_N;   // LS gains at the estimation carriers
   float2 *ptab = reinterpret_cast<float2 *>(gtab + DEMOD_NP);    // [2][128] phasor tables, this symbol's and the next one's
   float2 *pts = ptab + 256;
   float *s_known = reinterpret_cast<float *>(pts + 64);          // 192
@@ -502,7 +509,8 @@ template <bool TAPS, bool DRIFT> __global__ __launch_bounds__(S8_T, 4) void symb
             csi_tap[(size_t)s * S8_PAY + i] = 1.0f / (gx * gx + gy * gy);
           }
           int idx;
-          slow |= !s8_demap_cell(e, ip.inv_step, half_n, top, idx);
+          const bool cell_ok = s8_demap_cell(e, ip.inv_step, half_n, top, idx);
+          if (!(S8_EXP & 128)) slow |= !cell_ok;
           lab[i] = label_of[idx & 63];
         }
 #ifdef S8_BATCH
