@@ -170,12 +170,16 @@ def valu_issue(workload, nsf, alg_bytes, solo_ms, clock_hz, simds=1024, cycles_p
     return None
 
 
+NOMINAL_CLOCK_HZ = 2.4e9         # MI355X peak engine clock (MI355X_MICROARCH.md); the microbenchmarks in tools/ read 2400 MHz from hipDeviceAttributeClockRate
+
+
 def device_clock_hz(torch, local):
-    """the device's peak shader clock as the runtime reports it (0 when it does not)"""
+    """the device's peak shader clock: what the runtime reports, else the nominal figure (torch 2.10 on ROCm reports none)"""
     try:
-        return float(getattr(torch.cuda.get_device_properties(local), "clock_rate", 0) or 0) * 1e3      # kHz
+        hz = float(getattr(torch.cuda.get_device_properties(local), "clock_rate", 0) or 0) * 1e3      # kHz
     except Exception:
-        return 0.0
+        hz = 0.0
+    return hz if hz > 0 else NOMINAL_CLOCK_HZ
 
 
 STAGES = ("acq", "fft", "demod", "inner", "viterbi", "rs", "total")
