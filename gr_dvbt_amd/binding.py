@@ -47,7 +47,8 @@ class RxParams(C.Structure):
                 ("cell_id", C.c_int), ("snr_db", C.c_float), ("viterbi_bsize", C.c_int),
                 ("rs_oracle_compat", C.c_int), ("descramble", C.c_int), ("max_samples", C.c_size_t),
                 ("device", C.c_int), ("viterbi_chunk_bytes", C.c_int), ("resample_interp", C.c_int), ("resample_decim", C.c_int),
-                ("front_scale", C.c_float), ("soft_decision", C.c_int), ("hier_stream", C.c_int), ("launch_graph", C.c_int), ("front_priority", C.c_int)]
+                ("front_scale", C.c_float), ("soft_decision", C.c_int), ("hier_stream", C.c_int), ("launch_graph", C.c_int), ("front_priority", C.c_int),
+                ("viterbi_warm_windows", C.c_int)]
 
 
 class RxReport(C.Structure):
@@ -139,10 +140,11 @@ class Rx:
 
     def __init__(self, constellation, code_rate, mode, max_samples, guard=G1_32, hierarchy=NH, snr_db=30.0,
                  viterbi_bsize=768, rs_oracle_compat=0, descramble=1, device=0, viterbi_chunk_bytes=0, taps=False,
-                 resample=(0, 0), front_scale=0.0, soft_decision=0, hier_stream=0, launch_graph=0, front_priority=0):
+                 resample=(0, 0), front_scale=0.0, soft_decision=0, hier_stream=0, launch_graph=0, front_priority=0, viterbi_warm_windows=0):
         self.L = lib()
         self.p = RxParams(constellation, hierarchy, code_rate, guard, mode, 0, 0, snr_db, viterbi_bsize,
-                          rs_oracle_compat, descramble, max_samples, device, viterbi_chunk_bytes, resample[0], resample[1], front_scale, soft_decision, hier_stream, launch_graph, front_priority)
+                          rs_oracle_compat, descramble, max_samples, device, viterbi_chunk_bytes, resample[0], resample[1], front_scale, soft_decision, hier_stream, launch_graph, front_priority,
+                          viterbi_warm_windows)
         self.h = C.c_void_p()
         _chk(self.L.dvbt_rx_create(C.byref(self.p), C.byref(self.h)))
         self.dims = get_dims(constellation, code_rate, mode, guard, hierarchy)
@@ -256,7 +258,7 @@ class RxStream:
     """dvbt_rx_stream_*: push samples in calls of any size, pull the TS in order; the bytes are those of one chain over the whole stream."""
 
     def __init__(self, constellation, code_rate, mode, segment_superframes=0, guard=G1_32, hierarchy=NH, snr_db=30.0, viterbi_bsize=768,
-                 rs_oracle_compat=0, device=0, rank=0, world=0, soft_decision=0, ts_ring_bytes=0, borrow=0):
+                 rs_oracle_compat=0, device=0, rank=0, world=0, soft_decision=0, ts_ring_bytes=0, borrow=0, viterbi_warm_windows=0):
         self.L = lib()
         for fn in ("create", "push", "push_device", "finish", "status"):
             getattr(self.L, f"dvbt_rx_stream_{fn}").restype = C.c_int
@@ -269,6 +271,7 @@ class RxStream:
         self.L.dvbt_rx_stream_status.argtypes = [C.c_void_p, C.POINTER(StreamInfo)]
         self.L.dvbt_rx_stream_destroy.argtypes = [C.c_void_p]
         rx = RxParams(constellation, hierarchy, code_rate, guard, mode, 0, 0, snr_db, viterbi_bsize, rs_oracle_compat, 1, 0, device, 0, 0, 0, 0.0, soft_decision)
+        rx.viterbi_warm_windows = viterbi_warm_windows
         self.p = StreamParams(rx, segment_superframes, rank, world, ts_ring_bytes, borrow)
         self.L.dvbt_rx_stream_pull_chunk.restype = C.c_int64
         self.L.dvbt_rx_stream_pull_chunk.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int64)]

@@ -204,6 +204,16 @@ static void launch_viterbi(hipStream_t s, const uint8_t *in, uint8_t *out, const
   long long chunks = (max_out_bytes + vp.chunk_bytes - 1) / vp.chunk_bytes;
   if (chunks < 1) chunks = 1;
   const dim3 grid((unsigned)((chunks + 4 * V3_WGW - 1) / (4 * V3_WGW))), blk(64 * V3_WGW);
+  if (vp.warm != V3_WARM) {   // a warm-up other than the default (dvbt_rx_params.viterbi_warm_windows): the instantiation that reads it from the parameters
+    switch (vp.ntb) {
+      case 5: hipLaunchKernelGGL((viterbi3_kernel<5, 0>), grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
+      case 9: hipLaunchKernelGGL((viterbi3_kernel<9, 0>), grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
+      case 10: hipLaunchKernelGGL((viterbi3_kernel<10, 0>), grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
+      case 15: hipLaunchKernelGGL((viterbi3_kernel<15, 0>), grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
+      default: hipLaunchKernelGGL((viterbi3_kernel<24, 0>), grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
+    }
+    return;
+  }
   switch (vp.ntb) {   // the traceback depth is a template parameter (hop schedule fixed at compile time)
     case 5: hipLaunchKernelGGL(viterbi3_kernel<5>, grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
     case 9: hipLaunchKernelGGL(viterbi3_kernel<9>, grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
@@ -328,6 +338,9 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   if (d.hierarchy != 0 && d.m == 2) return fail(DVBT_ERR_INVALID, "hierarchical QPSK does not exist (the reference's bit_inner_deinterleaver divides by d_v - 2 = 0 in its constructor)");
   if (d.hierarchy != 0 && p->soft_decision) return fail(DVBT_ERR_INVALID, "soft decisions are built for the non-hierarchical modes");
   if (p->hier_stream < 0 || p->hier_stream > 1) return fail(DVBT_ERR_INVALID, "hier_stream must be 0 (HP) or 1 (LP)");
+  if (p->viterbi_warm_windows != 0 && (p->viterbi_warm_windows < 2 * V3_BLK || p->viterbi_warm_windows > V3_WARM_MAX || p->viterbi_warm_windows % V3_BLK != 0))
+    return fail(DVBT_ERR_INVALID, "viterbi_warm_windows must be 0 (default) or a multiple of 24 in [48, 1152]");
+  if (p->viterbi_warm_windows != 0 && p->soft_decision) return fail(DVBT_ERR_INVALID, "viterbi_warm_windows applies to the hard-decision decoder");
   HIPCHK(hipSetDevice(p->device));
   dvbt_rx *h = new dvbt_rx();
   h->prm = *p; h->d = d; h->T.d = d;
@@ -342,6 +355,7 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   h->fp = make_front_params(d, p->snr_db);
   int cb = p->viterbi_chunk_bytes > 0 ? p->viterbi_chunk_bytes : 768;
   h->vp = make_vit_params(d, p->viterbi_bsize, cb);
+  if (p->viterbi_warm_windows > 0) h->vp.warm = p->viterbi_warm_windows;
   h->max_samples = p->max_samples;
   h->max_calls = (int)((chain_max - (2 * d.N + d.cp + 16)) / (d.N + d.cp) + 1);
 #define RXCHK(x) do { int r_ = (x); if (r_) { rx_free(h); return r_; } } while (0)
@@ -683,8 +697,9 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
   // hierarchical modes: the decoder is handed bytes of which only two (HP) or m - 2 (LP) bits carry anything, unpacked as m coded bits each
   // (viterbi_decoder_impl.cc:236-243): a highly degenerate input -- two thirds of the "received" bits are constant zeros -- whose survivors need not merge
   // inside a chunk's warm-up.  The chunked decoder equals the streaming one only where they do, so here ONE decoder runs from the stream's
-  // start, as the reference's does: exact whatever the input, and slow (one wavefront) -- these modes are on no throughput path.
-  if (d.hierarchy != 0) vp.chunk_bytes = (int)std::min<long long>(max_vit + 64, 1ll << 30);
+  // start, as the reference's does: exact whatever the input, and slow (one wavefront).  With dvbt_rx_params.viterbi_warm_windows the caller chooses the chunked
+  // decoder with a warm-up of his own for these modes too (tools/hier_warmup.py: 60 of 15,000 chunk starts differ at 72 windows, none from 144 on).
+  if (d.hierarchy != 0 && h->prm.viterbi_warm_windows == 0) vp.chunk_bytes = (int)std::min<long long>(max_vit + 64, 1ll << 30);
   // hierarchical modes: the decoder reads the bit de-interleaver's output 0 (HP: what the flowgraphs connect), or its output 1 on request; it unpacks d_m
   // bits of every byte either way (viterbi_decoder_impl.cc:93,236-243: the reference's decoder knows no priority streams)
   launch_viterbi(s, (const uint8_t *)((h->prm.hier_stream && h->bitdeint_lp) ? h->bitdeint_lp : h->bitdeint), h->vit + o.vit_off, (const RxState *)h->st, 0ll, vp, 0ll, 0ll, max_vit);

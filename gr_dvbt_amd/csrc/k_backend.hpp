@@ -205,6 +205,7 @@ struct VitParams {
   int chunk_bytes;       // decoded bytes per wavefront chunk
   int payload;
   unsigned punct_mask;            // bit p = puncture vector entry p
+  int warm;                       // warm-up windows in front of a chunk (read by the WARM = 0 instantiation of viterbi3_kernel only; sits in what was padding)
   unsigned long long prefix_nib;  // nibble p = kept bits before phase p
   unsigned long long magic_plen, magic_m;   // ceil(2^64/d): x/d == umul64hi(x, magic) for x < 2^56
   unsigned long long punct_rep;             // the puncture vector repeated over 64 bits

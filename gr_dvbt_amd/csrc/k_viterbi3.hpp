@@ -51,7 +51,7 @@ inline VitParams make_vit_params(const Dims &d, int bsize, int chunk_bytes)
   VitParams v; memset(&v, 0, sizeof v);
   v.m = d.m; v.k = d.k; v.n = d.n; v.plen = d.plen; v.ntb = d.ntb; v.bsize = bsize;
   v.d_nsymbols = bsize * d.n / d.m; v.d_nbits = 2 * d.k * bsize;
-  v.chunk_bytes = chunk_bytes > 0 ? chunk_bytes : 768; v.payload = d.payload;
+  v.chunk_bytes = chunk_bytes > 0 ? chunk_bytes : 768; v.payload = d.payload; v.warm = 72;   // (= V3_WARM, declared below)
   memcpy(v.punct, d.punct, 16); memcpy(v.prefix, d.prefix, 16);
   v.punct_mask = 0; v.prefix_nib = 0;
   for (int i = 0; i < d.plen; i++) { v.punct_mask |= (unsigned)d.punct[i] << i; v.prefix_nib |= (unsigned long long)d.prefix[i] << (4 * i); }
@@ -82,7 +82,9 @@ constexpr int V3_WGW = V3_WGW_N;    // wavefronts per workgroup: independent (no
                                    // lifetime, 32 alternate s_setprio window by window, 64 s_nop after every step, 128 s_sleep per window,
                                    // 256 step words from registers (no LDS read in the loop)
 #endif
-constexpr int V3_WARM = 72;        // warm-up windows before a chunk's first byte
+constexpr int V3_WARM = 72;        // warm-up windows before a chunk's first byte (the default; dvbt_rx_params.viterbi_warm_windows selects the WARM = 0 instantiation, which reads VitParams.warm)
+constexpr int V3_WARM_MAX = 1152;  // the largest warm-up the parameter accepts
+static_assert(V3_WARM == 72, "make_vit_params (above) presets VitParams.warm to the default");
 constexpr int V3_BLK = 24;         // windows per forward block (multiple of 6: phase cycle x renormalisation cadence)
 constexpr int V3_RINGW = 64;       // windows kept in the LDS ring (power of two, >= 2*V3_BLK - 12 + max ntraceback - 1: the traceback of a
                                    // block runs during the first 12 windows of the next one).  20 KB of LDS per wavefront = 2 wavefronts
@@ -320,7 +322,11 @@ template <bool HOPS, int HOP0, int NTB> __device__ __forceinline__ void v3_fwd_s
 #if V3_EXP & 16
 __device__ unsigned long long *v3_dbg;     // tools/vit_kbench.hip: (hw id, start, end in 100 MHz ticks) per wavefront
 #endif
-template <int NTB> __global__ __launch_bounds__(64 * V3_WGW) void viterbi3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const RxState *st,
+// WARM: the warm-up in windows as a compile-time constant (the default instantiation: V3_WARM), or 0: taken from vp.warm (any multiple of V3_BLK up to V3_WARM_MAX).
+// How early a chunk's decoder must start for its survivors to have merged depends on the input: on streams whose pre-Viterbi bit error rate the code can cope with
+// (<= 2 %) no chunk start of 20,000 differs from the streaming decoder at 72 windows; on a collapsed channel (>= 3 % at rate 7/8) and on the degenerate input of the
+// hierarchical modes about one start in a thousand does, for up to ~125 windows (tools/hier_warmup.py)
+template <int NTB, int WARM = V3_WARM> __global__ __launch_bounds__(64 * V3_WGW) void viterbi3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const RxState *st,
                                                       long long steps_fixed, VitParams vp, long long in_base, long long out_lo)
 {
   __shared__ __attribute__((aligned(16))) unsigned char tab_[V3_WGW][V3_RINGW * 4 * 64];   // path bytes: [window][decoder][cell z]  (the ppresult ring)
@@ -347,7 +353,7 @@ template <int NTB> __global__ __launch_bounds__(64 * V3_WGW) void viterbi3_kerne
   const long long b0 = out_lo + (chunk0 + dd) * B;                // this lane's decoder
   const bool dec_active = b0 < total_out;
   const long long b1 = (b0 + B < total_out) ? b0 + B : total_out;
-  constexpr int warm = V3_WARM;
+  const int warm = WARM > 0 ? WARM : vp.warm;
   const long long w0 = b0 + 2 - warm;                              // absolute window of relative window 0
   const int J = ((warm + B + ntb - 1 + V3_BLK - 1) / V3_BLK) * V3_BLK;
   const long long n_in_bytes = (total_steps * 2 / vp.plen * vp.n + vp.m - 1) / vp.m;   // input bytes that exist

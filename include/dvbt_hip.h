@@ -299,6 +299,17 @@ typedef struct {
                               with the device's highest priority and joins the caller's stream in front of the Viterbi decoder.  With several segments in flight the
                               front end of segment k + 1 then gets the workgroup slots that segment k's decoder gives up instead of queueing behind them
                               (DESIGN.md 8).  Same kernels, same order within a segment, same bytes. */
+  int viterbi_warm_windows;/* 0: the default.  The Viterbi decoder runs as independent chunk decoders, each started `warm-up` windows (8 trellis steps = one decoded byte
+                              each) in front of its chunk from all-zero metrics; a chunk equals the streaming decoder of lib/d_viterbi.c once all its survivors have
+                              merged inside the warm-up -- which depends on the INPUT.  Default 72 windows: of 20,000 chunk starts per configuration none differs on
+                              streams whose pre-Viterbi bit error rate the code can cope with (<= 2 %, SURVEY 8d's prescribed 1e-2 included); on a collapsed channel
+                              (>= 3 % at rate 7/8: every RS word fails either way) about one chunk start in a thousand differs, for up to ~125 windows
+                              (tools/hier_warmup.py).  A multiple of 24 in [48, 1152]: that many windows instead (144: one start of 5,000 still differed on
+                              pure garbage, none of 15,000 at a bit error rate of 6 %; 192 and 288: none on any input tried; 144 costs +2.4 % of the decoder's time at
+                              the headline's chunk size, 288 +7 %).
+                              Hierarchical modes: 0 = ONE decoder from the stream's start (exact whatever the input, one wavefront: ~1.2x real time); > 0 = the chunked
+                              decoder with that warm-up -- the throughput path of those modes (their degenerate decoder input, two thirds constant zeros, differs at
+                              60 of 15,000 starts with 72 windows and at none from 144 on). */
 } dvbt_rx_params;
 
 typedef struct {

@@ -73,3 +73,22 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".inc", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "pyoracle" not in txt and "dvbt_oracle.h" not in txt and "liboracle" not in txt, os.path.join(dirpath, f)
+
+
+def test_ctypes_structures_have_the_headers_layout(tmp_path):
+    """the structures of gr_dvbt_amd/binding.py against include/dvbt_hip.h as a C compiler lays them out (sizes, the offsets of the newest fields): a field added on one
+    side only would shift everything behind it silently"""
+    import ctypes as C
+    import subprocess
+    import gr_dvbt_amd.binding as b
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "dvbt_hip.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(dvbt_rx_params), offsetof(dvbt_rx_params, viterbi_warm_windows), '
+                   'offsetof(dvbt_rx_params, max_samples), sizeof(dvbt_rx_stream_params), offsetof(dvbt_rx_stream_params, segment_superframes), '
+                   'offsetof(dvbt_rx_stream_params, borrow_device_pushes), sizeof(dvbt_rx_report)); return 0; }\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    want = [C.sizeof(b.RxParams), b.RxParams.viterbi_warm_windows.offset, b.RxParams.max_samples.offset, C.sizeof(b.StreamParams),
+            b.StreamParams.segment_superframes.offset, b.StreamParams.borrow_device_pushes.offset, C.sizeof(b.RxReport)]
+    assert got == want
