@@ -163,6 +163,8 @@ long long o_soft_viterbi(const o_cfg *c, const signed char *soft, long long n_so
 
 /* ---- the reference's own SSE2 Viterbi kernels (oracle/_ref), timed natively: decoded Mbit/s, -1 when the library is missing */
 double o_ref_viterbi_mbps(const char *so_path, size_t nsym, int ntraceback);
+/* the block's decode around the reference's own kernels, natively (the counterpart of o_viterbi_decode_n for comparisons on megabytes) */
+size_t o_ref_viterbi_decode_n(const char *so_path, const o_cfg *c, const unsigned char *in, size_t nsym, unsigned char *out);
 
 /* ---- whole RX chain, emulating the GNU Radio flowgraph in the 1-item regime ---- */
 typedef struct {

@@ -106,3 +106,36 @@ def test_block_decode_matches_stream(po):
                                   out.ctypes.data_as(C.c_void_p))
     assert n == 672 * 3 - 24
     assert (out[:n] == data[:n]).all()
+
+
+@pytest.mark.parametrize("const,cr,ber", [(2, 4, 0.0), (2, 4, 0.02), (2, 4, 0.06), (2, 4, 0.5), (0, 4, 0.06), (1, 0, 0.5), (2, 2, 0.08), (2, 3, 0.5)])
+def test_oracle_block_decode_equals_reference_kernels_on_megabytes(po, const, cr, ber):
+    """The block-level restatement (o_viterbi_decode_n: depuncturer + butterfly / output cadence) against the same loop around the REFERENCE's own kernels, driven
+    natively (oracle/o_refbench.c::o_ref_viterbi_decode_n), on ~1 MB of decoder input per case: clean, at the edge of what the code copes with, on collapsed channels and on
+    garbage -- the regimes in which the product's chunked decoder is compared with this restatement (tests/test_gpu_warmup.py, tools/hier_warmup.py)."""
+    import os
+    if not os.path.exists(po._REF):
+        pytest.skip("oracle/_ref is built only where /root/reference exists")
+    c = po.cfg(const, cr, po.T2k)
+    L = po.lib()
+    L.o_viterbi_decode_n.restype = C.c_size_t
+    L.o_viterbi_decode_n.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.o_ref_viterbi_decode_n.restype = C.c_size_t
+    L.o_ref_viterbi_decode_n.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    blk_in = 768 * c.n // c.m
+    nblocks = 1000000 // blk_in
+    # a coded stream: random payload through the reference's own encoder + puncturing would need the kernels' d_encode; the decoder's behaviour under comparison does not
+    # depend on the input being a codeword, so: the oracle chain's clean decoder input, repeated, with independent bit errors
+    ibits = c.payload * c.m * c.k // c.n
+    iq = po.tx(c, po.make_ts((272 * ibits * 2) // (204 * 8), 5), lead_in=500, tail=3 * c.N)
+    vin = po.rx(c, iq, want=("bitdeint",))["bitdeint"].reshape(-1)
+    vin = np.tile(vin, nblocks * blk_in // len(vin) + 1)[:nblocks * blk_in].copy()
+    rng = np.random.RandomState(17)
+    for b in range(c.m):
+        vin ^= (rng.rand(len(vin)) < ber).astype(np.uint8) << b
+    cap = len(vin) * c.m * c.k // (8 * c.n) + 64
+    a, r = np.zeros(cap, np.uint8), np.zeros(cap, np.uint8)
+    na = L.o_viterbi_decode_n(C.byref(c), vin.ctypes.data, len(vin), a.ctypes.data)
+    nr = L.o_ref_viterbi_decode_n(po._REF.encode(), C.byref(c), vin.ctypes.data, len(vin), r.ctypes.data)
+    assert nr != 2 ** 64 - 1, "reference kernels could not be loaded"
+    assert na == nr > 100000 and (a[:na] == r[:nr]).all()
