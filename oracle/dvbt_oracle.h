@@ -99,6 +99,8 @@ size_t o_viterbi_decode(const o_cfg *c, int bsize, const unsigned char *in, size
                         unsigned char *out);
 /* the same over exactly nsym input bytes (the depunctured bit count must be a multiple of 16) */
 size_t o_viterbi_decode_n(const o_cfg *c, const unsigned char *in, size_t nsym, unsigned char *out);
+/* ... with the 64 path metrics (minimum subtracted) right behind the snap_at[i]-th get_output call, 64 bytes each (test instrumentation) */
+size_t o_viterbi_decode_snap(const o_cfg *c, const unsigned char *in, size_t nsym, unsigned char *out, const long long *snap_at, int nsnap, unsigned char *snaps);
 
 /* ---- Forney byte de-interleaver (lib/convolutional_deinterleaver_impl.cc) ---- */
 /* closed form of the 12 FIFOs starting from all-zero state; n bytes -> n bytes */

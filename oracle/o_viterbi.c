@@ -119,18 +119,21 @@ int o_vit_ntraceback(int cr)
  * the depuncturer and the butterfly/output cadence (:241-292) depend only on the running bit count modulo the puncture
  * period and modulo 16, and a block is a whole number of both, so a run of blocks is one long block.  nsym must
  * make the depunctured bit count a multiple of 16 (any whole number of blocks does). */
-size_t o_viterbi_decode_n(const o_cfg *c, const unsigned char *in, size_t nsym, unsigned char *out)
+/* (snap_at / snaps: test instrumentation, see o_viterbi_decode_snap below; NULL in the decode proper) */
+static size_t decode_core(const o_cfg *c, const unsigned char *in, size_t nsym, unsigned char *out,
+                          const long long *snap_at, int nsnap, unsigned char *snaps)
 {
   int plen; const unsigned char *punct = o_vit_puncture(c->code_rate, &plen);
   int nt = o_vit_ntraceback(c->code_rate);
   o_vit_core v; v.store_pos = 0;
   o_vit_core_init(&v, nt);
   size_t out_count = 0, count = 0, ic = 0;
-  unsigned char bits[4]; int nb = 0;
+  unsigned char bits[4]; int nb = 0, si = 0;
   /* depuncture :241-256 feeding the decoder :261-292 four bits (two trellis steps) at a time */
 #define O_PUSH(b) do { bits[nb++] = (unsigned char)(b); count++; if (nb == 4) { nb = 0; \
     o_vit_butterfly2(&v, bits); \
-    if (ic > 0 && (ic % 16) == 8) { unsigned char ch = o_vit_get_output(&v); if (out_count >= (size_t)nt) out[out_count - nt] = ch; out_count++; } \
+    if (ic > 0 && (ic % 16) == 8) { unsigned char ch = o_vit_get_output(&v); if (out_count >= (size_t)nt) out[out_count - nt] = ch; out_count++; \
+      if (si < nsnap && (long long)out_count == snap_at[si]) { memcpy(snaps + 64 * (size_t)si, v.metric, 64); si++; } } \
     ic += 4; } } while (0)
   for (size_t i = 0; i < nsym; i++)
     for (int j = c->m - 1; j >= 0; j--) {
@@ -141,6 +144,15 @@ size_t o_viterbi_decode_n(const o_cfg *c, const unsigned char *in, size_t nsym, 
 #undef O_PUSH
   return out_count >= (size_t)nt ? out_count - nt : 0;
 }
+
+size_t o_viterbi_decode_n(const o_cfg *c, const unsigned char *in, size_t nsym, unsigned char *out)
+{ return decode_core(c, in, nsym, out, NULL, 0, NULL); }
+
+/* The same decode, and the decoder's 64 path metrics as they stand right behind its snap_at[i]-th call of get_output (calls counted from 1; snap_at ascending): get_output has just
+ * subtracted their minimum (:728-732) and cleared the path bytes, so two decoders over the same input whose vectors are EQUAL at the same call make identical decisions from there on.
+ * tests/test_viterbi_boundary_proof_model.py: the criterion a chunk-parallel decoder could prove its equality with the streaming decoder by, per run. */
+size_t o_viterbi_decode_snap(const o_cfg *c, const unsigned char *in, size_t nsym, unsigned char *out, const long long *snap_at, int nsnap, unsigned char *snaps)
+{ return decode_core(c, in, nsym, out, snap_at, nsnap, snaps); }
 
 /* block-level entry: whole blocks of bsize*n/m input bytes only (:149,:198) */
 size_t o_viterbi_decode(const o_cfg *c, int bsize, const unsigned char *in, size_t nsym,
