@@ -254,6 +254,8 @@ class Job:
             kw = {"soft_decision": 1} if soft else {}
             if getattr(a, "viterbi_warm", 0):
                 kw["viterbi_warm_windows"] = a.viterbi_warm
+            if getattr(a, "viterbi_verify", False):
+                kw["viterbi_verify"] = 1
             if from_file_rate:
                 rx_const = 0.0022097087 if mode == po.T2k else 0.00055242272           # blocks_multiply_const_vxx_0 of the RX flowgraph
                 iq = po.resample(iq / np.float32(rx_const), 70, 64, 1.0)                # what dvbt_tx_demo writes: the 10 Msps stream
@@ -772,6 +774,8 @@ def main():
     ap.add_argument("--front-priority", action="store_true", help="dvbt_rx_params.front_priority: a step's front end on a high-priority stream of the handle's own")
     ap.add_argument("--viterbi-warm", type=int, default=0, help="dvbt_rx_params.viterbi_warm_windows: warm-up of the Viterbi stage's chunk decoders in windows (0 = the default 72; a multiple of 24): "
                     "what equality with the streaming decoder on collapsed channels costs (DESIGN.md 2)")
+    ap.add_argument("--viterbi-verify", action="store_true", help="dvbt_rx_params.viterbi_verify: the decoder's launch proves chunk by chunk that it is the streaming decoder (config.viterbi_check = chunks, "
+                    "chunks not proven, of the last step)")
     ap.add_argument("--pipeline", type=int, default=3, help="steps in flight per piece: handles (own HIP stream each) that take the piece's steps in turn")
     ap.add_argument("--from-file-rate", action="store_true",
                     help="feed the 10 Msps file format: rational_resampler 64/70 + multiply_const run on the device in front of the chain "
@@ -855,6 +859,7 @@ def main():
                                    + (", input at the 10 Msps file rate (resampler 64/70 + scale on the device)" if a.from_file_rate else ""),
                        "stream_superframes": job.nsf, "superframes_per_gpu": a.superframes, "pieces_per_gpu": nseg, "steps_in_flight": depth,
                        "viterbi_warm_windows": a.viterbi_warm or 72,
+                       **({"viterbi_check": [dict(zip(("chunks", "not_proven"), p["rx"].viterbi_check())) for p in job.pieces]} if a.viterbi_verify else {}),
                        "stream_samples": n_stream, "samples_decoded_per_gpu_per_step": job.samples_decoded,
                        "parallelism": f"one stream cut into {world * nseg} pieces at superframe boundaries, {nseg} per GPU"
                                       + ((" + one RCCL gather of TS per step" if a.backend == "nccl" else " + one gloo gather of TS per step (host staged)") if dist else ""),

@@ -48,7 +48,7 @@ class RxParams(C.Structure):
                 ("rs_oracle_compat", C.c_int), ("descramble", C.c_int), ("max_samples", C.c_size_t),
                 ("device", C.c_int), ("viterbi_chunk_bytes", C.c_int), ("resample_interp", C.c_int), ("resample_decim", C.c_int),
                 ("front_scale", C.c_float), ("soft_decision", C.c_int), ("hier_stream", C.c_int), ("launch_graph", C.c_int), ("front_priority", C.c_int),
-                ("viterbi_warm_windows", C.c_int)]
+                ("viterbi_warm_windows", C.c_int), ("viterbi_verify", C.c_int)]
 
 
 class RxReport(C.Structure):
@@ -140,11 +140,11 @@ class Rx:
 
     def __init__(self, constellation, code_rate, mode, max_samples, guard=G1_32, hierarchy=NH, snr_db=30.0,
                  viterbi_bsize=768, rs_oracle_compat=0, descramble=1, device=0, viterbi_chunk_bytes=0, taps=False,
-                 resample=(0, 0), front_scale=0.0, soft_decision=0, hier_stream=0, launch_graph=0, front_priority=0, viterbi_warm_windows=0):
+                 resample=(0, 0), front_scale=0.0, soft_decision=0, hier_stream=0, launch_graph=0, front_priority=0, viterbi_warm_windows=0, viterbi_verify=0):
         self.L = lib()
         self.p = RxParams(constellation, hierarchy, code_rate, guard, mode, 0, 0, snr_db, viterbi_bsize,
                           rs_oracle_compat, descramble, max_samples, device, viterbi_chunk_bytes, resample[0], resample[1], front_scale, soft_decision, hier_stream, launch_graph, front_priority,
-                          viterbi_warm_windows)
+                          viterbi_warm_windows, viterbi_verify)
         self.h = C.c_void_p()
         _chk(self.L.dvbt_rx_create(C.byref(self.p), C.byref(self.h)))
         self.dims = get_dims(constellation, code_rate, mode, guard, hierarchy)
@@ -220,6 +220,13 @@ class Rx:
         self.L.dvbt_rx_walk_stats.argtypes = [C.c_void_p, C.POINTER(W)]
         _chk(self.L.dvbt_rx_walk_stats(self.h, C.byref(w)))
         return w.small_passes, w.general_passes, w.small_chunk_calls, w.small_max_calls
+
+    def viterbi_check(self):
+        """viterbi_verify = 1: (chunks of the last launch of the Viterbi decoder, chunks NOT proven equal to the streaming decoder)"""
+        a, b = C.c_int64(), C.c_int64()
+        self.L.dvbt_rx_viterbi_check.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        _chk(self.L.dvbt_rx_viterbi_check(self.h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def tap_device_ptr(self, tap):
         return self.L.dvbt_rx_tap_device_ptr(self.h, tap)

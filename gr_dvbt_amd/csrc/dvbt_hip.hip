@@ -199,11 +199,23 @@ struct Tables {          // device lookup tables for one configuration
 
 // A7: 4 chunks per wavefront, V3_WGW independent wavefronts per workgroup (k_viterbi3.hpp)
 static void launch_viterbi(hipStream_t s, const uint8_t *in, uint8_t *out, const RxState *st, long long steps_fixed, const VitParams &vp,
-                           long long in_base, long long out_lo, long long max_out_bytes)
+                           long long in_base, long long out_lo, long long max_out_bytes, int *snap = nullptr, int *check_result = nullptr)
 {
   long long chunks = (max_out_bytes + vp.chunk_bytes - 1) / vp.chunk_bytes;
   if (chunks < 1) chunks = 1;
   const dim3 grid((unsigned)((chunks + 4 * V3_WGW - 1) / (4 * V3_WGW))), blk(64 * V3_WGW);
+  if (snap) {   // dvbt_rx_params.viterbi_verify: the instantiation that leaves every chunk decoder's state at its chunk's first window, and the checker behind it (k_viterbi3.hpp)
+    const long long aux = (long long)(uintptr_t)snap;
+    switch (vp.ntb) {
+      case 5: hipLaunchKernelGGL((viterbi3_kernel<5, 0, true>), grid, blk, 0, s, in, out, st, steps_fixed, vp, aux, 0ll); break;
+      case 9: hipLaunchKernelGGL((viterbi3_kernel<9, 0, true>), grid, blk, 0, s, in, out, st, steps_fixed, vp, aux, 0ll); break;
+      case 10: hipLaunchKernelGGL((viterbi3_kernel<10, 0, true>), grid, blk, 0, s, in, out, st, steps_fixed, vp, aux, 0ll); break;
+      case 15: hipLaunchKernelGGL((viterbi3_kernel<15, 0, true>), grid, blk, 0, s, in, out, st, steps_fixed, vp, aux, 0ll); break;
+      default: hipLaunchKernelGGL((viterbi3_kernel<24, 0, true>), grid, blk, 0, s, in, out, st, steps_fixed, vp, aux, 0ll); break;
+    }
+    hipLaunchKernelGGL(viterbi_check_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s, (const int *)snap, st, steps_fixed, vp, check_result);
+    return;
+  }
   if (vp.warm != V3_WARM) {   // a warm-up other than the default (dvbt_rx_params.viterbi_warm_windows): the instantiation that reads it from the parameters
     switch (vp.ntb) {
       case 5: hipLaunchKernelGGL((viterbi3_kernel<5, 0>), grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
@@ -290,6 +302,7 @@ struct dvbt_rx {
   float2 *acq_tap = nullptr, *fft_out = nullptr, *eq = nullptr, *tpsval = nullptr; SymInfo *info = nullptr; int *maj = nullptr, *sym_index = nullptr;
   uint8_t *labels = nullptr, *symdeint_tap = nullptr, *bitdeint = nullptr, *vit = nullptr, *deint_tap = nullptr, *rs_out = nullptr, *ts_out = nullptr;
   uint8_t *bitdeint_lp = nullptr;           // hierarchical modes: the bit de-interleaver's second output
+  int *vit_snap = nullptr, *vit_check = nullptr; size_t vit_snap_words = 0; bool vit_checked = false;   // dvbt_rx_params.viterbi_verify: the chunk decoders' snapshots, {chunks, unproven}
   size_t vit_cap = 0; RsDefer *rs_defer = nullptr; int rs_defer_cap = 0;
   unsigned long long *rs_sync = nullptr;     // bit w: payload byte 0 of RS word w is 0xB8 (deint_rs_kernel / rs_fix_kernel -> descramble_scan_kernel)
   unsigned soft_grid = 0;     // workgroups the decision scratch has slots for
@@ -313,7 +326,7 @@ struct dvbt_rx {
 
 static void rx_free(dvbt_rx *h)
 {
-  void *all[] = {h->bitdeint_lp, h->st_ctx[0], h->st_ctx[1], h->st_ctx[2], h->meta_ctx[0], h->meta_ctx[1], h->meta_ctx[2], h->tps_prev_snap[0], h->tps_prev_snap[1], h->tps_snap[0], h->tps_snap[1], h->csi, h->soft_a, h->soft_tab, h->soft_scratch, h->rs_defer, h->rs_sync, h->drift_mem, h->drift.delta, h->drift_flags_ctx[0], h->drift_flags_ctx[1], h->drift_flags_ctx[2], h->tps_prev, h->descr_runs, h->descr_nruns, h->centre, h->anchor_pos, h->sym_ticket_ctx[0], h->sym_ticket_ctx[1], h->sym_ticket_ctx[2], h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags_ctx[0], h->trk_flags_ctx[1], h->trk_flags_ctx[2], h->trk_eps, h->d_iq, h->rs_iq, h->acq_carry, h->g_init, h->l_init, h->g_trk, h->l_trk, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
+  void *all[] = {h->vit_snap, h->vit_check, h->bitdeint_lp, h->st_ctx[0], h->st_ctx[1], h->st_ctx[2], h->meta_ctx[0], h->meta_ctx[1], h->meta_ctx[2], h->tps_prev_snap[0], h->tps_prev_snap[1], h->tps_snap[0], h->tps_snap[1], h->csi, h->soft_a, h->soft_tab, h->soft_scratch, h->rs_defer, h->rs_sync, h->drift_mem, h->drift.delta, h->drift_flags_ctx[0], h->drift_flags_ctx[1], h->drift_flags_ctx[2], h->tps_prev, h->descr_runs, h->descr_nruns, h->centre, h->anchor_pos, h->sym_ticket_ctx[0], h->sym_ticket_ctx[1], h->sym_ticket_ctx[2], h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags_ctx[0], h->trk_flags_ctx[1], h->trk_flags_ctx[2], h->trk_eps, h->d_iq, h->rs_iq, h->acq_carry, h->g_init, h->l_init, h->g_trk, h->l_trk, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
                  h->info, h->maj, h->sym_index, h->labels, h->symdeint_tap, h->bitdeint, h->vit, h->deint_tap, h->rs_out, h->ts_out};
   for (void *q : all) if (q) (void)hipFree(q);
   for (auto &ge : h->graphs) if (ge.exec) (void)hipGraphExecDestroy(ge.exec);
@@ -341,6 +354,8 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   if (p->viterbi_warm_windows != 0 && (p->viterbi_warm_windows < 2 * V3_BLK || p->viterbi_warm_windows > V3_WARM_MAX || p->viterbi_warm_windows % V3_BLK != 0))
     return fail(DVBT_ERR_INVALID, "viterbi_warm_windows must be 0 (default) or a multiple of 24 in [48, 1152]");
   if (p->viterbi_warm_windows != 0 && p->soft_decision) return fail(DVBT_ERR_INVALID, "viterbi_warm_windows applies to the hard-decision decoder");
+  if (p->viterbi_verify != 0 && p->viterbi_verify != 1) return fail(DVBT_ERR_INVALID, "viterbi_verify must be 0 or 1");
+  if (p->viterbi_verify && p->soft_decision) return fail(DVBT_ERR_INVALID, "viterbi_verify applies to the hard-decision decoder");
   HIPCHK(hipSetDevice(p->device));
   dvbt_rx *h = new dvbt_rx();
   h->prm = *p; h->d = d; h->T.d = d;
@@ -391,6 +406,11 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   RXHIP(hipMalloc((void **)&h->maj, sizeof(int) * C)); RXHIP(hipMalloc((void **)&h->sym_index, sizeof(int) * C));
   RXHIP(hipMalloc((void **)&h->bitdeint, C * P + 64));
   if (d.hierarchy != 0) RXHIP(hipMalloc((void **)&h->bitdeint_lp, C * P + 64));
+  if (p->viterbi_verify) {   // two snapshots of 32 words per chunk, chunks of >= 240 bytes
+    h->vit_snap_words = (size_t)((long long)C * P * d.m * d.k / (8 * d.n) / 240 + 8) * 64;
+    RXHIP(hipMalloc((void **)&h->vit_snap, h->vit_snap_words * sizeof(int))); RXHIP(hipMalloc((void **)&h->vit_check, 2 * sizeof(int)));
+    RXHIP(hipMemset(h->vit_check, 0, 2 * sizeof(int)));
+  }
   h->vit_cap = C * P * d.m * d.k / (8 * d.n) + 4096 + (2u << 20);   // (+ 2 MB: a walk of the streaming entry carries the tail of its Viterbi stream from window to window)
   h->rs_defer_cap = (int)((h->vit_cap / 204 / 64 + 2) * (RS_LANE_MIN - 1));
   RXHIP(hipMalloc((void **)&h->rs_defer, sizeof(RsDefer) * (size_t)h->rs_defer_cap));
@@ -700,9 +720,18 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
   // start, as the reference's does: exact whatever the input, and slow (one wavefront).  With dvbt_rx_params.viterbi_warm_windows the caller chooses the chunked
   // decoder with a warm-up of his own for these modes too (tools/hier_warmup.py: 60 of 15,000 chunk starts differ at 72 windows, none from 144 on).
   if (d.hierarchy != 0 && h->prm.viterbi_warm_windows == 0) vp.chunk_bytes = (int)std::min<long long>(max_vit + 64, 1ll << 30);
+  int *snap = nullptr;
+  if (h->vit_snap) {
+    // dvbt_rx_params.viterbi_verify: chunks of a whole number of blocks of windows (a decoder and its predecessor then both stand at the top of a block at the chunk's first window)
+    vp.chunk_bytes = (int)std::min<long long>(((long long)vp.chunk_bytes + V3_BLK - 1) / V3_BLK * V3_BLK, (1ll << 30) / V3_BLK * V3_BLK);
+    if ((size_t)(max_vit / vp.chunk_bytes + 2) * 64 > h->vit_snap_words) return fail(DVBT_ERR_CAPACITY, "viterbi_verify: snapshot buffer too small for this chunk size (viterbi_chunk_bytes >= 240)");
+    HIPCHK(hipMemsetAsync(h->vit_check, 0, 2 * sizeof(int), s));
+    snap = h->vit_snap; h->vit_checked = true;
+  }
   // hierarchical modes: the decoder reads the bit de-interleaver's output 0 (HP: what the flowgraphs connect), or its output 1 on request; it unpacks d_m
   // bits of every byte either way (viterbi_decoder_impl.cc:93,236-243: the reference's decoder knows no priority streams)
-  launch_viterbi(s, (const uint8_t *)((h->prm.hier_stream && h->bitdeint_lp) ? h->bitdeint_lp : h->bitdeint), h->vit + o.vit_off, (const RxState *)h->st, 0ll, vp, 0ll, 0ll, max_vit);
+  launch_viterbi(s, (const uint8_t *)((h->prm.hier_stream && h->bitdeint_lp) ? h->bitdeint_lp : h->bitdeint), h->vit + o.vit_off, (const RxState *)h->st, 0ll, vp, 0ll, 0ll, max_vit,
+                 snap, h->vit_check);
   }
   if (tmv) HIPCHK(hipEventRecord(h->ev[ST_RS], s));
   if (o.tail) { int r = enqueue_tail(h, s, max_vit / 204 + 1, -1); if (r) return r; }
@@ -1323,6 +1352,19 @@ extern "C" void *dvbt_rx_tap_device_ptr(dvbt_rx *h, int tap)
     case DVBT_TAP_FFT: return h->fft_out; case DVBT_TAP_EQ: return h->eq; case DVBT_TAP_BITDEINT: return h->bitdeint;
     default: return nullptr;
   }
+}
+
+// dvbt_rx_params.viterbi_verify: what the checker behind the handle's LAST launch of the Viterbi decoder found (call it behind dvbt_rx_segment_finish / a synchronous run)
+extern "C" int dvbt_rx_viterbi_check(dvbt_rx *h, int64_t *chunks, int64_t *unproven)
+{
+  if (!h || !chunks || !unproven) return fail(DVBT_ERR_INVALID, "null argument");
+  if (!h->vit_check) return fail(DVBT_ERR_STATE, "dvbt_rx_viterbi_check: the handle was created without viterbi_verify");
+  if (h->pending) return fail(DVBT_ERR_STATE, "dvbt_rx_viterbi_check: a segment is in flight (dvbt_rx_segment_finish first)");
+  HIPCHK(hipSetDevice(h->prm.device));
+  int r[2] = {0, 0};
+  if (h->vit_checked) HIPCHK(hipMemcpy(r, h->vit_check, sizeof r, hipMemcpyDeviceToHost));
+  *chunks = r[0]; *unproven = r[1];
+  return DVBT_OK;
 }
 
 extern "C" int dvbt_rx_lock_periods(dvbt_rx *h, dvbt_lock_period *out, int cap)

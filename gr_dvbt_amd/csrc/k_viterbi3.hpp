@@ -326,9 +326,17 @@ __device__ unsigned long long *v3_dbg;     // tools/vit_kbench.hip: (hw id, star
 // How early a chunk's decoder must start for its survivors to have merged depends on the input: on streams whose pre-Viterbi bit error rate the code can cope with
 // (<= 2 %) no chunk start of 20,000 differs from the streaming decoder at 72 windows; on a collapsed channel (>= 3 % at rate 7/8) and on the degenerate input of the
 // hierarchical modes about one start in a thousand does, for up to ~125 windows (tools/hier_warmup.py)
-template <int NTB, int WARM = V3_WARM> __global__ __launch_bounds__(64 * V3_WGW) void viterbi3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const RxState *st,
-                                                      long long steps_fixed, VitParams vp, long long in_base, long long out_lo)
+// CHECK (dvbt_rx_params.viterbi_verify; with WARM = 0): the chunk decoders leave what a checker needs to PROVE the launch equal to the streaming decoder (viterbi_check_kernel below).
+// A decoder's whole state at the top of a block of windows is its two registers of cells: the block starts at phase 0 right behind a renormalisation (best metric = 48) and the low nine
+// bits of a cell are a function of the lane and the phase alone (v3_step, ST == 2) -- two decoders over the same input whose registers are EQUAL there make identical decisions from
+// there on.  With B a multiple of V3_BLK the decoder of chunk c stands at the top of a block when it reaches its chunk's first window (relative window warm) and so does its
+// predecessor, B windows further into its own run (relative window warm + B): both store their registers.  The predecessor is the streaming decoder there by induction (chunk 0 starts
+// with the stream), so equality proves chunk c.  In this instantiation `aux` is the address of the snapshot buffer (the segment path's in_base is 0), out_lo must be 0.
+template <int NTB, int WARM = V3_WARM, bool CHECK = false> __global__ __launch_bounds__(64 * V3_WGW) void viterbi3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const RxState *st,
+                                                      long long steps_fixed, VitParams vp, long long aux, long long out_lo)
 {
+  const long long in_base = CHECK ? 0ll : aux;                    // (block API: the stream position of in[0])
+  int *const snap = CHECK ? reinterpret_cast<int *>(aux) : nullptr;
   __shared__ __attribute__((aligned(16))) unsigned char tab_[V3_WGW][V3_RINGW * 4 * 64];   // path bytes: [window][decoder][cell z]  (the ppresult ring)
   __shared__ __attribute__((aligned(16))) unsigned wbuf_[V3_WGW][4 * V3_BLK * 8];          // step words: [decoder][step in block]
   __shared__ unsigned char bests_[V3_WGW][4 * V3_RINGW];                                    // best state per window
@@ -460,6 +468,11 @@ template <int NTB, int WARM = V3_WARM> __global__ __launch_bounds__(64 * V3_WGW)
 
   stage_load(0);
   for (int jb = 0; jb < J; jb += V3_BLK) {
+    if (CHECK && (jb == warm || jb == warm + B) && dec_active) {   // (wave-uniform but for dec_active)
+      const int pred = jb == warm ? 0 : 1;                        // 0: this chunk's own first window; 1: the NEXT chunk's first window, seen by its predecessor
+      int *d = snap + (2 * (chunk0 + dd + pred) + pred) * 32 + pl * 2;
+      d[0] = v[0]; d[1] = v[1];
+    }
     if (!(V3_EXP & 8) || jb == 0) stage_words(jb);
     if (jb + V3_BLK < J && !(V3_EXP & 8)) stage_load(jb + V3_BLK);                  // the bytes of the next block travel during this block's forward pass
     const bool tr = jb > 0 && !(V3_EXP & 1);
@@ -489,6 +502,23 @@ template <int NTB, int WARM = V3_WARM> __global__ __launch_bounds__(64 * V3_WGW)
     d[0] = (id & 0xffffu) | ((xcc & 0xfu) << 16); d[1] = dbg_t0; d[2] = wall_clock64();
   }
 #endif
+}
+
+// The checker of the CHECK instantiation: chunk c >= 1 is proven when the registers its decoder held at its first window (slot 2c) equal those its predecessor held there (slot 2c + 1).
+// result[0] = chunks of the launch, result[1] = chunks that are NOT proven (both zeroed by the host in front of the decoder's launch).
+__global__ __launch_bounds__(256) void viterbi_check_kernel(const int *__restrict__ snap, const RxState *st, long long steps_fixed, VitParams vp, int *__restrict__ result)
+{
+  const long long total_steps = st ? st->n_vit_steps : steps_fixed;
+  const long long total_out = total_steps / 8 - vp.ntb;
+  const long long nch = total_out > 0 ? (total_out + vp.chunk_bytes - 1) / vp.chunk_bytes : 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) result[0] = (int)(nch < INT_MAX ? nch : INT_MAX);
+  const long long c = (long long)blockIdx.x * 256 + threadIdx.x + 1;
+  if (c >= nch) return;
+  const int4 *a = reinterpret_cast<const int4 *>(snap + 2 * c * 32), *b = a + 8;      // 32 words = 8 x int4 per slot
+  bool same = true;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { const int4 x = a[i], y = b[i]; same = same && x.x == y.x && x.y == y.y && x.z == y.z && x.w == y.w; }
+  if (!same) atomicAdd(result + 1, 1);
 }
 
 }  // namespace dvbt

@@ -310,6 +310,13 @@ typedef struct {
                               Hierarchical modes: 0 = ONE decoder from the stream's start (exact whatever the input, one wavefront: ~1.2x real time); > 0 = the chunked
                               decoder with that warm-up -- the throughput path of those modes (their degenerate decoder input, two thirds constant zeros, differs at
                               60 of 15,000 starts with 72 windows and at none from 144 on). */
+  int viterbi_verify;      /* 1: the launch of the Viterbi decoder PROVES, chunk by chunk, that it is the streaming decoder -- or says where it cannot.  Every chunk decoder
+                              leaves its state (64 path metrics) as it stands at its chunk's first window, its predecessor -- which is the streaming decoder there by
+                              induction from the stream's start -- leaves its own at the same window, a checker behind the launch compares: equal states make equal
+                              decisions from there on (oracle/o_viterbi.c::o_viterbi_decode_snap + tests/test_viterbi_boundary_proof_model.py hold the criterion on the
+                              CPU).  dvbt_rx_viterbi_check reports the chunks of the handle's last decoder launch and how many of them are NOT proven: 0 = the bytes are
+                              the reference's; otherwise decode again with a longer viterbi_warm_windows.  Same bytes as without it; chunk sizes are rounded up to a multiple
+                              of 24; costs two 128-byte stores per chunk and one small launch.  Hard-decision decoder, segment API. */
 } dvbt_rx_params;
 
 typedef struct {
@@ -428,6 +435,8 @@ typedef struct {
   int32_t n_symbols;          /* items the lock delivered before it was lost (or the segment ended) */
   int32_t first_out_symbol;   /* 1 + symbol of the period at which superframe_start fired, 0 if it delivered nothing downstream */
 } dvbt_lock_period;
+/* viterbi_verify: chunks of the handle's last launch of the Viterbi decoder and how many of them are not proven equal to the streaming decoder (see dvbt_rx_params) */
+int  dvbt_rx_viterbi_check(dvbt_rx *h, int64_t *chunks, int64_t *unproven);
 int  dvbt_rx_lock_periods(dvbt_rx *h, dvbt_lock_period *out, int cap);
 /* how the handle's lock-period walks ran so far: acquisition-only passes through the one-launch tracker (acq_small_kernel: look-ahead windows of up to
  * small_max_calls calls, the tracking metric in chunks of small_chunk_calls calls -- 16 for a short guard interval down to 2 for cp = 2048, what fits the LDS) and

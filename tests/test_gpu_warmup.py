@@ -111,3 +111,48 @@ def test_hierarchical_modes_chunked_decoder(po, g, const, hier, mode, cr):
     v = rx.tap(g.TAP_VITERBI)
     assert len(v) == n and (v == ref[:n]).all()
     rx.close()
+
+
+def test_viterbi_verify_proves_the_launch_or_says_where_it_cannot(po, g):
+    """dvbt_rx_params.viterbi_verify: every chunk decoder leaves its state at its chunk's first window, its predecessor (the streaming decoder there, by induction) its own,
+    a checker compares -- equal states make equal decisions (tests/test_viterbi_boundary_proof_model.py holds the criterion on the CPU).  A clean stream: every chunk proven, the
+    oracle's bytes.  The collapsed channel of the test above: with the default warm-up some chunks are NOT proven (and bytes do differ from the streaming decoder); with 288
+    windows every chunk is proven and the bytes are the streaming decoder's.  Nowhere: all chunks proven and a byte different."""
+    import ctypes as C
+    po.lib().o_viterbi_decode.restype = C.c_size_t
+    # clean, the headline's mode
+    c = po.cfg(po.QAM64, po.C7_8, po.T8k)
+    ibits = c.payload * c.m * c.k // c.n
+    iq = po.tx(c, po.make_ts((272 * ibits * 2) // (204 * 8), 21), lead_in=900, tail=3 * c.N)
+    o = po.rx(c, iq, want=("vit", "ts"))
+    rx = g.Rx(po.QAM64, po.C7_8, po.T8k, max_samples=len(iq), taps=True, viterbi_verify=1)
+    rx.run(iq)
+    chunks, unproven = rx.viterbi_check()
+    assert chunks >= 2 and unproven == 0, (chunks, unproven)
+    for name, tap in (("vit", g.TAP_VITERBI), ("ts", g.TAP_TS)):
+        a, b = rx.tap(tap).reshape(-1), o[name].reshape(-1)
+        assert a.size == b.size > 0 and (a == b).all(), name
+    rx.close()
+    with pytest.raises(RuntimeError):                                   # a handle without the checker has nothing to report
+        h = g.Rx(po.QAM64, po.C7_8, po.T8k, max_samples=len(iq)); h.run(iq); h.viterbi_check()
+    # the collapsed channel
+    c = po.cfg(po.QAM64, po.C7_8, po.T2k)
+    ibits = c.payload * c.m * c.k // c.n
+    iq = po.channel(po.tx(c, po.make_ts((272 * ibits * 6) // (204 * 8), 5), lead_in=500, tail=3 * c.N), c.N, snr_db=16, seed=5)
+    res = {}
+    for warm in (0, 288):
+        rx = g.Rx(po.QAM64, po.C7_8, po.T2k, max_samples=len(iq), taps=True, snr_db=16.0, viterbi_warm_windows=warm, viterbi_verify=1)
+        rx.run(iq)
+        chunks, unproven = rx.viterbi_check()
+        bd = np.ascontiguousarray(rx.tap(g.TAP_BITDEINT).reshape(-1))
+        ref = np.zeros(bd.size * c.m * c.k // (8 * c.n) + 64, np.uint8)
+        n = po.lib().o_viterbi_decode(C.byref(c), 768, bd.ctypes.data_as(C.c_void_p), C.c_size_t(bd.size), ref.ctypes.data_as(C.c_void_p))
+        v = rx.tap(g.TAP_VITERBI)
+        assert len(v) == n
+        res[warm] = (chunks, unproven, int((v != ref[:n]).sum()))
+        rx.close()
+    print("collapsed channel, (chunks, chunks not proven, bytes that differ from the streaming decoder) by warm-up (0 = the default 72):", res)
+    for chunks, unproven, diff in res.values():
+        assert chunks > 1000 and (unproven > 0 or diff == 0)            # all proven => no byte differs
+    assert res[288][1] == 0 and res[288][2] == 0, res
+    assert 0 < res[0][1] < res[0][0] // 20 and res[0][2] > 0, res      # the default on this input: a few chunks cannot be proven, and bytes do differ
