@@ -198,6 +198,8 @@ int  dvbt_viterbi_decoder_work(dvbt_viterbi_decoder *h, int noutput_items, int n
                                const void *in, void *out, dvbt_sideband *sb);
 int  dvbt_viterbi_decoder_work_device(dvbt_viterbi_decoder *h, int noutput_items, int ninput_items, const void *in_device, void *out_device,
                                        dvbt_sideband *sb, void *stream);
+/* the chunk decoders' warm-up for the single block (see dvbt_rx_params.viterbi_warm_windows): 0 = the default 72 windows, else a multiple of 24 in [48, 576] */
+int  dvbt_viterbi_decoder_set_warm_windows(dvbt_viterbi_decoder *h, int windows);
 void dvbt_viterbi_decoder_destroy(dvbt_viterbi_decoder *h);
 
 /* ------------------------------------------------------------------ A8 convolutional_deinterleaver

@@ -156,3 +156,41 @@ def test_viterbi_verify_proves_the_launch_or_says_where_it_cannot(po, g):
         assert chunks > 1000 and (unproven > 0 or diff == 0)            # all proven => no byte differs
     assert res[288][1] == 0 and res[288][2] == 0, res
     assert 0 < res[0][1] < res[0][0] // 20 and res[0][2] > 0, res      # the default on this input: a few chunks cannot be proven, and bytes do differ
+
+
+def test_viterbi_block_warm_up_setter(po, g):
+    """the single block (dvbt_viterbi_decoder_*, chunks of 256 bytes): on a decoder input with 6 % bit errors at rate 7/8 the default warm-up leaves some chunk starts different from
+    the streaming decoder, dvbt_viterbi_decoder_set_warm_windows(288) none -- fed in calls of 40 blocks, so that the warm-up also reaches back into the input the block has kept"""
+    import ctypes as C
+    c = po.cfg(po.QAM64, po.C7_8, po.T2k)
+    ibits = c.payload * c.m * c.k // c.n
+    iq = po.tx(c, po.make_ts((272 * ibits * 4) // (204 * 8), 5), lead_in=500, tail=3 * c.N)
+    vin = po.rx(c, iq, want=("bitdeint",))["bitdeint"].reshape(-1).copy()
+    rng = np.random.RandomState(3)
+    for b in range(c.m):
+        vin ^= (rng.rand(len(vin)) < 0.06).astype(np.uint8) << b
+    d_nsym, d_nout = 768 * c.n // c.m, 768 * c.k // 8
+    nblocks = len(vin) // d_nsym
+    vin = np.ascontiguousarray(vin[:nblocks * d_nsym])
+    ref = np.zeros(nblocks * d_nout + 64, np.uint8)
+    po.lib().o_viterbi_decode.restype = C.c_size_t
+    n_ref = po.lib().o_viterbi_decode(C.byref(c), 768, vin.ctypes.data_as(C.c_void_p), C.c_size_t(len(vin)), ref.ctypes.data_as(C.c_void_p))
+    L = g.lib()
+    L.dvbt_viterbi_decoder_set_warm_windows.argtypes = [C.c_void_p, C.c_int]
+    res = {}
+    for warm in (0, 288):
+        b = g.Block("viterbi_decoder", 2, 0, 4, 768, 0, -1)
+        assert L.dvbt_viterbi_decoder_set_warm_windows(b.h, 600) < 0 and L.dvbt_viterbi_decoder_set_warm_windows(b.h, warm) == 0
+        outs, pos, first = [], 0, True
+        while pos < nblocks:
+            nb = min(40, nblocks - pos)
+            o = np.zeros(nb * d_nout, np.uint8)
+            r, cons, _ = b.work(nb * d_nout, nb * d_nsym, vin[pos * d_nsym:(pos + nb) * d_nsym], o, tags=[(0, g.TAG_SUPERFRAME_START, 0xaa)] if first else [])
+            assert cons == nb * d_nsym
+            outs.append(o[:r]); pos += nb; first = False
+        out = np.concatenate(outs)
+        assert len(out) == n_ref
+        res[warm] = int((out != ref[:n_ref]).sum())
+        b.close()
+    print("viterbi block, 6 % bit errors at rate 7/8: bytes that differ from the streaming decoder by warm-up (0 = the default 72):", res, "of", n_ref)
+    assert res[288] == 0 and res[0] < n_ref // 100, res
