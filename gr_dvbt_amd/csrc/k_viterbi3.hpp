@@ -324,7 +324,7 @@ __device__ unsigned long long *v3_dbg;     // tools/vit_kbench.hip: (hw id, star
 #endif
 // WARM: the warm-up in windows as a compile-time constant (the default instantiation: V3_WARM), or 0: taken from vp.warm (any multiple of V3_BLK up to V3_WARM_MAX).
 // How early a chunk's decoder must start for its survivors to have merged depends on the input: on streams whose pre-Viterbi bit error rate the code can cope with
-// (<= 2 %) no chunk start of 20,000 differs from the streaming decoder at 72 windows; on a collapsed channel (>= 3 % at rate 7/8) and on the degenerate input of the
+// (1 %) no chunk start of 83,000 differs from the streaming decoder at 72 windows (two do at 2 %); on a collapsed channel (>= 3 % at rate 7/8) and on the degenerate input of the
 // hierarchical modes about one start in a thousand does, for up to ~125 windows (tools/hier_warmup.py)
 // CHECK (dvbt_rx_params.viterbi_verify; with WARM = 0): the chunk decoders leave what a checker needs to PROVE the launch equal to the streaming decoder (viterbi_check_kernel below).
 // A decoder's whole state at the top of a block of windows is its two registers of cells: the block starts at phase 0 right behind a renormalisation (best metric = 48) and the low nine

@@ -303,8 +303,8 @@ typedef struct {
                               (DESIGN.md 8).  Same kernels, same order within a segment, same bytes. */
   int viterbi_warm_windows;/* 0: the default.  The Viterbi decoder runs as independent chunk decoders, each started `warm-up` windows (8 trellis steps = one decoded byte
                               each) in front of its chunk from all-zero metrics; a chunk equals the streaming decoder of lib/d_viterbi.c once all its survivors have
-                              merged inside the warm-up -- which depends on the INPUT.  Default 72 windows: of 20,000 chunk starts per configuration none differs on
-                              streams whose pre-Viterbi bit error rate the code can cope with (<= 2 %, SURVEY 8d's prescribed 1e-2 included); on a collapsed channel
+                              merged inside the warm-up -- which depends on the INPUT.  Default 72 windows: of 83,000 chunk starts none differs at a pre-Viterbi bit error rate of
+                              1 % (rate 7/8; SURVEY 8d's prescribed level), two do at 2 %; on a collapsed channel
                               (>= 3 % at rate 7/8: every RS word fails either way) about one chunk start in a thousand differs, for up to ~125 windows
                               (tools/hier_warmup.py).  A multiple of 24 in [48, 1152]: that many windows instead (144: one start of 5,000 still differed on
                               pure garbage, none of 15,000 at a bit error rate of 6 %; 192 and 288: none on any input tried; 144 costs +2.4 % of the decoder's time at
