@@ -1,7 +1,7 @@
 """The chunk decoders' warm-up where the code copes with the channel, on many chunk starts (CPU, the oracle's decoder; tools/hier_warmup.py holds the collapsed regimes): for every block
 boundary of long streams at a pre-Viterbi bit error rate of 1 % and 2 % (rate 7/8, the worst puncturing) -- does a decoder started 72 windows early decode the streaming decoder's bytes,
 and is its metric vector at the chunk's first window the streaming decoder's (what dvbt_rx_params.viterbi_verify compares: a chunk that is flagged is decoded again for nothing)?
-python tools/warm_proof_series.py [streams per case] > profiles/rNN_warm_proof_series.json"""
+python tools/warm_proof_series.py [streams per case [bit error rates, comma separated]] > profiles/rNN_warm_proof_series.json"""
 import ctypes as C
 import json
 import os
@@ -45,11 +45,12 @@ def series(c, vin):
 
 def main():
     nstreams = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    bers = tuple(float(x) for x in sys.argv[2].split(",")) if len(sys.argv) > 2 else (0.01, 0.02)
     rows = []
     for const, label in ((po.QAM64, "QAM64 7/8"), (po.QPSK, "QPSK 7/8")):
         c = po.cfg(const, po.C7_8, po.T2k)
         ibits = c.payload * c.m * c.k // c.n
-        for ber in (0.01, 0.02):
+        for ber in bers:
             tot = [0, 0, 0, 0]
             for k in range(nstreams):
                 iq = po.tx(c, po.make_ts((272 * ibits * 40) // (204 * 8), 100 + k), lead_in=500, tail=3 * c.N)
