@@ -15,7 +15,7 @@ C1_2, C2_3, C3_4, C5_6, C7_8 = 0, 1, 2, 3, 4
 T2k, T8k = 0, 1
 G1_32, G1_16, G1_8, G1_4 = 0, 1, 2, 3
 (TAP_ACQ, TAP_FFT, TAP_EQ, TAP_DEMAP, TAP_SYMDEINT, TAP_BITDEINT, TAP_VITERBI, TAP_DEINT, TAP_RS,
- TAP_TS, TAP_CP_START, TAP_SYMBOL_INDEX, TAP_FREQ_OFFSET, TAP_BITDEINT_LP, TAP_SOFT, TAP_CSI) = range(16)
+ TAP_TS, TAP_CP_START, TAP_SYMBOL_INDEX, TAP_FREQ_OFFSET, TAP_BITDEINT_LP, TAP_SOFT, TAP_CSI, TAP_BITDEINT_LOG) = range(17)
 ALPHA1, ALPHA2, ALPHA4 = 1, 2, 3
 
 
@@ -67,6 +67,10 @@ class RxReport(C.Structure):
 class LockPeriod(C.Structure):
     _fields_ = [("offset", C.c_int64), ("first_call", C.c_int32), ("cp_start0", C.c_int32), ("n_symbols", C.c_int32),
                 ("first_out_symbol", C.c_int32)]
+
+
+class ViterbiProof(C.Structure):
+    _fields_ = [("chunks", C.c_int64), ("decoded_again", C.c_int64), ("sequential", C.c_int64), ("not_proven", C.c_int64)]
 
 
 class RxCut(C.Structure):
@@ -149,7 +153,7 @@ class Rx:
         _chk(self.L.dvbt_rx_create(C.byref(self.p), C.byref(self.h)))
         self.dims = get_dims(constellation, code_rate, mode, guard, hierarchy)
         if taps:
-            _chk(self.L.dvbt_rx_enable_taps(self.h, 1))
+            _chk(self.L.dvbt_rx_enable_taps(self.h, int(taps)))          # True / 1: the debug taps; 2: plus the per-lock-period log of the decoder's input
         self.report = None
 
     def run(self, iq):
@@ -221,8 +225,31 @@ class Rx:
         _chk(self.L.dvbt_rx_walk_stats(self.h, C.byref(w)))
         return w.small_passes, w.general_passes, w.small_chunk_calls, w.small_max_calls
 
+    def period_taps(self):
+        """taps=2: [(decoder input of the lock period (uint8), offset of its decoded bytes in the VITERBI tap, their count)] for every lock period of the
+        last run() / run_device() that reached the Viterbi decoder"""
+        class P(C.Structure):
+            _fields_ = [("bitdeint_offset", C.c_int64), ("bitdeint_bytes", C.c_int64), ("viterbi_offset", C.c_int64), ("viterbi_bytes", C.c_int64)]
+        self.L.dvbt_rx_period_taps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        n = _chk(self.L.dvbt_rx_period_taps(self.h, None, 0))
+        buf = (P * max(n, 1))()
+        _chk(self.L.dvbt_rx_period_taps(self.h, buf, n))
+        total = max([b.bitdeint_offset + b.bitdeint_bytes for b in buf[:n]] + [0])
+        log = np.zeros(total, np.uint8)
+        if total:
+            _chk(self.L.dvbt_rx_read_tap(self.h, TAP_BITDEINT_LOG, log.ctypes.data_as(C.c_void_p), total))
+        return [(log[b.bitdeint_offset:b.bitdeint_offset + b.bitdeint_bytes], int(b.viterbi_offset), int(b.viterbi_bytes)) for b in buf[:n]]
+
+    def viterbi_proof(self):
+        """what the proof + repair passes of the last launch of the Viterbi decoder did: dict(chunks, decoded_again, sequential, not_proven) -- not_proven is the
+        final check's count (viterbi_verify >= 1), -1 when it did not run"""
+        p = ViterbiProof()
+        self.L.dvbt_rx_viterbi_proof.argtypes = [C.c_void_p, C.POINTER(ViterbiProof)]
+        _chk(self.L.dvbt_rx_viterbi_proof(self.h, C.byref(p)))
+        return {"chunks": int(p.chunks), "decoded_again": int(p.decoded_again), "sequential": int(p.sequential), "not_proven": int(p.not_proven)}
+
     def viterbi_check(self):
-        """viterbi_verify = 1: (chunks of the last launch of the Viterbi decoder, chunks NOT proven equal to the streaming decoder)"""
+        """viterbi_verify >= 1: (chunks of the last launch of the Viterbi decoder, chunks NOT proven equal to the streaming decoder when the launch ends)"""
         a, b = C.c_int64(), C.c_int64()
         self.L.dvbt_rx_viterbi_check.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         _chk(self.L.dvbt_rx_viterbi_check(self.h, C.byref(a), C.byref(b)))
@@ -265,7 +292,7 @@ class RxStream:
     """dvbt_rx_stream_*: push samples in calls of any size, pull the TS in order; the bytes are those of one chain over the whole stream."""
 
     def __init__(self, constellation, code_rate, mode, segment_superframes=0, guard=G1_32, hierarchy=NH, snr_db=30.0, viterbi_bsize=768,
-                 rs_oracle_compat=0, device=0, rank=0, world=0, soft_decision=0, ts_ring_bytes=0, borrow=0, viterbi_warm_windows=0):
+                 rs_oracle_compat=0, device=0, rank=0, world=0, soft_decision=0, ts_ring_bytes=0, borrow=0, viterbi_warm_windows=0, viterbi_verify=0):
         self.L = lib()
         for fn in ("create", "push", "push_device", "finish", "status"):
             getattr(self.L, f"dvbt_rx_stream_{fn}").restype = C.c_int
@@ -279,6 +306,7 @@ class RxStream:
         self.L.dvbt_rx_stream_destroy.argtypes = [C.c_void_p]
         rx = RxParams(constellation, hierarchy, code_rate, guard, mode, 0, 0, snr_db, viterbi_bsize, rs_oracle_compat, 1, 0, device, 0, 0, 0, 0.0, soft_decision)
         rx.viterbi_warm_windows = viterbi_warm_windows
+        rx.viterbi_verify = viterbi_verify
         self.p = StreamParams(rx, segment_superframes, rank, world, ts_ring_bytes, borrow)
         self.L.dvbt_rx_stream_pull_chunk.restype = C.c_int64
         self.L.dvbt_rx_stream_pull_chunk.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int64)]
@@ -417,6 +445,13 @@ class Block:
         r = _chk(self._work_device(self.h, noutput_items, ninput_items, C.c_void_p(in_ptr), C.c_void_p(out_ptr), C.byref(sb),
                                    C.c_void_p(stream) if stream else None))
         return r, sb.n_consumed, [(tout[i].rel_offset, tout[i].key, tout[i].value) for i in range(min(sb.n_out_tags, 4096))]
+
+    def viterbi_proof(self):
+        """viterbi_decoder only: the proof + repair passes' counters summed over the calls since the last reset"""
+        p = ViterbiProof()
+        self.L.dvbt_viterbi_decoder_proof.argtypes = [C.c_void_p, C.POINTER(ViterbiProof)]
+        _chk(self.L.dvbt_viterbi_decoder_proof(self.h, C.byref(p)))
+        return {"chunks": int(p.chunks), "decoded_again": int(p.decoded_again), "sequential": int(p.sequential), "not_proven": int(p.not_proven)}
 
     def close(self):
         if self.h:

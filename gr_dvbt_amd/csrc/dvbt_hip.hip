@@ -198,41 +198,75 @@ struct Tables {          // device lookup tables for one configuration
 };
 
 // A7: 4 chunks per wavefront, V3_WGW independent wavefronts per workgroup (k_viterbi3.hpp)
+#define V3_NTB_SWITCH(ntb, CALL) switch (ntb) { case 5: CALL(5); break; case 9: CALL(9); break; case 10: CALL(10); break; case 15: CALL(15); break; default: CALL(24); break; }
+// device buffers of the proof and the repair passes; one launch of the decoder at a time per owner (stream order)
+struct VitProof {
+  int *snap = nullptr, *ctl = nullptr; long long cap = 0;
+  int reserve(long long chunks)
+  {
+    if (chunks <= cap) return DVBT_OK;
+    if (snap) (void)hipFree(snap); if (ctl) (void)hipFree(ctl);
+    snap = ctl = nullptr; cap = 0;
+    HIPCHK(hipMalloc((void **)&snap, v3_snap_words(chunks) * sizeof(int))); HIPCHK(hipMalloc((void **)&ctl, v3_ctl_words(chunks) * sizeof(int)));
+    HIPCHK(hipMemset(ctl, 0, v3_ctl_words(chunks) * sizeof(int)));
+    cap = chunks; return DVBT_OK;
+  }
+  V3Aux aux() const { V3Aux a; memset(&a, 0, sizeof a); a.snap = snap; a.ctl = ctl; a.cap = cap; a.carry_rel = -1; return a; }
+  ~VitProof() { if (snap) (void)hipFree(snap); if (ctl) (void)hipFree(ctl); }
+};
+enum { VIT_PLAIN = -1, VIT_REPAIR = 0, VIT_REPAIR_COUNT = 1, VIT_PROOF_ONLY = 2, VIT_FORCE_SEQ = 3 };   // dvbt_rx_params.viterbi_verify
+constexpr unsigned V3_REPAIR_GRID = 64;   // workgroups of the parallel repair pass: 1024 decoders at once, the rest in rounds (a wavefront without a listed chunk returns at once)
+
+// ax == null or mode == VIT_PLAIN: the chunk decoders alone.  Otherwise the launch that is the streaming decoder by construction: the decoders leave their states, the checker
+// lists the chunks that are not proven, the repair passes decode those again (k_viterbi3.hpp); nothing is read back.
 static void launch_viterbi(hipStream_t s, const uint8_t *in, uint8_t *out, const RxState *st, long long steps_fixed, const VitParams &vp,
-                           long long in_base, long long out_lo, long long max_out_bytes, int *snap = nullptr, int *check_result = nullptr)
+                           long long in_base, long long out_lo, long long max_out_bytes, const V3Aux *ax = nullptr, int mode = VIT_PLAIN)
 {
-  long long chunks = (max_out_bytes + vp.chunk_bytes - 1) / vp.chunk_bytes;
+  const bool proof = ax && mode != VIT_PLAIN;
+  const long long grid0 = proof ? ax->grid0 : out_lo;
+  long long chunks = (out_lo + max_out_bytes - grid0 + vp.chunk_bytes - 1) / vp.chunk_bytes;
   if (chunks < 1) chunks = 1;
   const dim3 grid((unsigned)((chunks + 4 * V3_WGW - 1) / (4 * V3_WGW))), blk(64 * V3_WGW);
-  if (snap) {   // dvbt_rx_params.viterbi_verify: the instantiation that leaves every chunk decoder's state at its chunk's first window, and the checker behind it (k_viterbi3.hpp)
-    const long long aux = (long long)(uintptr_t)snap;
-    switch (vp.ntb) {
-      case 5: hipLaunchKernelGGL((viterbi3_kernel<5, 0, true>), grid, blk, 0, s, in, out, st, steps_fixed, vp, aux, 0ll); break;
-      case 9: hipLaunchKernelGGL((viterbi3_kernel<9, 0, true>), grid, blk, 0, s, in, out, st, steps_fixed, vp, aux, 0ll); break;
-      case 10: hipLaunchKernelGGL((viterbi3_kernel<10, 0, true>), grid, blk, 0, s, in, out, st, steps_fixed, vp, aux, 0ll); break;
-      case 15: hipLaunchKernelGGL((viterbi3_kernel<15, 0, true>), grid, blk, 0, s, in, out, st, steps_fixed, vp, aux, 0ll); break;
-      default: hipLaunchKernelGGL((viterbi3_kernel<24, 0, true>), grid, blk, 0, s, in, out, st, steps_fixed, vp, aux, 0ll); break;
+  V3Aux none; memset(&none, 0, sizeof none);
+  if (proof) {
+    const V3Aux &a = *ax;
+    const dim3 cgrid((unsigned)((chunks + 255) / 256));
+    if (vp.warm == V3_WARM) {
+#define V3_CALL(N) hipLaunchKernelGGL((viterbi3_kernel<N, V3_WARM, 1>), grid, blk, 0, s, in, out, st, steps_fixed, vp, a, in_base, out_lo)
+      V3_NTB_SWITCH(vp.ntb, V3_CALL)
+#undef V3_CALL
+    } else {
+#define V3_CALL(N) hipLaunchKernelGGL((viterbi3_kernel<N, 0, 1>), grid, blk, 0, s, in, out, st, steps_fixed, vp, a, in_base, out_lo)
+      V3_NTB_SWITCH(vp.ntb, V3_CALL)
+#undef V3_CALL
     }
-    hipLaunchKernelGGL(viterbi_check_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s, (const int *)snap, st, steps_fixed, vp, check_result);
+    hipLaunchKernelGGL(viterbi_check_kernel, cgrid, dim3(256), 0, s, a, st, steps_fixed, vp, 0);
+    if (mode == VIT_REPAIR || mode == VIT_REPAIR_COUNT) {
+#define V3_CALL(N) hipLaunchKernelGGL(viterbi_repair_kernel<N>, dim3(V3_REPAIR_GRID), blk, 0, s, in, out, st, steps_fixed, vp, a, in_base, out_lo)
+      V3_NTB_SWITCH(vp.ntb, V3_CALL)
+#undef V3_CALL
+    }
+    if (mode != VIT_PROOF_ONLY) {
+      const int force = mode == VIT_FORCE_SEQ ? 1 : 0;
+#define V3_CALL(N) hipLaunchKernelGGL(viterbi_repair_seq_kernel<N>, dim3(1), dim3(64), 0, s, in, out, st, steps_fixed, vp, a, in_base, out_lo, force)
+      V3_NTB_SWITCH(vp.ntb, V3_CALL)
+#undef V3_CALL
+    }
+    if (mode != VIT_REPAIR) {   // the final check: chunks that are still not proven (none behind the repair passes)
+      hipLaunchKernelGGL(viterbi_check_kernel, dim3(1), dim3(256), 0, s, a, st, steps_fixed, vp, 1);
+      hipLaunchKernelGGL(viterbi_count_kernel, cgrid, dim3(256), 0, s, a, st, steps_fixed, vp);
+    }
     return;
   }
   if (vp.warm != V3_WARM) {   // a warm-up other than the default (dvbt_rx_params.viterbi_warm_windows): the instantiation that reads it from the parameters
-    switch (vp.ntb) {
-      case 5: hipLaunchKernelGGL((viterbi3_kernel<5, 0>), grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
-      case 9: hipLaunchKernelGGL((viterbi3_kernel<9, 0>), grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
-      case 10: hipLaunchKernelGGL((viterbi3_kernel<10, 0>), grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
-      case 15: hipLaunchKernelGGL((viterbi3_kernel<15, 0>), grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
-      default: hipLaunchKernelGGL((viterbi3_kernel<24, 0>), grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
-    }
+#define V3_CALL(N) hipLaunchKernelGGL((viterbi3_kernel<N, 0, 0>), grid, blk, 0, s, in, out, st, steps_fixed, vp, none, in_base, out_lo)
+    V3_NTB_SWITCH(vp.ntb, V3_CALL)
+#undef V3_CALL
     return;
   }
-  switch (vp.ntb) {   // the traceback depth is a template parameter (hop schedule fixed at compile time)
-    case 5: hipLaunchKernelGGL(viterbi3_kernel<5>, grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
-    case 9: hipLaunchKernelGGL(viterbi3_kernel<9>, grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
-    case 10: hipLaunchKernelGGL(viterbi3_kernel<10>, grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
-    case 15: hipLaunchKernelGGL(viterbi3_kernel<15>, grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
-    default: hipLaunchKernelGGL(viterbi3_kernel<24>, grid, blk, 0, s, in, out, st, steps_fixed, vp, in_base, out_lo); break;
-  }
+#define V3_CALL(N) hipLaunchKernelGGL((viterbi3_kernel<N, V3_WARM, 0>), grid, blk, 0, s, in, out, st, steps_fixed, vp, none, in_base, out_lo)
+  V3_NTB_SWITCH(vp.ntb, V3_CALL)   // the traceback depth is a template parameter (hop schedule fixed at compile time)
+#undef V3_CALL
 }
 
 // the plan of A8 + A9 + descrambler for a Viterbi stream that the host has laid out from several lock periods (segment_periods)
@@ -302,7 +336,8 @@ struct dvbt_rx {
   float2 *acq_tap = nullptr, *fft_out = nullptr, *eq = nullptr, *tpsval = nullptr; SymInfo *info = nullptr; int *maj = nullptr, *sym_index = nullptr;
   uint8_t *labels = nullptr, *symdeint_tap = nullptr, *bitdeint = nullptr, *vit = nullptr, *deint_tap = nullptr, *rs_out = nullptr, *ts_out = nullptr;
   uint8_t *bitdeint_lp = nullptr;           // hierarchical modes: the bit de-interleaver's second output
-  int *vit_snap = nullptr, *vit_check = nullptr; size_t vit_snap_words = 0; bool vit_checked = false;   // dvbt_rx_params.viterbi_verify: the chunk decoders' snapshots, {chunks, unproven}
+  uint8_t *bd_log = nullptr; std::vector<dvbt_period_tap> plog; size_t plog_bytes = 0;   // dvbt_rx_enable_taps(h, 2): every lock period's decoder input
+  VitProof vproof; bool vit_checked = false;   // the Viterbi stage's proof + repair passes (dvbt_rx_params.viterbi_verify): the chunk decoders' states, the passes' counters
   size_t vit_cap = 0; RsDefer *rs_defer = nullptr; int rs_defer_cap = 0;
   unsigned long long *rs_sync = nullptr;     // bit w: payload byte 0 of RS word w is 0xB8 (deint_rs_kernel / rs_fix_kernel -> descramble_scan_kernel)
   unsigned soft_grid = 0;     // workgroups the decision scratch has slots for
@@ -324,9 +359,12 @@ struct dvbt_rx {
   int *sym_ticket = nullptr;                // its symbol counter
 };
 
+constexpr long long kVitMaxChunk = 3000;
+static int vit_chunk_bytes(const dvbt_rx *h, long long max_vit);
+
 static void rx_free(dvbt_rx *h)
 {
-  void *all[] = {h->vit_snap, h->vit_check, h->bitdeint_lp, h->st_ctx[0], h->st_ctx[1], h->st_ctx[2], h->meta_ctx[0], h->meta_ctx[1], h->meta_ctx[2], h->tps_prev_snap[0], h->tps_prev_snap[1], h->tps_snap[0], h->tps_snap[1], h->csi, h->soft_a, h->soft_tab, h->soft_scratch, h->rs_defer, h->rs_sync, h->drift_mem, h->drift.delta, h->drift_flags_ctx[0], h->drift_flags_ctx[1], h->drift_flags_ctx[2], h->tps_prev, h->descr_runs, h->descr_nruns, h->centre, h->anchor_pos, h->sym_ticket_ctx[0], h->sym_ticket_ctx[1], h->sym_ticket_ctx[2], h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags_ctx[0], h->trk_flags_ctx[1], h->trk_flags_ctx[2], h->trk_eps, h->d_iq, h->rs_iq, h->acq_carry, h->g_init, h->l_init, h->g_trk, h->l_trk, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
+  void *all[] = {h->bd_log, h->bitdeint_lp, h->st_ctx[0], h->st_ctx[1], h->st_ctx[2], h->meta_ctx[0], h->meta_ctx[1], h->meta_ctx[2], h->tps_prev_snap[0], h->tps_prev_snap[1], h->tps_snap[0], h->tps_snap[1], h->csi, h->soft_a, h->soft_tab, h->soft_scratch, h->rs_defer, h->rs_sync, h->drift_mem, h->drift.delta, h->drift_flags_ctx[0], h->drift_flags_ctx[1], h->drift_flags_ctx[2], h->tps_prev, h->descr_runs, h->descr_nruns, h->centre, h->anchor_pos, h->sym_ticket_ctx[0], h->sym_ticket_ctx[1], h->sym_ticket_ctx[2], h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags_ctx[0], h->trk_flags_ctx[1], h->trk_flags_ctx[2], h->trk_eps, h->d_iq, h->rs_iq, h->acq_carry, h->g_init, h->l_init, h->g_trk, h->l_trk, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
                  h->info, h->maj, h->sym_index, h->labels, h->symdeint_tap, h->bitdeint, h->vit, h->deint_tap, h->rs_out, h->ts_out};
   for (void *q : all) if (q) (void)hipFree(q);
   for (auto &ge : h->graphs) if (ge.exec) (void)hipGraphExecDestroy(ge.exec);
@@ -354,8 +392,8 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   if (p->viterbi_warm_windows != 0 && (p->viterbi_warm_windows < 2 * V3_BLK || p->viterbi_warm_windows > V3_WARM_MAX || p->viterbi_warm_windows % V3_BLK != 0))
     return fail(DVBT_ERR_INVALID, "viterbi_warm_windows must be 0 (default) or a multiple of 24 in [48, 1152]");
   if (p->viterbi_warm_windows != 0 && p->soft_decision) return fail(DVBT_ERR_INVALID, "viterbi_warm_windows applies to the hard-decision decoder");
-  if (p->viterbi_verify != 0 && p->viterbi_verify != 1) return fail(DVBT_ERR_INVALID, "viterbi_verify must be 0 or 1");
-  if (p->viterbi_verify && p->soft_decision) return fail(DVBT_ERR_INVALID, "viterbi_verify applies to the hard-decision decoder");
+  if (p->viterbi_verify < VIT_PLAIN || p->viterbi_verify > VIT_FORCE_SEQ) return fail(DVBT_ERR_INVALID, "viterbi_verify must lie in [-1, 3]");
+  if (p->viterbi_verify > 0 && p->soft_decision) return fail(DVBT_ERR_INVALID, "viterbi_verify applies to the hard-decision decoder");
   HIPCHK(hipSetDevice(p->device));
   dvbt_rx *h = new dvbt_rx();
   h->prm = *p; h->d = d; h->T.d = d;
@@ -406,10 +444,13 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   RXHIP(hipMalloc((void **)&h->maj, sizeof(int) * C)); RXHIP(hipMalloc((void **)&h->sym_index, sizeof(int) * C));
   RXHIP(hipMalloc((void **)&h->bitdeint, C * P + 64));
   if (d.hierarchy != 0) RXHIP(hipMalloc((void **)&h->bitdeint_lp, C * P + 64));
-  if (p->viterbi_verify) {   // two snapshots of 32 words per chunk, chunks of >= 240 bytes
-    h->vit_snap_words = (size_t)((long long)C * P * d.m * d.k / (8 * d.n) / 240 + 8) * 64;
-    RXHIP(hipMalloc((void **)&h->vit_snap, h->vit_snap_words * sizeof(int))); RXHIP(hipMalloc((void **)&h->vit_check, 2 * sizeof(int)));
-    RXHIP(hipMemset(h->vit_check, 0, 2 * sizeof(int)));
+  { int ncu = 256; (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->prm.device); h->sym_grid = s8_grid(ncu); h->ncu = ncu; }
+  if (p->viterbi_verify != VIT_PLAIN && !p->soft_decision) {   // the proof's state slots for the most chunks a launch of this handle can have (vit_chunk_bytes)
+    const long long mv = (long long)C * P * d.m * d.k / (8 * d.n) + 1;
+    long long chunks;
+    if (p->viterbi_chunk_bytes > 0) chunks = mv / vit_chunk_bytes(h, mv) + 2;
+    else { const long long slots = (long long)h->ncu * V3_WAVES_PER_CU * 4; chunks = slots * ((mv + slots * kVitMaxChunk - 1) / (slots * kVitMaxChunk)) + 4; }
+    RXCHK(h->vproof.reserve(chunks));
   }
   h->vit_cap = C * P * d.m * d.k / (8 * d.n) + 4096 + (2u << 20);   // (+ 2 MB: a walk of the streaming entry carries the tail of its Viterbi stream from window to window)
   h->rs_defer_cap = (int)((h->vit_cap / 204 / 64 + 2) * (RS_LANE_MIN - 1));
@@ -443,7 +484,6 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   RXCHK(set_lds((const void *)symbol8k_kernel<true, false>, S8_LDS_BYTES)); RXCHK(set_lds((const void *)symbol8k_kernel<true, true>, S8_LDS_BYTES));
   RXCHK(set_lds((const void *)symbol2k_kernel<false, false>, S2_LDS_BYTES)); RXCHK(set_lds((const void *)symbol2k_kernel<false, true>, S2_LDS_BYTES));
   RXCHK(set_lds((const void *)symbol2k_kernel<true, false>, S2_LDS_BYTES)); RXCHK(set_lds((const void *)symbol2k_kernel<true, true>, S2_LDS_BYTES));
-  { int ncu = 256; (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->prm.device); h->sym_grid = s8_grid(ncu); h->ncu = ncu; }
   RXCHK(set_lds((const void *)inner_kernel<6>, inner_lds_bytes(P)));
   RXCHK(set_lds((const void *)acq_anchor_kernel, acq_anchor_lds_bytes((int)N, d.cp)));
   RXCHK(set_lds((const void *)acq_small_kernel, (size_t)acq_small_cpc(d.cp) * 2 * (d.cp + 2 * ACQ_R) * sizeof(float2)));
@@ -482,7 +522,9 @@ static int ensure_taps(dvbt_rx *h)
 extern "C" int dvbt_rx_enable_taps(dvbt_rx *h, int enable)
 {
   if (!h) return DVBT_ERR_INVALID;
+  if (enable == 2 && !h->bd_log) HIPCHK(hipMalloc((void **)&h->bd_log, (size_t)h->max_calls * h->d.payload + 64));
   if (enable) return ensure_taps(h);
+  if (h->bd_log) { (void)hipFree(h->bd_log); h->bd_log = nullptr; }
   // in soft-decision mode eq is not a debug tap but the soft demapper's input (allocated at create; it also selects the symbol kernel's instantiation that writes eq and csi)
   void **all[] = {(void **)&h->acq_tap, (void **)&h->fft_out, h->prm.soft_decision ? (void **)nullptr : (void **)&h->eq, (void **)&h->symdeint_tap, (void **)&h->deint_tap};
   for (void **q : all) if (q && *q) { (void)hipFree(*q); *q = nullptr; }
@@ -523,6 +565,26 @@ static int prepare_chain(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStrea
     *chain = h->rs_iq; *chain_n = (size_t)cnt;
   }
   return DVBT_OK;
+}
+
+// The Viterbi stage's chunk size for a stream of at most max_vit decoded bytes.  Chosen per segment so that the wavefront count is a whole number of "rounds" of the resident
+// wavefront slots (4 chunks per wavefront, V3_WAVES_PER_CU wavefronts per CU: 2 per SIMD): equal-length chunks then finish together instead of leaving a partial last round, and
+// longer chunks amortise the warm-up + traceback overlap (V3_WARM + ntraceback - 1 windows per chunk).  Measured on 65 superframes: 3 rounds of ~2900-byte chunks beat 5 rounds
+// of ~1700 (less overlap) and 1 round of ~8600 (the SIMD's arbiter favours the older of its two wavefronts, which then finishes long before the other:
+// profiles/r02_viterbi_attribution.jsonl).  With the proof: a whole number of blocks of windows (a decoder and its predecessor then both stand at the top of a block at the
+// chunk's first window).
+static int vit_chunk_bytes(const dvbt_rx *h, long long max_vit)
+{
+  long long B = h->prm.viterbi_chunk_bytes;
+  if (B <= 0) {
+    const long long slots = (long long)h->ncu * V3_WAVES_PER_CU * 4;   // chunks resident at once  (ncu is read at create: nothing but stream operations inside enqueue, which may be under capture)
+    long long rounds = (max_vit + slots * kVitMaxChunk - 1) / (slots * kVitMaxChunk);
+    if (rounds < 1) rounds = 1;
+    B = (max_vit + slots * rounds - 1) / (slots * rounds);
+    if (B < 256) B = 256;
+  }
+  if (h->prm.viterbi_verify != VIT_PLAIN && !h->prm.soft_decision) B = std::min<long long>((B + V3_BLK - 1) / V3_BLK * V3_BLK, (1ll << 30) / V3_BLK * V3_BLK);
+  return (int)B;
 }
 
 // A8 + A9 + energy_descramble over the segment's Viterbi stream.  words_fixed < 0: the word count is the device's (one period, no host round trip)
@@ -698,40 +760,20 @@ static int enqueue(dvbt_rx *h, const float2 *iq, size_t nsamples, hipStream_t s,
   { int r = join_front(); if (r) return r; }
   if (tmv) HIPCHK(hipEventRecord(h->ev[ST_VIT], s));
   VitParams vp = h->vp;
-  if (h->prm.viterbi_chunk_bytes <= 0) {
-    // chunk size chosen per segment so that the wavefront count is a whole number of "rounds" of the resident
-    // wavefront slots (4 chunks per wavefront, V3_WAVES_PER_CU wavefronts per CU: 2 per SIMD): equal-length chunks then
-    // finish together instead of leaving a partial last round, and longer chunks amortise the warm-up +
-    // traceback overlap (V3_WARM + ntraceback - 1 windows per chunk).  Measured on 65 superframes: 3 rounds of
-    // ~2900-byte chunks beat 5 rounds of ~1700 (less overlap) and 1 round of ~8600 (the SIMD's arbiter favours the older of its
-    // two wavefronts, which then finishes long before the other: profiles/r02_viterbi_attribution.jsonl)
-    const int ncu = h->ncu;                                        // (read at create: nothing but stream operations inside enqueue, which may be under capture)
-    const long long slots = (long long)ncu * V3_WAVES_PER_CU * 4;   // chunks resident at once
-    constexpr long long kMaxChunk = 3000;
-    long long rounds = (max_vit + slots * kMaxChunk - 1) / (slots * kMaxChunk);
-    if (rounds < 1) rounds = 1;
-    long long B = (max_vit + slots * rounds - 1) / (slots * rounds);
-    if (B < 256) B = 256;
-    vp.chunk_bytes = (int)B;
-  }
-  // hierarchical modes: the decoder is handed bytes of which only two (HP) or m - 2 (LP) bits carry anything, unpacked as m coded bits each
-  // (viterbi_decoder_impl.cc:236-243): a highly degenerate input -- two thirds of the "received" bits are constant zeros -- whose survivors need not merge
-  // inside a chunk's warm-up.  The chunked decoder equals the streaming one only where they do, so here ONE decoder runs from the stream's
-  // start, as the reference's does: exact whatever the input, and slow (one wavefront).  With dvbt_rx_params.viterbi_warm_windows the caller chooses the chunked
-  // decoder with a warm-up of his own for these modes too (tools/hier_warmup.py: 60 of 15,000 chunk starts differ at 72 windows, none from 144 on).
-  if (d.hierarchy != 0 && h->prm.viterbi_warm_windows == 0) vp.chunk_bytes = (int)std::min<long long>(max_vit + 64, 1ll << 30);
-  int *snap = nullptr;
-  if (h->vit_snap) {
-    // dvbt_rx_params.viterbi_verify: chunks of a whole number of blocks of windows (a decoder and its predecessor then both stand at the top of a block at the chunk's first window)
-    vp.chunk_bytes = (int)std::min<long long>(((long long)vp.chunk_bytes + V3_BLK - 1) / V3_BLK * V3_BLK, (1ll << 30) / V3_BLK * V3_BLK);
-    if ((size_t)(max_vit / vp.chunk_bytes + 2) * 64 > h->vit_snap_words) return fail(DVBT_ERR_CAPACITY, "viterbi_verify: snapshot buffer too small for this chunk size (viterbi_chunk_bytes >= 240)");
-    HIPCHK(hipMemsetAsync(h->vit_check, 0, 2 * sizeof(int), s));
-    snap = h->vit_snap; h->vit_checked = true;
+  vp.chunk_bytes = vit_chunk_bytes(h, max_vit);
+  // (hierarchical modes: the decoder is handed bytes of which only two (HP) or m - 2 (LP) bits carry anything, unpacked as m coded bits each, viterbi_decoder_impl.cc:236-243 --
+  // a degenerate input, two thirds constant zeros, whose survivors need not merge inside a chunk's warm-up: about one chunk start in 250 is not proven at 72 windows and is
+  // decoded again by the repair pass.  Until round 6 these modes ran ONE decoder from the stream's start, on one wavefront.)
+  const bool proof = h->vproof.snap && h->prm.viterbi_verify != VIT_PLAIN;
+  V3Aux ax = h->vproof.aux();
+  if (proof) {
+    if (max_vit / vp.chunk_bytes + 2 > h->vproof.cap) return fail(DVBT_ERR_CAPACITY, "Viterbi proof: state buffer too small for this segment's chunks");
+    h->vit_checked = true;
   }
   // hierarchical modes: the decoder reads the bit de-interleaver's output 0 (HP: what the flowgraphs connect), or its output 1 on request; it unpacks d_m
   // bits of every byte either way (viterbi_decoder_impl.cc:93,236-243: the reference's decoder knows no priority streams)
   launch_viterbi(s, (const uint8_t *)((h->prm.hier_stream && h->bitdeint_lp) ? h->bitdeint_lp : h->bitdeint), h->vit + o.vit_off, (const RxState *)h->st, 0ll, vp, 0ll, 0ll, max_vit,
-                 snap, h->vit_check);
+                 proof ? &ax : nullptr, h->prm.viterbi_verify);
   }
   if (tmv) HIPCHK(hipEventRecord(h->ev[ST_RS], s));
   if (o.tail) { int r = enqueue_tail(h, s, max_vit / 204 + 1, -1); if (r) return r; }
@@ -840,6 +882,7 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
   const Dims &d = h->d;
   const size_t L = (size_t)(d.N + d.cp), win = (size_t)(2 * d.N + d.cp + 16);
   std::vector<LockPeriod> per;
+  h->plog.clear(); h->plog_bytes = 0;
   bool capped = false;                                            // the walk was cut short: the rest of the segment is not decoded (status bit 8)
   h->periods.clear();
   // what the decode of the periods accumulates
@@ -876,6 +919,17 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
     if (st.tps_bits) tps_keep = st.tps_bits;
     bk.processed++; bk.any = true; bk.last_st = st; bk.last_off = per[p].off;
     h->periods[p].first_out_symbol = 0;
+    if (h->bd_log) {   // the period's decoder input, at a place that depends on the period alone (a period may be decoded twice: the entry is overwritten)
+      size_t base = 0; for (size_t q = 0; q < p; q++) base += (size_t)std::max(per[q].n_symbols, 0);
+      if (h->plog.size() <= p) h->plog.resize(p + 1, dvbt_period_tap{0, 0, 0, 0});
+      dvbt_period_tap e = {(int64_t)(base * d.payload), 0, (int64_t)pend.vit_off, 0};
+      if (st.first_out >= 0 && st.n_out_symbols > 0) {
+        e.bitdeint_bytes = (int64_t)st.n_out_symbols * d.payload; e.viterbi_bytes = st.n_vit_bytes;
+        HIPCHK(hipMemcpy(h->bd_log + e.bitdeint_offset, (h->prm.hier_stream && h->bitdeint_lp) ? h->bitdeint_lp : h->bitdeint, (size_t)e.bitdeint_bytes, hipMemcpyDeviceToDevice));
+        h->plog_bytes = std::max(h->plog_bytes, (size_t)(e.bitdeint_offset + e.bitdeint_bytes));
+      }
+      h->plog[p] = e;
+    }
     if (st.first_out >= 0) {
       h->periods[p].first_out_symbol = st.first_out + 1;
       if (bk.delivering == 0) { fill_report(h, st, bk.first_rep); bk.first_rep.segment_offset = (int64_t)per[p].off; }
@@ -1309,6 +1363,7 @@ static int tap_info(dvbt_rx *h, int tap, void **ptr, size_t *bytes)
     case DVBT_TAP_RS: *ptr = h->rs_out; *bytes = (size_t)r.n_rs_bytes; break;
     case DVBT_TAP_TS: *ptr = h->ts_out; *bytes = (size_t)r.n_ts_bytes; break;
     case DVBT_TAP_SYMBOL_INDEX: *ptr = h->sym_index; *bytes = (ns > 0 ? ns - 1 : 0) * 4; break;
+    case DVBT_TAP_BITDEINT_LOG: *ptr = h->bd_log; *bytes = h->plog_bytes; break;
     case DVBT_TAP_BITDEINT_LP: *ptr = h->bitdeint_lp; *bytes = no * d.payload; break;
     case DVBT_TAP_SOFT: *ptr = h->soft_a; *bytes = no * d.payload * d.m; break;
     case DVBT_TAP_CSI: *ptr = h->csi ? (void *)(h->csi + fo * d.payload) : nullptr; *bytes = no * d.payload * 4; break;
@@ -1354,17 +1409,35 @@ extern "C" void *dvbt_rx_tap_device_ptr(dvbt_rx *h, int tap)
   }
 }
 
-// dvbt_rx_params.viterbi_verify: what the checker behind the handle's LAST launch of the Viterbi decoder found (call it behind dvbt_rx_segment_finish / a synchronous run)
+// What the proof and repair passes behind the handle's LAST launch of the Viterbi decoder did (call it behind dvbt_rx_segment_finish / a synchronous run)
+extern "C" int dvbt_rx_viterbi_proof(dvbt_rx *h, dvbt_viterbi_proof *out)
+{
+  if (!h || !out) return fail(DVBT_ERR_INVALID, "null argument");
+  if (!h->vproof.ctl) return fail(DVBT_ERR_STATE, "dvbt_rx_viterbi_proof: the handle runs the plain chunk decoders (viterbi_verify = -1, or soft decisions)");
+  if (h->pending) return fail(DVBT_ERR_STATE, "dvbt_rx_viterbi_proof: a segment is in flight (dvbt_rx_segment_finish first)");
+  HIPCHK(hipSetDevice(h->prm.device));
+  int r[V3_CTL_HDR]; memset(r, 0, sizeof r); r[V3_CTL_UNPROVEN] = -1;
+  if (h->vit_checked) HIPCHK(hipMemcpy(r, h->vproof.ctl, sizeof r, hipMemcpyDeviceToHost));
+  out->chunks = r[V3_CTL_CHUNKS]; out->decoded_again = r[V3_CTL_MISMATCH]; out->sequential = r[V3_CTL_SEQ]; out->not_proven = r[V3_CTL_UNPROVEN];
+  return DVBT_OK;
+}
+// (chunks, chunks that are not proven when the launch ends) -- needs the final check, viterbi_verify >= 1
 extern "C" int dvbt_rx_viterbi_check(dvbt_rx *h, int64_t *chunks, int64_t *unproven)
 {
   if (!h || !chunks || !unproven) return fail(DVBT_ERR_INVALID, "null argument");
-  if (!h->vit_check) return fail(DVBT_ERR_STATE, "dvbt_rx_viterbi_check: the handle was created without viterbi_verify");
-  if (h->pending) return fail(DVBT_ERR_STATE, "dvbt_rx_viterbi_check: a segment is in flight (dvbt_rx_segment_finish first)");
-  HIPCHK(hipSetDevice(h->prm.device));
-  int r[2] = {0, 0};
-  if (h->vit_checked) HIPCHK(hipMemcpy(r, h->vit_check, sizeof r, hipMemcpyDeviceToHost));
-  *chunks = r[0]; *unproven = r[1];
+  if (h->prm.viterbi_verify < VIT_REPAIR_COUNT) return fail(DVBT_ERR_STATE, "dvbt_rx_viterbi_check: the handle was created without the final check (viterbi_verify >= 1)");
+  dvbt_viterbi_proof p; int r = dvbt_rx_viterbi_proof(h, &p); if (r) return r;
+  *chunks = p.chunks; *unproven = p.not_proven < 0 ? 0 : p.not_proven;
   return DVBT_OK;
+}
+
+extern "C" int dvbt_rx_period_taps(dvbt_rx *h, dvbt_period_tap *out, int cap)
+{
+  if (!h) return fail(DVBT_ERR_INVALID, "null handle");
+  if (!h->bd_log) return fail(DVBT_ERR_STATE, "dvbt_rx_period_taps: dvbt_rx_enable_taps(h, 2) before the segment");
+  int n = 0;
+  for (const dvbt_period_tap &e : h->plog) if (e.bitdeint_bytes > 0) { if (out && n < cap) out[n] = e; n++; }
+  return n;
 }
 
 extern "C" int dvbt_rx_lock_periods(dvbt_rx *h, dvbt_lock_period *out, int cap)

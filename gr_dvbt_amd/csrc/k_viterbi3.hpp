@@ -308,7 +308,7 @@ template <bool HOPS, int HOP0, int NTB> __device__ __forceinline__ void v3_fwd_s
   v3_fwd_window<4, HOPS, HOP0, NTB>(v, L, wrow, tab, bests, j0, dd, pl, T); v3_fwd_window<5, HOPS, HOP0, NTB>(v, L, wrow, tab, bests, j0, dd, pl, T);
 }
 
-// A chunk = vp.chunk_bytes decoded bytes; it is decoded by an independent decoder that starts V3_WARM windows early
+// A chunk = vp.chunk_bytes decoded bytes; it is decoded by an independent decoder that starts `warm` windows early
 // from all-zero metrics and runs ntraceback-1 windows past its end.  Per block of 24 windows:
 //   staging   depuncture (viterbi_decoder_impl.cc:241-256) + delta packing for 192 steps x 4 decoders.  The row
 //             loads the input bytes of its decoder (one 16-byte load per lane, issued one block ahead) and compacts
@@ -322,51 +322,48 @@ template <bool HOPS, int HOP0, int NTB> __device__ __forceinline__ void v3_fwd_s
 #if V3_EXP & 16
 __device__ unsigned long long *v3_dbg;     // tools/vit_kbench.hip: (hw id, start, end in 100 MHz ticks) per wavefront
 #endif
-// WARM: the warm-up in windows as a compile-time constant (the default instantiation: V3_WARM), or 0: taken from vp.warm (any multiple of V3_BLK up to V3_WARM_MAX).
-// How early a chunk's decoder must start for its survivors to have merged depends on the input: on streams whose pre-Viterbi bit error rate the code can cope with
-// (1 %) no chunk start of 83,000 differs from the streaming decoder at 72 windows (two do at 2 %); on a collapsed channel (>= 3 % at rate 7/8) and on the degenerate input of the
-// hierarchical modes about one start in a thousand does, for up to ~125 windows (tools/hier_warmup.py)
-// CHECK (dvbt_rx_params.viterbi_verify; with WARM = 0): the chunk decoders leave what a checker needs to PROVE the launch equal to the streaming decoder (viterbi_check_kernel below).
-// A decoder's whole state at the top of a block of windows is its two registers of cells: the block starts at phase 0 right behind a renormalisation (best metric = 48) and the low nine
-// bits of a cell are a function of the lane and the phase alone (v3_step, ST == 2) -- two decoders over the same input whose registers are EQUAL there make identical decisions from
-// there on.  With B a multiple of V3_BLK the decoder of chunk c stands at the top of a block when it reaches its chunk's first window (relative window warm) and so does its
-// predecessor, B windows further into its own run (relative window warm + B): both store their registers.  The predecessor is the streaming decoder there by induction (chunk 0 starts
-// with the stream), so equality proves chunk c.  In this instantiation `aux` is the address of the snapshot buffer (the segment path's in_base is 0), out_lo must be 0.
-template <int NTB, int WARM = V3_WARM, bool CHECK = false> __global__ __launch_bounds__(64 * V3_WGW) void viterbi3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const RxState *st,
-                                                      long long steps_fixed, VitParams vp, long long aux, long long out_lo)
+
+// ---- The chunk decoders ARE the reference's one streaming decoder (viterbi_decoder_impl.cc:192-324, d_viterbi.c:680-735), by construction: proof + repair.
+// A decoder's whole state at the top of a block of windows is its two registers of cells: the block starts at phase 0 right behind a renormalisation (best metric = 48) and the
+// low nine bits of a cell are a function of the lane and the phase alone (v3_step, ST == 2) -- two decoders over the same input whose registers are EQUAL there make identical
+// decisions from there on.  With B a multiple of V3_BLK the decoder of chunk c stands at the top of a block when it reaches its chunk's first window (relative window warm) and
+// so does its predecessor, B windows further into its own run: both store their registers (MODE 1).  Per chunk c three slots of 32 words:
+//   own[c]   the state, at the chunk's first window, of the decoder whose bytes fill chunk c
+//   pred[c]  the state there of the decoder whose bytes fill chunk c - 1
+//   fix[c]   (repair) the state there of a repaired chunk c - 1 where it is not pred[c]
+// Chunk 0 starts the stream (or is handed the streaming decoder's state: the single block carries it from call to call), so own[c] == pred[c] for every c >= 1 proves, by induction,
+// that every byte is the streaming decoder's.  viterbi_check_kernel lists the chunks where the two differ (their survivors had not merged inside the warm-up: none in 83,000 on
+// streams the code can cope with, one in a few hundred on a collapsed channel or the hierarchical modes' degenerate input); viterbi_repair_kernel decodes each of them again from
+// pred[c] (MODE 2: no warm-up, one chunk, in parallel) and compares the state it reaches at the next chunk's first window with pred[c + 1] -- equal: the chain holds (whoever
+// filled chunk c + 1 started from, or was checked against, that state).  Not equal (the repaired decoder and the unproven one have not merged over a whole chunk: never observed)
+// the chunk behind is flagged and viterbi_repair_seq_kernel, one decoder, walks on from there in stream order until its state is the own[] of the chunk it arrives at.  The host
+// reads no verdict: the launches are unconditional and return at once when there is nothing to do.
+constexpr int V3_SLOT = 32;          // words per state slot (16 lanes x 2 registers)
+constexpr int V3_CTL_CHUNKS = 0;     // ctl words: chunks of the launch
+constexpr int V3_CTL_MISMATCH = 1;   //            chunks the first check could not prove (= decoded again)
+constexpr int V3_CTL_CONFLICT = 2;   //            chunks left to the sequential pass
+constexpr int V3_CTL_UNPROVEN = 3;   //            chunks that are not proven after the repair (the final check; -1: not run)
+constexpr int V3_CTL_SEQ = 4;        //            chunks the sequential pass decoded
+constexpr int V3_CTL_ACC = 8;        //            [8..10] chunks, mismatches, sequential decodes summed over the launches since the owner cleared them
+constexpr int V3_CTL_HDR = 16;       // ... then the list of mismatching chunks (cap words), then the conflict flags (cap words)
+struct V3Aux {
+  int *snap;                         // 3 slots per chunk (own, pred, fix), cap + 2 chunks
+  int *ctl;
+  long long cap;                     // chunks the buffers hold
+  long long grid0;                   // absolute index of chunk 0's first byte (the single block: where the carried state stands, <= the first byte of the call)
+  const int *carry_in;               // the streaming decoder's state at grid0 (null: chunk 0 warms up like the others -- it starts the stream)
+  int *carry_out; int carry_rel;     // the last chunk's decoder leaves its state carry_rel windows into its chunk (a multiple of V3_BLK; carry_out null: no)
+};
+__device__ __forceinline__ int *v3_own(const V3Aux &ax, long long c) { return ax.snap + (3 * c) * V3_SLOT; }
+__device__ __forceinline__ int *v3_pred(const V3Aux &ax, long long c) { return ax.snap + (3 * c + 1) * V3_SLOT; }
+__device__ __forceinline__ int *v3_fix(const V3Aux &ax, long long c) { return ax.snap + (3 * c + 2) * V3_SLOT; }
+inline size_t v3_snap_words(long long cap) { return (size_t)(cap + 2) * 3 * V3_SLOT; }
+inline size_t v3_ctl_words(long long cap) { return (size_t)V3_CTL_HDR + 2 * (size_t)(cap + 2); }
+
+struct V3Lds { unsigned char *tab; unsigned *wbuf; unsigned char *bests; const unsigned *lut; };
+// the label-class deltas of a step as a function of (keep flags, next two received bits); every wavefront writes the same 16 words
+__device__ __forceinline__ void v3_init_lut(unsigned *lut, int lane)
 {
-  const long long in_base = CHECK ? 0ll : aux;                    // (block API: the stream position of in[0])
-  int *const snap = CHECK ? reinterpret_cast<int *>(aux) : nullptr;
-  __shared__ __attribute__((aligned(16))) unsigned char tab_[V3_WGW][V3_RINGW * 4 * 64];   // path bytes: [window][decoder][cell z]  (the ppresult ring)
-  __shared__ __attribute__((aligned(16))) unsigned wbuf_[V3_WGW][4 * V3_BLK * 8];          // step words: [decoder][step in block]
-  __shared__ unsigned char bests_[V3_WGW][4 * V3_RINGW];                                    // best state per window
-  const int wv = V3_WGW > 1 ? (int)(threadIdx.x >> 6) : 0;
-  unsigned char *const tab = tab_[wv]; unsigned *const wbuf = wbuf_[wv]; unsigned char *const bests = bests_[wv];
-  // compacted received bits per decoder (MSB first): V3_CBW words at the head of the decoder's wbuf row.  stage_words reads them (every
-  // lane its two words) before the wavefront writes the block's step words over them, and the previous block's step words are dead by
-  // then; a wavefront's LDS operations execute in order.  The overlay keeps the workgroup at 19,776 B of LDS: eight workgroups per CU
-  // (two wavefronts per SIMD) with room to spare
-  unsigned *const cbits = wbuf;
-  constexpr int V3_CBS = V3_BLK * 8;                                               // stride between the decoders' bit streams
-  static_assert(V3_CBW <= V3_CBS, "bit stream does not fit the step-word row");
-  __shared__ unsigned lut[16];                                                     // (keep flags, next two received bits) -> the step word
-  const int lane = threadIdx.x & 63, dd = lane >> 4, pl = lane & 15;
-
-  const long long total_steps = st ? st->n_vit_steps : steps_fixed;
-  const long long total_out = total_steps / 8 - vp.ntb;
-  const int B = vp.chunk_bytes, m = vp.m;
-  constexpr int ntb = NTB;                                         // == vp.ntb (the host picks the instantiation)
-  const long long chunk0 = ((long long)blockIdx.x * V3_WGW + wv) * 4;
-  if (out_lo + chunk0 * B >= total_out) return;                   // whole wavefront idle
-  const long long b0 = out_lo + (chunk0 + dd) * B;                // this lane's decoder
-  const bool dec_active = b0 < total_out;
-  const long long b1 = (b0 + B < total_out) ? b0 + B : total_out;
-  const int warm = WARM > 0 ? WARM : vp.warm;
-  const long long w0 = b0 + 2 - warm;                              // absolute window of relative window 0
-  const int J = ((warm + B + ntb - 1 + V3_BLK - 1) / V3_BLK) * V3_BLK;
-  const long long n_in_bytes = (total_steps * 2 / vp.plen * vp.n + vp.m - 1) / vp.m;   // input bytes that exist
-  const int nload = ((384 + 2 * m - 2) / m + 3 + 15) / 16;         // lanes whose 16 bytes a block can need (13, 7, 5)
-
   if (lane < 16) {
     // deltas of the four label classes, doubled (a step with one punctured symbol keeps the bias bit free):
     // class 0: u0+u1 | class 1 (c0=1): -u0+u1 | class 2 (c1=1): u0-u1 | class 3: -u0-u1, u = +1/-1 for a received 0/1, 0 if erased
@@ -376,11 +373,34 @@ template <int NTB, int WARM = V3_WARM, bool CHECK = false> __global__ __launch_b
     const unsigned d2 = (unsigned)(2 * (u0 - u1)) & 0xff, d3 = (unsigned)(2 * (-u0 - u1)) & 0xff;
     lut[lane] = d0 | (d1 << 8) | (d2 << 16) | (d3 << 24);
   }
-#if V3_EXP & 16
-  const unsigned long long dbg_t0 = wall_clock64();
-#endif
-  V3Lane L; v3_init_lane(pl, L);
-  int v[2] = {L.arm_org[0][0], L.arm_org[0][1]};                   // all-zero metrics, origin stamp of window 0, tie-break bits of its first three steps
+}
+
+// One decoder per DPP row over [b0, min(b0 + B, total_out)), the wavefront's four rows in step.
+// MODE 0: the plain chunk decoder.  MODE 1: the same, and it leaves own[] / pred[] (own, predn: this lane's two words of the slots; inject: the state chunk 0 is handed at its
+// first window instead of what its warm-up produced).  MODE 2: from the state in v, no warm-up (WARM is ignored); endv = the state at the next chunk's first window.
+// WARM: the warm-up in windows as a compile-time constant (the default instantiation: V3_WARM), or 0: taken from vp.warm (any multiple of V3_BLK up to V3_WARM_MAX).
+template <int NTB, int WARM, int MODE>
+__device__ __forceinline__ void v3_decode(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, long long total_steps, long long total_out, const VitParams &vp,
+                                          long long in_base, long long out_lo, long long b0, bool dec_active, const V3Lds &S, const V3Lane &L, int (&v)[2], int (&endv)[2],
+                                          int *own, int *predn, const int *inject, int *carry, int carry_rel)
+{
+  unsigned char *const tab = S.tab; unsigned *const wbuf = S.wbuf; unsigned char *const bests = S.bests; const unsigned *const lut = S.lut;
+  // compacted received bits per decoder (MSB first): V3_CBW words at the head of the decoder's wbuf row.  stage_words reads them (every
+  // lane its two words) before the wavefront writes the block's step words over them, and the previous block's step words are dead by
+  // then; a wavefront's LDS operations execute in order.  The overlay keeps the workgroup at 19,776 B of LDS per wavefront: eight workgroups per CU
+  // (two wavefronts per SIMD) with room to spare
+  unsigned *const cbits = wbuf;
+  constexpr int V3_CBS = V3_BLK * 8;                                               // stride between the decoders' bit streams
+  static_assert(V3_CBW <= V3_CBS, "bit stream does not fit the step-word row");
+  const int lane = threadIdx.x & 63, dd = lane >> 4, pl = lane & 15;
+  const int B = vp.chunk_bytes, m = vp.m;
+  constexpr int ntb = NTB;                                         // == vp.ntb (the host picks the instantiation)
+  const long long b1 = (b0 + B < total_out) ? b0 + B : total_out;
+  const int warm = MODE == 2 ? 0 : WARM > 0 ? WARM : vp.warm;
+  const long long w0 = b0 + 2 - warm;                              // absolute window of relative window 0
+  const int J = ((warm + B + ntb - 1 + V3_BLK - 1) / V3_BLK) * V3_BLK;
+  const long long n_in_bytes = (total_steps * 2 / vp.plen * vp.n + vp.m - 1) / vp.m;   // input bytes that exist
+  const int nload = ((384 + 2 * m - 2) / m + 3 + 15) / 16;         // lanes whose 16 bytes a block can need (13, 7, 5)
 
   // ---- staging, first half: where block jb starts in the input (row-uniform) and the load of its bytes
   int ph0 = 0, bo0 = 0, off = 0; uint4 q = make_uint4(0, 0, 0, 0);
@@ -457,7 +477,7 @@ template <int NTB, int WARM = V3_WARM, bool CHECK = false> __global__ __launch_b
     for (int c = 0; c < 2; c++) {
       int jj = jp + c * 16 + pl;
       T.ob[c] = b0 + (jj - (warm + ntb - 1));
-      T.ok[c] = (c * 16 + pl < V3_BLK) && dec_active && jj >= warm + ntb - 1 && T.ob[c] < b1;
+      T.ok[c] = (c * 16 + pl < V3_BLK) && dec_active && jj >= warm + ntb - 1 && T.ob[c] < b1 && (MODE != 1 || T.ob[c] >= out_lo);
       if (!T.ok[c]) jj = jp;                                       // any window inside the ring: result unused
       const int sb = 63 - (bests[dd * V3_RINGW + (jj & (V3_RINGW - 1))] & 63);
       T.wsh[c] = ((jj << 8) & 0x3f00) | (dd * 64);
@@ -468,10 +488,15 @@ template <int NTB, int WARM = V3_WARM, bool CHECK = false> __global__ __launch_b
 
   stage_load(0);
   for (int jb = 0; jb < J; jb += V3_BLK) {
-    if (CHECK && (jb == warm || jb == warm + B) && dec_active) {   // (wave-uniform but for dec_active)
-      const int pred = jb == warm ? 0 : 1;                        // 0: this chunk's own first window; 1: the NEXT chunk's first window, seen by its predecessor
-      int *d = snap + (2 * (chunk0 + dd + pred) + pred) * 32 + pl * 2;
-      d[0] = v[0]; d[1] = v[1];
+    if (MODE == 1 && dec_active) {                                 // (wave-uniform but for dec_active and the pointers)
+      if (jb == warm) { if (inject) { v[0] = inject[0]; v[1] = inject[1]; } own[0] = v[0]; own[1] = v[1]; }
+      if (jb == warm + B) { predn[0] = v[0]; predn[1] = v[1]; }   // the NEXT chunk's first window, seen by its predecessor
+      if (carry && jb == warm + carry_rel) { carry[0] = v[0]; carry[1] = v[1]; }
+    }
+    if (MODE == 2) {
+      if (jb == 0 && dec_active) { own[0] = v[0]; own[1] = v[1]; }
+      if (jb == B) { endv[0] = v[0]; endv[1] = v[1]; }
+      if (carry && dec_active && jb == carry_rel) { carry[0] = v[0]; carry[1] = v[1]; }
     }
     if (!(V3_EXP & 8) || jb == 0) stage_words(jb);
     if (jb + V3_BLK < J && !(V3_EXP & 8)) stage_load(jb + V3_BLK);                  // the bytes of the next block travel during this block's forward pass
@@ -493,6 +518,46 @@ template <int NTB, int WARM = V3_WARM, bool CHECK = false> __global__ __launch_b
   trace_init(J - V3_BLK);
   for (int h = 0; h < ntb - 1; h++) v3_hop(T, tab, dd * 64);
   v3_trace_out(T, tab, dd * 64, out, out_lo);
+}
+
+#define V3_LDS_DECL(NW) \
+  __shared__ __attribute__((aligned(16))) unsigned char tab_[NW][V3_RINGW * 4 * 64];   /* path bytes: [window][decoder][cell z]  (the ppresult ring) */ \
+  __shared__ __attribute__((aligned(16))) unsigned wbuf_[NW][4 * V3_BLK * 8];          /* step words: [decoder][step in block] */ \
+  __shared__ unsigned char bests_[NW][4 * V3_RINGW];                                    /* best state per window */ \
+  __shared__ unsigned lut[16];                                                          /* (keep flags, next two received bits) -> the step word */
+
+// MODE 0 / 1 (see v3_decode).  MODE 0: out_lo is also the index of chunk 0's first byte (the block API's former layout); MODE 1: ax.grid0 is, out_lo the first byte that is written.
+template <int NTB, int WARM = V3_WARM, int MODE = 0> __global__ __launch_bounds__(64 * V3_WGW) void viterbi3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const RxState *st,
+                                                      long long steps_fixed, VitParams vp, V3Aux ax, long long in_base, long long out_lo)
+{
+  V3_LDS_DECL(V3_WGW)
+  const int wv = V3_WGW > 1 ? (int)(threadIdx.x >> 6) : 0;
+  const V3Lds S = {tab_[wv], wbuf_[wv], bests_[wv], lut};
+  const int lane = threadIdx.x & 63, dd = lane >> 4, pl = lane & 15;
+  const long long total_steps = st ? st->n_vit_steps : steps_fixed;
+  const long long total_out = total_steps / 8 - vp.ntb;
+  const int B = vp.chunk_bytes;
+  if (MODE == 1 && blockIdx.x == 0 && threadIdx.x == 0) {        // the counters of the passes behind this launch
+    ax.ctl[V3_CTL_MISMATCH] = 0; ax.ctl[V3_CTL_CONFLICT] = 0; ax.ctl[V3_CTL_UNPROVEN] = -1; ax.ctl[V3_CTL_SEQ] = 0;
+  }
+  const long long grid0 = MODE == 1 ? ax.grid0 : out_lo;
+  const long long chunk0 = ((long long)blockIdx.x * V3_WGW + wv) * 4;
+  if (grid0 + chunk0 * B >= total_out) return;                    // whole wavefront idle
+  const long long c = chunk0 + dd, b0 = grid0 + c * B;            // this lane's decoder
+  const bool dec_active = b0 < total_out;
+  v3_init_lut(lut, lane);
+#if V3_EXP & 16
+  const unsigned long long dbg_t0 = wall_clock64();
+#endif
+  V3Lane L; v3_init_lane(pl, L);
+  int v[2] = {L.arm_org[0][0], L.arm_org[0][1]}, endv[2];          // all-zero metrics, origin stamp of window 0, tie-break bits of its first three steps
+  int *own = nullptr, *predn = nullptr, *carry = nullptr; const int *inject = nullptr;
+  if (MODE == 1) {
+    own = v3_own(ax, c) + 2 * pl; predn = v3_pred(ax, c + 1) + 2 * pl;
+    if (c == 0 && ax.carry_in) inject = ax.carry_in + 2 * pl;
+    if (ax.carry_out && b0 + B >= total_out) carry = ax.carry_out + 2 * pl;      // the launch's last chunk
+  }
+  v3_decode<NTB, WARM, MODE>(in, out, total_steps, total_out, vp, in_base, out_lo, b0, dec_active, S, L, v, endv, own, predn, inject, carry, ax.carry_rel);
 #if V3_EXP & 16
   if (lane == 0) {
     unsigned id, xcc;
@@ -504,21 +569,136 @@ template <int NTB, int WARM = V3_WARM, bool CHECK = false> __global__ __launch_b
 #endif
 }
 
-// The checker of the CHECK instantiation: chunk c >= 1 is proven when the registers its decoder held at its first window (slot 2c) equal those its predecessor held there (slot 2c + 1).
-// result[0] = chunks of the launch, result[1] = chunks that are NOT proven (both zeroed by the host in front of the decoder's launch).
-__global__ __launch_bounds__(256) void viterbi_check_kernel(const int *__restrict__ snap, const RxState *st, long long steps_fixed, VitParams vp, int *__restrict__ result)
+__device__ __forceinline__ long long v3_nchunks(long long total_out, long long grid0, int B) { return total_out > grid0 ? (total_out - grid0 + B - 1) / B : 0; }
+__device__ __forceinline__ bool v3_slots_equal(const int *a_, const int *b_)
 {
-  const long long total_steps = st ? st->n_vit_steps : steps_fixed;
-  const long long total_out = total_steps / 8 - vp.ntb;
-  const long long nch = total_out > 0 ? (total_out + vp.chunk_bytes - 1) / vp.chunk_bytes : 0;
-  if (blockIdx.x == 0 && threadIdx.x == 0) result[0] = (int)(nch < INT_MAX ? nch : INT_MAX);
-  const long long c = (long long)blockIdx.x * 256 + threadIdx.x + 1;
-  if (c >= nch) return;
-  const int4 *a = reinterpret_cast<const int4 *>(snap + 2 * c * 32), *b = a + 8;      // 32 words = 8 x int4 per slot
+  const int4 *a = reinterpret_cast<const int4 *>(a_), *b = reinterpret_cast<const int4 *>(b_);      // 32 words = 8 x int4 per slot
   bool same = true;
 #pragma unroll
   for (int i = 0; i < 8; i++) { const int4 x = a[i], y = b[i]; same = same && x.x == y.x && x.y == y.y && x.z == y.z && x.w == y.w; }
-  if (!same) atomicAdd(result + 1, 1);
+  return same;
+}
+
+// pass 0: the chunks c >= 1 whose own[c] is not pred[c] go on the list (ctl[V3_CTL_MISMATCH] of them), the conflict flags are cleared.
+// pass 1 (the final check, dvbt_rx_params.viterbi_verify): they are counted in ctl[V3_CTL_UNPROVEN] (zero behind the repair passes, by construction).
+__global__ __launch_bounds__(256) void viterbi_check_kernel(V3Aux ax, const RxState *st, long long steps_fixed, VitParams vp, int pass)
+{
+  const long long total_steps = st ? st->n_vit_steps : steps_fixed;
+  const long long nch = v3_nchunks(total_steps / 8 - vp.ntb, ax.grid0, vp.chunk_bytes);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { ax.ctl[V3_CTL_CHUNKS] = (int)(nch < INT_MAX ? nch : INT_MAX); if (pass == 1) ax.ctl[V3_CTL_UNPROVEN] = 0; }
+  const long long c = (long long)blockIdx.x * 256 + threadIdx.x + 1;
+  if (c >= nch || c > ax.cap) return;
+  const bool same = v3_slots_equal(v3_own(ax, c), v3_pred(ax, c));
+  if (pass == 0) {
+    ax.ctl[V3_CTL_HDR + (ax.cap + 2) + c] = 0;
+    if (!same) ax.ctl[V3_CTL_HDR + atomicAdd(ax.ctl + V3_CTL_MISMATCH, 1)] = (int)c;
+  }
+}
+// (the final check's count needs its zero before any thread adds to it: a second kernel rather than a grid-wide handshake)
+__global__ __launch_bounds__(256) void viterbi_count_kernel(V3Aux ax, const RxState *st, long long steps_fixed, VitParams vp)
+{
+  const long long total_steps = st ? st->n_vit_steps : steps_fixed;
+  const long long nch = v3_nchunks(total_steps / 8 - vp.ntb, ax.grid0, vp.chunk_bytes);
+  const long long c = (long long)blockIdx.x * 256 + threadIdx.x + 1;
+  if (c >= nch || c > ax.cap) return;
+  if (!v3_slots_equal(v3_own(ax, c), v3_pred(ax, c))) atomicAdd(ax.ctl + V3_CTL_UNPROVEN, 1);
+}
+
+// every lane of the row: do the row's 16 lanes hold the same two words in a and b?
+__device__ __forceinline__ bool v3_row_equal(const int (&a)[2], const int (&b)[2], int dd)
+{
+  const unsigned long long ne = __ballot(a[0] != b[0] || a[1] != b[1]);
+  return ((ne >> (16 * dd)) & 0xffffull) == 0;
+}
+
+// The parallel repair pass: one decoder (row) per listed chunk, from pred[c], over that chunk alone.
+template <int NTB> __global__ __launch_bounds__(64 * V3_WGW) void viterbi_repair_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const RxState *st,
+                                                      long long steps_fixed, VitParams vp, V3Aux ax, long long in_base, long long out_lo)
+{
+  V3_LDS_DECL(V3_WGW)
+  const int n = ax.ctl[V3_CTL_MISMATCH];
+  const int wv = V3_WGW > 1 ? (int)(threadIdx.x >> 6) : 0;
+  const long long rows = (long long)gridDim.x * V3_WGW * 4, row0 = ((long long)blockIdx.x * V3_WGW + wv) * 4;
+  if (row0 >= n) return;
+  const V3Lds S = {tab_[wv], wbuf_[wv], bests_[wv], lut};
+  const int lane = threadIdx.x & 63, dd = lane >> 4, pl = lane & 15;
+  const long long total_steps = st ? st->n_vit_steps : steps_fixed;
+  const long long total_out = total_steps / 8 - vp.ntb;
+  const int B = vp.chunk_bytes;
+  const long long nch = v3_nchunks(total_out, ax.grid0, B);
+  v3_init_lut(lut, lane);
+  V3Lane L; v3_init_lane(pl, L);
+  for (long long i0 = row0; i0 < n; i0 += rows) {
+    const bool act = i0 + dd < n;
+    const long long c = act ? ax.ctl[V3_CTL_HDR + i0 + dd] : 1;
+    const long long b0 = ax.grid0 + c * B;
+    int v[2], endv[2] = {0, 0};
+    { const int *p = v3_pred(ax, c) + 2 * pl; v[0] = p[0]; v[1] = p[1]; }
+    int *carry = (act && ax.carry_out && b0 + B >= total_out) ? ax.carry_out + 2 * pl : nullptr;
+    v3_decode<NTB, 0, 2>(in, out, total_steps, total_out, vp, in_base, out_lo, b0, act && b0 < total_out, S, L, v, endv, v3_own(ax, c) + 2 * pl, nullptr, nullptr, carry, ax.carry_rel);
+    int pn[2] = {endv[0], endv[1]};
+    if (act && c + 1 < nch) { const int *p = v3_pred(ax, c + 1) + 2 * pl; pn[0] = p[0]; pn[1] = p[1]; }
+    if (!v3_row_equal(endv, pn, dd)) {                               // the repaired decoder does not arrive where the unproven one did: the sequential pass goes on from here
+      int *f = v3_fix(ax, c + 1) + 2 * pl; f[0] = endv[0]; f[1] = endv[1];
+      if (pl == 0) { ax.ctl[V3_CTL_HDR + (ax.cap + 2) + c + 1] = 1; atomicAdd(ax.ctl + V3_CTL_CONFLICT, 1); }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");          // (the next round's staging overwrites this round's LDS)
+  }
+}
+
+// The sequential pass: ONE decoder walks the flagged chunks in stream order.  From fix[c] it decodes chunk c; where the state it reaches at chunk c + 1 is own[c + 1] the bytes behind
+// are the streaming decoder's already, otherwise it goes on through chunk c + 1.  force (a test hook, dvbt_rx_params.viterbi_verify = 3: the parallel pass is not launched): every
+// chunk whose own[] is not pred[] is taken, from pred[].  One wavefront, its first row.
+template <int NTB> __global__ __launch_bounds__(64) void viterbi_repair_seq_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const RxState *st,
+                                                      long long steps_fixed, VitParams vp, V3Aux ax, long long in_base, long long out_lo, int force)
+{
+  V3_LDS_DECL(1)
+  if (threadIdx.x == 0) { ax.ctl[V3_CTL_ACC] += ax.ctl[V3_CTL_CHUNKS]; ax.ctl[V3_CTL_ACC + 1] += ax.ctl[V3_CTL_MISMATCH]; }   // (the last pass of every repairing launch)
+  if (!force && ax.ctl[V3_CTL_CONFLICT] == 0) return;
+  const V3Lds S = {tab_[0], wbuf_[0], bests_[0], lut};
+  const int lane = threadIdx.x & 63, dd = lane >> 4, pl = lane & 15;
+  const long long total_steps = st ? st->n_vit_steps : steps_fixed;
+  const long long total_out = total_steps / 8 - vp.ntb;
+  const int B = vp.chunk_bytes;
+  long long nch = v3_nchunks(total_out, ax.grid0, B);
+  if (nch > ax.cap) nch = ax.cap;
+  const int *cflag = ax.ctl + V3_CTL_HDR + (ax.cap + 2);
+  v3_init_lut(lut, lane);
+  V3Lane L; v3_init_lane(pl, L);
+  int done = 0;
+  long long pos = 0;                                                 // everything up to and including chunk pos is the streaming decoder's
+  for (;;) {
+    // the next chunk behind pos that is flagged (64 candidates per round, one per lane)
+    long long cn = -1;
+    for (long long c0 = pos + 1; c0 < nch && cn < 0; c0 += 64) {
+      const long long c = c0 + lane;
+      bool hit = false;
+      if (c < nch) hit = cflag[c] != 0 || (force && !v3_slots_equal(v3_own(ax, c), v3_pred(ax, c)));
+      const unsigned long long b = __ballot(hit);
+      if (b) cn = c0 + __builtin_ctzll(b);
+    }
+    if (cn < 0) break;
+    long long c = cn;
+    int v[2];
+    { const int *p = (cflag[c] ? v3_fix(ax, c) : v3_pred(ax, c)) + 2 * pl; v[0] = p[0]; v[1] = p[1]; }
+    for (;;) {
+      const long long b0 = ax.grid0 + c * B;
+      const bool act = dd == 0;
+      int st0[2] = {v[0], v[1]}, endv[2] = {0, 0};
+      if (act) { int *p = v3_pred(ax, c) + 2 * pl; p[0] = v[0]; p[1] = v[1]; }
+      int *carry = (act && ax.carry_out && b0 + B >= total_out) ? ax.carry_out + 2 * pl : nullptr;
+      v3_decode<NTB, 0, 2>(in, out, total_steps, total_out, vp, in_base, out_lo, b0, act, S, L, st0, endv, v3_own(ax, c) + 2 * pl, nullptr, nullptr, carry, ax.carry_rel);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      done++;
+      if (c + 1 >= nch) { pos = nch; break; }
+      int on[2]; { const int *p = v3_own(ax, c + 1) + 2 * pl; on[0] = p[0]; on[1] = p[1]; }
+      const bool eq = (__ballot(on[0] != endv[0] || on[1] != endv[1]) & 0xffffull) == 0;
+      if (act) { int *p = v3_pred(ax, c + 1) + 2 * pl; p[0] = endv[0]; p[1] = endv[1]; }
+      if (eq) { pos = c + 1; break; }
+      c++; v[0] = endv[0]; v[1] = endv[1];
+    }
+  }
+  if (threadIdx.x == 0) { ax.ctl[V3_CTL_SEQ] = done; ax.ctl[V3_CTL_ACC + 2] += done; }
 }
 
 }  // namespace dvbt

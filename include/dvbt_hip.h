@@ -190,6 +190,13 @@ void dvbt_bit_inner_deinterleaver_destroy(dvbt_bit_inner_deinterleaver *h);
  * noutput_items must be a multiple of bsize*k/8 (set_output_multiple, :141). A SUPERFRAME_START tag
  * at rel_offset 0 resets the decoder; at rel_offset>0 the call consumes up to the tag and returns 0 (:213-229).
  * Unlike the reference (file-scope static state) any number of instances may coexist. */
+/* what the Viterbi stage's proof + repair passes did (dvbt_rx_params.viterbi_verify; dvbt_rx_viterbi_proof, dvbt_viterbi_decoder_proof) */
+typedef struct {
+  int64_t chunks;             /* chunk decoders of the launch */
+  int64_t decoded_again;      /* chunks the warm-up alone did not prove (decoded again by the parallel repair pass) */
+  int64_t sequential;         /* chunks the sequential pass decoded (a repaired decoder that had not merged with the unproven one after a whole chunk: never observed) */
+  int64_t not_proven;         /* chunks that are not proven when the launch ends: the final check's count (viterbi_verify >= 1), -1 when it did not run */
+} dvbt_viterbi_proof;
 typedef struct { int constellation, hierarchy, code_rate, bsize, S0, SK; } dvbt_viterbi_decoder_params;
 typedef struct dvbt_viterbi_decoder dvbt_viterbi_decoder;
 int  dvbt_viterbi_decoder_create(const dvbt_viterbi_decoder_params *p, dvbt_viterbi_decoder **out);
@@ -198,8 +205,11 @@ int  dvbt_viterbi_decoder_work(dvbt_viterbi_decoder *h, int noutput_items, int n
                                const void *in, void *out, dvbt_sideband *sb);
 int  dvbt_viterbi_decoder_work_device(dvbt_viterbi_decoder *h, int noutput_items, int ninput_items, const void *in_device, void *out_device,
                                        dvbt_sideband *sb, void *stream);
-/* the chunk decoders' warm-up for the single block (see dvbt_rx_params.viterbi_warm_windows): 0 = the default 72 windows, else a multiple of 24 in [48, 576] */
+/* the chunk decoders' warm-up for the single block (see dvbt_rx_params.viterbi_warm_windows): 0 = the default 72 windows, else a multiple of 24 in [48, 576].
+ * Speed only: the block proves and repairs every launch and carries the streaming decoder's state from call to call (dvbt_rx_params.viterbi_verify). */
 int  dvbt_viterbi_decoder_set_warm_windows(dvbt_viterbi_decoder *h, int windows);
+/* counters of the block's proof + repair passes, summed over its calls since the last reset (chunks, decoded_again, sequential; not_proven = -1: the block runs no final check) */
+int  dvbt_viterbi_decoder_proof(dvbt_viterbi_decoder *h, dvbt_viterbi_proof *out);
 void dvbt_viterbi_decoder_destroy(dvbt_viterbi_decoder *h);
 
 /* ------------------------------------------------------------------ A8 convolutional_deinterleaver
@@ -301,24 +311,27 @@ typedef struct {
                               with the device's highest priority and joins the caller's stream in front of the Viterbi decoder.  With several segments in flight the
                               front end of segment k + 1 then gets the workgroup slots that segment k's decoder gives up instead of queueing behind them
                               (DESIGN.md 8).  Same kernels, same order within a segment, same bytes. */
-  int viterbi_warm_windows;/* 0: the default.  The Viterbi decoder runs as independent chunk decoders, each started `warm-up` windows (8 trellis steps = one decoded byte
-                              each) in front of its chunk from all-zero metrics; a chunk equals the streaming decoder of lib/d_viterbi.c once all its survivors have
-                              merged inside the warm-up -- which depends on the INPUT.  Default 72 windows: of 83,000 chunk starts none differs at a pre-Viterbi bit error rate of
-                              1 % (rate 7/8; SURVEY 8d's prescribed level), two do at 2 %; on a collapsed channel
-                              (>= 3 % at rate 7/8: every RS word fails either way) about one chunk start in a thousand differs, for up to ~125 windows
-                              (tools/hier_warmup.py).  A multiple of 24 in [48, 1152]: that many windows instead (144: one start of 5,000 still differed on
-                              pure garbage, none of 15,000 at a bit error rate of 6 %; 192 and 288: none on any input tried; 144 costs +2.4 % of the decoder's time at
-                              the headline's chunk size, 288 +7.9 %: measured).
-                              Hierarchical modes: 0 = ONE decoder from the stream's start (exact whatever the input, one wavefront: ~1.2x real time); > 0 = the chunked
-                              decoder with that warm-up -- the throughput path of those modes (their degenerate decoder input, two thirds constant zeros, differs at
-                              60 of 15,000 starts with 72 windows and at none from 144 on). */
-  int viterbi_verify;      /* 1: the launch of the Viterbi decoder PROVES, chunk by chunk, that it is the streaming decoder -- or says where it cannot.  Every chunk decoder
-                              leaves its state (64 path metrics) as it stands at its chunk's first window, its predecessor -- which is the streaming decoder there by
-                              induction from the stream's start -- leaves its own at the same window, a checker behind the launch compares: equal states make equal
-                              decisions from there on (oracle/o_viterbi.c::o_viterbi_decode_snap + tests/test_viterbi_boundary_proof_model.py hold the criterion on the
-                              CPU).  dvbt_rx_viterbi_check reports the chunks of the handle's last decoder launch and how many of them are NOT proven: 0 = the bytes are
-                              the reference's; otherwise decode again with a longer viterbi_warm_windows.  Same bytes as without it; chunk sizes are rounded up to a multiple
-                              of 24; costs two 128-byte stores per chunk and one small launch.  Hard-decision decoder, segment API. */
+  int viterbi_warm_windows;/* 0: the default (72).  The Viterbi decoder runs as independent chunk decoders, each started `warm-up` windows (8 trellis steps = one decoded byte
+                              each) in front of its chunk from all-zero metrics; a chunk's decoder IS the streaming decoder of lib/d_viterbi.c from the window on at which
+                              its state equals its predecessor's -- inside the warm-up or not depends on the INPUT (of 83,000 chunk starts none is late at a pre-Viterbi bit
+                              error rate of 1 %, rate 7/8, SURVEY 8d's prescribed level; two at 2 %; about one in a few hundred on a collapsed channel, >= 3 %, and on the
+                              hierarchical modes' degenerate decoder input, for up to ~125 windows: tools/hier_warmup.py).  Since round 6 this parameter
+                              moves SPEED only: the launch proves every chunk and decodes the late ones again (viterbi_verify below), so the bytes are the streaming
+                              decoder's at any warm-up.  A multiple of 24 in [48, 1152]: that many windows instead of 72 (fewer chunks to decode again, more windows per
+                              chunk: 144 costs +2.4 % of the decoder's time at the headline's chunk size, 288 +7.9 %).  Hard-decision decoder. */
+  int viterbi_verify;      /* The Viterbi stage is the reference's ONE streaming decoder (viterbi_decoder_impl.cc:192-324, d_viterbi.c:680-735) by construction: every chunk
+                              decoder leaves its state (64 path metrics + tie-break bits: two registers per lane) as it stands at its chunk's first window, its
+                              predecessor leaves its own at the same window; equal states make equal decisions from there on (oracle/o_viterbi.c::o_viterbi_decode_snap +
+                              tests/test_viterbi_boundary_proof_model.py hold the criterion on the CPU), and chunk 0 starts the stream.  A checker lists the chunks whose
+                              two states differ, a repair pass decodes each of them again from its predecessor's state (no warm-up needed), and where a repaired decoder
+                              does not arrive in the state the next chunk was checked against, one sequential decoder walks on in stream order.  All on the device, the
+                              host reads no verdict; the passes return at once when every chunk is proven (the usual case: three small launches, +2 % of the decoder).
+                                0  (default) proof + repair;  1  the same plus a final check whose count dvbt_rx_viterbi_check / dvbt_rx_viterbi_proof report (0 by
+                                construction);  2  proof only, nothing decoded again: the count says how many chunks the warm-up alone does not prove (statistics);
+                                3  test hook: the sequential pass does all the repairs;  -1  the plain chunk decoders (no states, no passes: equal to the streaming decoder
+                                where the warm-up suffices, as until round 5).
+                              Chunk sizes are rounded up to a multiple of 24 (unless -1).  Hard-decision decoder; every entry (segment API, streaming entry, hierarchical
+                              modes -- which ran ONE decoder on one wavefront until round 5).  The single viterbi_decoder block does the same and carries the state from call to call. */
 } dvbt_rx_params;
 
 typedef struct {
@@ -381,6 +394,7 @@ typedef enum {
   DVBT_TAP_BITDEINT_LP = 13, /* u8[n_out_symbols][payload]  hierarchical modes: the bit de-interleaver's second output (BITDEINT holds the first) */
   DVBT_TAP_SOFT = 14,      /* i8[n_out_symbols][payload * m]  soft-decision mode: the log-likelihood ratio of every coded bit in the decoder's input order (behind both
                               inner de-interleavers); > 0: the bit is more likely 0.  The EQ tap is its input (always filled in this mode) ... */
+  DVBT_TAP_BITDEINT_LOG = 16, /* u8[...]  dvbt_rx_enable_taps(h, 2): the Viterbi decoder's input of every lock period (dvbt_rx_period_taps says where) */
   DVBT_TAP_CSI = 15        /* f32[n_out_symbols][payload]  ... together with the channel state of every carrier, 1 / |interpolated equaliser gain|^2 */
 } dvbt_tap;
 
@@ -437,7 +451,9 @@ typedef struct {
   int32_t n_symbols;          /* items the lock delivered before it was lost (or the segment ended) */
   int32_t first_out_symbol;   /* 1 + symbol of the period at which superframe_start fired, 0 if it delivered nothing downstream */
 } dvbt_lock_period;
-/* viterbi_verify: chunks of the handle's last launch of the Viterbi decoder and how many of them are not proven equal to the streaming decoder (see dvbt_rx_params) */
+/* what the proof + repair passes of the handle's last launch of the Viterbi decoder did (see dvbt_rx_params.viterbi_verify) */
+int  dvbt_rx_viterbi_proof(dvbt_rx *h, dvbt_viterbi_proof *out);
+/* (chunks, not_proven) of the same; needs the final check (viterbi_verify >= 1) */
 int  dvbt_rx_viterbi_check(dvbt_rx *h, int64_t *chunks, int64_t *unproven);
 int  dvbt_rx_lock_periods(dvbt_rx *h, dvbt_lock_period *out, int cap);
 /* how the handle's lock-period walks ran so far: acquisition-only passes through the one-launch tracker (acq_small_kernel: look-ahead windows of up to
@@ -456,8 +472,14 @@ void *dvbt_rx_tap_device_ptr(dvbt_rx *h, int tap);
 double dvbt_rx_stage_ms(dvbt_rx *h, const char *stage);
 int  dvbt_rx_enable_timing(dvbt_rx *h, int enable);
 /* allocate (1) / free (0) the debug-only taps ACQ, DEMAP, SYMDEINT, DEINT; the other taps are
- * pipeline buffers and always readable.  Call before the segment whose taps are wanted. */
+ * pipeline buffers and always readable.  Call before the segment whose taps are wanted.
+ * 2: the same plus the per-lock-period log of the Viterbi decoder's input (dvbt_rx_period_taps): the BITDEINT tap holds the LAST period of a
+ * segment that lost its lock, the log keeps every period's (synchronous entries dvbt_rx_segment_run / _run_device). */
 int  dvbt_rx_enable_taps(dvbt_rx *h, int enable);
+/* one entry per lock period of the last synchronous run that reached the Viterbi decoder, in stream order: where its decoder input lies in the
+ * log (DVBT_TAP_BITDEINT_LOG) and where its decoded bytes lie in the VITERBI tap */
+typedef struct { int64_t bitdeint_offset, bitdeint_bytes, viterbi_offset, viterbi_bytes; } dvbt_period_tap;
+int  dvbt_rx_period_taps(dvbt_rx *h, dvbt_period_tap *out, int cap);   /* returns the number of entries */
 void dvbt_rx_destroy(dvbt_rx *h);
 
 /* ------------------------------------------------------------------ streaming entry: the whole chain behind push / pull

@@ -77,3 +77,42 @@ def test_lock_period_walk_on_every_guard_interval(po, mode, guard, snr, holes, c
         a = rx.tap(g.TAP_RS)
         assert (a != o["rs"]).mean() < 1e-3                        # identical but for what failed RS words pass through (a decision within float rounding of a boundary)
     rx.close()
+
+
+@pytest.mark.parametrize("snr", [9.0, 8.0])
+def test_viterbi_stage_is_the_streaming_decoder_on_every_lock_period(po, snr):
+    """BASELINE config 5 (8k QPSK 7/8 + AWGN) at the prescribed noise, where the Viterbi tap differs from the oracle's in a handful of bytes: is that the decoder, or
+    its INPUT (a hard decision within float rounding of a boundary)?  The handle keeps every lock period's decoder input (dvbt_rx_enable_taps(h, 2)); per
+    period the HIP decoder's bytes must equal the streaming decoder (oracle/o_viterbi.c, pinned to the reference's lib/d_viterbi.c) over THAT input -- all of them, with
+    default parameters.  Whatever differs from the oracle's chain at the tap is then the input's few bits, counted here too."""
+    import ctypes as C
+    import numpy as np
+    import gr_dvbt_amd as g
+    import snr_sweep
+    c = po.cfg(po.QPSK, po.C7_8, po.T8k)
+    iq = po.channel(po.stream_slice(c, 3, snr_sweep.SEED_TS), c.N, snr_db=snr, seed=snr_sweep.SEED_NOISE)
+    o = po.rx(c, iq, snr_db=snr, want=("bitdeint", "vit"))
+    rx = g.Rx(po.QPSK, po.C7_8, po.T8k, max_samples=len(iq), snr_db=snr, taps=2, viterbi_verify=1)
+    rep = rx.run(iq)
+    vit = rx.tap(g.TAP_VITERBI)
+    periods = rx.period_taps()
+    assert len(periods) == rep.n_lock_periods >= 1 and rep.n_viterbi_bytes == len(o["vit"])
+    po.lib().o_viterbi_decode.restype = C.c_size_t
+    total = 0
+    for bd, voff, vbytes in periods:
+        bd = np.ascontiguousarray(bd)
+        ref = np.zeros(bd.size * c.m * c.k // (8 * c.n) + 64, np.uint8)
+        n = po.lib().o_viterbi_decode(C.byref(c), 768, bd.ctypes.data_as(C.c_void_p), C.c_size_t(bd.size), ref.ctypes.data_as(C.c_void_p))
+        assert n == vbytes, (n, vbytes)
+        assert (vit[voff:voff + n] == ref[:n]).all(), ("lock period at Viterbi offset", voff, int((vit[voff:voff + n] != ref[:n]).sum()))
+        total += n
+    assert total > 100000
+    # the decoder's input against the oracle chain's: the same symbols, a few bits apart (a demapper decision within float rounding of a boundary)
+    mine = np.concatenate([bd for bd, _, _ in periods])
+    theirs = o["bitdeint"].reshape(-1)
+    assert mine.size == theirs.size
+    nbits = int(np.unpackbits(mine ^ theirs).sum())
+    print(f"config 5 at {snr} dB: {len(periods)} lock periods, {total} Viterbi bytes == the streaming decoder over the chain's own input; decoder-input bits that differ from the oracle chain's: "
+          f"{nbits} of {mine.size * c.m}; Viterbi bytes that differ from the oracle chain's: {int((vit != o['vit']).sum())}; proof of the last launch: {rx.viterbi_proof()}")
+    assert nbits <= 1e-4 * mine.size * c.m
+    rx.close()
