@@ -170,6 +170,36 @@ def valu_issue(workload, nsf, alg_bytes, solo_ms, clock_hz, simds=1024, cycles_p
     return None
 
 
+def second_kernel(workload, nsf, vit_alg_bytes, reps, d, c, solo, nseg):
+    """symbol8k_kernel / symbol2k_kernel (A1 tail + A2 + A3 + A4 in one kernel), the kernel furthest below the roof that binds it: per OFDM symbol it reads the N + cp samples
+    (8 B each) and writes the payload's label bytes and the TPS carriers' values (SURVEY 8d rows A1..A4 fused: 67,584 + 6,048 + 544 B at 8k QAM64).  Duration: the `fft` stage of
+    the handle's HIP events with ONE step in flight (the drift model's small launches in front of the symbol kernel are inside that interval: ~15 us).  The PMC figures come from
+    the same committed passes as the dominant kernel's.  Never raises."""
+    import glob
+    try:
+        name = "symbol8k_kernel" if c.N == 8192 else "symbol2k_kernel"
+        nsym = sum(int(r.n_symbols) for r in reps) / nseg
+        alg = nsym * ((c.N + c.cp) * 8 + d.payload_length + 8 * 68)
+        ms = solo.get("fft") or 0.0
+        out = {"kernel": name, "bound": "hbm", "algorithmic_bytes_per_launch": int(alg), "launch_ms": ms, "unit": "GB/s", "peak": HBM_PEAK_GBS}
+        if ms > 0:
+            out["achieved"] = round(alg / (ms * 1e-3) / 1e9, 1); out["frac"] = round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_summary_{workload}_{nsf}sf.json")), reverse=True):
+            k = json.load(open(f))
+            if abs(k.get("viterbi_algorithmic_bytes", 0) - vit_alg_bytes) > 0.01 * vit_alg_bytes or name not in k["kernels"]:
+                continue
+            k = k["kernels"][name]
+            if "hbm_bytes_corrected" in k:
+                out["traffic"] = int(k["hbm_bytes_corrected"])
+            if k.get("SQ_INSTS_VALU") and k.get("GRBM_GUI_ACTIVE"):
+                out["valu_issue_frac_pmc"] = round(float(k["SQ_INSTS_VALU"]) * 4.0 / 1024 / (float(k["GRBM_GUI_ACTIVE"]) / 8.0), 4)
+            out["source"] = os.path.relpath(f, ROOT)
+            break
+        return out
+    except Exception as e:                                      # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"[:200]}
+
+
 NOMINAL_CLOCK_HZ = 2.4e9         # MI355X peak engine clock (MI355X_MICROARCH.md); the microbenchmarks in tools/ read 2400 MHz from hipDeviceAttributeClockRate
 
 
@@ -180,6 +210,13 @@ def device_clock_hz(torch, local):
     except Exception:
         hz = 0.0
     return hz if hz > 0 else NOMINAL_CLOCK_HZ
+
+
+def viterbi_check_of(rx):
+    """the proof + repair passes of the handle's last launch of the Viterbi decoder (dvbt_rx_viterbi_proof): chunks, chunks the warm-up alone did not prove (decoded again), chunks the
+    sequential pass took, chunks not proven when the launch ended (the final check; None when it did not run)"""
+    p = rx.viterbi_proof()
+    return {"chunks": p["chunks"], "decoded_again": p["decoded_again"], "sequential": p["sequential"], "not_proven_after_repair": p["not_proven"] if p["not_proven"] >= 0 else None}
 
 
 STAGES = ("acq", "fft", "demod", "inner", "viterbi", "rs", "total")
@@ -254,8 +291,8 @@ class Job:
             kw = {"soft_decision": 1} if soft else {}
             if getattr(a, "viterbi_warm", 0):
                 kw["viterbi_warm_windows"] = a.viterbi_warm
-            if getattr(a, "viterbi_verify", False):
-                kw["viterbi_verify"] = 1
+            if getattr(a, "viterbi_verify", 0) and not soft:
+                kw["viterbi_verify"] = a.viterbi_verify
             if from_file_rate:
                 rx_const = 0.0022097087 if mode == po.T2k else 0.00055242272           # blocks_multiply_const_vxx_0 of the RX flowgraph
                 iq = po.resample(iq / np.float32(rx_const), 70, 64, 1.0)                # what dvbt_tx_demo writes: the 10 Msps stream
@@ -425,39 +462,39 @@ def extra_workloads(a, torch, g, local):
     return res
 
 
-def hierarchical_line(torch, g, nsf=4, reps=3):
+def hierarchical_line(torch, g, nsf=4, reps=20):
     """A hierarchical transmission (2k 64-QAM, alpha = 2, rate 2/3; rows A0 / A4 / A6 of the scope table) through the segment API, samples resident: the demapper on the
-    shifted grid and the bit de-interleaver's two outputs run at the chain's speed, but the reference's Viterbi decoder knows no priority streams (it unpacks d_m bits of
-    every byte): two thirds of its input are constant, the chunked decoder's default warm-up does not hold (17 of 3,000 chunk starts differ: tools/hier_warmup.py), and by
-    default ONE decoder runs from the stream's start ("exact, slow"): this line's `value` is the number behind "slow".  `chunked_decoder_warm_up_288` is the
-    same stream through the chunked decoder with dvbt_rx_params.viterbi_warm_windows = 288 (the modes' throughput path), its Viterbi output compared with the default's."""
+    shifted grid, the bit de-interleaver's two outputs, and the reference's Viterbi decoder, which knows no priority streams (it unpacks d_m bits of every byte): two thirds of
+    its input are constant, and a chunk decoder's default warm-up does not always hold on it (about one chunk start in 250 is not proven: config.viterbi_check.decoded_again).
+    Until round 5 these modes therefore ran ONE decoder on one wavefront (1.17x real time); now the chunk decoders run with default parameters and the launch's proof +
+    repair passes make them the streaming decoder.  `viterbi_bytes_equal_the_streaming_decoder`: the HIP Viterbi tap against oracle/o_viterbi.c over the chain's own decoder input."""
+    import ctypes as C
     from oracle import pyoracle as po
     c = po.cfg(po.QAM64, po.C2_3, po.T2k, hierarchy=g.ALPHA2)
     ibits = c.payload * c.m * c.k // c.n
     iq = po.tx(c, po.make_ts((272 * ibits * nsf) // (204 * 8), 5), lead_in=500, tail=3 * c.N)
     dev = torch.from_numpy(iq.view(np.float32)).cuda()
     torch.cuda.synchronize()
-
-    def one(warm, reps):
-        rx = g.Rx(po.QAM64, po.C2_3, po.T2k, max_samples=len(iq), hierarchy=g.ALPHA2, viterbi_warm_windows=warm)
-        rx.enable_timing(True)
+    rx = g.Rx(po.QAM64, po.C2_3, po.T2k, max_samples=len(iq), hierarchy=g.ALPHA2, viterbi_verify=1)
+    rx.enable_timing(True)
+    rx.enqueue_device(dev.data_ptr(), len(iq)); rep = rx.finish()
+    rx.enable_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(reps):
         rx.enqueue_device(dev.data_ptr(), len(iq)); rep = rx.finish()
-        rx.enable_timing(True)
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            rx.enqueue_device(dev.data_ptr(), len(iq)); rep = rx.finish()
-        dt = (time.perf_counter() - t0) / reps
-        stages = {k: round(rx.stage_ms(k), 3) for k in STAGES}
-        vit = rx.tap(g.TAP_VITERBI).copy()
-        rx.close()
-        return {"value": round(len(iq) / dt / 1e6, 2), "unit": "Msamples/s", "x_realtime": round(len(iq) / dt / 1e6 / REALTIME_MSPS, 2),
-                "ms_per_run": round(dt * 1e3, 3), "stage_ms": stages, "samples": int(len(iq)), "viterbi_bytes": int(rep.n_viterbi_bytes), "symbols": int(rep.n_symbols)}, vit
-    res, v0 = one(0, reps)
-    res = {"workload": "2k QAM64 alpha 2 rate 2/3, %d superframes" % nsf, **res}
-    fast, v1 = one(288, 20)
-    fast["viterbi_bytes_equal_the_one_decoder_path"] = bool(len(v0) == len(v1) > 0 and (v0 == v1).all())
-    res["chunked_decoder_warm_up_288"] = fast
-    return res
+    dt = (time.perf_counter() - t0) / reps
+    stages = {k: round(rx.stage_ms(k), 3) for k in STAGES}
+    vit = rx.tap(g.TAP_VITERBI).copy()
+    bd = np.ascontiguousarray(rx.tap(g.TAP_BITDEINT).reshape(-1))
+    proof = viterbi_check_of(rx)
+    rx.close()
+    ref = np.zeros(bd.size * c.m * c.k // (8 * c.n) + 64, np.uint8)
+    po.lib().o_viterbi_decode.restype = C.c_size_t
+    n = po.lib().o_viterbi_decode(C.byref(c), 768, bd.ctypes.data_as(C.c_void_p), C.c_size_t(bd.size), ref.ctypes.data_as(C.c_void_p))
+    return {"workload": "2k QAM64 alpha 2 rate 2/3, %d superframes" % nsf, "value": round(len(iq) / dt / 1e6, 2), "unit": "Msamples/s",
+            "x_realtime": round(len(iq) / dt / 1e6 / REALTIME_MSPS, 2), "ms_per_run": round(dt * 1e3, 3), "stage_ms": stages, "samples": int(len(iq)),
+            "viterbi_bytes": int(rep.n_viterbi_bytes), "symbols": int(rep.n_symbols), "viterbi_check": proof,
+            "viterbi_bytes_equal_the_streaming_decoder": bool(n == len(vit) > 0 and (vit == ref[:n]).all())}
 
 
 def config5_noise(torch, g, nsf=16, snrs=(9.0, 8.0), reps=5):
@@ -774,8 +811,9 @@ def main():
     ap.add_argument("--front-priority", action="store_true", help="dvbt_rx_params.front_priority: a step's front end on a high-priority stream of the handle's own")
     ap.add_argument("--viterbi-warm", type=int, default=0, help="dvbt_rx_params.viterbi_warm_windows: warm-up of the Viterbi stage's chunk decoders in windows (0 = the default 72; a multiple of 24): "
                     "what equality with the streaming decoder on collapsed channels costs (DESIGN.md 2)")
-    ap.add_argument("--viterbi-verify", action="store_true", help="dvbt_rx_params.viterbi_verify: the decoder's launch proves chunk by chunk that it is the streaming decoder (config.viterbi_check = chunks, "
-                    "chunks not proven, of the last step)")
+    ap.add_argument("--viterbi-verify", type=int, default=1, help="dvbt_rx_params.viterbi_verify: 1 (the bench's default) = the library's default path -- every launch of the decoder proves chunk by chunk "
+                    "that it is the streaming decoder and decodes the unproven chunks again -- plus the final check whose count is config.viterbi_check.not_proven_after_repair; 0 = the same "
+                    "without the final check's two small launches (what a handle gets by default); -1 = the plain chunk decoders (no proof: the round-5 default, for A/B)")
     ap.add_argument("--pipeline", type=int, default=3, help="steps in flight per piece: handles (own HIP stream each) that take the piece's steps in turn")
     ap.add_argument("--from-file-rate", action="store_true",
                     help="feed the 10 Msps file format: rational_resampler 64/70 + multiply_const run on the device in front of the chain "
@@ -859,7 +897,8 @@ def main():
                                    + (", input at the 10 Msps file rate (resampler 64/70 + scale on the device)" if a.from_file_rate else ""),
                        "stream_superframes": job.nsf, "superframes_per_gpu": a.superframes, "pieces_per_gpu": nseg, "steps_in_flight": depth,
                        "viterbi_warm_windows": a.viterbi_warm or 72,
-                       **({"viterbi_check": [dict(zip(("chunks", "not_proven"), p["rx"].viterbi_check())) for p in job.pieces]} if a.viterbi_verify else {}),
+                       "viterbi_verify": a.viterbi_verify,
+                       **({"viterbi_check": [viterbi_check_of(p["rx"]) for p in job.pieces]} if a.viterbi_verify >= 0 else {}),
                        "stream_samples": n_stream, "samples_decoded_per_gpu_per_step": job.samples_decoded,
                        "parallelism": f"one stream cut into {world * nseg} pieces at superframe boundaries, {nseg} per GPU"
                                       + ((" + one RCCL gather of TS per step" if a.backend == "nccl" else " + one gloo gather of TS per step (host staged)") if dist else ""),
@@ -881,7 +920,9 @@ def main():
                          "in_flight_launch_ms": round(vit_ms, 4) if vit_ms > 0 else None, "in_flight_achieved": round(alg_bytes / (vit_ms * 1e-3) / 1e9, 2) if vit_ms > 0 else None,
                          "chain_frac": round(msps / world * 1e6 * (8 + n_ts / n_stream) / 1e9 / HBM_PEAK_GBS, 6),
                          "hbm_copy_gbs": hbm_copy_gbs(torch, f"cuda:{local}"),
-                         "valu_issue": valu_issue(a.workload, job.nsf, int(alg_bytes), solo_ms, device_clock_hz(torch, local))},
+                         "second_kernel": second_kernel(a.workload, job.nsf, int(alg_bytes), reps, d, job.c, solo, nseg)},
+            # what actually bounds the dominant kernel (top level: the driver's parser keeps `roofline`'s contract keys only)
+            "valu_issue": valu_issue(a.workload, job.nsf, int(alg_bytes), solo_ms, device_clock_hz(torch, local)),
             "ms_per_step_dispersion": job.step_ms,
             "stage_ms_per_piece": stage_avg,
             "stage_ms_per_piece_solo": solo,

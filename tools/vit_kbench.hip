@@ -45,7 +45,7 @@ int main(int argc, char **argv)
     {
       static hipStream_t s2 = nullptr; static unsigned long long *pr = nullptr;
       if (!s2) { (void)hipStreamCreate(&s2); (void)hipMalloc((void **)&pr, 16); }
-      hipLaunchKernelGGL(viterbi3_kernel<24>, grid, dim3(64 * V3_WGW), 0, 0, (const uint8_t *)din, dout, (const RxState *)nullptr, steps, vp, 0ll, 0ll);
+      hipLaunchKernelGGL(viterbi3_kernel<24>, grid, dim3(64 * V3_WGW), 0, 0, (const uint8_t *)din, dout, (const RxState *)nullptr, steps, vp, V3Aux{}, 0ll, 0ll);
       hipLaunchKernelGGL(clock_probe, dim3(1), dim3(64), 0, s2, pr, 200000ll);       // 2 ms at 100 MHz, inside the decoder's launch
       (void)hipDeviceSynchronize();
       unsigned long long h2[2]; (void)hipMemcpy(h2, pr, 16, hipMemcpyDeviceToHost);
@@ -53,7 +53,7 @@ int main(int argc, char **argv)
     }
     for (int rep = 0; rep < 4; rep++) {
       (void)hipEventRecord(e0);
-      hipLaunchKernelGGL(viterbi3_kernel<24>, grid, dim3(64 * V3_WGW), 0, 0, (const uint8_t *)din, dout, (const RxState *)nullptr, steps, vp, 0ll, 0ll);
+      hipLaunchKernelGGL(viterbi3_kernel<24>, grid, dim3(64 * V3_WGW), 0, 0, (const uint8_t *)din, dout, (const RxState *)nullptr, steps, vp, V3Aux{}, 0ll, 0ll);
       (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
       float ms; (void)hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
     }
@@ -61,7 +61,7 @@ int main(int argc, char **argv)
     {   // per-wavefront lifetimes (100 MHz ticks) and residency per SIMD
       const size_t nw = (size_t)grid.x * V3_WGW;
       (void)hipMemset(dbg, 0, 8 * 3 * nw);
-      hipLaunchKernelGGL(viterbi3_kernel<24>, grid, dim3(64 * V3_WGW), 0, 0, (const uint8_t *)din, dout, (const RxState *)nullptr, steps, vp, 0ll, 0ll);
+      hipLaunchKernelGGL(viterbi3_kernel<24>, grid, dim3(64 * V3_WGW), 0, 0, (const uint8_t *)din, dout, (const RxState *)nullptr, steps, vp, V3Aux{}, 0ll, 0ll);
       (void)hipDeviceSynchronize();
       std::vector<unsigned long long> hd(3 * nw); (void)hipMemcpy(hd.data(), dbg, 8 * 3 * nw, hipMemcpyDeviceToHost);
       unsigned long long tmin = ~0ull, tmax = 0; std::vector<double> durs;
