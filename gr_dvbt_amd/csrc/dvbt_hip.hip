@@ -362,6 +362,14 @@ struct dvbt_rx {
 constexpr long long kVitMaxChunk = 3000;
 static int vit_chunk_bytes(const dvbt_rx *h, long long max_vit);
 
+// launch_graph: a captured launch sequence holds the handle's buffers and choices as they were when it was captured -- the tap buffers and the `taps` instantiations, the
+// acquisition context in use (state block, tracker flags, ticket, page-locked copy), the stage events.  Whatever changes one of them drops the graphs.
+static void drop_graphs(dvbt_rx *h)
+{
+  for (auto &ge : h->graphs) if (ge.exec) (void)hipGraphExecDestroy(ge.exec);
+  h->graphs.clear();
+}
+
 static void rx_free(dvbt_rx *h)
 {
   void *all[] = {h->bd_log, h->bitdeint_lp, h->st_ctx[0], h->st_ctx[1], h->st_ctx[2], h->meta_ctx[0], h->meta_ctx[1], h->meta_ctx[2], h->tps_prev_snap[0], h->tps_prev_snap[1], h->tps_snap[0], h->tps_snap[1], h->csi, h->soft_a, h->soft_tab, h->soft_scratch, h->rs_defer, h->rs_sync, h->drift_mem, h->drift.delta, h->drift_flags_ctx[0], h->drift_flags_ctx[1], h->drift_flags_ctx[2], h->tps_prev, h->descr_runs, h->descr_nruns, h->centre, h->anchor_pos, h->sym_ticket_ctx[0], h->sym_ticket_ctx[1], h->sym_ticket_ctx[2], h->tps_edges, h->trk_cp_a, h->trk_cp_b, h->trk_flags_ctx[0], h->trk_flags_ctx[1], h->trk_flags_ctx[2], h->trk_eps, h->d_iq, h->rs_iq, h->acq_carry, h->g_init, h->l_init, h->g_trk, h->l_trk, h->tps_state, h->acq_tap, h->fft_out, h->eq, h->tpsval,
@@ -504,7 +512,32 @@ extern "C" int dvbt_rx_enable_timing(dvbt_rx *h, int enable)
 {
   if (!h) return DVBT_ERR_INVALID;
   h->timing = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
+  drop_graphs(h);
   if (enable) { for (int i = 0; i <= ST_END; i++) h->acc_ms[i] = 0.0; h->n_timed = 0; }     // a new measurement window: dvbt_rx_stage_ms averages from here on
+  return DVBT_OK;
+}
+
+// The buffers behind the Viterbi decoder for a stream of at least `cap` bytes (contents kept).  A handle is created for one launch over max_samples; the streaming entry's
+// walk lays the lock periods of a WINDOW out in h->vit -- up to two pieces and a threshold of samples when a lost piece is harvested late -- in front of an open period that
+// alone may fill a launch (dvbt_rx_stream_push failed with DVBT_ERR_CAPACITY there).  Grows, never shrinks; synchronises the device (a walk is synchronous anyway).
+static int rx_reserve_vit(dvbt_rx *h, size_t cap)
+{
+  if (cap <= h->vit_cap) return DVBT_OK;
+  HIPCHK(hipDeviceSynchronize());
+  drop_graphs(h);
+  const size_t old = h->vit_cap;
+  uint8_t **bufs[] = {&h->vit, &h->rs_out, &h->ts_out, &h->deint_tap};
+  for (uint8_t **b : bufs) {
+    if (!*b) continue;                                             // (deint_tap: a debug tap, there only on request)
+    uint8_t *q = nullptr; HIPCHK(hipMalloc((void **)&q, cap));
+    HIPCHK(hipMemcpy(q, *b, old, hipMemcpyDeviceToDevice));
+    (void)hipFree(*b); *b = q;
+  }
+  const int dcap = (int)((cap / 204 / 64 + 2) * (RS_LANE_MIN - 1));
+  { RsDefer *q = nullptr; HIPCHK(hipMalloc((void **)&q, sizeof(RsDefer) * (size_t)dcap)); (void)hipFree(h->rs_defer); h->rs_defer = q; h->rs_defer_cap = dcap; }
+  { unsigned long long *q = nullptr; HIPCHK(hipMalloc((void **)&q, sizeof(unsigned long long) * (cap / 204 / 64 + 2)));
+    HIPCHK(hipMemcpy(q, h->rs_sync, sizeof(unsigned long long) * (old / 204 / 64 + 2), hipMemcpyDeviceToDevice)); (void)hipFree(h->rs_sync); h->rs_sync = q; }
+  h->vit_cap = cap;
   return DVBT_OK;
 }
 
@@ -522,6 +555,8 @@ static int ensure_taps(dvbt_rx *h)
 extern "C" int dvbt_rx_enable_taps(dvbt_rx *h, int enable)
 {
   if (!h) return DVBT_ERR_INVALID;
+  if (h->pending) return fail(DVBT_ERR_STATE, "dvbt_rx_enable_taps: a segment is in flight (dvbt_rx_segment_finish first)");
+  drop_graphs(h);
   if (enable == 2 && !h->bd_log) HIPCHK(hipMalloc((void **)&h->bd_log, (size_t)h->max_calls * h->d.payload + 64));
   if (enable) return ensure_taps(h);
   if (h->bd_log) { (void)hipFree(h->bd_log); h->bd_log = nullptr; }
@@ -793,7 +828,7 @@ extern "C" int dvbt_rx_segment_enqueue_device(dvbt_rx *h, const void *iq_device,
   const float2 *chain; size_t chain_n;
   int r = prepare_chain(h, (const float2 *)iq_device, nsamples, s, &chain, &chain_n); if (r) return r;
   h->n_periods = 1; h->seg_offset = 0;
-  if (h->prm.launch_graph && !h->timing && !h->rsd.ri) {
+  if (h->prm.launch_graph && !h->timing && !h->rsd.ri && !(h->acq_tap || h->fft_out || h->symdeint_tap || h->deint_tap)) {   // (not with the debug taps: a replay would write buffers that dvbt_rx_enable_taps(h, 0) frees)
     // the launch sequence as ONE graph launch: captured the first time this (segment, length, stream, cut) is seen
     for (auto &ge : h->graphs)
       if (ge.iq == chain && ge.n == chain_n && ge.s == s && ge.sym_off == h->cut.stream_symbol_offset && ge.delay == h->cut.start_delay_symbols && ge.phase == h->cut.descr_call_phase) {
@@ -873,6 +908,7 @@ extern "C" int dvbt_rx_segment_finish(dvbt_rx *h, dvbt_rx_report *rep)
 struct LockPeriod { size_t off; int n_symbols; float avg_in; bool carry; int call0, cp_start0; bool lost; };
 static void set_ctx(dvbt_rx *h, int k)
 {
+  if (k != h->ctx && !h->graphs.empty()) drop_graphs(h);
   h->ctx = k; h->st = h->st_ctx[k]; h->meta = h->meta_ctx[k]; h->trk_flags = h->trk_flags_ctx[k]; h->sym_ticket = h->sym_ticket_ctx[k]; h->drift.flags = h->drift_flags_ctx[k];
   h->st_host = h->st_host_ctx[k];
 }
@@ -895,7 +931,8 @@ static int segment_periods(dvbt_rx *h, const float2 *chain, size_t chain_n, hipS
   bool need_full = false;
   int ctx_last = -1;                                              // acquisition context of the last decoded period (-1: none yet): acquisitions go to the other one
   auto acq_ctx = [&]() -> int {                                   // switch to the context an acquisition may write (the other one may be in use by a decode in flight;
-    const int k = ctx_last < 0 ? h->ctx : (ctx_last ^ 1);         // what has to live through the periods of a segment -- the stream's TPS word -- is kept on the host)
+    const int k = ctx_last < 0 ? h->ctx : (ctx_last == 0 ? 1 : 0);   // what has to live through the periods of a segment -- the stream's TPS word -- is kept on the host)
+                                                                  // (three contexts exist, the streaming entry's walk uses all of them: never ctx_last ^ 1, which is 3 for 2)
     if (k != h->ctx) set_ctx(h, k);
     return DVBT_OK;
   };

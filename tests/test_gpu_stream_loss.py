@@ -142,3 +142,29 @@ def test_auto_configured_stream_through_a_lost_lock(po):
     ts = np.concatenate(out)
     assert info.auto_configured == 1 and (info.constellation, info.code_rate) == (const, cr) and info.status & 2
     assert len(ts) == len(single) and (ts == single).all(), (len(ts), len(single))
+
+
+def test_mid_piece_dropout_in_long_pieces_pushed_without_pulls(po):
+    """pieces of 16 superframes (2k QAM64 7/8: 4.3 MB behind the Viterbi decoder each), a dropout ten superframes into a piece, and a caller that pushes the whole stream
+    before it pulls: the lost piece is harvested late, the walk's window reaches over two pieces and a threshold, and the lock period in front of the dropout alone fills
+    more of the walk handle's Viterbi stream than the 2 MB of slack a piece's handle had until round 6 (dvbt_rx_stream_push failed with DVBT_ERR_CAPACITY and
+    the stream was dead).  The stream is the single chain's TS, which is the oracle's."""
+    const, cr, mode = g.QAM64, g.C7_8, g.T2k
+    c = po.cfg(const, cr, mode)
+    L = c.N + c.cp
+    iq = po.stream_slice(c, 58, 9).copy()
+    a = po.STREAM_LEAD_IN + (272 * 29 + 100) * L
+    iq[a:a + 25 * L] = 0
+    o, single = _single_chain(po, const, cr, mode, iq, 30.0)
+    assert len(o["lock_periods"]) == 2 and len(single) == len(o["ts"]) > 0 and (single == o["ts"]).all()
+    st = g.RxStream(const, cr, mode, segment_superframes=16)
+    for p in range(0, len(iq), 64 * L):
+        st.push(iq[p:p + 64 * L])
+    st.finish()
+    out = [st.pull()]
+    while len(out[-1]):
+        out.append(st.pull())
+    info = st.info(); st.close()
+    ts = np.concatenate(out)
+    assert info.status & 2
+    assert len(ts) == len(single) and (ts == single).all(), (len(ts), len(single))
