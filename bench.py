@@ -670,12 +670,13 @@ def per_block_cpp(iq, workload):
 def cpp_multi_host(workload, loops=160, seg_sf=64):
     """BASELINE config 4's host in C++ (gr_dvbt_amd/host/rx_multi_example.cpp, one rank: one GPU per box) on the bench line's workload: the baseband resident in
     device memory (uploaded before the clock starts), pushed through dvbt_rx_stream_push_device in calls of eight superframes, pieces of 64 superframes, ONE
-    asynchronous double-buffered RCCL step per piece's worth of pushes (dvbt_rx_stream_gather_enqueue / _wait, the packets device resident until the root's
-    download; the root looks at them in the step's page-locked buffer).  The stretch of 64 superframes behind the first one is pushed `loops` times (a seamless
+    asynchronous double-buffered RCCL step per piece's worth of pushes (dvbt_rx_stream_gather_enqueue_ex with DVBT_GATHER_DEVICE / _wait: the runs stay in rank 0's
+    device memory -- north_star's clock ends at "last TS byte resident on rank 0", as the Python line's does; `with_page_locked_mirror` is the same host with the root's
+    download of exactly the bytes the headers declare, dvbt_rx_stream_gather_enqueue).  The stretch of 64 superframes behind the first one is pushed `loops` times (a seamless
     stream but for the encoder's memory at the seam); a warm-up stream runs first.  The samples are LENT to the stream (dvbt_rx_stream_params.borrow_device_pushes: the
     stretch lies four times back to back in device memory and the pushes walk through that ring, so three pieces of four are decoded where they lie and the
     fourth, across the ring's wrap, is gathered); `every_push_copies` is the same host under the default push contract (the samples are COPIED into the
-    library: 1.0 ms of blit kernels per piece, rocprofv3).  Both pay for the root's download of the TS (15 GB/s at the headline rate), which the Python line does not."""
+    library: 1.0 ms of blit kernels per piece, rocprofv3)."""
     import subprocess
     import tempfile
     from oracle import pyoracle as po
@@ -690,13 +691,13 @@ def cpp_multi_host(workload, loops=160, seg_sf=64):
     try:
         iq.tofile(fin)
         res = {}
-        for mode in ("lent", "copy"):
+        for mode in ("lent", "mirror", "copy"):
             best = None
             for _ in range(2):
                 if os.path.exists(idf):
                     os.remove(idf)
                 r = subprocess.run([exe, "0", "1", idf, "8k", "qam64", "7/8", fin, os.path.join(tmp, "none.ts"), str(seg_sf), "0", "bench", str(loops),
-                                    str(po.STREAM_LEAD_IN + sf), str(64 * sf), str(8 * sf), "8", "400000"] + (["copy"] if mode == "copy" else []),
+                                    str(po.STREAM_LEAD_IN + sf), str(64 * sf), str(8 * sf), "8", "400000"] + (["copy"] if mode == "copy" else ["mirror"] if mode == "mirror" else []),
                                    capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
                 if r.returncode != 0:
                     return {"error": (r.stdout[-200:] + r.stderr[-300:])}
@@ -706,8 +707,9 @@ def cpp_multi_host(workload, loops=160, seg_sf=64):
         best = res["lent"]
         return {"value": best["msamples_per_s"], "unit": "Msamples/s", "x_realtime": round(best["msamples_per_s"] / REALTIME_MSPS, 1), "world": 1, "samples": best["samples"],
                 "seconds": best["seconds"], "exchange_steps": best["exchange_steps"], "ts_bytes": best["ts_bytes"], "status": best["status"],
-                "entry": "dvbt_rx_stream_push_device (samples lent: borrow_device_pushes) + dvbt_rx_stream_gather_enqueue / _wait (RCCL, one rank)", "segment_superframes": seg_sf,
-                "superframes_per_push": 8, "pushes_per_exchange_step": 8,
+                "entry": "dvbt_rx_stream_push_device (samples lent: borrow_device_pushes) + dvbt_rx_stream_gather_enqueue_ex(DVBT_GATHER_DEVICE) / _wait (RCCL, one rank; the runs stay in rank 0's device memory)",
+                "segment_superframes": seg_sf, "superframes_per_push": 8, "pushes_per_exchange_step": 8,
+                "with_page_locked_mirror": {"value": res["mirror"]["msamples_per_s"], "seconds": res["mirror"]["seconds"], "status": res["mirror"]["status"]},
                 "every_push_copies": {"value": res["copy"]["msamples_per_s"], "seconds": res["copy"]["seconds"], "status": res["copy"]["status"]}}
     finally:
         for f in (fin, idf):

@@ -65,6 +65,9 @@ int main(int argc, char **argv)
     dvbt_dims d; check(dvbt_get_dims(con, DVBT_NH, cr, DVBT_G1_32, mode, &d));
     check(dvbt_rx_stream_set_device_output(st, 0));                    // the decoded TS waits in device memory for the exchange step
     const bool bench = argc > 15 && !std::strcmp(argv[11], "bench");
+    // bench: the runs stay in rank 0's device memory (north_star: the clock ends at "last TS byte resident on rank 0") unless "mirror" asks for the page-locked copy as well
+    bool mirror = false; for (int i = 16; i < argc; i++) if (!std::strcmp(argv[i], "mirror")) mirror = true;
+    const int gflags = bench && !mirror ? DVBT_GATHER_DEVICE : 0;
     std::FILE *f = std::fopen(argv[7], "rb"); if (!f) { std::perror("open"); return 1; }
     const size_t call = (size_t)64 * (d.fft_length + d.cp_length);
     const int GATHER_EVERY = 8, SLOT_PACKETS = bench ? (argc > 17 ? std::atoi(argv[17]) : 1 << 16) : 4096;
@@ -87,7 +90,7 @@ int main(int argc, char **argv)
       }
     };
     auto step = [&]() {                                              // issue a step; consume the one before it while this one travels
-      check(dvbt_rx_stream_gather_enqueue(st, comm, 0, SLOT_PACKETS));
+      check(dvbt_rx_stream_gather_enqueue_ex(st, comm, 0, SLOT_PACKETS, gflags));
       in_flight++; steps++;
       if (in_flight == 2) take();
     };
@@ -109,7 +112,8 @@ int main(int argc, char **argv)
         dvbt_rx_stream *w = nullptr; check(dvbt_rx_stream_create(&p, &w)); check(dvbt_rx_stream_set_device_output(w, 0));
         check(dvbt_rx_stream_push_device(w, dev, (size_t)(loop_from + loop_len), nullptr)); check(dvbt_rx_stream_finish(w));
         int wd = 0, fl = 0;
-        while (!wd) { check(dvbt_rx_stream_gather_enqueue(w, comm, 0, SLOT_PACKETS)); fl++; const long long r = dvbt_rx_stream_gather_wait(w, comm, nullptr, 0, rank == 0 ? chunks.data() : nullptr, &wd); check((int)(r < 0 ? r : 0)); fl--; }
+        check(dvbt_rccl_comm_reserve(comm, 0, SLOT_PACKETS, gflags));   // (an allocation failure here, in front of the first step, not inside one)
+        while (!wd) { check(dvbt_rx_stream_gather_enqueue_ex(w, comm, 0, SLOT_PACKETS, gflags)); fl++; const long long r = dvbt_rx_stream_gather_wait(w, comm, nullptr, 0, rank == 0 ? chunks.data() : nullptr, &wd); check((int)(r < 0 ? r : 0)); fl--; }
         dvbt_rx_stream_destroy(w);
       }
       const auto t0 = std::chrono::steady_clock::now();
@@ -143,8 +147,8 @@ int main(int argc, char **argv)
     dvbt_rx_stream_info inf; check(dvbt_rx_stream_status(st, &inf));
     int rc = 0;
     if (rank == 0 && bench) {
-      std::printf("{\"world\": %d, \"samples\": %lld, \"seconds\": %.4f, \"msamples_per_s\": %.1f, \"ts_bytes\": %lld, \"exchange_steps\": %lld, \"order_errors\": %lld, \"status\": %d}\n",
-                  world, samples, seconds, samples / seconds / 1e6, ts_bytes, steps, order_errors, inf.status);
+      std::printf("{\"world\": %d, \"samples\": %lld, \"seconds\": %.4f, \"msamples_per_s\": %.1f, \"ts_bytes\": %lld, \"exchange_steps\": %lld, \"order_errors\": %lld, \"status\": %d, \"runs\": \"%s\"}\n",
+                  world, samples, seconds, samples / seconds / 1e6, ts_bytes, steps, order_errors, inf.status, mirror ? "page-locked mirror on rank 0 (exact download)" : "resident in rank 0's device memory");
       if (order_errors) rc = 1;
     } else if (rank == 0) {
       std::FILE *o = std::fopen(argv[8], "wb"); if (!o) { std::perror("open"); return 1; }

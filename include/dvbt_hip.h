@@ -594,8 +594,19 @@ int  dvbt_rx_stream_set_device_output(dvbt_rx_stream *s, size_t ring_bytes);
 int  dvbt_rx_stream_gather_enqueue(dvbt_rx_stream *s, dvbt_rccl_comm *c, int root, int slot_packets);
 int64_t dvbt_rx_stream_gather_wait(dvbt_rx_stream *s, dvbt_rccl_comm *c, void *ts_host, size_t cap, dvbt_gather_chunk *chunks, int *all_done);
 /* root, after a wait with ts_host = NULL: the runs stay where the step's download put them -- chunks[r].offset then counts from this page-locked buffer (valid
- * until the second next wait): a root that writes the packets on needs no copy of its own (at the headline rate the TS is ~15 GB/s) */
+ * until the second next wait): a root that writes the packets on needs no copy of its own (at the headline rate the TS is ~15 GB/s).  The download copies, per
+ * rank, the header and the bytes the header declares -- not the slot. */
 const void *dvbt_rccl_step_buffer(const dvbt_rccl_comm *c);
+/* The step that leaves the runs in the ROOT'S DEVICE MEMORY (north_star: the clock ends at "last TS byte resident on rank 0"): dvbt_rx_stream_gather_enqueue_ex with
+ * DVBT_GATHER_DEVICE downloads nothing but the 64-byte headers; dvbt_rx_stream_gather_wait (ts_host = NULL) describes the runs in chunks[], offsets counted from
+ * dvbt_rccl_step_device_buffer (device pointer, valid until the second next wait).  flags = 0: dvbt_rx_stream_gather_enqueue.  Same flags on every rank. */
+#define DVBT_GATHER_DEVICE 1
+int  dvbt_rx_stream_gather_enqueue_ex(dvbt_rx_stream *s, dvbt_rccl_comm *c, int root, int slot_packets, int flags);
+const void *dvbt_rccl_step_device_buffer(const dvbt_rccl_comm *c);
+/* the exchange buffers for steps of slot_packets packets towards root (flags as above: without DVBT_GATHER_DEVICE the root also gets its page-locked mirror).  The
+ * enqueue calls it itself; called first, on every rank, it moves an allocation failure in front of the first step (inside a step such a failure becomes an error-flag
+ * slot sent from the stream's sample buffer, so that no rank waits -- see dvbt_rccl.inc) */
+int  dvbt_rccl_comm_reserve(dvbt_rccl_comm *c, int root, int slot_packets, int flags);
 /* the two at once (blocking): one group and one synchronisation per step */
 int64_t dvbt_rx_stream_gather(dvbt_rx_stream *s, dvbt_rccl_comm *c, int root, int slot_packets, void *ts_host, size_t cap, dvbt_gather_chunk *chunks, int *all_done);
 

@@ -133,3 +133,67 @@ def test_cpp_host_bench_mode_on_resident_samples(tmp_path):
     assert d["order_errors"] == 0 and d["samples"] == po.STREAM_LEAD_IN + sf + loops * 4 * sf
     # the stream: 1 + 3 x 4 superframes, the reference's chain starts one frame early and holds two items back at the end
     assert abs(d["ts_bytes"] // 188 - (1 + loops * 4) * pps) <= pps, d
+
+
+def test_cpp_host_device_resident_runs_and_exact_mirror(tmp_path):
+    """the exchange step's two forms on rank 0: DVBT_GATHER_DEVICE leaves the runs in the root's device memory (nothing but the 64-byte headers is downloaded), the plain
+    step mirrors them in page-locked memory -- per rank the header and the bytes the header declares, not the slot.  Driven through ctypes with one rank: both forms must
+    deliver the same runs, which are the oracle's TS; the device-resident form refuses a host destination."""
+    import ctypes as C
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from oracle import pyoracle as po
+    import gr_dvbt_amd as g
+    from gr_dvbt_amd import binding as b
+    L = g.lib()
+    c = po.cfg(g.QAM16, g.C1_2, g.T2k)
+    iq = po.stream_slice(c, 7, 6)
+    want = po.rx(c, iq, want=("ts",))["ts"]
+    idb = (C.c_char * 128)()
+    assert L.dvbt_rccl_unique_id(idb) == 0
+    comm = C.c_void_p()
+    L.dvbt_rccl_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    assert L.dvbt_rccl_comm_create(idb, 0, 1, 0, C.byref(comm)) == 0
+
+    class Chunk(C.Structure):
+        _fields_ = [("first_packet", C.c_int64), ("nbytes", C.c_int64), ("offset", C.c_int64)]
+    L.dvbt_rx_stream_gather_enqueue_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.dvbt_rx_stream_gather_wait.restype = C.c_int64
+    L.dvbt_rx_stream_gather_wait.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(Chunk), C.POINTER(C.c_int)]
+    L.dvbt_rccl_step_buffer.restype = C.c_void_p; L.dvbt_rccl_step_buffer.argtypes = [C.c_void_p]
+    L.dvbt_rccl_step_device_buffer.restype = C.c_void_p; L.dvbt_rccl_step_device_buffer.argtypes = [C.c_void_p]
+    L.dvbt_rccl_comm_reserve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.dvbt_rx_stream_set_device_output.argtypes = [C.c_void_p, C.c_size_t]
+    L.dvbt_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    SLOT = 3000
+    outs = {}
+    for flags in (1, 0):
+        st = g.RxStream(g.QAM16, g.C1_2, g.T2k, segment_superframes=2, rank=0, world=1)
+        assert L.dvbt_rx_stream_set_device_output(st.h, 0) == 0
+        assert L.dvbt_rccl_comm_reserve(comm, 0, SLOT, flags) == 0
+        runs, done, ch = {}, C.c_int(0), (Chunk * 1)()
+        step = 40 * (c.N + c.cp)
+        pos = 0
+        while not done.value:
+            if pos < len(iq):
+                st.push(iq[pos:pos + step]); pos += step
+                if pos >= len(iq):
+                    st.finish()
+            assert L.dvbt_rx_stream_gather_enqueue_ex(st.h, comm, 0, SLOT, flags) == 0, L.dvbt_last_error()
+            if flags:
+                assert L.dvbt_rx_stream_gather_wait(st.h, comm, (C.c_char * 16)(), 16, ch, C.byref(done)) < 0       # a device-resident step has no host destination (the step stays in flight)
+            n = L.dvbt_rx_stream_gather_wait(st.h, comm, None, 0, ch, C.byref(done))
+            assert n >= 0 and n == ch[0].nbytes <= SLOT * 188
+            if n:
+                buf = np.zeros(n, np.uint8)
+                if flags:
+                    assert L.dvbt_rccl_step_buffer(comm) is None
+                    assert L.dvbt_copy_to_host(buf.ctypes.data_as(C.c_void_p), C.c_void_p(L.dvbt_rccl_step_device_buffer(comm) + ch[0].offset), n) == 0
+                else:
+                    C.memmove(buf.ctypes.data_as(C.c_void_p), C.c_void_p(L.dvbt_rccl_step_buffer(comm) + ch[0].offset), n)
+                runs[ch[0].first_packet] = buf
+        st.close()
+        outs[flags] = np.concatenate([runs[k] for k in sorted(runs)])
+    L.dvbt_rccl_comm_destroy.argtypes = [C.c_void_p]
+    L.dvbt_rccl_comm_destroy(comm)
+    assert len(outs[1]) == len(outs[0]) == len(want) > 0 and (outs[1] == want).all() and (outs[0] == want).all()
