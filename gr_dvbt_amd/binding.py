@@ -357,6 +357,13 @@ class RxStream:
         self.L.dvbt_rx_stream_trace(self.h, buf, len(buf))
         return buf.value.decode()
 
+    def viterbi_proof(self):
+        """the Viterbi stage's proof + repair passes summed over the stream's launches so far: dict(chunks, decoded_again, sequential, not_proven = -1)"""
+        p = ViterbiProof()
+        self.L.dvbt_rx_stream_viterbi_proof.argtypes = [C.c_void_p, C.POINTER(ViterbiProof)]
+        _chk(self.L.dvbt_rx_stream_viterbi_proof(self.h, C.byref(p)))
+        return {"chunks": int(p.chunks), "decoded_again": int(p.decoded_again), "sequential": int(p.sequential), "not_proven": int(p.not_proven)}
+
     def info(self):
         i = StreamInfo()
         _chk(self.L.dvbt_rx_stream_status(self.h, C.byref(i)))

@@ -566,6 +566,8 @@ int  dvbt_rx_stream_status(const dvbt_rx_stream *s, dvbt_rx_stream_info *info);
 /* what the stream did, as text: one line per walk window, per epoch that was established, per piece that left its epoch (a lost CP lock) or whose descrambler
  * had to be followed on the host; returns the trace's length (the text is cut to cap - 1 characters, 0-terminated).  Bounded at 64 KB. */
 int64_t dvbt_rx_stream_trace(const dvbt_rx_stream *s, char *dst, size_t cap);
+/* the Viterbi stage's proof + repair passes (dvbt_rx_params.viterbi_verify: the stream's chains run them like every handle) summed over the stream's launches so far */
+int  dvbt_rx_stream_viterbi_proof(const dvbt_rx_stream *s, dvbt_viterbi_proof *out);
 void dvbt_rx_stream_destroy(dvbt_rx_stream *s);
 
 /* ------------------------------------------------------------------ the exchange step of a sharded stream

@@ -217,3 +217,27 @@ def test_viterbi_block_is_the_streaming_decoder(po, g):
     for warm, (diff, pr) in res.items():
         assert diff == 0, res
     assert res[0][1]["decoded_again"] > 0 and res[48][1]["decoded_again"] > 0, res
+
+
+def test_streaming_entry_repairs_its_chunks_too(po, g):
+    """dvbt_rx_stream_* on the collapsed channel (2k QAM64 7/8 at 16 dB, pieces of two superframes, ragged pushes): the stream's chains prove and repair every launch like any
+    handle -- the TS is the single chain's (whose Viterbi stage is the streaming decoder, test above), and chunks WERE decoded again on the way"""
+    c = po.cfg(po.QAM64, po.C7_8, po.T2k)
+    ibits = c.payload * c.m * c.k // c.n
+    iq = po.channel(po.tx(c, po.make_ts((272 * ibits * 9) // (204 * 8), 5), lead_in=500, tail=3 * c.N), c.N, snr_db=16, seed=5)
+    rx = g.Rx(po.QAM64, po.C7_8, po.T2k, max_samples=len(iq), snr_db=16.0)
+    rep = rx.run(iq)
+    single = rx.tap(g.TAP_TS).copy()
+    rx.close()
+    assert rep.n_lock_periods == 1 and len(single) > 1000000
+    st = g.RxStream(po.QAM64, po.C7_8, po.T2k, segment_superframes=2, snr_db=16.0)
+    out = []
+    for a in range(0, len(iq), 123457):
+        st.push(iq[a:a + 123457]); out.append(st.pull())
+    st.finish(); out.append(st.pull())
+    pr = st.viterbi_proof()
+    st.close()
+    ts = np.concatenate(out)
+    print("streaming entry on the collapsed channel:", pr)
+    assert len(ts) == len(single) and (ts == single).all()
+    assert pr["chunks"] > 1000 and pr["decoded_again"] > 0
