@@ -10,7 +10,7 @@ The batch is ONE stream (1 lead-in superframe + N x --superframes payload superf
 superframe boundaries into N x --segments pieces (gr_dvbt_amd/multi.py::plan_cuts, SURVEY 8e); every
 rank (one process per GPU, torch.distributed / RCCL) generates and decodes only ITS pieces, each on its own
 handle and HIP stream, and the decoded packets travel to rank 0 in the design's single collective per step
-(multi.gather_pieces).  --pipeline steps are in flight per piece (default 3): the piece's handles take its steps in turn, each on
+(multi.gather_pieces).  --pipeline steps are in flight per piece (default 4): the piece's handles take its steps in turn, each on
 its own HIP stream, so that the next steps' latency-bound front-end kernels run while the Viterbi decoder of the current step holds the machine
 (one step in flight: --pipeline 1; stage_ms_per_piece_solo has those kernel times).  After the timed loop rank 0 stitches the pieces of the last step and compares the TS
 with the packets that were transmitted: the bench fails (exit 1) when a single byte differs.
@@ -816,7 +816,8 @@ def main():
     ap.add_argument("--viterbi-verify", type=int, default=1, help="dvbt_rx_params.viterbi_verify: 1 (the bench's default) = the library's default path -- every launch of the decoder proves chunk by chunk "
                     "that it is the streaming decoder and decodes the unproven chunks again -- plus the final check whose count is config.viterbi_check.not_proven_after_repair; 0 = the same "
                     "without the final check's two small launches (what a handle gets by default); -1 = the plain chunk decoders (no proof: the round-5 default, for A/B)")
-    ap.add_argument("--pipeline", type=int, default=3, help="steps in flight per piece: handles (own HIP stream each) that take the piece's steps in turn")
+    ap.add_argument("--pipeline", type=int, default=4, help="steps in flight per piece: handles (own HIP stream each) that take the piece's steps in turn (round 6 on the final code: 4.52 / 4.30 / 4.42 / 4.39 ms per "
+                    "step with 3 / 4 / 5 / 6 in flight, profiles/r06_pipeline_depth.jsonl: four is the default)")
     ap.add_argument("--from-file-rate", action="store_true",
                     help="feed the 10 Msps file format: rational_resampler 64/70 + multiply_const run on the device in front of the chain "
                          "(SURVEY 8f row 2; samples are then counted at the 10 Msps input; single piece only)")
