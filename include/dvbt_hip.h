@@ -510,7 +510,12 @@ void dvbt_rx_destroy(dvbt_rx *h);
  * that loss (a few symbols later; the walk takes over beyond six): it is not a loss of the stream and is not reported as one.
  * Memory per stream object (S = segment_superframes, sf = one superframe of samples = 272 (N + cp) x 8 bytes: 18.4 MB at 8k, 4.6 MB at 2k, guard 1/32):
  *   device: two sample buffers of (S + 3.7) sf each + the two chains' own buffers (~0.55 x a sample buffer each; x 2.2 in soft-decision mode);
- *   S = 16 at 8k: 2 x 362 MB + 2 x ~200 MB.  The first lost lock adds two walk buffers of twice a sample buffer each (2 x 725 MB at S = 16, 8k);
+ *   S = 16 at 8k: 2 x 362 MB + 2 x ~200 MB.  The first lost lock adds two walk buffers of twice a sample buffer each (2 x 725 MB at S = 16, 8k), and the buffers behind the
+ *   walking chain's Viterbi decoder grow to what a window of that size can lay out (three more buffers of ~2.2 x a piece's decoded bytes: +115 MB at S = 16, 8k QAM64 7/8).
+ *   A walk's window is bounded by those buffers: a lock that holds for more than two pieces and a threshold of samples (2 x the sample buffer + (STREAM_PRE + 272) symbols)
+ *   without ever reaching a superframe start -- no decodable TPS word: nothing the reference would deliver either -- is cut: the walk starts afresh two superframes back, status bits
+ *   2 and 5 are raised and dvbt_rx_stream_trace says so.  With device output (dvbt_rx_stream_set_device_output) a piece's packets are handed over in the chain's TS buffer and the chain
+ *   takes a spare one: up to one more TS buffer (~0.25 x a sample buffer) per piece whose packets wait for an exchange step;
  *   page-locked host: the TS ring (ts_ring_bytes, default 96 MB; a consumer that falls further behind is served from the heap) and 32 MB of staging for host
  *   pushes below 2 MB; both taken at create (page-locking them takes ~10 ms: set-up, not the first piece's latency).
  * Threading: like every handle, one thread at a time. */
@@ -585,7 +590,8 @@ void dvbt_rccl_comm_destroy(dvbt_rccl_comm *c);
 typedef struct { int64_t first_packet; int64_t nbytes; int64_t offset; } dvbt_gather_chunk;   /* rank r's run: packet index in the stream's TS, bytes, where they sit in ts_host */
 /* The step, asynchronous and double-buffered (what a host that wants the exchange behind its decode calls; bench.py's Python path does the same with
  * torch.distributed).  dvbt_rx_stream_set_device_output (before the first push): the decoded TS stays in device memory (a ring of ring_bytes, 0 = 64 MB; pull /
- * pull_chunk then refuse) and a step copies its run device to device into the send slot -- no PCIe hop on any rank but the root's one download.
+ * pull_chunk then refuse; a piece's packets wait in the very buffer they were decoded into, ring_bytes holds the walk's smaller runs) and a step copies its run device to
+ * device into the send slot -- no PCIe hop on any rank but the root's one download (none with DVBT_GATHER_DEVICE, below).
  * dvbt_rx_stream_gather_enqueue: collective (the same root and slot_packets on every rank; a rank gives at most slot_packets packets per step); issues ONE group of
  * ncclSend / ncclRecv on the communicator's own HIP stream -- the slot to the root, the 64-byte header to every rank -- and returns at once; at most two steps in
  * flight.  dvbt_rx_stream_gather_wait: the oldest step in flight.  root: ts_host (cap >= world * slot_packets * 188) receives the runs in rank order, chunks[world]

@@ -229,7 +229,7 @@ def test_streaming_entry_repairs_its_chunks_too(po, g):
     rep = rx.run(iq)
     single = rx.tap(g.TAP_TS).copy()
     rx.close()
-    assert rep.n_lock_periods == 1 and len(single) > 1000000
+    assert rep.n_lock_periods == 1 and rep.n_viterbi_bytes > 2000000 and len(single) > 100000      # (the descrambler finds its NSYNC in a fraction of the garbage only)
     st = g.RxStream(po.QAM64, po.C7_8, po.T2k, segment_superframes=2, snr_db=16.0)
     out = []
     for a in range(0, len(iq), 123457):

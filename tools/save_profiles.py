@@ -2,7 +2,7 @@
 import csv, glob, collections, json, os, shutil, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
-tag = args[0] if args else "r04"
+tag = args[0] if args else "r06"
 pmc_only = "--pmc-only" in sys.argv
 
 
@@ -49,6 +49,12 @@ for extra in ("config5_walk.jsonl", "snr_sweep.jsonl", "rs_load.jsonl", "ubench_
 cpp = sorted(glob.glob(os.path.join(root, "gpurun_out", "prof_cpp_lent", "*kernel_stats.csv")), key=os.path.getmtime)
 if cpp:
     shutil.copy(cpp[-1], os.path.join(root, "profiles", f"{tag}_kernel_stats_cpp_host.csv"))                     # tools/cpp_prof.py: the C++ multi-GPU host's bench mode, samples lent
+cpc = sorted(glob.glob(os.path.join(root, "gpurun_out", "prof_cpp_lent", "*memory_copy_stats.csv")), key=os.path.getmtime)
+if cpc:
+    shutil.copy(cpc[-1], os.path.join(root, "profiles", f"{tag}_memory_copy_stats_cpp_host.csv"))                # ... and its copies by direction (no device-to-host copy of a slot: the runs stay on the device)
+for src, dst in (("verify_ab.jsonl", "verify_ab_one_step_in_flight.jsonl"), ("bench_short.json", "bench_short.json")):
+    if os.path.exists(os.path.join(root, "gpurun_out", src)) and os.path.getsize(os.path.join(root, "gpurun_out", src)) > 0 and fresh(os.path.join(root, "gpurun_out", src)):
+        shutil.copy(os.path.join(root, "gpurun_out", src), os.path.join(root, "profiles", f"{tag}_{dst}"))
 for src, dst in (("front_priority.jsonl", "front_priority.jsonl"), ("shard_scan.txt", "shard_scan.txt"), ("parity_sweep.txt", "parity_sweep.txt"), ("parity_sweep4.txt", "parity_sweep4.txt")):
     if os.path.exists(os.path.join(root, "gpurun_out", src)) and os.path.getsize(os.path.join(root, "gpurun_out", src)) > 0:
         shutil.copy(os.path.join(root, "gpurun_out", src), os.path.join(root, "profiles", f"{tag}_{dst}"))
