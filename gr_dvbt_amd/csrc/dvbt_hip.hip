@@ -240,6 +240,16 @@ static void launch_viterbi(hipStream_t s, const uint8_t *in, uint8_t *out, const
       V3_NTB_SWITCH(vp.ntb, V3_CALL)
 #undef V3_CALL
     }
+    if (chunks <= V3_FIX_SMALL && mode != VIT_PROOF_ONLY) {   // few chunks: the three passes as ONE launch of one workgroup
+#define V3_CALL(N) hipLaunchKernelGGL(viterbi_fix_kernel<N>, dim3(1), blk, 0, s, in, out, st, steps_fixed, vp, a, in_base, out_lo, mode == VIT_FORCE_SEQ ? 1 : 0)
+      V3_NTB_SWITCH(vp.ntb, V3_CALL)
+#undef V3_CALL
+      if (mode != VIT_REPAIR) {
+        hipLaunchKernelGGL(viterbi_check_kernel, dim3(1), dim3(256), 0, s, a, st, steps_fixed, vp, 1);
+        hipLaunchKernelGGL(viterbi_count_kernel, cgrid, dim3(256), 0, s, a, st, steps_fixed, vp);
+      }
+      return;
+    }
     hipLaunchKernelGGL(viterbi_check_kernel, cgrid, dim3(256), 0, s, a, st, steps_fixed, vp, 0);
     if (mode == VIT_REPAIR || mode == VIT_REPAIR_COUNT) {
 #define V3_CALL(N) hipLaunchKernelGGL(viterbi_repair_kernel<N>, dim3(V3_REPAIR_GRID), blk, 0, s, in, out, st, steps_fixed, vp, a, in_base, out_lo)

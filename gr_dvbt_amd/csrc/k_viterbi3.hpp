@@ -611,23 +611,14 @@ __device__ __forceinline__ bool v3_row_equal(const int (&a)[2], const int (&b)[2
   return ((ne >> (16 * dd)) & 0xffffull) == 0;
 }
 
-// The parallel repair pass: one decoder (row) per listed chunk, from pred[c], over that chunk alone.
-template <int NTB> __global__ __launch_bounds__(64 * V3_WGW) void viterbi_repair_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const RxState *st,
-                                                      long long steps_fixed, VitParams vp, V3Aux ax, long long in_base, long long out_lo)
+// The parallel repair pass: one decoder (row) per listed chunk, from pred[c], over that chunk alone.  `rows` decoder rows work through the list, this wavefront's first is row0.
+template <int NTB> __device__ __forceinline__ void v3_repair_rows(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, long long total_steps, const VitParams &vp, const V3Aux &ax,
+                                                                  long long in_base, long long out_lo, const V3Lds &S, const V3Lane &L, long long rows, long long row0, int n)
 {
-  V3_LDS_DECL(V3_WGW)
-  const int n = ax.ctl[V3_CTL_MISMATCH];
-  const int wv = V3_WGW > 1 ? (int)(threadIdx.x >> 6) : 0;
-  const long long rows = (long long)gridDim.x * V3_WGW * 4, row0 = ((long long)blockIdx.x * V3_WGW + wv) * 4;
-  if (row0 >= n) return;
-  const V3Lds S = {tab_[wv], wbuf_[wv], bests_[wv], lut};
   const int lane = threadIdx.x & 63, dd = lane >> 4, pl = lane & 15;
-  const long long total_steps = st ? st->n_vit_steps : steps_fixed;
   const long long total_out = total_steps / 8 - vp.ntb;
   const int B = vp.chunk_bytes;
   const long long nch = v3_nchunks(total_out, ax.grid0, B);
-  v3_init_lut(lut, lane);
-  V3Lane L; v3_init_lane(pl, L);
   for (long long i0 = row0; i0 < n; i0 += rows) {
     const bool act = i0 + dd < n;
     const long long c = act ? ax.ctl[V3_CTL_HDR + i0 + dd] : 1;
@@ -645,26 +636,34 @@ template <int NTB> __global__ __launch_bounds__(64 * V3_WGW) void viterbi_repair
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");          // (the next round's staging overwrites this round's LDS)
   }
 }
+template <int NTB> __global__ __launch_bounds__(64 * V3_WGW) void viterbi_repair_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const RxState *st,
+                                                      long long steps_fixed, VitParams vp, V3Aux ax, long long in_base, long long out_lo)
+{
+  V3_LDS_DECL(V3_WGW)
+  const int n = ax.ctl[V3_CTL_MISMATCH];
+  const int wv = V3_WGW > 1 ? (int)(threadIdx.x >> 6) : 0;
+  const long long rows = (long long)gridDim.x * V3_WGW * 4, row0 = ((long long)blockIdx.x * V3_WGW + wv) * 4;
+  if (row0 >= n) return;
+  const V3Lds S = {tab_[wv], wbuf_[wv], bests_[wv], lut};
+  v3_init_lut(lut, threadIdx.x & 63);
+  V3Lane L; v3_init_lane(threadIdx.x & 15, L);
+  v3_repair_rows<NTB>(in, out, st ? st->n_vit_steps : steps_fixed, vp, ax, in_base, out_lo, S, L, rows, row0, n);
+}
 
 // The sequential pass: ONE decoder walks the flagged chunks in stream order.  From fix[c] it decodes chunk c; where the state it reaches at chunk c + 1 is own[c + 1] the bytes behind
 // are the streaming decoder's already, otherwise it goes on through chunk c + 1.  force (a test hook, dvbt_rx_params.viterbi_verify = 3: the parallel pass is not launched): every
 // chunk whose own[] is not pred[] is taken, from pred[].  One wavefront, its first row.
-template <int NTB> __global__ __launch_bounds__(64) void viterbi_repair_seq_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const RxState *st,
-                                                      long long steps_fixed, VitParams vp, V3Aux ax, long long in_base, long long out_lo, int force)
+template <int NTB> __device__ __forceinline__ void v3_seq_walk(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, long long total_steps, const VitParams &vp, const V3Aux &ax,
+                                                               long long in_base, long long out_lo, const V3Lds &S, const V3Lane &L, int force)
 {
-  V3_LDS_DECL(1)
-  if (threadIdx.x == 0) { ax.ctl[V3_CTL_ACC] += ax.ctl[V3_CTL_CHUNKS]; ax.ctl[V3_CTL_ACC + 1] += ax.ctl[V3_CTL_MISMATCH]; }   // (the last pass of every repairing launch)
-  if (!force && ax.ctl[V3_CTL_CONFLICT] == 0) return;
-  const V3Lds S = {tab_[0], wbuf_[0], bests_[0], lut};
   const int lane = threadIdx.x & 63, dd = lane >> 4, pl = lane & 15;
-  const long long total_steps = st ? st->n_vit_steps : steps_fixed;
+  if (lane == 0) { ax.ctl[V3_CTL_ACC] += ax.ctl[V3_CTL_CHUNKS]; ax.ctl[V3_CTL_ACC + 1] += ax.ctl[V3_CTL_MISMATCH]; }   // (the last pass of every repairing launch)
+  if (!force && ax.ctl[V3_CTL_CONFLICT] == 0) return;
   const long long total_out = total_steps / 8 - vp.ntb;
   const int B = vp.chunk_bytes;
   long long nch = v3_nchunks(total_out, ax.grid0, B);
   if (nch > ax.cap) nch = ax.cap;
   const int *cflag = ax.ctl + V3_CTL_HDR + (ax.cap + 2);
-  v3_init_lut(lut, lane);
-  V3Lane L; v3_init_lane(pl, L);
   int done = 0;
   long long pos = 0;                                                 // everything up to and including chunk pos is the streaming decoder's
   for (;;) {
@@ -698,7 +697,42 @@ template <int NTB> __global__ __launch_bounds__(64) void viterbi_repair_seq_kern
       c++; v[0] = endv[0]; v[1] = endv[1];
     }
   }
-  if (threadIdx.x == 0) { ax.ctl[V3_CTL_SEQ] = done; ax.ctl[V3_CTL_ACC + 2] += done; }
+  if (lane == 0) { ax.ctl[V3_CTL_SEQ] = done; ax.ctl[V3_CTL_ACC + 2] += done; }
+}
+template <int NTB> __global__ __launch_bounds__(64) void viterbi_repair_seq_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const RxState *st,
+                                                      long long steps_fixed, VitParams vp, V3Aux ax, long long in_base, long long out_lo, int force)
+{
+  V3_LDS_DECL(1)
+  const V3Lds S = {tab_[0], wbuf_[0], bests_[0], lut};
+  v3_init_lut(lut, threadIdx.x & 63);
+  V3Lane L; v3_init_lane(threadIdx.x & 15, L);
+  v3_seq_walk<NTB>(in, out, st ? st->n_vit_steps : steps_fixed, vp, ax, in_base, out_lo, S, L, force);
+}
+
+// Check, parallel repair (16 decoder rows) and sequential pass in ONE launch of one workgroup, for launches of few chunks (V3_FIX_SMALL): the lock periods of a walk, the single
+// block's calls, short pieces -- where three launches that mostly find nothing to do cost more than they compute (BASELINE config 5 at the prescribed noise: 121 Viterbi launches
+// per 16 superframes).  The same passes in the same order; the workgroup's barriers stand where the launch boundaries stood.
+constexpr long long V3_FIX_SMALL = 1024;
+template <int NTB> __global__ __launch_bounds__(64 * V3_WGW) void viterbi_fix_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const RxState *st,
+                                                      long long steps_fixed, VitParams vp, V3Aux ax, long long in_base, long long out_lo, int force)
+{
+  V3_LDS_DECL(V3_WGW)
+  const int wv = V3_WGW > 1 ? (int)(threadIdx.x >> 6) : 0;
+  const long long total_steps = st ? st->n_vit_steps : steps_fixed;
+  const long long nch = v3_nchunks(total_steps / 8 - vp.ntb, ax.grid0, vp.chunk_bytes);
+  if (threadIdx.x == 0) ax.ctl[V3_CTL_CHUNKS] = (int)(nch < INT_MAX ? nch : INT_MAX);
+  for (long long c = 1 + threadIdx.x; c < nch && c <= ax.cap; c += 64 * V3_WGW) {
+    ax.ctl[V3_CTL_HDR + (ax.cap + 2) + c] = 0;
+    if (!v3_slots_equal(v3_own(ax, c), v3_pred(ax, c))) ax.ctl[V3_CTL_HDR + atomicAdd(ax.ctl + V3_CTL_MISMATCH, 1)] = (int)c;
+  }
+  __threadfence(); __syncthreads();
+  const int n = *(volatile int *)(ax.ctl + V3_CTL_MISMATCH);
+  const V3Lds S = {tab_[wv], wbuf_[wv], bests_[wv], lut};
+  v3_init_lut(lut, threadIdx.x & 63);
+  V3Lane L; v3_init_lane(threadIdx.x & 15, L);
+  if (!force && n > 0) v3_repair_rows<NTB>(in, out, total_steps, vp, ax, in_base, out_lo, S, L, 4 * V3_WGW, 4 * wv, n);
+  __threadfence(); __syncthreads();
+  if (wv == 0) v3_seq_walk<NTB>(in, out, total_steps, vp, ax, in_base, out_lo, S, L, force);
 }
 
 }  // namespace dvbt
