@@ -691,13 +691,13 @@ def cpp_multi_host(workload, loops=160, seg_sf=64):
     try:
         iq.tofile(fin)
         res = {}
-        for mode in ("lent", "mirror", "copy"):
+        for mode in ("lent", "two_chains", "mirror", "copy"):
             best = None
             for _ in range(2):
                 if os.path.exists(idf):
                     os.remove(idf)
                 r = subprocess.run([exe, "0", "1", idf, "8k", "qam64", "7/8", fin, os.path.join(tmp, "none.ts"), str(seg_sf), "0", "bench", str(loops),
-                                    str(po.STREAM_LEAD_IN + sf), str(64 * sf), str(8 * sf), "8", "400000"] + (["copy"] if mode == "copy" else ["mirror"] if mode == "mirror" else []),
+                                    str(po.STREAM_LEAD_IN + sf), str(64 * sf), str(8 * sf), "8", "400000"] + (["copy"] if mode == "copy" else ["mirror"] if mode == "mirror" else []) + ([] if mode == "two_chains" else ["chains=4"]),
                                    capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
                 if r.returncode != 0:
                     return {"error": (r.stdout[-200:] + r.stderr[-300:])}
@@ -709,6 +709,8 @@ def cpp_multi_host(workload, loops=160, seg_sf=64):
                 "seconds": best["seconds"], "exchange_steps": best["exchange_steps"], "ts_bytes": best["ts_bytes"], "status": best["status"],
                 "entry": "dvbt_rx_stream_push_device (samples lent: borrow_device_pushes) + dvbt_rx_stream_gather_enqueue_ex(DVBT_GATHER_DEVICE) / _wait (RCCL, one rank; the runs stay in rank 0's device memory)",
                 "segment_superframes": seg_sf, "superframes_per_push": 8, "pushes_per_exchange_step": 8,
+                "chains": 4, "chains_note": "dvbt_rx_stream_params.chains = 4: three pieces decode while the fourth fills (the Python line's four steps in flight); with_two_chains = the default stream object",
+                "with_two_chains": {"value": res["two_chains"]["msamples_per_s"], "seconds": res["two_chains"]["seconds"], "status": res["two_chains"]["status"]},
                 "with_page_locked_mirror": {"value": res["mirror"]["msamples_per_s"], "seconds": res["mirror"]["seconds"], "status": res["mirror"]["status"]},
                 "every_push_copies": {"value": res["copy"]["msamples_per_s"], "seconds": res["copy"]["seconds"], "status": res["copy"]["status"]}}
     finally:

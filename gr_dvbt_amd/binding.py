@@ -278,7 +278,7 @@ class Rx:
 
 
 class StreamParams(C.Structure):
-    _fields_ = [("rx", RxParams), ("segment_superframes", C.c_int), ("rank", C.c_int), ("world", C.c_int), ("ts_ring_bytes", C.c_int64), ("borrow_device_pushes", C.c_int)]
+    _fields_ = [("rx", RxParams), ("segment_superframes", C.c_int), ("rank", C.c_int), ("world", C.c_int), ("ts_ring_bytes", C.c_int64), ("borrow_device_pushes", C.c_int), ("chains", C.c_int)]
 
 
 class StreamInfo(C.Structure):
@@ -292,7 +292,7 @@ class RxStream:
     """dvbt_rx_stream_*: push samples in calls of any size, pull the TS in order; the bytes are those of one chain over the whole stream."""
 
     def __init__(self, constellation, code_rate, mode, segment_superframes=0, guard=G1_32, hierarchy=NH, snr_db=30.0, viterbi_bsize=768,
-                 rs_oracle_compat=0, device=0, rank=0, world=0, soft_decision=0, ts_ring_bytes=0, borrow=0, viterbi_warm_windows=0, viterbi_verify=0):
+                 rs_oracle_compat=0, device=0, rank=0, world=0, soft_decision=0, ts_ring_bytes=0, borrow=0, viterbi_warm_windows=0, viterbi_verify=0, chains=0):
         self.L = lib()
         for fn in ("create", "push", "push_device", "finish", "status"):
             getattr(self.L, f"dvbt_rx_stream_{fn}").restype = C.c_int
@@ -307,7 +307,7 @@ class RxStream:
         rx = RxParams(constellation, hierarchy, code_rate, guard, mode, 0, 0, snr_db, viterbi_bsize, rs_oracle_compat, 1, 0, device, 0, 0, 0, 0.0, soft_decision)
         rx.viterbi_warm_windows = viterbi_warm_windows
         rx.viterbi_verify = viterbi_verify
-        self.p = StreamParams(rx, segment_superframes, rank, world, ts_ring_bytes, borrow)
+        self.p = StreamParams(rx, segment_superframes, rank, world, ts_ring_bytes, borrow, chains)
         self.L.dvbt_rx_stream_pull_chunk.restype = C.c_int64
         self.L.dvbt_rx_stream_pull_chunk.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int64)]
         self.h = C.c_void_p()

@@ -7,7 +7,7 @@
 // TS of one chain over the whole stream -- and writes the file.  No RCCL headers: the communicator comes from the library (dvbt_rccl_unique_id on rank 0, the
 // 128 bytes carried to the others through a file, dvbt_rccl_comm_create everywhere).
 //   rx_multi_example <rank> <world> <id file> <2k|8k> <qpsk|qam16|qam64> <1/2|2/3|3/4|5/6|7/8> <baseband.cf32> <out.ts> [superframes per piece] [device]
-//                    [bench <loops> <loop_from> <loop_len> <samples per push> [pushes per exchange step] [slot packets] [copy]]
+//                    [bench <loops> <loop_from> <loop_len> <samples per push> [pushes per exchange step] [slot packets] [copy] [mirror] [chains=N]]
 // started once per rank (e.g. `for r in 0 1 ... ; do rx_multi_example $r 8 /tmp/id ... & done`); rank r uses device r unless told otherwise.
 // bench: the throughput of this host on samples that are RESIDENT in device memory (what bench.py's line measures for the Python host): the file is uploaded
 // once, then pushed from device memory (dvbt_rx_stream_push_device) -- its first loop_from + loop_len samples, then the stretch [loop_from, loop_from + loop_len)
@@ -60,6 +60,7 @@ int main(int argc, char **argv)
     p.segment_superframes = seg_sf; p.rank = rank; p.world = world;
     const bool bench_mode = argc > 15 && !std::strcmp(argv[11], "bench");
     p.borrow_device_pushes = bench_mode && !(argc > 18 && !std::strcmp(argv[18], "copy")) ? 1 : 0;   // bench: the resident samples are lent to the stream, not copied ("copy": the default contract)
+    for (int i = 16; i < argc; i++) if (!std::strncmp(argv[i], "chains=", 7)) p.chains = std::atoi(argv[i] + 7);   // bench: chains of the stream object (dvbt_rx_stream_params.chains: 2 .. 4)
     dvbt_rx_stream *st = nullptr;
     check(dvbt_rx_stream_create(&p, &st));
     dvbt_dims d; check(dvbt_get_dims(con, DVBT_NH, cr, DVBT_G1_32, mode, &d));
@@ -147,8 +148,8 @@ int main(int argc, char **argv)
     dvbt_rx_stream_info inf; check(dvbt_rx_stream_status(st, &inf));
     int rc = 0;
     if (rank == 0 && bench) {
-      std::printf("{\"world\": %d, \"samples\": %lld, \"seconds\": %.4f, \"msamples_per_s\": %.1f, \"ts_bytes\": %lld, \"exchange_steps\": %lld, \"order_errors\": %lld, \"status\": %d, \"runs\": \"%s\"}\n",
-                  world, samples, seconds, samples / seconds / 1e6, ts_bytes, steps, order_errors, inf.status, mirror ? "page-locked mirror on rank 0 (exact download)" : "resident in rank 0's device memory");
+      std::printf("{\"world\": %d, \"samples\": %lld, \"seconds\": %.4f, \"msamples_per_s\": %.1f, \"ts_bytes\": %lld, \"exchange_steps\": %lld, \"order_errors\": %lld, \"status\": %d, \"chains\": %d, \"runs\": \"%s\"}\n",
+                  world, samples, seconds, samples / seconds / 1e6, ts_bytes, steps, order_errors, inf.status, p.chains ? p.chains : 2, mirror ? "page-locked mirror on rank 0 (exact download)" : "resident in rank 0's device memory");
       if (order_errors) rc = 1;
     } else if (rank == 0) {
       std::FILE *o = std::fopen(argv[8], "wb"); if (!o) { std::perror("open"); return 1; }

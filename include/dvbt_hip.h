@@ -509,7 +509,7 @@ void dvbt_rx_destroy(dvbt_rx *h);
  * At the lock's edge a piece's fresh acquisition may drop -- or not find -- a lock that the chain before it has seen hold; the piece is then started again behind
  * that loss (a few symbols later; the walk takes over beyond six): it is not a loss of the stream and is not reported as one.
  * Memory per stream object (S = segment_superframes, sf = one superframe of samples = 272 (N + cp) x 8 bytes: 18.4 MB at 8k, 4.6 MB at 2k, guard 1/32):
- *   device: two sample buffers of (S + 3.7) sf each + the two chains' own buffers (~0.55 x a sample buffer each; x 2.2 in soft-decision mode);
+ *   device: per chain (two by default, `chains`) a sample buffer of (S + 3.7) sf + the chain's own buffers (~0.55 x a sample buffer; x 2.2 in soft-decision mode);
  *   S = 16 at 8k: 2 x 362 MB + 2 x ~200 MB.  The first lost lock adds two walk buffers of twice a sample buffer each (2 x 725 MB at S = 16, 8k), and the buffers behind the
  *   walking chain's Viterbi decoder grow to what a window of that size can lay out (three more buffers of ~2.2 x a piece's decoded bytes: +115 MB at S = 16, 8k QAM64 7/8).
  *   A walk's window is bounded by those buffers: a lock that holds for more than two pieces and a threshold of samples (2 x the sample buffer + (STREAM_PRE + 272) symbols)
@@ -539,6 +539,11 @@ typedef struct {
    * the samples valid and unchanged until dvbt_rx_stream_info.samples_released has passed them (a ring of segments resident in HBM does).  dvbt_rx_stream_push (host memory)
    * is refused on such a stream; not together with DVBT_AUTO.  0: every push copies (the default: the caller's buffer is free when the call returns). */
   int borrow_device_pushes;
+  /* chains (handle + sample buffer + HIP stream) of the stream object: 0 = 2 (the default), or 2 .. 4.  The pieces take them in turn; `chains - 1` pieces decode while the next one
+   * fills, and the small latency-bound kernels of the later pieces run in the gaps of the earlier pieces' decoders (the segment API's "several segments in flight"):
+   * 4 chains: 4.3 instead of 4.5 ms per 64-superframe piece at the headline workload -- for twice the device memory (every chain has its sample buffer and its buffers behind the
+   * decoder; the walk's buffers hold `chains` sample buffers and a threshold).  Same bytes. */
+  int chains;
 } dvbt_rx_stream_params;
 typedef struct {
   int32_t status;              /* dvbt_rx_report.status bits of the pieces, OR-ed (bit 1 only when the lock was lost inside a piece) | bit 5: a piece

@@ -22,8 +22,8 @@ def whole(po, const, cr, mode, iq, snr_db=30.0):
     return want
 
 
-def streamed(const, cr, mode, iq, seg_sf, call, pull_every=7):
-    st = g.RxStream(const, cr, mode, segment_superframes=seg_sf)
+def streamed(const, cr, mode, iq, seg_sf, call, pull_every=7, **kw):
+    st = g.RxStream(const, cr, mode, segment_superframes=seg_sf, **kw)
     out, k = [], 0
     rng = np.random.RandomState(3)
     pos = 0
@@ -302,3 +302,25 @@ def test_borrowed_device_pushes(po, hole):
             s2.push(iq[:1000])
         finally:
             s2.close()
+
+
+@pytest.mark.parametrize("chains,pull_every", [(3, 7), (4, 7), (4, 10000)], ids=["three chains", "four chains", "four chains, pushed without pulls"])
+def test_more_chains_per_stream_object(po, chains, pull_every):
+    """dvbt_rx_stream_params.chains: three / four chains take the pieces in turn (two / three pieces decode while the next one fills) -- the same bytes: a clean stream of
+    one-superframe pieces (every chain busy), and dropouts at several places, where the walk takes over from a lost piece whose samples lie in the buffers of up to three pieces
+    behind it (pushed without a single pull: every piece behind the lost one is in flight or filled when the loss is found)"""
+    const, cr, mode = g.QAM16, g.C1_2, g.T2k
+    c = po.cfg(const, cr, mode)
+    L = c.N + c.cp
+    iq = po.stream_slice(c, 14, 9)
+    ref = whole(po, const, cr, mode, iq)
+    ts, info = streamed(const, cr, mode, iq, 1, (1000, 50000), pull_every=pull_every, chains=chains)
+    assert info.status & ~2 == 0 and len(ts) == len(ref) > 0 and (ts == ref).all()
+    for hole_symbol in (272 * 6 + 100, 272 * 7 + 40, 272 * 9 + 200):
+        iq = _holed(po, c, 15, hole_symbol)
+        ref = whole(po, const, cr, mode, iq)
+        ts, info = streamed(const, cr, mode, iq, 1, 64 * L, pull_every=pull_every, chains=chains)
+        assert info.status & 2
+        assert len(ts) == len(ref) > 0 and (ts == ref).all(), (hole_symbol, len(ts), len(ref))
+    with pytest.raises(RuntimeError):
+        g.RxStream(const, cr, mode, chains=5)
