@@ -214,7 +214,7 @@ struct VitProof {
   V3Aux aux() const { V3Aux a; memset(&a, 0, sizeof a); a.snap = snap; a.ctl = ctl; a.cap = cap; a.carry_rel = -1; return a; }
   ~VitProof() { if (snap) (void)hipFree(snap); if (ctl) (void)hipFree(ctl); }
 };
-enum { VIT_PLAIN = -1, VIT_REPAIR = 0, VIT_REPAIR_COUNT = 1, VIT_PROOF_ONLY = 2, VIT_FORCE_SEQ = 3 };   // dvbt_rx_params.viterbi_verify
+enum { VIT_PLAIN = -1, VIT_REPAIR = 0, VIT_REPAIR_COUNT = 1, VIT_PROOF_ONLY = 2, VIT_FORCE_SEQ = 3, VIT_FORCE_CONFLICT = 4 };   // dvbt_rx_params.viterbi_verify
 constexpr unsigned V3_REPAIR_GRID = 64;   // workgroups of the parallel repair pass: 1024 decoders at once, the rest in rounds (a wavefront without a listed chunk returns at once)
 
 // ax == null or mode == VIT_PLAIN: the chunk decoders alone.  Otherwise the launch that is the streaming decoder by construction: the decoders leave their states, the checker
@@ -229,7 +229,8 @@ static void launch_viterbi(hipStream_t s, const uint8_t *in, uint8_t *out, const
   const dim3 grid((unsigned)((chunks + 4 * V3_WGW - 1) / (4 * V3_WGW))), blk(64 * V3_WGW);
   V3Aux none; memset(&none, 0, sizeof none);
   if (proof) {
-    const V3Aux &a = *ax;
+    V3Aux a = *ax;
+    if (mode == VIT_FORCE_CONFLICT) { a.debug = 1; mode = VIT_REPAIR_COUNT; }
     const dim3 cgrid((unsigned)((chunks + 255) / 256));
     if (vp.warm == V3_WARM) {
 #define V3_CALL(N) hipLaunchKernelGGL((viterbi3_kernel<N, V3_WARM, 1>), grid, blk, 0, s, in, out, st, steps_fixed, vp, a, in_base, out_lo)
@@ -410,7 +411,7 @@ extern "C" int dvbt_rx_create(const dvbt_rx_params *p, dvbt_rx **out)
   if (p->viterbi_warm_windows != 0 && (p->viterbi_warm_windows < 2 * V3_BLK || p->viterbi_warm_windows > V3_WARM_MAX || p->viterbi_warm_windows % V3_BLK != 0))
     return fail(DVBT_ERR_INVALID, "viterbi_warm_windows must be 0 (default) or a multiple of 24 in [48, 1152]");
   if (p->viterbi_warm_windows != 0 && p->soft_decision) return fail(DVBT_ERR_INVALID, "viterbi_warm_windows applies to the hard-decision decoder");
-  if (p->viterbi_verify < VIT_PLAIN || p->viterbi_verify > VIT_FORCE_SEQ) return fail(DVBT_ERR_INVALID, "viterbi_verify must lie in [-1, 3]");
+  if (p->viterbi_verify < VIT_PLAIN || p->viterbi_verify > VIT_FORCE_CONFLICT) return fail(DVBT_ERR_INVALID, "viterbi_verify must lie in [-1, 4]");
   if (p->viterbi_verify > 0 && p->soft_decision) return fail(DVBT_ERR_INVALID, "viterbi_verify applies to the hard-decision decoder");
   HIPCHK(hipSetDevice(p->device));
   dvbt_rx *h = new dvbt_rx();

@@ -353,6 +353,8 @@ struct V3Aux {
   long long grid0;                   // absolute index of chunk 0's first byte (the single block: where the carried state stands, <= the first byte of the call)
   const int *carry_in;               // the streaming decoder's state at grid0 (null: chunk 0 warms up like the others -- it starts the stream)
   int *carry_out; int carry_rel;     // the last chunk's decoder leaves its state carry_rel windows into its chunk (a multiple of V3_BLK; carry_out null: no)
+  int debug;                         // test hook (dvbt_rx_params.viterbi_verify = 4): bit 0 = every repaired chunk flags the chunk behind it as if its decoder had not arrived in
+                                     // pred[] (the flag / fix[] hand-over to the sequential pass is otherwise reached only by inputs nobody has seen)
 };
 __device__ __forceinline__ int *v3_own(const V3Aux &ax, long long c) { return ax.snap + (3 * c) * V3_SLOT; }
 __device__ __forceinline__ int *v3_pred(const V3Aux &ax, long long c) { return ax.snap + (3 * c + 1) * V3_SLOT; }
@@ -629,7 +631,7 @@ template <int NTB> __device__ __forceinline__ void v3_repair_rows(const uint8_t 
     v3_decode<NTB, 0, 2>(in, out, total_steps, total_out, vp, in_base, out_lo, b0, act && b0 < total_out, S, L, v, endv, v3_own(ax, c) + 2 * pl, nullptr, nullptr, carry, ax.carry_rel);
     int pn[2] = {endv[0], endv[1]};
     if (act && c + 1 < nch) { const int *p = v3_pred(ax, c + 1) + 2 * pl; pn[0] = p[0]; pn[1] = p[1]; }
-    if (!v3_row_equal(endv, pn, dd)) {                               // the repaired decoder does not arrive where the unproven one did: the sequential pass goes on from here
+    if (!v3_row_equal(endv, pn, dd) || ((ax.debug & 1) && act && c + 1 < nch)) {   // the repaired decoder does not arrive where the unproven one did: the sequential pass goes on from here
       int *f = v3_fix(ax, c + 1) + 2 * pl; f[0] = endv[0]; f[1] = endv[1];
       if (pl == 0) { ax.ctl[V3_CTL_HDR + (ax.cap + 2) + c + 1] = 1; atomicAdd(ax.ctl + V3_CTL_CONFLICT, 1); }
     }

@@ -328,7 +328,7 @@ typedef struct {
                               host reads no verdict; the passes return at once when every chunk is proven (the usual case: three small launches, +2 % of the decoder).
                                 0  (default) proof + repair;  1  the same plus a final check whose count dvbt_rx_viterbi_check / dvbt_rx_viterbi_proof report (0 by
                                 construction);  2  proof only, nothing decoded again: the count says how many chunks the warm-up alone does not prove (statistics);
-                                3  test hook: the sequential pass does all the repairs;  -1  the plain chunk decoders (no states, no passes: equal to the streaming decoder
+                                3  test hook: the sequential pass does all the repairs;  4  test hook: every repaired chunk hands the chunk behind it to the sequential pass;  -1  the plain chunk decoders (no states, no passes: equal to the streaming decoder
                                 where the warm-up suffices, as until round 5).
                               Chunk sizes are rounded up to a multiple of 24 (unless -1).  Hard-decision decoder; every entry (segment API, streaming entry, hierarchical
                               modes -- which ran ONE decoder on one wavefront until round 5).  The single viterbi_decoder block does the same and carries the state from call to call. */

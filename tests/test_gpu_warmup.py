@@ -82,7 +82,7 @@ def test_collapsed_channel_is_the_streaming_decoder_with_default_parameters(po, 
     assert len(o["lock_periods"]) == 1 and len(o["vit"]) > 1000000
     res = {}
     for name, kw in (("plain", dict(viterbi_verify=-1)), ("default", dict()), ("default+count", dict(viterbi_verify=1)), ("warm 48", dict(viterbi_warm_windows=48, viterbi_verify=1)),
-                     ("warm 288", dict(viterbi_warm_windows=288, viterbi_verify=1)), ("sequential", dict(viterbi_verify=3))):
+                     ("warm 288", dict(viterbi_warm_windows=288, viterbi_verify=1)), ("sequential", dict(viterbi_verify=3)), ("hand-over", dict(viterbi_verify=4))):
         rx = g.Rx(po.QAM64, po.C7_8, po.T2k, max_samples=len(iq), taps=True, snr_db=16.0, **kw)
         rep = rx.run(iq)
         assert rep.first_out_symbol == o["first_out_symbol"] and rep.n_lock_periods == 1
@@ -95,7 +95,7 @@ def test_collapsed_channel_is_the_streaming_decoder_with_default_parameters(po, 
         rx.close()
     print("collapsed channel, (Viterbi bytes that differ from the streaming decoder over the same input, the passes' counters):", res)
     assert 0 < res["plain"][0] < len(o["vit"]) // 200, res               # the plain chunk decoders: wrong at a small fraction of the chunk starts
-    for name in ("default", "default+count", "warm 48", "warm 288", "sequential"):
+    for name in ("default", "default+count", "warm 48", "warm 288", "sequential", "hand-over"):
         assert res[name][0] == 0, (name, res)
     p = res["default+count"][1]
     assert p["chunks"] > 1000 and 0 < p["decoded_again"] < p["chunks"] // 20 and p["not_proven"] == 0, p
@@ -103,6 +103,10 @@ def test_collapsed_channel_is_the_streaming_decoder_with_default_parameters(po, 
     assert res["warm 48"][1]["decoded_again"] > p["decoded_again"] > res["warm 288"][1]["decoded_again"] == 0, res   # the warm-up moves the number of repairs, not the bytes
     q = res["sequential"][1]
     assert q["sequential"] >= q["decoded_again"] == p["decoded_again"] and q["not_proven"] == 0, q
+    # viterbi_verify = 4: every repaired chunk flags the chunk behind it with the state it arrived in -- the hand-over the sequential pass exists for, which no input seen so far
+    # reaches by itself: that pass then decodes the flagged chunks (one each: it arrives in the state they were decoded from), and the bytes stay the streaming decoder's
+    q = res["hand-over"][1]
+    assert q["decoded_again"] == p["decoded_again"] and q["sequential"] >= 1 and q["not_proven"] == 0, q
 
 
 @pytest.mark.parametrize("const,hier,mode,cr", [(2, 2, 0, 2), (2, 3, 1, 4), (1, 2, 0, 0)], ids=["2k QAM64 alpha 2 2/3", "8k QAM64 alpha 4 7/8", "2k QAM16 alpha 2 1/2"])
@@ -159,7 +163,7 @@ def test_viterbi_proof_counts(po, g):
     with pytest.raises(RuntimeError):                                   # ... and the plain chunk decoders keep no states at all
         h = g.Rx(po.QAM64, po.C7_8, po.T8k, max_samples=len(iq), viterbi_verify=-1); h.run(iq); h.viterbi_proof()
     with pytest.raises(RuntimeError):
-        g.Rx(po.QAM64, po.C7_8, po.T8k, max_samples=len(iq), viterbi_verify=4)
+        g.Rx(po.QAM64, po.C7_8, po.T8k, max_samples=len(iq), viterbi_verify=5)
     # the collapsed channel, proof only
     c = po.cfg(po.QAM64, po.C7_8, po.T2k)
     ibits = c.payload * c.m * c.k // c.n
