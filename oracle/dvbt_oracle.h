@@ -101,6 +101,9 @@ size_t o_viterbi_decode(const o_cfg *c, int bsize, const unsigned char *in, size
 size_t o_viterbi_decode_n(const o_cfg *c, const unsigned char *in, size_t nsym, unsigned char *out);
 /* ... with the 64 path metrics (minimum subtracted) right behind the snap_at[i]-th get_output call, 64 bytes each (test instrumentation) */
 size_t o_viterbi_decode_snap(const o_cfg *c, const unsigned char *in, size_t nsym, unsigned char *out, const long long *snap_at, int nsnap, unsigned char *snaps);
+/* ... and a decoder that takes the stream up in the state init[64] right behind get_output call from_call (0: at in[0]); out[] valid from index from_call - 1 on (test instrumentation) */
+size_t o_viterbi_decode_from(const o_cfg *c, const unsigned char *in, size_t nsym, unsigned char *out, long long from_call, const unsigned char *init,
+                             const long long *snap_at, int nsnap, unsigned char *snaps);
 
 /* ---- Forney byte de-interleaver (lib/convolutional_deinterleaver_impl.cc) ---- */
 /* closed form of the 12 FIFOs starting from all-zero state; n bytes -> n bytes */

@@ -145,6 +145,38 @@ static size_t decode_core(const o_cfg *c, const unsigned char *in, size_t nsym, 
   return out_count >= (size_t)nt ? out_count - nt : 0;
 }
 
+/* A decoder that takes up the stream in the state `init` (64 path metrics, minimum subtracted: what o_viterbi_decode_snap reports) right behind get_output call `from_call`
+ * of a decode that starts with in[0]: the depuncturer and the output cadence run from in[0] as in decode_core, the trellis only from there on.  out[] is indexed like decode_core's;
+ * valid from index from_call - 1 on (the tracebacks of earlier bytes reach into windows this decoder has not seen).  Test instrumentation: the CPU model of the repair passes that
+ * make the HIP chunk decoders the streaming decoder (tests/test_viterbi_repair_model.py; k_viterbi3.hpp's viterbi_repair_kernel / viterbi_repair_seq_kernel start decoders the same way). */
+size_t o_viterbi_decode_from(const o_cfg *c, const unsigned char *in, size_t nsym, unsigned char *out, long long from_call, const unsigned char *init,
+                             const long long *snap_at, int nsnap, unsigned char *snaps)
+{
+  int plen; const unsigned char *punct = o_vit_puncture(c->code_rate, &plen);
+  int nt = o_vit_ntraceback(c->code_rate);
+  o_vit_core v; v.store_pos = 0;
+  o_vit_core_init(&v, nt);
+  size_t out_count = 0, count = 0, ic = 0;
+  unsigned char bits[4]; int nb = 0, si = 0, live = from_call <= 0;
+  if (live && init) memcpy(v.metric, init, 64);
+#define O_PUSH(b) do { bits[nb++] = (unsigned char)(b); count++; if (nb == 4) { nb = 0; \
+    if (live) o_vit_butterfly2(&v, bits); \
+    if (ic > 0 && (ic % 16) == 8) { \
+      if (live) { unsigned char ch = o_vit_get_output(&v); if (out_count >= (size_t)nt) out[out_count - nt] = ch; } \
+      out_count++; \
+      if (!live && (long long)out_count == from_call) { memcpy(v.metric, init, 64); memset(v.path, 0, 64); live = 1; } \
+      if (live && si < nsnap && (long long)out_count == snap_at[si]) { memcpy(snaps + 64 * (size_t)si, v.metric, 64); si++; } } \
+    ic += 4; } } while (0)
+  for (size_t i = 0; i < nsym; i++)
+    for (int j = c->m - 1; j >= 0; j--) {
+      while (punct[count % (size_t)(2 * c->k)] == 0) O_PUSH(2);
+      O_PUSH((in[i] >> j) & 1);
+      while (punct[count % (size_t)(2 * c->k)] == 0) O_PUSH(2);
+    }
+#undef O_PUSH
+  return out_count >= (size_t)nt ? out_count - nt : 0;
+}
+
 size_t o_viterbi_decode_n(const o_cfg *c, const unsigned char *in, size_t nsym, unsigned char *out)
 { return decode_core(c, in, nsym, out, NULL, 0, NULL); }
 
