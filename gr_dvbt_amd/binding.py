@@ -248,6 +248,13 @@ class Rx:
         _chk(self.L.dvbt_rx_viterbi_proof(self.h, C.byref(p)))
         return {"chunks": int(p.chunks), "decoded_again": int(p.decoded_again), "sequential": int(p.sequential), "not_proven": int(p.not_proven)}
 
+    def viterbi_proof_total(self):
+        """the passes' counters summed over every launch of the handle's decoder since it was created: dict(chunks, decoded_again, sequential, not_proven = -1)"""
+        p = ViterbiProof()
+        self.L.dvbt_rx_viterbi_proof_total.argtypes = [C.c_void_p, C.POINTER(ViterbiProof)]
+        _chk(self.L.dvbt_rx_viterbi_proof_total(self.h, C.byref(p)))
+        return {"chunks": int(p.chunks), "decoded_again": int(p.decoded_again), "sequential": int(p.sequential), "not_proven": int(p.not_proven)}
+
     def viterbi_check(self):
         """viterbi_verify >= 1: (chunks of the last launch of the Viterbi decoder, chunks NOT proven equal to the streaming decoder when the launch ends)"""
         a, b = C.c_int64(), C.c_int64()

@@ -1469,6 +1469,18 @@ extern "C" int dvbt_rx_viterbi_proof(dvbt_rx *h, dvbt_viterbi_proof *out)
   out->chunks = r[V3_CTL_CHUNKS]; out->decoded_again = r[V3_CTL_MISMATCH]; out->sequential = r[V3_CTL_SEQ]; out->not_proven = r[V3_CTL_UNPROVEN];
   return DVBT_OK;
 }
+// ... and summed over every launch of the handle's decoder since it was created (the lock periods of a synchronous run are launches of their own); not_proven = -1
+extern "C" int dvbt_rx_viterbi_proof_total(dvbt_rx *h, dvbt_viterbi_proof *out)
+{
+  if (!h || !out) return fail(DVBT_ERR_INVALID, "null argument");
+  if (!h->vproof.ctl) return fail(DVBT_ERR_STATE, "dvbt_rx_viterbi_proof_total: the handle runs the plain chunk decoders (viterbi_verify = -1, or soft decisions)");
+  if (h->pending) return fail(DVBT_ERR_STATE, "dvbt_rx_viterbi_proof_total: a segment is in flight (dvbt_rx_segment_finish first)");
+  HIPCHK(hipSetDevice(h->prm.device));
+  int acc[3] = {0, 0, 0};
+  HIPCHK(hipMemcpy(acc, h->vproof.ctl + V3_CTL_ACC, sizeof acc, hipMemcpyDeviceToHost));
+  out->chunks = acc[0]; out->decoded_again = acc[1]; out->sequential = acc[2]; out->not_proven = -1;
+  return DVBT_OK;
+}
 // (chunks, chunks that are not proven when the launch ends) -- needs the final check, viterbi_verify >= 1
 extern "C" int dvbt_rx_viterbi_check(dvbt_rx *h, int64_t *chunks, int64_t *unproven)
 {

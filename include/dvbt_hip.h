@@ -453,6 +453,8 @@ typedef struct {
 } dvbt_lock_period;
 /* what the proof + repair passes of the handle's last launch of the Viterbi decoder did (see dvbt_rx_params.viterbi_verify) */
 int  dvbt_rx_viterbi_proof(dvbt_rx *h, dvbt_viterbi_proof *out);
+/* the same counters summed over every launch of the handle's decoder since it was created (a synchronous run launches the decoder once per lock period); not_proven = -1 */
+int  dvbt_rx_viterbi_proof_total(dvbt_rx *h, dvbt_viterbi_proof *out);
 /* (chunks, not_proven) of the same; needs the final check (viterbi_verify >= 1) */
 int  dvbt_rx_viterbi_check(dvbt_rx *h, int64_t *chunks, int64_t *unproven);
 int  dvbt_rx_lock_periods(dvbt_rx *h, dvbt_lock_period *out, int cap);
