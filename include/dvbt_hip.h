@@ -635,6 +635,12 @@ int dvbt_debug_peak_detect(const float *lambda_host, const float *avg_host, int 
  * far, ascending: the state it carries from window to window is what is under test) and reports the calls it delivers as runs of (first packet, packets) in runs[2 k],
  * runs[2 k + 1].  Returns the number of runs, or a negative error.  No device needed. */
 int64_t dvbt_debug_descr_follow(const uint8_t *rs, size_t nitems, const int64_t *windows, int nwindows, int64_t *runs, size_t cap_runs);
+/* the exchange step's world > 1 logic on ONE device (RCCL refuses two ranks on a device, a test box has one): a loopback transport whose ranks are threads of one process -- a send
+ * is a posted message, a receive copies device to device behind the sender's stream, a group ends when everything posted has been taken.  *group: NULL on the first call (created and
+ * returned), the returned value for the other ranks.  dvbt_rccl_debug_fail_steps: the communicator's next n steps behave as if their exchange buffers could not be allocated (the
+ * error-flag slot, sent from the stream's sample buffer).  tests/test_gpu_rccl.py::test_exchange_step_world_2_over_the_loopback_transport */
+int dvbt_rccl_comm_create_loopback(void **group, int rank, int world, int device, dvbt_rccl_comm **out);
+int dvbt_rccl_debug_fail_steps(dvbt_rccl_comm *c, int n);
 
 #ifdef __cplusplus
 }

@@ -197,3 +197,100 @@ def test_cpp_host_device_resident_runs_and_exact_mirror(tmp_path):
     L.dvbt_rccl_comm_destroy.argtypes = [C.c_void_p]
     L.dvbt_rccl_comm_destroy(comm)
     assert len(outs[1]) == len(outs[0]) == len(want) > 0 and (outs[1] == want).all() and (outs[0] == want).all()
+
+
+def test_exchange_step_world_2_over_the_loopback_transport():
+    """The exchange step's world > 1 logic on the one GPU of a test box (RCCL refuses two ranks on a device): dvbt_rccl_comm_create_loopback -- the ranks are two threads, a send
+    is a posted message, a receive copies device to device behind the sender's stream -- under the real dvbt_rx_stream_gather_enqueue_ex / _wait: two sharded streams pushed the
+    same samples, every step one group (the slot to the root, the headers to both ranks), the root takes the runs from its device memory (DVBT_GATHER_DEVICE) or from the page-locked
+    mirror (the OTHER rank's fill is read on the device by gather_download_kernel); ordered by packet index they are the oracle's TS.  Then a step in which rank 1's buffers are
+    declared missing (dvbt_rccl_debug_fail_steps): its slot travels from the stream's sample buffer with the error flag, BOTH ranks' waits report the failure, nobody hangs."""
+    import ctypes as C
+    import threading
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from oracle import pyoracle as po
+    import gr_dvbt_amd as g
+    L = g.lib()
+    c = po.cfg(g.QAM16, g.C1_2, g.T2k)
+    iq = po.stream_slice(c, 9, 6)
+    want = po.rx(c, iq, want=("ts",))["ts"]
+
+    class Chunk(C.Structure):
+        _fields_ = [("first_packet", C.c_int64), ("nbytes", C.c_int64), ("offset", C.c_int64)]
+    L.dvbt_rccl_comm_create_loopback.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.dvbt_rccl_debug_fail_steps.argtypes = [C.c_void_p, C.c_int]
+    L.dvbt_rx_stream_gather_enqueue_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.dvbt_rx_stream_gather_wait.restype = C.c_int64
+    L.dvbt_rx_stream_gather_wait.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(Chunk), C.POINTER(C.c_int)]
+    L.dvbt_rccl_step_buffer.restype = C.c_void_p; L.dvbt_rccl_step_buffer.argtypes = [C.c_void_p]
+    L.dvbt_rccl_step_device_buffer.restype = C.c_void_p; L.dvbt_rccl_step_device_buffer.argtypes = [C.c_void_p]
+    L.dvbt_rx_stream_set_device_output.argtypes = [C.c_void_p, C.c_size_t]
+    L.dvbt_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.dvbt_rccl_comm_destroy.argtypes = [C.c_void_p]
+    SLOT, WORLD = 2500, 2
+    step = 48 * (c.N + c.cp)
+    for flags, fail_at in ((1, None), (0, None), (1, 3)):
+        group = C.c_void_p()
+        comms = []
+        for r in range(WORLD):
+            cm = C.c_void_p()
+            assert L.dvbt_rccl_comm_create_loopback(C.byref(group), r, WORLD, 0, C.byref(cm)) == 0, L.dvbt_last_error()
+            comms.append(cm)
+        runs, errors, failed_steps = {}, [], [0, 0]
+        barrier = threading.Barrier(WORLD)
+
+        def rank_main(r):
+            try:
+                st = g.RxStream(g.QAM16, g.C1_2, g.T2k, segment_superframes=2, rank=r, world=WORLD)
+                assert L.dvbt_rx_stream_set_device_output(st.h, 0) == 0
+                done, ch, pos, k = C.c_int(0), (Chunk * WORLD)(), 0, 0
+                while not done.value:
+                    if pos < len(iq):
+                        st.push(iq[pos:pos + step]); pos += step
+                        if pos >= len(iq):
+                            st.finish()
+                    k += 1
+                    if fail_at is not None and r == 1 and k == fail_at:
+                        assert L.dvbt_rccl_debug_fail_steps(comms[r], 1) == 0
+                    assert L.dvbt_rx_stream_gather_enqueue_ex(st.h, comms[r], 0, SLOT, flags) == 0, L.dvbt_last_error()
+                    n = L.dvbt_rx_stream_gather_wait(st.h, comms[r], None, 0, ch if r == 0 else None, C.byref(done))
+                    if n < 0:
+                        failed_steps[r] += 1
+                        assert fail_at is not None and k == fail_at, (r, k, L.dvbt_last_error())
+                        continue
+                    if r == 0:
+                        for q in range(WORLD):
+                            nb = ch[q].nbytes
+                            if nb:
+                                buf = np.zeros(nb, np.uint8)
+                                if flags:
+                                    assert L.dvbt_copy_to_host(buf.ctypes.data_as(C.c_void_p), C.c_void_p(L.dvbt_rccl_step_device_buffer(comms[0]) + ch[q].offset), nb) == 0
+                                else:
+                                    C.memmove(buf.ctypes.data_as(C.c_void_p), C.c_void_p(L.dvbt_rccl_step_buffer(comms[0]) + ch[q].offset), nb)
+                                runs[ch[q].first_packet] = (q, buf)
+                barrier.wait(timeout=120)
+                st.close()
+            except BaseException as e:      # noqa: BLE001
+                errors.append((r, repr(e)))
+                try:
+                    barrier.abort()
+                except Exception:           # noqa: BLE001
+                    pass
+        ths = [threading.Thread(target=rank_main, args=(r,)) for r in range(WORLD)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join(timeout=300)
+        assert not any(t.is_alive() for t in ths), "a rank hangs"
+        assert not errors, errors
+        for cm in comms:
+            L.dvbt_rccl_comm_destroy(cm)
+        ranks_seen = {q for q, _ in runs.values()}
+        if fail_at is None:
+            ts = np.concatenate([runs[k][1] for k in sorted(runs)])
+            assert ranks_seen == {0, 1}, ranks_seen                                    # both ranks contributed runs
+            assert len(ts) == len(want) > 0 and (ts == want).all(), (flags, len(ts), len(want))
+            assert failed_steps == [0, 0]
+        else:
+            assert failed_steps == [1, 1], failed_steps                               # the failure of rank 1's step reached BOTH waits; the streams went on
