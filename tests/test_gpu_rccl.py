@@ -199,7 +199,8 @@ def test_cpp_host_device_resident_runs_and_exact_mirror(tmp_path):
     assert len(outs[1]) == len(outs[0]) == len(want) > 0 and (outs[1] == want).all() and (outs[0] == want).all()
 
 
-def test_exchange_step_world_2_over_the_loopback_transport():
+@pytest.mark.parametrize("WORLD", [2, 3])
+def test_exchange_step_world_2_over_the_loopback_transport(WORLD):
     """The exchange step's world > 1 logic on the one GPU of a test box (RCCL refuses two ranks on a device): dvbt_rccl_comm_create_loopback -- the ranks are two threads, a send
     is a posted message, a receive copies device to device behind the sender's stream -- under the real dvbt_rx_stream_gather_enqueue_ex / _wait: two sharded streams pushed the
     same samples, every step one group (the slot to the root, the headers to both ranks), the root takes the runs from its device memory (DVBT_GATHER_DEVICE) or from the page-locked
@@ -228,7 +229,7 @@ def test_exchange_step_world_2_over_the_loopback_transport():
     L.dvbt_rx_stream_set_device_output.argtypes = [C.c_void_p, C.c_size_t]
     L.dvbt_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.dvbt_rccl_comm_destroy.argtypes = [C.c_void_p]
-    SLOT, WORLD = 2500, 2
+    SLOT = 2500
     step = 48 * (c.N + c.cp)
     for flags, fail_at in ((1, None), (0, None), (1, 3)):
         group = C.c_void_p()
@@ -237,7 +238,7 @@ def test_exchange_step_world_2_over_the_loopback_transport():
             cm = C.c_void_p()
             assert L.dvbt_rccl_comm_create_loopback(C.byref(group), r, WORLD, 0, C.byref(cm)) == 0, L.dvbt_last_error()
             comms.append(cm)
-        runs, errors, failed_steps = {}, [], [0, 0]
+        runs, errors, failed_steps = {}, [], [0] * WORLD
         barrier = threading.Barrier(WORLD)
 
         def rank_main(r):
@@ -289,8 +290,8 @@ def test_exchange_step_world_2_over_the_loopback_transport():
         ranks_seen = {q for q, _ in runs.values()}
         if fail_at is None:
             ts = np.concatenate([runs[k][1] for k in sorted(runs)])
-            assert ranks_seen == {0, 1}, ranks_seen                                    # both ranks contributed runs
+            assert ranks_seen == set(range(WORLD)), ranks_seen                         # every rank contributed runs
             assert len(ts) == len(want) > 0 and (ts == want).all(), (flags, len(ts), len(want))
-            assert failed_steps == [0, 0]
+            assert failed_steps == [0] * WORLD
         else:
-            assert failed_steps == [1, 1], failed_steps                               # the failure of rank 1's step reached BOTH waits; the streams went on
+            assert failed_steps == [1] * WORLD, failed_steps                          # the failure of rank 1's step reached EVERY rank's wait; the streams went on
